@@ -1,0 +1,135 @@
+"""Seeded synthetic inputs and parameters (the engine's "fake" data source, cf. the
+reference's read_from: fake, base_dataset.py:81-86).  Shared by bench.py, the tests, the
+oracle and the golden generator: data generation only, no model arithmetic.
+Everything is a pure function of integer seeds so that both sides of a parity
+check (reference/oracle on CPU, HIP engine on the GPU) see bit-identical
+inputs and parameters (SURVEY.md s8(d) "Synthetic inputs").
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+SOT, EOT, MASK_TOKEN, VOCAB = 49407, 49408, 49406, 49409  # simple_tokenizer.py:73-75
+
+
+def synth_images(b, views=1, res=224, seed=0):
+    g = torch.Generator().manual_seed(1000 + seed)
+    return torch.randn(b, 3 * views, res, res, generator=g)
+
+
+def synth_tokens(b, ctx=77, seed=1, vocab=VOCAB, min_len=6, max_len=None):
+    """[b,ctx] int64: SOT, len~U{min..max} ids < MASK_TOKEN, EOT (= max id), zero pad
+    (reference text_transformer.py:144-180 produces exactly this layout)."""
+    g = torch.Generator().manual_seed(2000 + seed)
+    max_len = (ctx - 2) if max_len is None else min(max_len, ctx - 2)
+    min_len = min(min_len, max_len)
+    ids = torch.zeros(b, ctx, dtype=torch.long)
+    lens = torch.randint(min_len, max_len + 1, (b,), generator=g)
+    hi = min(vocab - 3, MASK_TOKEN)
+    for i in range(b):
+        n = int(lens[i])
+        ids[i, 0] = vocab - 2
+        ids[i, 1:1 + n] = torch.randint(0, hi, (n,), generator=g)
+        ids[i, 1 + n] = vocab - 1
+    return ids
+
+
+def vit_shapes(width, layers, patch, res, embed_dim, prefix="visual."):
+    s = OrderedDict()
+    n_tok = (res // patch) ** 2 + 1
+    s[prefix + "class_embedding"] = (width,)
+    s[prefix + "positional_embedding"] = (n_tok, width)
+    s[prefix + "proj"] = (width, embed_dim)
+    s[prefix + "conv1.weight"] = (width, 3, patch, patch)
+    s[prefix + "ln_pre.weight"] = (width,)
+    s[prefix + "ln_pre.bias"] = (width,)
+    _block_shapes(s, prefix + "transformer.resblocks.", width, layers)
+    s[prefix + "ln_post.weight"] = (width,)
+    s[prefix + "ln_post.bias"] = (width,)
+    return s
+
+
+def text_shapes(width, layers, ctx, embed_dim, vocab=VOCAB, prefix="encode_text."):
+    s = OrderedDict()
+    s[prefix + "positional_embedding"] = (ctx, width)
+    _block_shapes(s, prefix + "transformer.resblocks.", width, layers)
+    s[prefix + "token_embedding.weight"] = (vocab, width)
+    s[prefix + "ln_final.weight"] = (width,)
+    s[prefix + "ln_final.bias"] = (width,)
+    s[prefix + "text_projection.weight"] = (embed_dim, width)
+    s[prefix + "text_projection.bias"] = (embed_dim,)
+    return s
+
+
+def _block_shapes(s, prefix, d, layers):
+    for i in range(layers):
+        p = "%s%d." % (prefix, i)
+        s[p + "attn.in_proj_weight"] = (3 * d, d)
+        s[p + "attn.in_proj_bias"] = (3 * d,)
+        s[p + "attn.out_proj.weight"] = (d, d)
+        s[p + "attn.out_proj.bias"] = (d,)
+        s[p + "ln_1.weight"] = (d,)
+        s[p + "ln_1.bias"] = (d,)
+        s[p + "mlp.c_fc.weight"] = (4 * d, d)
+        s[p + "mlp.c_fc.bias"] = (4 * d,)
+        s[p + "mlp.c_proj.weight"] = (d, 4 * d)
+        s[p + "mlp.c_proj.bias"] = (d,)
+        s[p + "ln_2.weight"] = (d,)
+        s[p + "ln_2.bias"] = (d,)
+
+
+def synth_state(shapes, seed=0, logit_scale=None):
+    """Deterministic, non-degenerate parameter values for a name->shape map.
+
+    Not the reference's init (un-seeded, visual_transformer.py:29-38): both sides
+    of every parity check load THIS state.  Each tensor has its own generator
+    keyed by (seed, index) so adding tensors never shifts the others."""
+    sd = OrderedDict()
+    for idx, (name, shape) in enumerate(shapes.items()):
+        g = torch.Generator().manual_seed(seed * 100003 + idx * 7919 + 17)
+        leaf = name.rsplit(".", 1)[-1]
+        is_norm = any(t in name for t in (".ln_", "ln_pre", "ln_post", "ln_final", ".bn"))
+        if name.endswith("logit_scale") or name.endswith("logit_scale_dense"):
+            v = torch.full(shape, math.log(1 / 0.07) if logit_scale is None else logit_scale)
+        elif is_norm and leaf == "weight":
+            v = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif leaf in ("bias", "in_proj_bias"):
+            v = 0.02 * torch.randn(shape, generator=g)
+        elif leaf in ("running_mean",):
+            v = torch.zeros(shape)
+        elif leaf in ("running_var",):
+            v = torch.ones(shape)
+        elif leaf == "num_batches_tracked":
+            v = torch.zeros(shape, dtype=torch.long)
+        elif "positional_embedding" in name or "token_embedding" in name:
+            v = 0.02 * torch.randn(shape, generator=g)
+        elif "class_embedding" in name:
+            v = shape[0] ** -0.5 * torch.randn(shape, generator=g)
+        elif len(shape) >= 2:
+            fan_in = 1
+            for k in shape[1:]:
+                fan_in *= k
+            if leaf == "proj":  # visual.proj is [width, embed] (x @ proj)
+                fan_in = shape[0]
+            v = fan_in ** -0.5 * torch.randn(shape, generator=g)
+        else:
+            v = 0.02 * torch.randn(shape, generator=g)
+        sd[name] = v
+    return sd
+
+
+def clip_shapes(cfg):
+    """cfg keys: v_width v_layers patch res t_width t_layers ctx embed_dim vocab"""
+    s = OrderedDict()
+    s["logit_scale"] = (1,)
+    s.update(vit_shapes(cfg["v_width"], cfg["v_layers"], cfg["patch"], cfg["res"], cfg["embed_dim"]))
+    s.update(text_shapes(cfg["t_width"], cfg["t_layers"], cfg["ctx"], cfg["embed_dim"],
+                         cfg.get("vocab", VOCAB), prefix=cfg.get("text_prefix", "encode_text.")))
+    return s
+
+
+VITB32 = dict(v_width=768, v_layers=12, v_heads=12, patch=32, res=224,
+              t_width=512, t_layers=12, t_heads=8, ctx=77, embed_dim=512, vocab=VOCAB)
+TINY = dict(v_width=128, v_layers=2, v_heads=2, patch=32, res=96,
+            t_width=128, t_layers=2, t_heads=2, ctx=16, embed_dim=64, vocab=VOCAB)

@@ -1,0 +1,151 @@
+"""Generate tests/golden/*.pt from the UNMODIFIED reference (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden [--only clip_tiny ...]
+
+Each fixture records the config + seeds (inputs/params are re-generated from
+declip_amd.synth by the tests) and what the reference produced on CPU fp32:
+loss, logits, normalised features, and per-parameter gradient digests
+(L2 norm, first 8 elements, a seeded random projection).  TEST INFRASTRUCTURE.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from declip_amd import synth  # noqa: E402
+from oracle import ref_harness  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def grad_digest(named_grads):
+    out = {}
+    for idx, (name, g) in enumerate(named_grads):
+        if g is None:
+            out[name] = None
+            continue
+        g = g.detach().double().flatten()
+        gen = torch.Generator().manual_seed(4242 + idx)
+        r = torch.randn(g.numel(), generator=gen, dtype=torch.float64)
+        out[name] = dict(norm=float(g.norm()), head=g[:8].float().clone(),
+                         proj=float((g * r).sum() / max(1.0, g.numel() ** 0.5)))
+    return out
+
+
+def build_ref_clip(ref, cfg, use_allgather):
+    vt = ref.modules["prototype.model.image_encoder.visual_transformer"]
+    tt = ref.modules["prototype.model.text_encoder.text_transformer"]
+    vis = vt.VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
+                               layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"],
+                               checkpoint=False)
+    txt = tt.TextTransformer(embed_dim=cfg["embed_dim"], context_length=cfg["ctx"],
+                             transformer_width=cfg["t_width"], transformer_heads=cfg["t_heads"],
+                             transformer_layers=cfg["t_layers"], positional_embedding_flag=True,
+                             checkpoint=False, bpe_path=ref_harness.synthetic_bpe_path(),
+                             text_encode_type="Transformer", text_model_utils={"random": False, "freeze": False})
+    model = ref.modules["prototype.model.clip"].CLIP(vis, txt, use_allgather)
+    return model
+
+
+def patch_tokenize(text_module, ids_by_key):
+    """text_transformer.py:144: replace BPE by a lookup of pre-tokenised ids.  The
+    'captions' we feed are integer keys (row indices)."""
+    def tokenize(texts, context_length=77, return_length=False, mask_type=None):
+        rows = torch.stack([ids_by_key[int(t)] for t in texts])
+        assert mask_type is None
+        return rows
+    text_module.tokenize = tokenize
+
+
+def run_clip_rank(rank, world, cfg, b, seed, logit_scale, ret):
+    """One reference rank: local rows [rank*b,(rank+1)*b) of the global batch."""
+    import contextlib
+    import io
+    os.environ["SLURM_PROCID"] = str(rank)
+    os.environ["SLURM_NTASKS"] = str(world)
+    ref = ref_harness.load_reference()
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world,
+                                init_method="tcp://127.0.0.1:29541")
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = build_ref_clip(ref, cfg, use_allgather=(world > 1))
+        sd = synth.synth_state(synth.clip_shapes(cfg), seed=seed, logit_scale=logit_scale)
+        missing = model.load_state_dict(sd, strict=True)
+        model.train()
+    B = b * world
+    images = synth.synth_images(B, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
+    sl = slice(rank * b, (rank + 1) * b)
+    patch_tokenize(model.encode_text, {i: ids[i] for i in range(B)})
+    batch = {"images": images[sl], "captions": [[i] for i in range(rank * b, (rank + 1) * b)]}
+    logits_i, logits_t = model(batch)
+    crit = ref.modules["prototype.loss_functions.loss"].ClipInfoCELoss()
+    loss, labels = crit(logits_i, logits_t)
+    loss = loss / world                                   # clip_solver.py:418
+    loss.backward()
+    grads = []
+    for name, p in model.named_parameters():
+        g = p.grad
+        if g is not None and world > 1:
+            dist.all_reduce(g)                            # utils/dist.py:71-74 (SUM)
+        grads.append((name, g))
+    total = loss.detach().clone()
+    if world > 1:
+        dist.all_reduce(total)
+    if rank == 0:
+        ret.update(loss=float(total), loss_rank0=float(loss.detach() * world),
+                   logits_i=logits_i.detach().clone(), logits_t=logits_t.detach().clone(),
+                   labels=labels.clone(), grads=grad_digest(grads))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _spawn_entry(rank, world, cfg, b, seed, logit_scale, path):
+    ret = {}
+    run_clip_rank(rank, world, cfg, b, seed, logit_scale, ret)
+    if rank == 0:
+        torch.save(ret, path)
+
+
+def gen_clip(name, cfg, b, world=1, seed=0, logit_scale=None):
+    if world == 1:
+        ret = {}
+        run_clip_rank(0, 1, cfg, b, seed, logit_scale, ret)
+    else:
+        import torch.multiprocessing as mp
+        tmp = "/tmp/_golden_%s.pt" % name
+        mp.spawn(_spawn_entry, args=(world, cfg, b, seed, logit_scale, tmp), nprocs=world, join=True)
+        ret = torch.load(tmp)
+        os.remove(tmp)
+    ret.update(kind="clip", cfg=cfg, b=b, world=world, seed=seed, logit_scale=logit_scale,
+               torch_version=torch.__version__)
+    path = os.path.join(GOLDEN_DIR, name + ".pt")
+    torch.save(ret, path)
+    print("wrote %s  loss=%.6f  (%d KB)" % (path, ret["loss"], os.path.getsize(path) // 1024))
+
+
+FIXTURES = {
+    "clip_tiny": lambda: gen_clip("clip_tiny", synth.TINY, b=4),
+    "clip_tiny_scale5": lambda: gen_clip("clip_tiny_scale5", synth.TINY, b=4, seed=3, logit_scale=5.0),
+    "clip_tiny_w2": lambda: gen_clip("clip_tiny_w2", synth.TINY, b=3, world=2, seed=5),
+    "clip_vitb32_b8": lambda: gen_clip("clip_vitb32_b8", synth.VITB32, b=8, seed=1),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    names = args.only or list(FIXTURES)
+    for n in names:
+        FIXTURES[n]()
+
+
+if __name__ == "__main__":
+    main()

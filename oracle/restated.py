@@ -1,0 +1,167 @@
+"""CPU fp32 restatement of the reference hot path (TEST INFRASTRUCTURE ONLY).
+
+Pure-functional torch (CPU, fp32) re-statement of what the reference computes on
+the contrastive training path.  Every function cites the reference file:line it
+follows (paths relative to /root/reference/prototype).  Parameters come in as a
+flat ``sd`` dict with the reference's state_dict names, so the same dict can be
+loaded into the reference modules (oracle/gen_golden.py) and into the HIP engine.
+
+Pinned by tests/golden/*.pt (generated from the unmodified reference by
+oracle/gen_golden.py; checked in tests/test_oracle_golden.py).
+"""
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- blocks
+def layer_norm(x, w, b, eps=1e-5):
+    """model/image_encoder/base_transformer.py:10-18 (nn.LayerNorm, eps 1e-5)."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
+
+
+def quick_gelu(x):
+    """base_transformer.py:24-26."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def attention(h, w_in, b_in, w_out, b_out, heads, causal):
+    """base_transformer.py:33,45-48 -> nn.MultiheadAttention(x,x,x, attn_mask):
+    packed in_proj rows ordered q,k,v; q scaled by head_dim**-0.5; additive -inf
+    causal mask (text_transformer.py:136-142); softmax; out_proj.  h: [b,L,d]."""
+    b, L, d = h.shape
+    hd = d // heads
+    qkv = h @ w_in.t() + b_in
+    q, k, v = qkv.split(d, dim=-1)
+    q = q.reshape(b, L, heads, hd).transpose(1, 2) * (hd ** -0.5)
+    k = k.reshape(b, L, heads, hd).transpose(1, 2)
+    v = v.reshape(b, L, heads, hd).transpose(1, 2)
+    s = q @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    p = torch.softmax(s, dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(b, L, d)
+    return o @ w_out.t() + b_out
+
+
+def residual_block(x, sd, p, heads, causal):
+    """base_transformer.py:50-53."""
+    h = layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"])
+    x = x + attention(h, sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"],
+                      sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"], heads, causal)
+    h = layer_norm(x, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"])
+    u = h @ sd[p + "mlp.c_fc.weight"].t() + sd[p + "mlp.c_fc.bias"]
+    return x + quick_gelu(u) @ sd[p + "mlp.c_proj.weight"].t() + sd[p + "mlp.c_proj.bias"]
+
+
+def transformer(x, sd, prefix, layers, heads, causal):
+    """base_transformer.py:56-79 (dropout 0, no checkpointing)."""
+    for i in range(layers):
+        x = residual_block(x, sd, "%sresblocks.%d." % (prefix, i), heads, causal)
+    return x
+
+
+# ----------------------------------------------------------------------------- towers
+def patchify(images, patch):
+    """im2row of the stride-P conv (visual_transformer.py:14-15,56-59):
+    [b,3,H,W] -> [b, gh*gw, 3*P*P] with inner order (c, ph, pw) == conv1.weight.reshape(width,-1)."""
+    b, c, H, W = images.shape
+    gh, gw = H // patch, W // patch
+    x = images.reshape(b, c, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5)
+    return x.reshape(b, gh * gw, c * patch * patch)
+
+
+def vision_tower(images, sd, cfg, prefix="visual.", return_dense=False, return_feature=False):
+    """visual_transformer.py:55-82."""
+    w = sd[prefix + "conv1.weight"]
+    x = patchify(images, cfg["patch"]) @ w.reshape(w.shape[0], -1).t()
+    cls = sd[prefix + "class_embedding"].expand(x.shape[0], 1, -1)
+    x = torch.cat([cls, x], dim=1) + sd[prefix + "positional_embedding"]
+    x = layer_norm(x, sd[prefix + "ln_pre.weight"], sd[prefix + "ln_pre.bias"])
+    x = transformer(x, sd, prefix + "transformer.", cfg["v_layers"], cfg["v_heads"], causal=False)
+    dense = x[:, 1:, :]
+    feat = layer_norm(x[:, 0, :], sd[prefix + "ln_post.weight"], sd[prefix + "ln_post.bias"])
+    out = feat @ sd[prefix + "proj"]
+    ret = [out]
+    if return_dense:
+        ret.append(dense)
+    if return_feature:
+        ret.append(feat)
+    return ret[0] if len(ret) == 1 else tuple(ret)
+
+
+def text_tower(ids, sd, cfg, prefix="encode_text.", return_dense=False):
+    """text_transformer.py:183-204 with pre-tokenised ids [b,ctx] (tokenize() is
+    patched out on the reference side, see gen_golden.py)."""
+    x = sd[prefix + "token_embedding.weight"][ids] + sd[prefix + "positional_embedding"]
+    x = transformer(x, sd, prefix + "transformer.", cfg["t_layers"], cfg["t_heads"], causal=True)
+    x = layer_norm(x, sd[prefix + "ln_final.weight"], sd[prefix + "ln_final.bias"])
+    pooled = x[torch.arange(x.shape[0]), ids.argmax(dim=-1)]
+    out = pooled @ sd[prefix + "text_projection.weight"].t() + sd[prefix + "text_projection.bias"]
+    return (out, x) if return_dense else out
+
+
+# ----------------------------------------------------------------------------- CLIP
+def clamp_scale(log_scale, clamp_max=100.0):
+    """clip.py:133-134: exp() then a `.data` clamp -- the forward value is clamped,
+    autograd still differentiates the unclamped exp (saved output)."""
+    s = log_scale.exp()
+    if clamp_max is None:
+        return s
+    return s + (s.clamp(max=clamp_max) - s).detach()
+
+
+def normalize_features(img, txt):
+    """clip.py:129-130 (image: no eps; text: +1e-10)."""
+    return (img / img.norm(dim=-1, keepdim=True),
+            txt / (txt.norm(dim=-1, keepdim=True) + 1e-10))
+
+
+def clip_forward(images, ids, sd, cfg, world=1):
+    """clip.py:118-146 for `world` emulated ranks on one process.
+
+    images [B,3,H,W], ids [B,ctx] hold the GLOBAL batch, rank r owning rows
+    [r*b,(r+1)*b).  Returns per-rank (logits_per_image, logits_per_text), each
+    [b,B] (local rows x gathered columns, clip.py:136-141)."""
+    img = vision_tower(images, sd, cfg)
+    txt = text_tower(ids, sd, cfg, prefix=cfg.get("text_prefix", "encode_text."))
+    img, txt = normalize_features(img, txt)
+    s = clamp_scale(sd["logit_scale"], cfg.get("scale_clamp", 100.0))
+    B = img.shape[0]
+    b = B // world
+    out = []
+    for r in range(world):
+        sl = slice(r * b, (r + 1) * b)
+        out.append((s * img[sl] @ txt.t(), s * txt[sl] @ img.t()))
+    return out, (img, txt)
+
+
+def info_nce(logits_i, logits_t, rank=0):
+    """loss_functions/loss.py:37-47."""
+    bs, l_bs = logits_i.shape
+    labels = torch.arange(bs) if l_bs == bs else rank * bs + torch.arange(bs)
+    loss = (F.cross_entropy(logits_i, labels) + F.cross_entropy(logits_t, labels)) / 2
+    return loss, labels
+
+
+def accuracy(output, target, topk=(1, 5)):
+    """utils/misc.py:415-428 (percent)."""
+    maxk = min(max(topk), output.shape[1])
+    _, pred = output.topk(maxk, 1, True, True)
+    correct = pred.t().eq(target.view(1, -1))
+    return [correct[:min(k, maxk)].reshape(-1).float().sum() * (100.0 / target.shape[0]) for k in topk]
+
+
+def clip_step_loss(images, ids, sd, cfg, world=1):
+    """solver/clip_solver.py:413-430: per-rank loss/world summed over ranks is what
+    the SUM-all-reduced gradients correspond to (quirk 14)."""
+    per_rank, feats = clip_forward(images, ids, sd, cfg, world)
+    total = 0.0
+    metrics = []
+    for r, (li, lt) in enumerate(per_rank):
+        loss, labels = info_nce(li, lt, r)
+        total = total + loss / world
+        p1, p5 = accuracy(li.detach(), labels)
+        metrics.append(dict(loss=loss.detach(), top1=p1, top5=p5))
+    return total, per_rank, feats, metrics

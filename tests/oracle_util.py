@@ -1,0 +1,61 @@
+"""Shared helpers for parity tests (oracle = checker, never the product)."""
+import os
+
+import torch
+
+from declip_amd import synth
+from oracle import restated
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return torch.load(os.path.join(GOLDEN, name + ".pt"), weights_only=False)
+
+
+def grad_digest_of(name, idx, g):
+    g = g.detach().double().flatten()
+    gen = torch.Generator().manual_seed(4242 + idx)
+    r = torch.randn(g.numel(), generator=gen, dtype=torch.float64)
+    return dict(norm=float(g.norm()), head=g[:8].float().clone(),
+                proj=float((g * r).sum() / max(1.0, g.numel() ** 0.5)))
+
+
+def oracle_clip_run(cfg, b, world=1, seed=0, logit_scale=None):
+    """Run the restated CLIP step on CPU fp32; returns loss, per-rank logits, grads by name."""
+    shapes = synth.clip_shapes(cfg)
+    sd = synth.synth_state(shapes, seed=seed, logit_scale=logit_scale)
+    frozen = {"visual.conv1.weight"}                       # visual_transformer.py:45-51
+    for k, v in sd.items():
+        v.requires_grad_(k not in frozen)
+    B = b * world
+    images = synth.synth_images(B, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
+    total, per_rank, feats, metrics = restated.clip_step_loss(images, ids, sd, cfg, world)
+    total.backward()
+    grads = {k: v.grad for k, v in sd.items()}
+    return dict(loss=total.detach(), per_rank=per_rank, feats=feats, grads=grads, sd=sd,
+                images=images, ids=ids, metrics=metrics)
+
+
+def check_grad_digests(golden_grads, grads, rtol, atol_frac=1e-4):
+    """Compare gradient digests: norm, 8-element head, seeded projection."""
+    names = list(golden_grads.keys())
+    bad = []
+    for idx, name in enumerate(names):
+        ref = golden_grads[name]
+        g = grads.get(name)
+        if ref is None:
+            assert g is None or float(g.abs().max()) == 0.0, name
+            continue
+        assert g is not None, "missing grad for " + name
+        d = grad_digest_of(name, idx, g)
+        scale = max(ref["norm"], 1e-12)
+        if abs(d["norm"] - ref["norm"]) > rtol * scale:
+            bad.append((name, "norm", d["norm"], ref["norm"]))
+        if abs(d["proj"] - ref["proj"]) > rtol * scale + atol_frac * scale:
+            bad.append((name, "proj", d["proj"], ref["proj"]))
+        head_tol = rtol * max(float(ref["head"].abs().max()), scale / max(1.0, g.numel() ** 0.5)) + 1e-12
+        if float((d["head"] - ref["head"]).abs().max()) > head_tol * 4:
+            bad.append((name, "head", d["head"].tolist(), ref["head"].tolist()))
+    assert not bad, "gradient digest mismatches (first 5): %s" % (bad[:5],)
