@@ -1,0 +1,177 @@
+"""Throughput of the CLIP ViT-B/32 training step (BASELINE.json metric: image-text pairs/sec).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + fused InfoNCE + backward + gradient all-reduce + fused AdamW on one synthetic
+batch (per-GPU batch 512, bf16, BASELINE.json configs[1]); weak scaling.  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+GFLOP_PER_PAIR = 43.87          # CLIP ViT-B/32 fwd+bwd, SURVEY.md s8(d) / BASELINE.md s3
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(batch=16, steps=2):
+    """The oracle restatement (kind "port") of the same step on the host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from declip_amd import synth
+    from oracle import restated
+    cfg = synth.VITB32
+    threads = torch.get_num_threads()
+    sd = synth.synth_state(synth.clip_shapes(cfg), seed=0)
+    for k, v in sd.items():
+        v.requires_grad_(k != "visual.conv1.weight")
+    opt = torch.optim.AdamW([v for v in sd.values() if v.requires_grad], lr=1e-4, betas=(0.9, 0.98), weight_decay=0.1)
+    images = synth.synth_images(batch, seed=0)
+    ids = synth.synth_tokens(batch, seed=0)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.time()
+        opt.zero_grad()
+        total, _, _, _ = restated.clip_step_loss(images, ids, sd, cfg, 1)
+        total.backward()
+        opt.step()
+        times.append(time.time() - t0)
+    dt = sorted(times[1:])[len(times[1:]) // 2]
+    return dict(value=round(batch / dt, 3), unit="pairs/s", cores=threads, kind="port",
+                sample="CLIP ViT-B/32 fp32 fwd+bwd+AdamW, batch %d, 1 warm-up + %d timed steps (median), torch CPU oracle restatement" % (batch, steps))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from declip_amd import dist as dh_dist
+    from declip_amd import ops, synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.optim import build_adamw
+    from declip_amd.testing import build_clip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dh_dist.initialize("nccl")
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    cfg = synth.VITB32
+    b = args.batch
+    model = build_clip(cfg, dtype=args.dtype, use_allgather=(world > 1), seed=0, load_synth=False)
+    wrapped = dh_dist.DistModule(model, sync=False)
+    opt = build_adamw(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
+    crit = ClipInfoCELoss()
+    images = synth.synth_images(b, seed=rank).to(dev)
+    ids = synth.synth_tokens(b, seed=rank).to(dev)
+    batch = {"images": images, "captions": ids}
+
+    def step():
+        opt.zero_grad()
+        li, lt = wrapped(batch)
+        loss, _ = crit(li, lt)
+        loss = loss / world                      # clip_solver.py:418
+        loss.backward()                          # gradient all-reduce overlaps inside (dist.FlatReducer)
+        wrapped.sync_gradients()
+        model.logit_scale.data.clamp_(3, 6)      # grad_clip: logit_scale_param_value (config.yaml:20-23)
+        opt.step()
+        model.logit_scale.data.clamp_(3, 6)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    ms_per_step = elapsed / args.steps * 1e3
+    pairs_per_s = b * world * args.steps / elapsed
+
+    roofline = None
+    if not args.no_roofline:
+        # dominant kernel = the MFMA GEMM family: bracket every dh_gemm launch of 2 extra steps with
+        # events on the launch stream; achieved = algorithmic 2*M*N*K flops / measured kernel time.
+        records = []
+        orig = ops.gemm
+
+        def timed_gemm(A, B, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(A, B, **kw)
+            e1.record()
+            M, K = (A.shape[1], A.shape[0]) if kw.get("a_kmajor") else (A.shape[0], A.shape[1])
+            N = B.shape[1] if kw.get("b_kmajor") else B.shape[0]
+            records.append((e0, e1, 2.0 * M * N * K, A.dtype))
+            return out
+
+        ops.gemm = timed_gemm
+        import declip_amd.engine as eng
+        eng.ops.gemm = timed_gemm
+        sync()
+        nprof = 2
+        tp0 = time.perf_counter()
+        for _ in range(nprof):
+            step()
+        sync()
+        tprof = time.perf_counter() - tp0
+        ops.gemm = orig
+        eng.ops.gemm = orig
+        flops = sum(r[2] for r in records if r[3] == torch.bfloat16 or args.dtype != "bf16")
+        ms = sum(r[0].elapsed_time(r[1]) for r in records if r[3] == torch.bfloat16 or args.dtype != "bf16")
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = dict(bound="mfma", kernel="gemm_mfma_kernel (all tower GEMMs of a step)", achieved=round(achieved, 2),
+                        peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
+                        launches_per_step=len(records) // nprof, gemm_ms_per_step=round(ms / nprof, 3),
+                        gemm_gflop_per_step=round(flops / nprof / 1e9, 1),
+                        step_mfma_frac=round(pairs_per_s * GFLOP_PER_PAIR / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
+
+    out = dict(metric="image-text pairs/sec CLIP ViT-B/32", value=round(pairs_per_s, 2), unit="pairs/s", n_gpus=world,
+               steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
+               config=dict(workload="CLIP ViT-B/32 + 12-layer text transformer, InfoNCE, fwd+bwd+grad-allreduce+AdamW; "
+                                    "per-GPU batch %d, 224x224 images, 77-token captions, random-init weights" % b,
+                           global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world),
+               loss=round(float(loss) * world, 5))
+    if roofline is not None:
+        out["roofline"] = roofline
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

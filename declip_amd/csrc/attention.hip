@@ -1,0 +1,479 @@
+// Multi-head self-attention core for short sequences (L <= 128: ViT-B/32 has 50 tokens, the
+// text tower 77) -- nn.MultiheadAttention(x,x,x,attn_mask) in base_transformer.py:33,45-48.
+//
+// One workgroup per (batch, head); the whole sequence lives in LDS, the [L,L] score matrix
+// never touches HBM.  bf16 path: v_mfma_f32_16x16x32_bf16, one wave per 16-query block.
+//   fwd:  S^T = K Q^T (so every lane owns ONE query column: softmax is in-lane + 2 shuffles),
+//         P written to LDS as the transpose of the C fragment (8-byte stores), O = P V with V^T
+//         staged in LDS.
+//   bwd:  P recomputed from q,k,lse; dP = dO V^T; dS = P o (dP - rowsum(dO o O)) / sqrt(hd);
+//         dV = P^T dO, dK = dS^T Q, dQ = dS K  (all five products on MFMA).
+// fp32 path (validation precision): same math, scalar FMA, any head dim <= 64.
+#include "dh_common.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int RS = HD + 8;  // row stride (elements) of row-major [L][64] bf16 tiles: 144 B, 16-B aligned
+
+__device__ __forceinline__ bf16x8_t lds_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// reduce across the 4 lane groups (lanes with equal lane&15)
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// stage rows [0,L) x 64 of a q/k/v/do block (global row stride gs elements) into LDS:
+//   rm != null: row-major tile rm[L16][RS]   (rows >= L zero)
+//   tr != null: transposed tile tr[64][TS]   (cols >= L zero up to Lt)
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long gs, int L, int Lrows, bf16_t* rm,
+                                           bf16_t* tr, int TS, int Lt, int tid, int nthr) {
+  const int ntask = (Lrows > Lt ? Lrows : Lt) * 8;  // (row, 16-B chunk)
+  for (int task = tid; task < ntask; task += nthr) {
+    const int r = task >> 3, c = task & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < L) v = *reinterpret_cast<const uint4*>(g + (long)r * gs + c * 8);
+    if (rm && r < Lrows) *reinterpret_cast<uint4*>(rm + r * RS + c * 8) = v;
+    if (tr && r < Lt) {
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        tr[(c * 8 + 2 * i) * TS + r] = (bf16_t)(w[i] & 0xffffu);
+        tr[(c * 8 + 2 * i + 1) * TS + r] = (bf16_t)(w[i] >> 16);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward, bf16 / MFMA.  blockDim = 64 * (L16/16); wave w owns queries [16w, 16w+16)
+// ------------------------------------------------------------------------------------------
+template <int NKB>  // number of 16-key blocks (L16/16), compile-time so scores stay in registers
+__global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
+                                     int L, int heads, int causal, float scale) {
+  constexpr int L16 = NKB * 16;
+  constexpr int L32 = (L16 + 31) / 32 * 32;
+  constexpr int TS = L32 + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);  // [L16][RS]
+  bf16_t* Ks = Qs + L16 * RS;                        // [L16][RS]
+  bf16_t* Vt = Ks + L16 * RS;                        // [64][TS]
+  bf16_t* Ps = Vt + HD * TS;                         // [L16][TS]
+
+  const int bh = blockIdx.x;
+  const int bi = bh / heads, h = bh % heads;
+  const int d_model = heads * HD;
+  const long gs = 3L * d_model;
+  const bf16_t* qg = qkv + (long)bi * L * gs + h * HD;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6;
+
+  stage_tile(qg, gs, L, L16, Qs, nullptr, 0, 0, tid, nthr);
+  stage_tile(qg + d_model, gs, L, L16, Ks, nullptr, 0, 0, tid, nthr);
+  stage_tile(qg + 2 * d_model, gs, L, 0, nullptr, Vt, TS, L32, tid, nthr);
+  __syncthreads();
+
+  const int qb = wave;
+  const int q = qb * 16 + (lane & 15);  // this lane's query (column of S^T)
+  // S^T[key][q]: A = K rows, B = Q rows
+  f32x4_t s[NKB];
+  bf16x8_t qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) qf[ks] = lds_frag(Qs + q * RS + ks * 32 + 8 * (lane >> 4));
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t kf = lds_frag(Ks + (kb * 16 + (lane & 15)) * RS + ks * 32 + 8 * (lane >> 4));
+      acc = mfma16(kf, qf[ks], acc);
+    }
+    s[kb] = acc;
+  }
+  // lane holds keys kb*16 + 4*(lane>>4) + r for its query q
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kb * 16 + 4 * (lane >> 4) + r;
+      float v = s[kb][r] * scale;
+      if (key >= L || (causal && key > q)) v = -INFINITY;
+      s[kb][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  mx = quad_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float p = __expf(s[kb][r] - mx);
+      s[kb][r] = p;
+      sum += p;
+    }
+  sum = quad_sum(sum);
+  const float inv = 1.f / sum;
+  if (q < L && (lane >> 4) == 0) lse[((long)bi * heads + h) * L + q] = mx + __logf(sum);
+  // P[q][key..key+3] <- transpose of the C fragment: one 8-byte store per fragment
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    uint2 w;
+    w.x = pack2bf(s[kb][0] * inv, s[kb][1] * inv);
+    w.y = pack2bf(s[kb][2] * inv, s[kb][3] * inv);
+    *reinterpret_cast<uint2*>(Ps + q * TS + kb * 16 + 4 * (lane >> 4)) = w;
+  }
+  if (L32 > L16) {  // zero the key padding columns read by the last 32-wide k-step
+    uint2 z = make_uint2(0, 0);
+    *reinterpret_cast<uint2*>(Ps + q * TS + L16 + 4 * (lane >> 4)) = z;
+  }
+  __syncthreads();
+  // O[q][d] = sum_key P[q][key] V[key][d]: A = P rows (this wave's queries), B = V^T rows
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < L32 / 32; ++ks) {
+      bf16x8_t pf = lds_frag(Ps + (qb * 16 + (lane & 15)) * TS + ks * 32 + 8 * (lane >> 4));
+      bf16x8_t vf = lds_frag(Vt + (db * 16 + (lane & 15)) * TS + ks * 32 + 8 * (lane >> 4));
+      acc = mfma16(pf, vf, acc);
+    }
+    // C layout: row (query) = 4*(lane>>4)+r, col (d) = lane&15
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = qb * 16 + 4 * (lane >> 4) + r;
+      if (qq < L) out[((long)bi * L + qq) * d_model + h * HD + db * 16 + (lane & 15)] = f2bf(acc[r]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, bf16 / MFMA
+// ------------------------------------------------------------------------------------------
+template <int NKB>
+__global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                     const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                     bf16_t* __restrict__ dqkv, int L, int heads, int causal, float scale) {
+  constexpr int L16 = NKB * 16;
+  constexpr int L32 = (L16 + 31) / 32 * 32;
+  constexpr int TS = L32 + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);  // [L16][RS]
+  bf16_t* Ks = Qs + L16 * RS;
+  bf16_t* Vs = Ks + L16 * RS;
+  bf16_t* Gs = Vs + L16 * RS;     // dO row-major
+  bf16_t* Qt = Gs + L16 * RS;     // [64][TS]
+  bf16_t* Kt = Qt + HD * TS;
+  bf16_t* Gt = Kt + HD * TS;      // dO^T
+  bf16_t* Pt = Gt + HD * TS;      // P^T  [key][q]   [L16][TS]
+  bf16_t* dSt = Pt + L16 * TS;    // dS^T [key][q]
+  bf16_t* dSs = dSt + L16 * TS;   // dS   [q][key]
+  float* Dq = reinterpret_cast<float*>(dSs + L16 * TS);  // [L16] rowsum(dO o O)
+
+  const int bh = blockIdx.x;
+  const int bi = bh / heads, h = bh % heads;
+  const int d_model = heads * HD;
+  const long gs = 3L * d_model;
+  const bf16_t* qg = qkv + (long)bi * L * gs + h * HD;
+  const bf16_t* og = out + (long)bi * L * d_model + h * HD;
+  const bf16_t* gg = dout + (long)bi * L * d_model + h * HD;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6;
+
+  stage_tile(qg, gs, L, L16, Qs, Qt, TS, L32, tid, nthr);
+  stage_tile(qg + d_model, gs, L, L16, Ks, Kt, TS, L32, tid, nthr);
+  stage_tile(qg + 2 * d_model, gs, L, L16, Vs, nullptr, 0, 0, tid, nthr);
+  stage_tile(gg, d_model, L, L16, Gs, Gt, TS, L32, tid, nthr);
+  // D[q] = sum_d dO[q][d] * O[q][d]   (4 lanes per row, 16 columns each)
+  for (int task = tid; task < L16 * 4; task += nthr) {
+    const int r = task >> 2, part = task & 3;
+    float acc = 0.f;
+    if (r < L) {
+      float a[8], b[8];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        ld8(og + (long)r * d_model + part * 16 + c * 8, a);
+        ld8(gg + (long)r * d_model + part * 16 + c * 8, b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += a[i] * b[i];
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0) Dq[r] = acc;
+  }
+  // zero the q-padding columns [L16, L32) of the transposed score tiles
+  if (L32 > L16) {
+    for (int i = tid; i < L16 * (L32 - L16); i += nthr) {
+      const int r = i / (L32 - L16), c = L16 + i % (L32 - L16);
+      Pt[r * TS + c] = 0; dSt[r * TS + c] = 0; dSs[r * TS + c] = 0;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 1: wave owns query block qb: S[q][key] (rows q), dP[q][key]
+  {
+    const int qb = wave;
+    bf16x8_t qf[2], gf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[ks] = lds_frag(Qs + (qb * 16 + (lane & 15)) * RS + ks * 32 + 8 * (lane >> 4));
+      gf[ks] = lds_frag(Gs + (qb * 16 + (lane & 15)) * RS + ks * 32 + 8 * (lane >> 4));
+    }
+    float lse_r[4], d_r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = qb * 16 + 4 * (lane >> 4) + r;
+      lse_r[r] = qq < L ? lse[((long)bi * heads + h) * L + qq] : 0.f;
+      d_r[r] = Dq[qq];
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t kf = lds_frag(Ks + (kb * 16 + (lane & 15)) * RS + ks * 32 + 8 * (lane >> 4));
+        bf16x8_t vf = lds_frag(Vs + (kb * 16 + (lane & 15)) * RS + ks * 32 + 8 * (lane >> 4));
+        sacc = mfma16(qf[ks], kf, sacc);  // rows q, cols key
+        pacc = mfma16(gf[ks], vf, pacc);  // dP[q][key]
+      }
+      const int key = kb * 16 + (lane & 15);
+      float p[4], ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq = qb * 16 + 4 * (lane >> 4) + r;
+        const bool masked = key >= L || qq >= L || (causal && key > qq);
+        p[r] = masked ? 0.f : __expf(sacc[r] * scale - lse_r[r]);
+        ds[r] = p[r] * (pacc[r] - d_r[r]) * scale;
+      }
+      // transposed fragment stores: [key][q..q+3], 8 bytes
+      uint2 w;
+      w.x = pack2bf(p[0], p[1]); w.y = pack2bf(p[2], p[3]);
+      *reinterpret_cast<uint2*>(Pt + key * TS + qb * 16 + 4 * (lane >> 4)) = w;
+      w.x = pack2bf(ds[0], ds[1]); w.y = pack2bf(ds[2], ds[3]);
+      *reinterpret_cast<uint2*>(dSt + key * TS + qb * 16 + 4 * (lane >> 4)) = w;
+      // straight stores: dS[q][key]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dSs[(qb * 16 + 4 * (lane >> 4) + r) * TS + key] = f2bf(ds[r]);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: wave owns row block rb (keys for dV/dK, queries for dQ)
+  {
+    const int rb = wave;
+    bf16_t* dq_g = dqkv + (long)bi * L * gs + h * HD;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      f32x4_t av = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < L32 / 32; ++ks) {
+        const int ro = (rb * 16 + (lane & 15)) * TS + ks * 32 + 8 * (lane >> 4);
+        const int co = (db * 16 + (lane & 15)) * TS + ks * 32 + 8 * (lane >> 4);
+        av = mfma16(lds_frag(Pt + ro), lds_frag(Gt + co), av);   // dV[key][d] = sum_q P^T[key][q] dO[q][d]
+        ak = mfma16(lds_frag(dSt + ro), lds_frag(Qt + co), ak);  // dK[key][d] = sum_q dS^T[key][q] Q[q][d]
+        aq = mfma16(lds_frag(dSs + ro), lds_frag(Kt + co), aq);  // dQ[q][d]  = sum_key dS[q][key] K[key][d]
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rb * 16 + 4 * (lane >> 4) + r;
+        if (row < L) {
+          const long o = (long)row * gs + db * 16 + (lane & 15);
+          dq_g[o] = f2bf(aq[r]);
+          dq_g[o + d_model] = f2bf(ak[r]);
+          dq_g[o + 2 * d_model] = f2bf(av[r]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 validation path: one workgroup (256 threads) per (batch, head); hd <= 64, L <= 128
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                               float* __restrict__ lse, int L, int heads, int hd,
+                                                               int causal, float scale) {
+  extern __shared__ float smf[];
+  const int hs = hd + 1;
+  float* Q = smf; float* K = Q + L * hs; float* V = K + L * hs; float* S = V + L * hs;  // S [L][L+1]
+  const int bh = blockIdx.x, bi = bh / heads, h = bh % heads;
+  const int dm = heads * hd;
+  const long gs = 3L * dm;
+  const T* base = qkv + (long)bi * L * gs + h * hd;
+  for (int i = threadIdx.x; i < L * hd; i += 256) {
+    int r = i / hd, c = i % hd;
+    Q[r * hs + c] = ld<T>(base + (long)r * gs + c);
+    K[r * hs + c] = ld<T>(base + (long)r * gs + dm + c);
+    V[r * hs + c] = ld<T>(base + (long)r * gs + 2 * dm + c);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L * L; i += 256) {
+    int q = i / L, k = i % L;
+    float a = 0.f;
+    for (int c = 0; c < hd; ++c) a = fmaf(Q[q * hs + c], K[k * hs + c], a);
+    a *= scale;
+    if (causal && k > q) a = -INFINITY;
+    S[q * (L + 1) + k] = a;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q = wave; q < L; q += 4) {
+    float mx = -INFINITY;
+    for (int k = lane; k < L; k += 64) mx = fmaxf(mx, S[q * (L + 1) + k]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < L; k += 64) { float p = __expf(S[q * (L + 1) + k] - mx); S[q * (L + 1) + k] = p; sum += p; }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int k = lane; k < L; k += 64) S[q * (L + 1) + k] *= inv;
+    if (lane == 0) lse[((long)bi * heads + h) * L + q] = mx + __logf(sum);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L * hd; i += 256) {
+    int q = i / hd, c = i % hd;
+    float a = 0.f;
+    for (int k = 0; k < L; ++k) a = fmaf(S[q * (L + 1) + k], V[k * hs + c], a);
+    st<T>(out + ((long)bi * L + q) * dm + h * hd + c, a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                               const T* __restrict__ dout, const float* __restrict__ lse,
+                                                               T* __restrict__ dqkv, int L, int heads, int hd,
+                                                               int causal, float scale) {
+  extern __shared__ float smf[];
+  const int hs = hd + 1, ls = L + 1;
+  float* Q = smf; float* K = Q + L * hs; float* V = K + L * hs; float* G = V + L * hs;
+  float* P = G + L * hs; float* dS = P + L * ls; float* Dq = dS + L * ls;
+  const int bh = blockIdx.x, bi = bh / heads, h = bh % heads;
+  const int dm = heads * hd;
+  const long gs = 3L * dm;
+  const T* base = qkv + (long)bi * L * gs + h * hd;
+  const T* ob = out + (long)bi * L * dm + h * hd;
+  const T* gb = dout + (long)bi * L * dm + h * hd;
+  for (int i = threadIdx.x; i < L * hd; i += 256) {
+    int r = i / hd, c = i % hd;
+    Q[r * hs + c] = ld<T>(base + (long)r * gs + c);
+    K[r * hs + c] = ld<T>(base + (long)r * gs + dm + c);
+    V[r * hs + c] = ld<T>(base + (long)r * gs + 2 * dm + c);
+    G[r * hs + c] = ld<T>(gb + (long)r * dm + c);
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < L; q += 256) {
+    float a = 0.f;
+    for (int c = 0; c < hd; ++c) a = fmaf(G[q * hs + c], ld<T>(ob + (long)q * dm + c), a);
+    Dq[q] = a;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L * L; i += 256) {
+    int q = i / L, k = i % L;
+    float s = 0.f, dp = 0.f;
+    for (int c = 0; c < hd; ++c) { s = fmaf(Q[q * hs + c], K[k * hs + c], s); dp = fmaf(G[q * hs + c], V[k * hs + c], dp); }
+    float p = (causal && k > q) ? 0.f : __expf(s * scale - lse[((long)bi * heads + h) * L + q]);
+    P[q * ls + k] = p;
+    dS[q * ls + k] = p * (dp - Dq[q]) * scale;
+  }
+  __syncthreads();
+  T* dbase = dqkv + (long)bi * L * gs + h * hd;
+  for (int i = threadIdx.x; i < L * hd; i += 256) {
+    int r = i / hd, c = i % hd;
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int j = 0; j < L; ++j) {
+      dq = fmaf(dS[r * ls + j], K[j * hs + c], dq);
+      dk = fmaf(dS[j * ls + r], Q[j * hs + c], dk);
+      dv = fmaf(P[j * ls + r], G[j * hs + c], dv);
+    }
+    st<T>(dbase + (long)r * gs + c, dq);
+    st<T>(dbase + (long)r * gs + dm + c, dk);
+    st<T>(dbase + (long)r * gs + 2 * dm + c, dv);
+  }
+}
+
+template <int NKB>
+int launch_fwd_mfma(const bf16_t* qkv, bf16_t* out, float* lse, int b, int L, int heads, int causal, float scale,
+                    hipStream_t st) {
+  constexpr int L16 = NKB * 16, L32 = (L16 + 31) / 32 * 32, TS = L32 + 8;
+  size_t lds = (size_t)(2 * L16 * RS + HD * TS + L16 * TS) * sizeof(bf16_t);
+  hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(attn_fwd_mfma_kernel<NKB>, dim3(b * heads), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale);
+  return 0;
+}
+template <int NKB>
+int launch_bwd_mfma(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int b,
+                    int L, int heads, int causal, float scale, hipStream_t st) {
+  constexpr int L16 = NKB * 16, L32 = (L16 + 31) / 32 * 32, TS = L32 + 8;
+  size_t lds = (size_t)(4 * L16 * RS + 3 * HD * TS + 3 * L16 * TS) * sizeof(bf16_t) + L16 * sizeof(float);
+  hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(attn_bwd_mfma_kernel<NKB>, dim3(b * heads), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale);
+  return 0;
+}
+
+}  // namespace
+
+#define DISPATCH_NKB(nkb, CALL)                 \
+  switch (nkb) {                                \
+    case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
+    case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break; \
+    default: DH_FAIL(DH_ERR_UNSUPPORTED, "attention: L=%d unsupported", L); \
+  }
+
+extern "C" int dh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, int b, int L, int heads, int hd,
+                           int causal, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(qkv && out && lse && b > 0 && L > 0 && heads > 0, "dh_attn_fwd: bad args");
+  DH_REQUIRE(L <= 128 && hd <= 64, "dh_attn_fwd: L<=128 and hd<=64 required (got %d, %d)", L, hd);
+  const float scale = 1.0f / sqrtf((float)hd);
+  if (dtype == DH_BF16 && hd == 64) {
+    const int nkb = (L + 15) / 16;
+#define CALL(N) launch_fwd_mfma<N>((const bf16_t*)qkv, (bf16_t*)out, lse, b, L, heads, causal, scale, st)
+    DISPATCH_NKB(nkb, CALL)
+#undef CALL
+  } else {
+    size_t lds = (size_t)(3 * L * (hd + 1) + L * (L + 1)) * sizeof(float);
+    if (dtype == DH_BF16) {
+      hipFuncSetAttribute((const void*)attn_fwd_generic_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_fwd_generic_kernel<bf16_t>, dim3(b * heads), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, lse, L, heads, hd, causal, scale);
+    } else {
+      hipFuncSetAttribute((const void*)attn_fwd_generic_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_fwd_generic_kernel<float>, dim3(b * heads), dim3(256), lds, st, (const float*)qkv, (float*)out, lse, L, heads, hd, causal, scale);
+    }
+  }
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                           int b, int L, int heads, int hd, int causal, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(qkv && out && dout && lse && dqkv && b > 0 && L > 0 && heads > 0, "dh_attn_bwd: bad args");
+  DH_REQUIRE(L <= 96 && hd <= 64, "dh_attn_bwd: L<=96 and hd<=64 required (got %d, %d)", L, hd);
+  const float scale = 1.0f / sqrtf((float)hd);
+  if (dtype == DH_BF16 && hd == 64) {
+    const int nkb = (L + 15) / 16;
+#define CALL(N) launch_bwd_mfma<N>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, b, L, heads, causal, scale, st)
+    DISPATCH_NKB(nkb, CALL)
+#undef CALL
+  } else {
+    size_t lds = (size_t)(4 * L * (hd + 1) + 2 * L * (L + 1) + L) * sizeof(float);
+    DH_REQUIRE(lds <= 160 * 1024, "dh_attn_bwd: sequence too long for the fp32 path");
+    if (dtype == DH_BF16) {
+      hipFuncSetAttribute((const void*)attn_bwd_generic_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_bwd_generic_kernel<bf16_t>, dim3(b * heads), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, L, heads, hd, causal, scale);
+    } else {
+      hipFuncSetAttribute((const void*)attn_bwd_generic_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_bwd_generic_kernel<float>, dim3(b * heads), dim3(256), lds, st, (const float*)qkv, (const float*)out, (const float*)dout, lse, (float*)dqkv, L, heads, hd, causal, scale);
+    }
+  }
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}

@@ -1,0 +1,112 @@
+// Common device/host helpers for libdeclip_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/declip_hip.h"
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+#define DH_WAVE 64
+
+// ----------------------------------------------------------------------------- errors
+void dh_set_error(const char* fmt, ...);
+#define DH_FAIL(code, ...)        \
+  do {                            \
+    dh_set_error(__VA_ARGS__);    \
+    return (code);                \
+  } while (0)
+#define DH_CHECK_LAUNCH()                                              \
+  do {                                                                 \
+    hipError_t e__ = hipGetLastError();                                \
+    if (e__ != hipSuccess) DH_FAIL(DH_ERR_LAUNCH, "%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+  } while (0)
+#define DH_REQUIRE(cond, ...)                       \
+  do {                                              \
+    if (!(cond)) DH_FAIL(DH_ERR_ARG, __VA_ARGS__);  \
+  } while (0)
+
+// ----------------------------------------------------------------------------- bf16
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// typed load/store of activation element types (T = float or bf16_t)
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// load 8 consecutive elements as floats (p must be 16B aligned for bf16, 32B for float)
+__device__ __forceinline__ void ld8(const bf16_t* p, float* o) {
+  uint4 v = *reinterpret_cast<const uint4*>(p);
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[2 * i] = __uint_as_float(w[i] << 16);
+    o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void ld8(const float* p, float* o) {
+  float4 a = *reinterpret_cast<const float4*>(p);
+  float4 b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float* o) {
+  uint4 v;
+  v.x = pack2bf(o[0], o[1]); v.y = pack2bf(o[2], o[3]); v.z = pack2bf(o[4], o[5]); v.w = pack2bf(o[6], o[7]);
+  *reinterpret_cast<uint4*>(p) = v;
+}
+__device__ __forceinline__ void st8(float* p, const float* o) {
+  *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+}
+
+// ----------------------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block reductions for blockDim.x == 256 (4 waves); `red` is >= 8 floats of LDS
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max256(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu_grad_f(float x) {
+  float s = 1.f / (1.f + __expf(-1.702f * x));
+  return s * (1.f + 1.702f * x * (1.f - s));
+}
+
+static inline int dh_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

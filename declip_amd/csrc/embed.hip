@@ -1,0 +1,406 @@
+// Token / patch embedding, pooling and L2-normalisation kernels (all HBM-bound, 16-byte vectors).
+//   text : text_encoder/text_transformer.py:188-190,203     vision: image_encoder/visual_transformer.py:56-66
+//   norm : model/clip.py:129-130
+#include "dh_common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void text_embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                             const float* __restrict__ pos, T* __restrict__ x, int rows,
+                                                             int L, int d) {
+  const int nchunk = d >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)rows * nchunk; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / nchunk), ch = (int)(i % nchunk);
+    const long id = ids[row];
+    float a[8], p[8];
+    ld8(table + id * d + ch * 8, a);
+    ld8(pos + (long)(row % L) * d + ch * 8, p);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += p[k];
+    st8(x + (long)row * d + ch * 8, a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void text_embed_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dx,
+                                                             float* __restrict__ dtable, float* __restrict__ dpos,
+                                                             int rows, int L, int d) {
+  // dtable: scatter-add rows (atomic); dpos handled by vit_assemble-style column reduction below
+  const int nchunk = d >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)rows * nchunk; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / nchunk), ch = (int)(i % nchunk);
+    const long id = ids[row];
+    float g[8];
+    ld8(dx + (long)row * d + ch * 8, g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(dtable + id * d + ch * 8 + k, g[k]);
+  }
+}
+
+// out[l, :] += sum_b dx[b, l, :]  for l in [0, Lx); used for positional-embedding grads.
+// grid (ceil(d/64), Lx, bsplit); block 256 = 64 columns x 4 batch lanes
+template <typename T>
+__global__ __launch_bounds__(256) void batch_reduce_kernel(const T* __restrict__ dx, float* __restrict__ out, int b,
+                                                           int Lx, int d, int b_per_block) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int l = blockIdx.y;
+  const int bl = threadIdx.x >> 6;
+  const int b0 = blockIdx.z * b_per_block, b1 = min(b, b0 + b_per_block);
+  float s = 0.f;
+  if (c < d)
+    for (int bi = b0 + bl; bi < b1; bi += 4) s += ld<T>(dx + ((long)bi * Lx + l) * d + c);
+  red[bl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (bl == 0 && c < d) atomicAdd(out + (long)l * d + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void im2row_kernel(const float* __restrict__ img, int c_total, int c0, T* __restrict__ rows,
+                                                     int b, int H, int W, int P) {
+  // one task = 8 consecutive pw of one (b, gy, gx, c, ph)
+  const int gh = H / P, gw = W / P;
+  const int pc = P >> 3;
+  const long ntask = (long)b * gh * gw * 3 * P * pc;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ntask; i += (long)gridDim.x * 256) {
+    long r = i;
+    const int pw8 = (int)(r % pc); r /= pc;
+    const int ph = (int)(r % P); r /= P;
+    const int c = (int)(r % 3); r /= 3;
+    const int gx = (int)(r % gw); r /= gw;
+    const int gy = (int)(r % gh); r /= gh;
+    const int bi = (int)r;
+    const float* src = img + (((long)bi * c_total + c0 + c) * H + gy * P + ph) * W + gx * P + pw8 * 8;
+    float v[8];
+    ld8(src, v);
+    T* dst = rows + (((long)bi * gh + gy) * gw + gx) * (3L * P * P) + ((long)c * P + ph) * P + pw8 * 8;
+    st8(dst, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vit_assemble_fwd_kernel(const T* __restrict__ patches, const float* __restrict__ cls,
+                                                               const float* __restrict__ pos, T* __restrict__ x, int b,
+                                                               int np, int d) {
+  const int nchunk = d >> 3, Lx = np + 1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)b * Lx * nchunk; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nchunk);
+    const long row = i / nchunk;
+    const int l = (int)(row % Lx), bi = (int)(row / Lx);
+    float a[8], p[8];
+    if (l == 0) ld8(cls + ch * 8, a); else ld8(patches + ((long)bi * np + l - 1) * d + ch * 8, a);
+    ld8(pos + (long)l * d + ch * 8, p);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += p[k];
+    st8(x + row * d + ch * 8, a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_rows_fwd_kernel(const T* __restrict__ x, const int64_t* __restrict__ idx,
+                                                            T* __restrict__ out, int b, int L, int d) {
+  const int nchunk = d >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)b * nchunk; i += (long)gridDim.x * 256) {
+    const int bi = (int)(i / nchunk), ch = (int)(i % nchunk);
+    const long l = idx ? idx[bi] : 0;
+    float a[8];
+    ld8(x + ((long)bi * L + l) * d + ch * 8, a);
+    st8(out + (long)bi * d + ch * 8, a);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pool_rows_bwd_kernel(const T* __restrict__ dout, const int64_t* __restrict__ idx,
+                                                            T* __restrict__ dx, int b, int L, int d) {
+  const int nchunk = d >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)b * L * nchunk; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nchunk);
+    const long row = i / nchunk;
+    const int l = (int)(row % L), bi = (int)(row / L);
+    const long tgt = idx ? idx[bi] : 0;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (l == tgt) ld8(dout + (long)bi * d + ch * 8, a);
+    st8(dx + row * d + ch * 8, a);
+  }
+}
+
+// y = x / (||x|| + eps): one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ norm, int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+    float s = 0.f;
+    for (int i = lane; i < d; i += 64) { float v = ld<T>(x + (long)row * d + i); s += v * v; }
+    const float n = sqrtf(wave_sum(s));
+    if (lane == 0 && norm) norm[row] = n;
+    const float inv = 1.f / (n + eps);
+    for (int i = lane; i < d; i += 64) y[(long)row * d + i] = ld<T>(x + (long)row * d + i) * inv;
+  }
+}
+// y = x / (n + eps), n = ||x||:  dx = dy/(n+eps) - x * <dy,x> / (n * (n+eps)^2)
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ x, const float* __restrict__ norm,
+                                                         const float* __restrict__ dy, T* __restrict__ dx, int rows,
+                                                         int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+    float s = 0.f;
+    for (int i = lane; i < d; i += 64) s += dy[(long)row * d + i] * ld<T>(x + (long)row * d + i);
+    s = wave_sum(s);
+    const float n = norm[row];
+    const float inv = 1.f / (n + eps);
+    const float coef = s * inv * inv / fmaxf(n, 1e-30f);
+    for (int i = lane; i < d; i += 64)
+      st<T>(dx + (long)row * d + i, dy[(long)row * d + i] * inv - ld<T>(x + (long)row * d + i) * coef);
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ pb, long n, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                    float gscale) {
+  // torch.optim.AdamW (single-tensor path): p *= 1 - lr*wd; m,v update; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 pv = reinterpret_cast<float4*>(p)[i], gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float pp[4] = {pv.x, pv.y, pv.z, pv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+    float mm[4] = {mv.x, mv.y, mv.z, mv.w}, vq[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = gg[k] * gscale;
+      pp[k] *= (1.f - lr * wd);
+      mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+      vq[k] = b2 * vq[k] + (1.f - b2) * gk * gk;
+      pp[k] -= (lr / bc1) * mm[k] / (sqrtf(vq[k]) / bc2_sqrt + eps);
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+    if (pb) reinterpret_cast<uint2*>(pb)[i] = make_uint2(pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3]));
+  }
+  // tail (n % 4)
+  for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gk = g[i] * gscale;
+    float pp = p[i] * (1.f - lr * wd);
+    const float mm = b1 * m[i] + (1.f - b1) * gk, vq = b2 * v[i] + (1.f - b2) * gk * gk;
+    pp -= (lr / bc1) * mm / (sqrtf(vq) / bc2_sqrt + eps);
+    p[i] = pp; m[i] = mm; v[i] = vq;
+    if (pb) pb[i] = f2bf(pp);
+  }
+}
+
+// Segmented variant: hyper-parameters (lr, weight decay) vary per contiguous segment of the flat
+// buffer (param groups of utils/misc.py:267-412 `param_group_all`); ONE launch for the whole model.
+// seg_start[nseg+1] (element offsets, multiples of 4, ascending), seg_lr[nseg], seg_wd[nseg].
+__global__ __launch_bounds__(256) void adamw_seg_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, bf16_t* __restrict__ pb, long n4,
+                                                        const long* __restrict__ seg_start, const float* __restrict__ seg_lr,
+                                                        const float* __restrict__ seg_wd, int nseg, float b1, float b2,
+                                                        float eps, float bc1, float bc2_sqrt, float gscale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long e = i * 4;
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (seg_start[mid] <= e) lo = mid; else hi = mid - 1; }
+    const float lr = seg_lr[lo], wd = seg_wd[lo];
+    if (lr == 0.f && wd == 0.f) { if (pb) { float4 q = reinterpret_cast<float4*>(p)[i]; reinterpret_cast<uint2*>(pb)[i] = make_uint2(pack2bf(q.x, q.y), pack2bf(q.z, q.w)); } continue; }
+    float4 pv = reinterpret_cast<float4*>(p)[i], gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float pp[4] = {pv.x, pv.y, pv.z, pv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+    float mm[4] = {mv.x, mv.y, mv.z, mv.w}, vq[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = gg[k] * gscale;
+      pp[k] *= (1.f - lr * wd);
+      mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+      vq[k] = b2 * vq[k] + (1.f - b2) * gk * gk;
+      pp[k] -= (lr / bc1) * mm[k] / (sqrtf(vq[k]) / bc2_sqrt + eps);
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+    if (pb) reinterpret_cast<uint2*>(pb)[i] = make_uint2(pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3]));
+  }
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, long n) {
+  const long n8 = n >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    float v[8];
+    ld8(s + i * 8, v);
+    st8(d + i * 8, v);
+  }
+  for (long i = n8 * 8 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) st<TD>(d + i, ld<TS>(s + i));
+}
+
+int grid_for(long work_items) {
+  long g = (work_items + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+#define DH_DISPATCH_T(dtype, KERNEL, grid, block, lds, st, ...)                                   \
+  do {                                                                                             \
+    if ((dtype) == DH_BF16) hipLaunchKernelGGL(KERNEL<bf16_t>, grid, block, lds, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<float>, grid, block, lds, st, __VA_ARGS__);                     \
+  } while (0)
+
+extern "C" int dh_text_embed_fwd(int dtype, const int64_t* ids, const float* table, const float* pos, void* x, int b,
+                                 int L, int d, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(ids && table && pos && x && d % 8 == 0, "dh_text_embed_fwd: bad args (d %% 8 == 0 required)");
+  const int rows = b * L;
+  if (dtype == DH_BF16) hipLaunchKernelGGL(text_embed_fwd_kernel<bf16_t>, dim3(grid_for((long)rows * d / 8)), dim3(256), 0, st, ids, table, pos, (bf16_t*)x, rows, L, d);
+  else hipLaunchKernelGGL(text_embed_fwd_kernel<float>, dim3(grid_for((long)rows * d / 8)), dim3(256), 0, st, ids, table, pos, (float*)x, rows, L, d);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+static int launch_batch_reduce(int dtype, const void* dx, float* out, int b, int Lx, int d, hipStream_t st) {
+  int bsplit = b >= 64 ? 8 : 1;
+  int bpb = dh_cdiv(b, bsplit);
+  dim3 grid(dh_cdiv(d, 64), Lx, dh_cdiv(b, bpb));
+  if (dtype == DH_BF16) hipLaunchKernelGGL(batch_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dx, out, b, Lx, d, bpb);
+  else hipLaunchKernelGGL(batch_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dx, out, b, Lx, d, bpb);
+  return 0;
+}
+
+extern "C" int dh_text_embed_bwd(int dtype, const int64_t* ids, const void* dx, float* dtable, float* dpos, int b,
+                                 int L, int d, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(ids && dx && d % 8 == 0, "dh_text_embed_bwd: bad args");
+  const int rows = b * L;
+  if (dtable) {
+    if (dtype == DH_BF16) hipLaunchKernelGGL(text_embed_bwd_kernel<bf16_t>, dim3(grid_for((long)rows * d / 8)), dim3(256), 0, st, ids, (const bf16_t*)dx, dtable, dpos, rows, L, d);
+    else hipLaunchKernelGGL(text_embed_bwd_kernel<float>, dim3(grid_for((long)rows * d / 8)), dim3(256), 0, st, ids, (const float*)dx, dtable, dpos, rows, L, d);
+    DH_CHECK_LAUNCH();
+  }
+  if (dpos) launch_batch_reduce(dtype, dx, dpos, b, L, d, st);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_im2row(int dtype, const float* images, int c_total, int c0, void* rows, int b, int H, int W, int P,
+                         dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(images && rows && P % 8 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0, "dh_im2row: bad args");
+  long ntask = (long)b * (H / P) * (W / P) * 3 * P * (P / 8);
+  if (dtype == DH_BF16) hipLaunchKernelGGL(im2row_kernel<bf16_t>, dim3(grid_for(ntask)), dim3(256), 0, st, images, c_total, c0, (bf16_t*)rows, b, H, W, P);
+  else hipLaunchKernelGGL(im2row_kernel<float>, dim3(grid_for(ntask)), dim3(256), 0, st, images, c_total, c0, (float*)rows, b, H, W, P);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_vit_assemble_fwd(int dtype, const void* patches, const float* cls, const float* pos, void* x, int b,
+                                   int np, int d, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(patches && cls && pos && x && d % 8 == 0, "dh_vit_assemble_fwd: bad args");
+  long n = (long)b * (np + 1) * d / 8;
+  if (dtype == DH_BF16) hipLaunchKernelGGL(vit_assemble_fwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)patches, cls, pos, (bf16_t*)x, b, np, d);
+  else hipLaunchKernelGGL(vit_assemble_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)patches, cls, pos, (float*)x, b, np, d);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_vit_assemble_bwd(int dtype, const void* dx, float* dcls, float* dpos, int b, int np, int d,
+                                   dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(dx && dpos, "dh_vit_assemble_bwd: bad args");
+  // dpos[l] += sum_b dx[b,l]; dcls += sum_b dx[b,0]
+  launch_batch_reduce(dtype, dx, dpos, b, np + 1, d, st);
+  DH_CHECK_LAUNCH();
+  if (dcls) {
+    // the cls row: same reduction restricted to l = 0 (row stride (np+1)*d)
+    int bsplit = b >= 64 ? 8 : 1;
+    int bpb = dh_cdiv(b, bsplit);
+    dim3 grid(dh_cdiv(d, 64), 1, dh_cdiv(b, bpb));
+    if (dtype == DH_BF16) hipLaunchKernelGGL(batch_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dx, dcls, b, np + 1, d, bpb);
+    else hipLaunchKernelGGL(batch_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dx, dcls, b, np + 1, d, bpb);
+    DH_CHECK_LAUNCH();
+  }
+  return DH_OK;
+}
+
+extern "C" int dh_pool_rows_fwd(int dtype, const void* x, const int64_t* idx, void* out, int b, int L, int d,
+                                dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(x && out && d % 8 == 0, "dh_pool_rows_fwd: bad args");
+  if (dtype == DH_BF16) hipLaunchKernelGGL(pool_rows_fwd_kernel<bf16_t>, dim3(grid_for((long)b * d / 8)), dim3(256), 0, st, (const bf16_t*)x, idx, (bf16_t*)out, b, L, d);
+  else hipLaunchKernelGGL(pool_rows_fwd_kernel<float>, dim3(grid_for((long)b * d / 8)), dim3(256), 0, st, (const float*)x, idx, (float*)out, b, L, d);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+extern "C" int dh_pool_rows_bwd(int dtype, const void* dout, const int64_t* idx, void* dx, int b, int L, int d,
+                                dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(dout && dx && d % 8 == 0, "dh_pool_rows_bwd: bad args");
+  if (dtype == DH_BF16) hipLaunchKernelGGL(pool_rows_bwd_kernel<bf16_t>, dim3(grid_for((long)b * L * d / 8)), dim3(256), 0, st, (const bf16_t*)dout, idx, (bf16_t*)dx, b, L, d);
+  else hipLaunchKernelGGL(pool_rows_bwd_kernel<float>, dim3(grid_for((long)b * L * d / 8)), dim3(256), 0, st, (const float*)dout, idx, (float*)dx, b, L, d);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_l2norm_fwd(int dtype, const void* x, float* y, float* norm, int rows, int d, float eps,
+                             dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(x && y && rows > 0, "dh_l2norm_fwd: bad args");
+  dim3 grid(dh_cdiv(rows, 4) > 1024 ? 1024 : dh_cdiv(rows, 4));
+  if (dtype == DH_BF16) hipLaunchKernelGGL(l2norm_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, y, norm, rows, d, eps);
+  else hipLaunchKernelGGL(l2norm_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, y, norm, rows, d, eps);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+extern "C" int dh_l2norm_bwd(int dtype, const void* x, const float* norm, const float* dy, void* dx, int rows, int d,
+                             float eps, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(x && norm && dy && dx && rows > 0, "dh_l2norm_bwd: bad args");
+  dim3 grid(dh_cdiv(rows, 4) > 1024 ? 1024 : dh_cdiv(rows, 4));
+  if (dtype == DH_BF16) hipLaunchKernelGGL(l2norm_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, norm, dy, (bf16_t*)dx, rows, d, eps);
+  else hipLaunchKernelGGL(l2norm_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, norm, dy, (float*)dx, rows, d, eps);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int step, float grad_scale, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(p && g && m && v && n > 0 && step >= 1, "dh_adamw: bad args");
+  DH_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "dh_adamw: 16-byte alignment required");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, p, g, m, v, (bf16_t*)p_bf16, (long)n, lr,
+                     beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_adamw_segmented(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n,
+                                  const int64_t* seg_start_dev, const float* seg_lr_dev, const float* seg_wd_dev, int nseg,
+                                  float beta1, float beta2, float eps, int step, float grad_scale, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1 && nseg >= 1 && seg_start_dev && seg_lr_dev && seg_wd_dev,
+             "dh_adamw_segmented: bad args (n must be a multiple of 4)");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_seg_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, p, g, m, v, (bf16_t*)p_bf16, (long)(n / 4),
+                     (const long*)seg_start_dev, seg_lr_dev, seg_wd_dev, nseg, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(src && dst && n > 0, "dh_cast: bad args");
+  dim3 grid(grid_for(n / 8 + 1));
+  if (src_dtype == DH_F32 && dst_dtype == DH_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, (long)n);
+  else if (src_dtype == DH_BF16 && dst_dtype == DH_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const bf16_t*)src, (float*)dst, (long)n);
+  else if (src_dtype == DH_F32 && dst_dtype == DH_F32) hipLaunchKernelGGL((cast_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, (long)n);
+  else hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, (long)n);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}

@@ -1,0 +1,354 @@
+// Fused contrastive (InfoNCE) loss: logits = scale * Q K^T are produced tile by tile in LDS/registers,
+// consumed by an online log-sum-exp and never written to HBM (unless the caller asks for them).
+//   forward : model/clip.py:140-141 + loss_functions/loss.py:37-47 + utils/misc.py:415-428
+//   backward: autograd of the above; two passes with swapped roles (rows of Q, then rows of K) so
+//             neither needs atomics on the [B,D] gradient.
+// All arithmetic fp32 (features are fp32): the loss is what parity is judged on.
+#include "dh_common.h"
+#include <type_traits>
+
+#define DH_MAX_PAIRS 16
+
+namespace {
+
+struct PairTable {
+  const float* Q[DH_MAX_PAIRS];
+  const float* K[DH_MAX_PAIRS];
+  float* dQ[DH_MAX_PAIRS];
+  float* dK[DH_MAX_PAIRS];
+};
+
+constexpr int CT = 64;   // columns per tile
+constexpr int KC = 32;   // contraction chunk
+
+// acc[rr][cc] for rows ty*RPT+rr, cols tx*4+cc of the (RT x 64) tile: X rows from LDS Xs[RT][D+1],
+// Y tile streamed from global through Ys[64][KC+1].
+template <int RT>
+__device__ __forceinline__ void tile_dots(const float* Xs, int D, const float* __restrict__ Y, int y0, int ny, float* Ys,
+                                          float (&acc)[RT / 16][4]) {
+  constexpr int RPT = RT / 16;
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+#pragma unroll
+  for (int r = 0; r < RPT; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+  for (int k0 = 0; k0 < D; k0 += KC) {
+    __syncthreads();
+    // load Y[y0..y0+64)[k0..k0+32) : 2048 floats, 8 per thread
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      int idx = t + p * 256;
+      int kk = idx & 31, yy = idx >> 5;
+      int y = y0 + yy, k = k0 + kk;
+      Ys[yy * (KC + 1) + kk] = (y < ny && k < D) ? Y[(long)y * D + k] : 0.f;
+    }
+    __syncthreads();
+    const int kmax = min(KC, D - k0);
+    for (int kk = 0; kk < kmax; ++kk) {
+      float x[RPT], y[4];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) x[r] = Xs[(ty * RPT + r) * (D + 1) + k0 + kk];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) y[c] = Ys[(tx * 4 + c) * (KC + 1) + kk];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(x[r], y[c], acc[r][c]);
+    }
+  }
+}
+
+template <int RT>
+__device__ __forceinline__ void load_rows(float* Xs, const float* __restrict__ X, int x0, int nx, int D) {
+  for (int i = threadIdx.x; i < RT * D; i += 256) {
+    int r = i / D, k = i % D;
+    Xs[r * (D + 1) + k] = (x0 + r < nx) ? X[(long)(x0 + r) * D + k] : 0.f;
+  }
+}
+
+// merge (m, s) online-softmax states
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
+  float mm = fmaxf(m, m2);
+  if (mm == -INFINITY) { m = mm; s = 0.f; return; }
+  s = s * __expf(m - mm) + s2 * __expf(m2 - mm);
+  m = mm;
+}
+
+template <int RT>
+__global__ __launch_bounds__(256) void nce_fwd_kernel(PairTable pt, int b, int B, int D, const float* __restrict__ scale_p, int label0,
+                                                      float* __restrict__ row_loss, float* __restrict__ row_lse,
+                                                      float* __restrict__ correct1, float* __restrict__ correct5,
+                                                      float* __restrict__ logits_out) {
+  constexpr int RPT = RT / 16;
+  const float scale = *scale_p;
+  extern __shared__ float sm[];
+  float* Xs = sm;                      // [RT][D+1]
+  float* Ys = Xs + RT * (D + 1);       // [64][KC+1]
+  float* lab = Ys + CT * (KC + 1);     // [RT] label logits
+  const int pair = blockIdx.y;
+  const float* Q = pt.Q[pair];
+  const float* K = pt.K[pair];
+  const int r0 = blockIdx.x * RT;
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  load_rows<RT>(Xs, Q, r0, b, D);
+  __syncthreads();
+  // label logit: 8 threads per row (RT <= 32)
+  {
+    const int r = t >> 3, part = t & 7;
+    float a = 0.f;
+    if (r < RT && r0 + r < b) {
+      const float* kr = K + (long)(label0 + r0 + r) * D;
+      for (int k = part; k < D; k += 8) a = fmaf(Xs[r * (D + 1) + k], kr[k], a);
+    }
+    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+    if (r < RT && part == 0) lab[r] = a * scale;
+  }
+  __syncthreads();
+  float m[RPT], s[RPT], cnt[RPT], ll[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) { m[r] = -INFINITY; s[r] = 0.f; cnt[r] = 0.f; ll[r] = lab[ty * RPT + r]; }
+  for (int c0 = 0; c0 < B; c0 += CT) {
+    float acc[RPT][4];
+    tile_dots<RT>(Xs, D, K, c0, B, Ys, acc);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int row = r0 + ty * RPT + r;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int col = c0 + tx * 4 + c;
+        if (col < B) {
+          const float v = acc[r][c] * scale;
+          if (logits_out && row < b) logits_out[((long)pair * b + row) * B + col] = v;
+          if (col != label0 + row && v > ll[r]) cnt[r] += 1.f;
+          if (v > m[r]) { s[r] = s[r] * __expf(m[r] - v) + 1.f; m[r] = v; } else s[r] += __expf(v - m[r]);
+        }
+      }
+    }
+  }
+  // combine the 16 threads (tx) that share rows: lanes differing in bits 0..3
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      float m2 = __shfl_xor(m[r], o, 64), s2 = __shfl_xor(s[r], o, 64);
+      lse_merge(m[r], s[r], m2, s2);
+      cnt[r] += __shfl_xor(cnt[r], o, 64);
+    }
+    const int row = r0 + ty * RPT + r;
+    if (tx == 0 && row < b) {
+      const float lse = m[r] + __logf(s[r]);
+      const long o = (long)pair * b + row;
+      row_lse[o] = lse;
+      row_loss[o] = lse - ll[r];
+      if (correct1) correct1[o] = cnt[r] < 0.5f ? 1.f : 0.f;
+      if (correct5) correct5[o] = cnt[r] < 4.5f ? 1.f : 0.f;
+    }
+  }
+}
+
+// dX_x = scale * sum_y G(x,y) Y_y for a tile of RT rows of X against all rows of Y.
+//   mode 0 (X = Q rows i, Y = K rows j): G = g_i (exp(scale<Q_i,K_j> - lse_i) - [j == label0 + i]); also dscale.
+//   mode 1 (X = K rows j, Y = Q rows i): same G, statistics indexed by the Y row.
+template <int RT>
+__global__ __launch_bounds__(256) void nce_bwd_kernel(PairTable pt, int mode, int b, int B, int D, const float* __restrict__ scale_p,
+                                                      int label0, const float* __restrict__ row_lse,
+                                                      const float* __restrict__ g_row, float* __restrict__ dscale) {
+  constexpr int RPT = RT / 16;
+  const float scale = *scale_p;
+  extern __shared__ float sm[];
+  float* Xs = sm;                        // [RT][D+1]
+  float* dXs = Xs + RT * (D + 1);        // [RT][D+1]
+  float* Ys = dXs + RT * (D + 1);        // [64][KC+1]
+  float* Gs = Ys + CT * (KC + 1);        // [RT][65]
+  float* red = Gs + RT * (CT + 1);       // [8]
+  const int pair = blockIdx.y;
+  const float* X = mode == 0 ? pt.Q[pair] : pt.K[pair];
+  const float* Y = mode == 0 ? pt.K[pair] : pt.Q[pair];
+  float* dX = mode == 0 ? pt.dQ[pair] : pt.dK[pair];
+  const int nx = mode == 0 ? b : B, ny = mode == 0 ? B : b;
+  const int r0 = blockIdx.x * RT;
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  const float* lse_p = row_lse + (long)pair * b;
+  const float* g_p = g_row + (long)pair * b;
+  load_rows<RT>(Xs, X, r0, nx, D);
+  for (int i = t; i < RT * (D + 1); i += 256) dXs[i] = 0.f;
+  float ds_acc = 0.f;
+  for (int c0 = 0; c0 < ny; c0 += CT) {
+    float acc[RPT][4];
+    tile_dots<RT>(Xs, D, Y, c0, ny, Ys, acc);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int xr = r0 + ty * RPT + r;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int yc = c0 + tx * 4 + c;
+        float gval = 0.f;
+        if (xr < nx && yc < ny) {
+          const int i = mode == 0 ? xr : yc;   // Q row (local)
+          const int j = mode == 0 ? yc : xr;   // K row (global)
+          const float logit = acc[r][c] * scale;
+          const float p = __expf(logit - lse_p[i]);
+          gval = g_p[i] * (p - (j == label0 + i ? 1.f : 0.f));
+          ds_acc += gval * acc[r][c];
+        }
+        Gs[(ty * RPT + r) * (CT + 1) + tx * 4 + c] = gval;
+      }
+    }
+    // dX[RT][D] += G[RT][64] . Y[64][D], streamed over D chunks (Y chunk re-read through Ys)
+    for (int k0 = 0; k0 < D; k0 += KC) {
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        int idx = t + p * 256;
+        int kk = idx & 31, yy = idx >> 5;
+        int y = c0 + yy, k = k0 + kk;
+        Ys[yy * (KC + 1) + kk] = (y < ny && k < D) ? Y[(long)y * D + k] : 0.f;
+      }
+      __syncthreads();
+      // thread owns rows ty*RPT+r, chunk columns tx and tx+16
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        float a0 = 0.f, a1 = 0.f;
+        const float* grow = Gs + (ty * RPT + r) * (CT + 1);
+#pragma unroll 8
+        for (int yy = 0; yy < CT; ++yy) {
+          const float gv = grow[yy];
+          a0 = fmaf(gv, Ys[yy * (KC + 1) + tx], a0);
+          a1 = fmaf(gv, Ys[yy * (KC + 1) + tx + 16], a1);
+        }
+        float* drow = dXs + (ty * RPT + r) * (D + 1) + k0;
+        if (k0 + tx < D) drow[tx] += a0;
+        if (k0 + tx + 16 < D) drow[tx + 16] += a1;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < RT * D; i += 256) {
+    int r = i / D, k = i % D;
+    if (r0 + r < nx) dX[(long)(r0 + r) * D + k] = dXs[r * (D + 1) + k] * scale;
+  }
+  if (mode == 0 && dscale) {
+    float tot = block_sum256(ds_acc, red);
+    if (t == 0) atomicAdd(dscale, tot);
+  }
+}
+
+// ---- plain row-wise softmax cross-entropy on materialised logits [rows, C] (fp32):
+// used for logits handed in as tensors (loss_functions/loss.py:44-45) and for the MLM head
+// (model/declip.py:326-334).  label < 0 (e.g. -100) rows are ignored (loss 0, zero grad).
+__global__ __launch_bounds__(256) void ce_rows_fwd_kernel(const float* __restrict__ logits, long ld, const int64_t* __restrict__ labels,
+                                                          int rows, int C, float* __restrict__ row_loss, float* __restrict__ row_lse,
+                                                          float* __restrict__ correct1, float* __restrict__ correct5) {
+  __shared__ float red[8];
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const float* lr = logits + (long)row * ld;
+    const long lab = labels[row];
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, lr[c]);
+    m = block_max256(m, red);
+    const float ll = (lab >= 0 && lab < C) ? lr[lab] : 0.f;
+    float s = 0.f, cnt = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) { float v = lr[c]; s += __expf(v - m); if (c != lab && v > ll) cnt += 1.f; }
+    s = block_sum256(s, red);
+    cnt = block_sum256(cnt, red);
+    if (threadIdx.x == 0) {
+      const float lse = m + __logf(s);
+      const bool valid = lab >= 0 && lab < C;
+      row_lse[row] = lse;
+      row_loss[row] = valid ? lse - ll : 0.f;
+      if (correct1) correct1[row] = (valid && cnt < 0.5f) ? 1.f : 0.f;
+      if (correct5) correct5[row] = (valid && cnt < 4.5f) ? 1.f : 0.f;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void ce_rows_bwd_kernel(const float* __restrict__ logits, long ld, const int64_t* __restrict__ labels,
+                                                          int rows, int C, const float* __restrict__ row_lse, const float* __restrict__ g_row,
+                                                          float* __restrict__ dlogits, long ldd) {
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const long lab = labels[row];
+    const bool valid = lab >= 0 && lab < C;
+    const float g = valid ? g_row[row] : 0.f, lse = row_lse[row];
+    for (int c = threadIdx.x; c < C; c += 256)
+      dlogits[(long)row * ldd + c] = g * (__expf(logits[(long)row * ld + c] - lse) - (c == lab ? 1.f : 0.f));
+  }
+}
+
+int fill_table(PairTable& pt, const dh_nce_pair* pairs, int n) {
+  for (int i = 0; i < DH_MAX_PAIRS; ++i) { pt.Q[i] = nullptr; pt.K[i] = nullptr; pt.dQ[i] = nullptr; pt.dK[i] = nullptr; }
+  for (int i = 0; i < n; ++i) { pt.Q[i] = pairs[i].Q; pt.K[i] = pairs[i].K; pt.dQ[i] = pairs[i].dQ; pt.dK[i] = pairs[i].dK; }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int dh_infonce_fwd(const dh_nce_pair* pairs, int n_pairs, int b, int B, int D, const float* scale, int label0,
+                              float* row_loss, float* row_lse, float* correct1, float* correct5, float* logits_out,
+                              dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(pairs && n_pairs >= 1 && n_pairs <= DH_MAX_PAIRS, "dh_infonce_fwd: 1..%d pairs", DH_MAX_PAIRS);
+  DH_REQUIRE(b > 0 && B >= b && D > 0 && row_loss && row_lse && scale, "dh_infonce_fwd: bad args");
+  DH_REQUIRE(label0 >= 0 && label0 + b <= B, "dh_infonce_fwd: labels out of range");
+  PairTable pt;
+  fill_table(pt, pairs, n_pairs);
+  for (int i = 0; i < n_pairs; ++i) DH_REQUIRE(pt.Q[i] && pt.K[i], "dh_infonce_fwd: null feature pointer");
+  if (D <= 1024) {
+    constexpr int RT = 32;
+    size_t lds = (size_t)(RT * (D + 1) + CT * (KC + 1) + RT) * sizeof(float);
+    hipFuncSetAttribute((const void*)nce_fwd_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nce_fwd_kernel<RT>, dim3(dh_cdiv(b, RT), n_pairs), dim3(256), lds, st, pt, b, B, D, scale, label0,
+                       row_loss, row_lse, correct1, correct5, logits_out);
+  } else {
+    DH_FAIL(DH_ERR_UNSUPPORTED, "dh_infonce_fwd: D=%d > 1024", D);
+  }
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_infonce_bwd(const dh_nce_pair* pairs, int n_pairs, int b, int B, int D, const float* scale, int label0,
+                              const float* row_lse, const float* g_row, float* dscale, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(pairs && n_pairs >= 1 && n_pairs <= DH_MAX_PAIRS, "dh_infonce_bwd: 1..%d pairs", DH_MAX_PAIRS);
+  DH_REQUIRE(b > 0 && B >= b && D > 0 && row_lse && g_row && scale, "dh_infonce_bwd: bad args");
+  PairTable pt;
+  fill_table(pt, pairs, n_pairs);
+  for (int i = 0; i < n_pairs; ++i) DH_REQUIRE(pt.Q[i] && pt.K[i] && pt.dQ[i] && pt.dK[i], "dh_infonce_bwd: null pointer");
+  auto launch = [&](auto rt_tag, int mode) {
+    constexpr int RT = decltype(rt_tag)::value;
+    size_t lds = (size_t)(2 * RT * (D + 1) + CT * (KC + 1) + RT * (CT + 1) + 8) * sizeof(float);
+    hipFuncSetAttribute((const void*)nce_bwd_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int nx = mode == 0 ? b : B;
+    hipLaunchKernelGGL(nce_bwd_kernel<RT>, dim3(dh_cdiv(nx, RT), n_pairs), dim3(256), lds, st, pt, mode, b, B, D, scale,
+                       label0, row_lse, g_row, dscale);
+  };
+  if (D <= 512) {
+    launch(std::integral_constant<int, 32>{}, 0);
+    launch(std::integral_constant<int, 32>{}, 1);
+  } else if (D <= 1024) {
+    launch(std::integral_constant<int, 16>{}, 0);
+    launch(std::integral_constant<int, 16>{}, 1);
+  } else {
+    DH_FAIL(DH_ERR_UNSUPPORTED, "dh_infonce_bwd: D=%d > 1024", D);
+  }
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_ce_rows_fwd(const float* logits, int64_t ld, const int64_t* labels, int rows, int C, float* row_loss,
+                              float* row_lse, float* correct1, float* correct5, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(logits && labels && rows > 0 && C > 0 && row_loss && row_lse, "dh_ce_rows_fwd: bad args");
+  hipLaunchKernelGGL(ce_rows_fwd_kernel, dim3(rows > 4096 ? 4096 : rows), dim3(256), 0, st, logits, (long)ld, labels, rows, C,
+                     row_loss, row_lse, correct1, correct5);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+extern "C" int dh_ce_rows_bwd(const float* logits, int64_t ld, const int64_t* labels, int rows, int C, const float* row_lse,
+                              const float* g_row, float* dlogits, int64_t ldd, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(logits && labels && rows > 0 && C > 0 && row_lse && g_row && dlogits, "dh_ce_rows_bwd: bad args");
+  hipLaunchKernelGGL(ce_rows_bwd_kernel, dim3(rows > 4096 ? 4096 : rows), dim3(256), 0, st, logits, (long)ld, labels, rows, C,
+                     row_lse, g_row, dlogits, (long)ldd);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}

@@ -1,0 +1,247 @@
+// LayerNorm forward/backward (base_transformer.py:10-18; nn.LayerNorm eps=1e-5).
+// HBM-bound: one wave per row, 16-byte vector loads, fp32 statistics in registers.
+// Backward fuses the residual-branch gradient add (dx = LN'(dy) + dres) and produces
+// dgamma/dbeta through per-block partials + a second tiny reduce kernel (no atomics storm).
+#include "dh_common.h"
+
+namespace {
+
+constexpr int LN_MAXC = 4;  // up to 4 chunks of 8 per lane -> d <= 2048 on the vector path
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                     int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const int nchunk = d >> 3;
+  for (int row = wave_global; row < rows; row += nwaves) {
+    const T* xr = x + (long)row * d;
+    float v[LN_MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        ld8(xr + ch * 8, v[c]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[c][i];
+      }
+    }
+    const float mu = wave_sum(s) / d;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      int ch = lane + 64 * c;
+      if (ch < nchunk) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { float t = v[c][i] - mu; q += t * t; }
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) / d + eps);
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+    T* yr = y + (long)row * d;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        float wv[8], bv[8], o[8];
+        ld8(w + ch * 8, wv);
+        ld8(b + ch * 8, bv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mu) * rs * wv[i] + bv[i];
+        st8(yr + ch * 8, o);
+      }
+    }
+  }
+}
+
+// scalar fallback (any d): one wave per row, three passes over the row.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_scalar_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, T* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int nwaves = gridDim.x * 4;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nwaves) {
+    const T* xr = x + (long)row * d;
+    float s = 0.f;
+    for (int i = lane; i < d; i += 64) s += ld<T>(xr + i);
+    const float mu = wave_sum(s) / d;
+    float q = 0.f;
+    for (int i = lane; i < d; i += 64) { float t = ld<T>(xr + i) - mu; q += t * t; }
+    const float rs = rsqrtf(wave_sum(q) / d + eps);
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+    for (int i = lane; i < d; i += 64) st<T>(y + (long)row * d + i, (ld<T>(xr + i) - mu) * rs * w[i] + b[i]);
+  }
+}
+
+// backward: wave per row (grid-stride); per-lane register partials for dw/db of the
+// lane's own columns; block partial written to part[block][2][d].
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ w, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                     T* __restrict__ dx, float* __restrict__ part, int rows, int d) {
+  extern __shared__ float sm[];  // [4 waves][2][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwaves = gridDim.x * 4;
+  const int nchunk = d >> 3;
+  float aw[LN_MAXC][8], ab[LN_MAXC][8];
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { aw[c][i] = 0.f; ab[c][i] = 0.f; }
+
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += nwaves) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[LN_MAXC][8], g[LN_MAXC][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        float xv[8], dv[8], wv[8];
+        ld8(x + (long)row * d + ch * 8, xv);
+        ld8(dy + (long)row * d + ch * 8, dv);
+        ld8(w + ch * 8, wv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          xh[c][i] = (xv[i] - mu) * rs;
+          g[c][i] = dv[i] * wv[i];
+          s1 += g[c][i];
+          s2 += g[c][i] * xh[c][i];
+          aw[c][i] += dv[i] * xh[c][i];
+          ab[c][i] += dv[i];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = rs * (g[c][i] - c1 - xh[c][i] * c2);
+        if (dres) {
+          float r[8];
+          ld8(dres + (long)row * d + ch * 8, r);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += r[i];
+        }
+        st8(dx + (long)row * d + ch * 8, o);
+      }
+    }
+  }
+  // block reduce of the 4 waves' partials through LDS
+  float* my = sm + wave * 2 * d;
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c) {
+    int ch = lane + 64 * c;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { my[ch * 8 + i] = aw[c][i]; my[d + ch * 8 + i] = ab[c][i]; }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * d; i += 256)
+    part[(long)blockIdx.x * 2 * d + i] = sm[i] + sm[2 * d + i] + sm[4 * d + i] + sm[6 * d + i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_scalar_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ w, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                            T* __restrict__ dx, float* __restrict__ dw,
+                                                            float* __restrict__ db, int rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int nwaves = gridDim.x * 4;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nwaves) {
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < d; i += 64) {
+      float xh = (ld<T>(x + (long)row * d + i) - mu) * rs, dv = ld<T>(dy + (long)row * d + i), g = dv * w[i];
+      s1 += g; s2 += g * xh;
+      atomicAdd(dw + i, dv * xh);
+      atomicAdd(db + i, dv);
+    }
+    const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
+    for (int i = lane; i < d; i += 64) {
+      float xh = (ld<T>(x + (long)row * d + i) - mu) * rs, g = ld<T>(dy + (long)row * d + i) * w[i];
+      float o = rs * (g - c1 - xh * c2);
+      if (dres) o += ld<T>(dres + (long)row * d + i);
+      st<T>(dx + (long)row * d + i, o);
+    }
+  }
+}
+
+__global__ void ln_reduce_kernel(const float* __restrict__ part, int nblocks, int d, float* __restrict__ dw,
+                                 float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 2*d
+  if (i >= 2 * d) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += part[(long)b * 2 * d + i];
+  if (i < d) dw[i] += s; else db[i - d] += s;
+}
+
+}  // namespace
+
+static int ln_grid(int rows) {
+  int g = dh_cdiv(rows, 4);
+  return g > 1024 ? 1024 : g;
+}
+
+extern "C" int dh_layernorm_fwd(int dtype, const void* x, const float* w, const float* b, void* y, float* mean,
+                                float* rstd, int rows, int d, float eps, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(x && w && b && y && rows > 0 && d > 0, "dh_layernorm_fwd: bad args");
+  const bool vec = (d % 8 == 0) && d <= 8 * 64 * LN_MAXC;
+  dim3 grid(ln_grid(rows));
+  if (dtype == DH_BF16) {
+    if (vec) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, w, b, (bf16_t*)y, mean, rstd, rows, d, eps);
+    else hipLaunchKernelGGL(ln_fwd_scalar_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, w, b, (bf16_t*)y, mean, rstd, rows, d, eps);
+  } else {
+    if (vec) hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, w, b, (float*)y, mean, rstd, rows, d, eps);
+    else hipLaunchKernelGGL(ln_fwd_scalar_kernel<float>, grid, dim3(256), 0, st, (const float*)x, w, b, (float*)y, mean, rstd, rows, d, eps);
+  }
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int64_t dh_layernorm_bwd_ws_bytes(int rows, int d) {
+  int nb = dh_cdiv(rows, 4);
+  if (nb > 256) nb = 256;
+  return (int64_t)nb * 2 * d * sizeof(float);
+}
+
+extern "C" int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const float* w, const float* mean,
+                                const float* rstd, const void* dres, void* dx, float* dw, float* db, int rows, int d,
+                                void* ws, int64_t ws_bytes, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(dy && x && w && mean && rstd && dx && dw && db && rows > 0 && d > 0, "dh_layernorm_bwd: bad args");
+  const bool vec = (d % 8 == 0) && d <= 8 * 64 * LN_MAXC && (size_t)(8 * d * sizeof(float)) <= 64 * 1024;
+  if (vec) {
+    int nb = dh_cdiv(rows, 4);
+    if (nb > 256) nb = 256;
+    DH_REQUIRE(ws && ws_bytes >= (int64_t)nb * 2 * d * (int64_t)sizeof(float), "dh_layernorm_bwd: workspace too small");
+    size_t lds = 8 * d * sizeof(float);
+    if (dtype == DH_BF16)
+      hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, st, (const bf16_t*)dy, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)ws, rows, d);
+    else
+      hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), lds, st, (const float*)dy, (const float*)x, w, mean, rstd, (const float*)dres, (float*)dx, (float*)ws, rows, d);
+    DH_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3(dh_cdiv(2 * d, 256)), dim3(256), 0, st, (const float*)ws, nb, d, dw, db);
+  } else {
+    dim3 grid(ln_grid(rows) > 256 ? 256 : ln_grid(rows));
+    if (dtype == DH_BF16)
+      hipLaunchKernelGGL(ln_bwd_scalar_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw, db, rows, d);
+    else
+      hipLaunchKernelGGL(ln_bwd_scalar_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)x, w, mean, rstd, (const float*)dres, (float*)dx, dw, db, rows, d);
+  }
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}

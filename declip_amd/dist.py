@@ -1,0 +1,214 @@
+"""Data-parallel plumbing over RCCL (torch.distributed backend "nccl" on ROCm) / gloo (CPU tests).
+
+Reference: linklink/__init__.py:13-71 (backend facade), model/clip.py:25-49 (AllGather with
+all-reduce backward), utils/dist.py:49-88 (DistModule: per-parameter async all-reduce hooks).
+
+MI355X-first re-design:
+  * ONE packed all-gather for all feature tensors of a step ([b, sum D_k] -> [B, sum D_k]);
+    its backward is ONE reduce-scatter (W x less traffic than the reference's
+    all-reduce + slice, clip.py:43-49) -- mathematically identical.
+  * gradients live in one flat fp32 buffer (engine.FlatParams); FlatReducer all-reduces
+    contiguous slices of it as soon as the backward of a layer group has finished, on RCCL's
+    own stream (async_op=True), overlapped with the rest of the backward.  No per-parameter
+    collectives, no packing copies, no host syncs.
+"""
+import os
+
+import torch
+import torch.distributed as tdist
+
+
+def is_dist():
+    return tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
+
+
+def get_rank():
+    if tdist.is_available() and tdist.is_initialized():
+        return tdist.get_rank()
+    return int(os.environ.get("RANK", os.environ.get("SLURM_PROCID", 0)))
+
+
+def get_world_size():
+    if tdist.is_available() and tdist.is_initialized():
+        return tdist.get_world_size()
+    return int(os.environ.get("WORLD_SIZE", os.environ.get("SLURM_NTASKS", 1)))
+
+
+def get_local_rank():
+    return int(os.environ.get("LOCAL_RANK", get_rank() % max(1, torch.cuda.device_count() or 1)))
+
+
+def initialize(backend="nccl"):
+    """linklink.initialize (linklink/__init__.py:42-67) accepting torchrun env (RANK/WORLD_SIZE/LOCAL_RANK/
+    MASTER_*) as well as the SLURM variables the reference requires."""
+    if tdist.is_initialized():
+        return
+    rank = int(os.environ.get("RANK", os.environ.get("SLURM_PROCID", 0)))
+    world = int(os.environ.get("WORLD_SIZE", os.environ.get("SLURM_NTASKS", 1)))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "12345")
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(get_local_rank())
+    else:
+        backend = "gloo"
+    kw = {}
+    if backend == "nccl" and torch.cuda.is_available():
+        kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+    tdist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+
+
+def barrier():
+    """linklink.barrier (linklink/__init__.py:30-34) without the host round trip: collectives are
+    stream-ordered, so inside the step this is a no-op; kept for API compatibility."""
+    return None
+
+
+def _backend_has_reduce_scatter():
+    return tdist.get_backend() != "gloo"
+
+
+class _AllGatherPacked(torch.autograd.Function):
+    """forward: [b, D] -> [W*b, D] (rank-major, == torch.cat(all_gather) of clip.py:34-38);
+    backward: reduce-scatter(SUM) of the [W*b, D] gradient (== all-reduce + slice[rank], clip.py:43-49)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        W = tdist.get_world_size()
+        out = torch.empty((W * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+        tdist.all_gather_into_tensor(out, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        W, r = tdist.get_world_size(), tdist.get_rank()
+        b = g.shape[0] // W
+        if _backend_has_reduce_scatter():
+            out = torch.empty((b,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
+            tdist.reduce_scatter_tensor(out, g, op=tdist.ReduceOp.SUM)
+            return out
+        g = g.clone()
+        tdist.all_reduce(g)
+        return g[r * b:(r + 1) * b].clone()
+
+
+def all_gather_cat(x):
+    """[b, ...] -> [B, ...] differentiable gather (CLIP.all_gather, clip.py:113-116)."""
+    if not is_dist():
+        return x
+    return _AllGatherPacked.apply(x)
+
+
+def all_gather_cat_many(tensors):
+    """Gather several [b, D_k] feature tensors with ONE collective (packed along the feature dim)."""
+    if not is_dist():
+        return list(tensors)
+    if len(tensors) == 1:
+        return [all_gather_cat(tensors[0])]
+    dims = [t.shape[1] for t in tensors]
+    packed = torch.cat([t.reshape(t.shape[0], -1) for t in tensors], dim=1)
+    gathered = _AllGatherPacked.apply(packed)
+    return list(torch.split(gathered, dims, dim=1))
+
+
+class FlatReducer:
+    """Bucketed SUM all-reduce of FlatParams.flat_g, launched as backward progresses.
+
+    ready(lo, hi) marks a flat range whose gradients are final; adjacent ranges coalesce and are
+    launched (async, on RCCL's stream) once a contiguous run reaches the bucket size.  finish()
+    reduces everything that is left (small/odd ranges, parameters handled by torch autograd) as
+    maximal contiguous runs and waits for all collectives (stream-ordered: no host sync)."""
+
+    SLACK = 64   # alignment padding between consecutive parameters (engine.ALIGN)
+
+    def __init__(self, flat, bucket_bytes=48 << 20):
+        self.flat = flat
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.done = []       # launched [lo, hi)
+        self.runs = []       # coalesced ready-but-not-launched [lo, hi)
+        self.works = []
+
+    def begin(self):
+        self.done, self.runs, self.works = [], [], []
+
+    def _launch(self, lo, hi):
+        if hi <= lo:
+            return
+        self.done.append((lo, hi))
+        if is_dist():
+            self.works.append(tdist.all_reduce(self.flat.flat_g[lo:hi], op=tdist.ReduceOp.SUM, async_op=True))
+
+    def ready(self, lo, hi):
+        runs = sorted(self.runs + [(lo, hi)])
+        merged = [list(runs[0])]
+        for a, b in runs[1:]:
+            if a <= merged[-1][1] + self.SLACK:
+                merged[-1][1] = max(merged[-1][1], b)
+            else:
+                merged.append([a, b])
+        self.runs = []
+        for a, b in merged:
+            if b - a >= self.bucket_elems:
+                self._launch(a, b)
+            else:
+                self.runs.append((a, b))
+
+    def finish(self):
+        self.runs = []
+        cur = 0
+        for lo, hi in sorted(self.done):
+            if lo > cur:
+                self._launch(cur, lo)
+            cur = max(cur, hi)
+        if cur < self.flat.total:
+            self._launch(cur, self.flat.total)
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+class DistModule(torch.nn.Module):
+    """utils/dist.py:49-88 surface: wraps the model, broadcasts parameters from rank 0 and
+    arranges gradient averaging (the loss is pre-divided by world size, clip_solver.py:418, so
+    SUM == mean).  `sync` is accepted for config compatibility; both modes reduce flat buckets."""
+
+    def __init__(self, module, sync=False, bucket_bytes=48 << 20):
+        super().__init__()
+        self.module = module
+        self.sync = sync
+        flat = module.__dict__.get("_flat_store")
+        if flat is None:
+            raise RuntimeError("DistModule expects a declip_amd engine model (with a flat parameter store)")
+        self._flat = flat
+        if torch.cuda.is_available() and next(module.parameters()).is_cuda:
+            flat.ensure()
+            self.broadcast_params()
+            flat.reducer = FlatReducer(flat, bucket_bytes)
+        else:
+            flat.reducer = FlatReducer(flat, bucket_bytes)
+
+    def forward(self, *inputs, **kwargs):
+        return self.module(*inputs, **kwargs)
+
+    def sync_gradients(self):
+        """Reference: device sync / blocking all-reduce.  Here the reducer already waited on its
+        collectives inside the autograd callback (stream-ordered, no host sync)."""
+        return None
+
+    def broadcast_params(self):
+        if not is_dist():
+            return
+        tdist.broadcast(self._flat.flat_p, 0)          # one flattened broadcast instead of ~300
+        for b in self.module.buffers():
+            tdist.broadcast(b, 0)
+
+
+def broadcast_object(obj, src=0):
+    """utils/dist.py:111-126."""
+    if not is_dist():
+        return obj
+    lst = [obj]
+    tdist.broadcast_object_list(lst, src=src)
+    return lst[0]

@@ -1,0 +1,463 @@
+"""Host-side engine: flat parameter store + the fused tower / loss autograd Functions.
+
+MI355X-first layout: all parameters live in ONE flat fp32 buffer (288 GB HBM: no
+reason to scatter 300 tensors), their gradients in one flat fp32 buffer written in place by
+the HIP kernels (dW GEMMs accumulate straight into it), and -- in bf16 mode -- a flat bf16
+mirror refreshed by one cast kernel per step.  Gradient all-reduce then works on contiguous
+slices of the flat buffer (declip_amd/dist.py) without any packing copies.
+
+Every arithmetic step goes through declip_amd.ops (= the C-ABI); torch is used for memory,
+streams and the autograd graph plumbing only.
+"""
+import torch
+
+from . import ops
+from .lib import DeclipHipError, EPI_DGELU, EPI_GELU, EPI_NONE
+
+ALIGN = 64  # elements; keeps every parameter 256-byte aligned inside the flat buffers
+
+
+def _require_gpu(p, name):
+    if not p.is_cuda:
+        raise DeclipHipError("parameter %s is not on the GPU: call model.cuda() first (no CPU path)" % name)
+
+
+class FlatParams:
+    """Re-homes a module's parameters into flat buffers (values, grads, bf16 mirror)."""
+
+    def __init__(self, module, act_dtype=torch.bfloat16):
+        self.module = module
+        self.act_dtype = act_dtype
+        self.params = []
+        self.index = {}
+        self.total = 0
+        self.flat_p = self.flat_g = self.flat_b = None
+        self.anchor = None
+        self._in_backward = False
+        self.mirror_fresh = False
+        self.reducer = None          # set by dist.DistModule
+        self.names = {}
+
+    # ------------------------------------------------------------------ construction
+    def attach(self):
+        seen = set()
+        off = 0
+        self.params, self.index = [], {}
+        for name, p in self.module.named_parameters():
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            _require_gpu(p, name)
+            if p.dtype != torch.float32:
+                raise DeclipHipError("parameter %s must be fp32 master weights (got %s)" % (name, p.dtype))
+            n = p.numel()
+            self.index[id(p)] = (off, n)
+            self.names[id(p)] = name
+            self.params.append(p)
+            off += (n + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        dev = self.params[0].device
+        self.flat_p = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
+        for p in self.params:
+            o, n = self.index[id(p)]
+            view = self.flat_p[o:o + n].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = None
+        if self.act_dtype == torch.bfloat16:
+            self.flat_b = torch.empty(off, device=dev, dtype=torch.bfloat16)
+        self.anchor = torch.zeros(1, device=dev, dtype=torch.float32, requires_grad=True)
+        self.mirror_fresh = False
+        return self
+
+    def attached(self):
+        if self.flat_p is None:
+            return False
+        p = self.params[0]
+        o, n = self.index[id(p)]
+        return p.data_ptr() == self.flat_p.data_ptr() + 4 * o
+
+    def ensure(self):
+        if not self.attached():
+            self.attach()
+        return self
+
+    # ------------------------------------------------------------------ views
+    def gview(self, p):
+        o, n = self.index[id(p)]
+        return self.flat_g[o:o + n].view(p.shape)
+
+    def wview(self, p):
+        """weight in the compute dtype (bf16 mirror in bf16 mode, the fp32 master otherwise)."""
+        if self.flat_b is None:
+            return p.data
+        o, n = self.index[id(p)]
+        return self.flat_b[o:o + n].view(p.shape)
+
+    def span(self, params):
+        """(lo, hi) flat range covering the given parameters (for bucketed gradient reduction)."""
+        lo = min(self.index[id(p)][0] for p in params)
+        hi = max(self.index[id(p)][0] + self.index[id(p)][1] for p in params)
+        return lo, hi
+
+    def refresh_mirror(self):
+        if self.flat_b is not None and not self.mirror_fresh:
+            ops.cast(self.flat_p, self.flat_b)
+            self.mirror_fresh = True
+
+    def begin_step(self):
+        """Call at the start of every forward in training: parameters may have changed."""
+        self.ensure()
+        self.mirror_fresh = False
+        self.refresh_mirror()
+
+    # ------------------------------------------------------------------ backward protocol
+    def begin_backward(self):
+        """First engine backward of an autograd pass: establish the accumulate-into contract."""
+        if self._in_backward:
+            return
+        self._in_backward = True
+        none = [p for p in self.params if p.grad is None]
+        if len(none) == len(self.params):
+            self.flat_g.zero_()
+        else:
+            for p in none:
+                self.gview(p).zero_()
+        if self.reducer is not None:
+            self.reducer.begin()
+        torch.autograd.Variable._execution_engine.queue_callback(self._end_backward)
+
+    def _end_backward(self):
+        self._in_backward = False
+        for p in self.params:
+            if not p.requires_grad:
+                continue
+            view = self.gview(p)
+            if p.grad is None:
+                p.grad = view
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.add_(p.grad)   # a parameter that torch autograd handled itself
+                p.grad = view
+        if self.reducer is not None:
+            self.reducer.finish()
+
+    def grads_ready(self, params):
+        """gradients of `params` are final for this backward pass (bucketed reduction may start)."""
+        if self.reducer is not None:
+            for p in params:
+                o, n = self.index[id(p)]
+                self.reducer.ready(o, o + n)
+
+
+# ---------------------------------------------------------------------------------------------
+# transformer blocks (base_transformer.py:29-79)
+# ---------------------------------------------------------------------------------------------
+class BlockRefs:
+    """Tensors of one ResidualAttentionBlock: weights in compute dtype, fp32 biases/LN, grad views."""
+
+    def __init__(self, flat, blk):
+        a = blk.attn
+        self.params = [a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, blk.ln_1.weight,
+                       blk.ln_1.bias, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, blk.mlp.c_proj.weight,
+                       blk.mlp.c_proj.bias, blk.ln_2.weight, blk.ln_2.bias]
+        w, g = flat.wview, flat.gview
+        self.w_in, self.b_in, self.w_out, self.b_out = w(a.in_proj_weight), a.in_proj_bias.data, w(a.out_proj.weight), a.out_proj.bias.data
+        self.ln1_w, self.ln1_b, self.ln2_w, self.ln2_b = blk.ln_1.weight.data, blk.ln_1.bias.data, blk.ln_2.weight.data, blk.ln_2.bias.data
+        self.w_fc, self.b_fc, self.w_proj, self.b_proj = w(blk.mlp.c_fc.weight), blk.mlp.c_fc.bias.data, w(blk.mlp.c_proj.weight), blk.mlp.c_proj.bias.data
+        self.g_w_in, self.g_b_in, self.g_w_out, self.g_b_out = g(a.in_proj_weight), g(a.in_proj_bias), g(a.out_proj.weight), g(a.out_proj.bias)
+        self.g_ln1_w, self.g_ln1_b, self.g_ln2_w, self.g_ln2_b = g(blk.ln_1.weight), g(blk.ln_1.bias), g(blk.ln_2.weight), g(blk.ln_2.bias)
+        self.g_w_fc, self.g_b_fc, self.g_w_proj, self.g_b_proj = g(blk.mlp.c_fc.weight), g(blk.mlp.c_fc.bias), g(blk.mlp.c_proj.weight), g(blk.mlp.c_proj.bias)
+        self.eps1, self.eps2 = blk.ln_1.eps, blk.ln_2.eps
+        self.trainable = all(p.requires_grad for p in self.params)
+
+
+def _split_k(mg, ng, kg):
+    tiles = ((mg + 127) // 128) * ((ng + 127) // 128)
+    s = max(1, min(1024 // max(tiles, 1), kg // 512))
+    return s
+
+
+def weight_grad(dy, x, gw):
+    """gw[out,in] += dy[rows,out]^T x[rows,in]  (contraction over rows: both operands k-major)."""
+    ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=gw, accumulate=True, split_k=_split_k(gw.shape[0], gw.shape[1], dy.shape[0]))
+
+
+def block_fwd(x, r, b, L, heads, causal, save):
+    """x: [b*L, d].  Returns x_out; if `save`, also the tuple needed by block_bwd."""
+    h1, mean1, rstd1 = ops.layernorm_fwd(x, r.ln1_w, r.ln1_b, r.eps1)
+    qkv = ops.gemm(h1, r.w_in, bias=r.b_in)
+    a, lse = ops.attn_fwd(qkv, b, L, heads, causal)
+    x_mid = ops.gemm(a, r.w_out, bias=r.b_out, residual=x)
+    h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, r.ln2_w, r.ln2_b, r.eps2)
+    u = torch.empty(x.shape[0], r.w_fc.shape[0], device=x.device, dtype=x.dtype) if save else None
+    g = ops.gemm(h2, r.w_fc, bias=r.b_fc, epilogue=EPI_GELU, aux=u)
+    x_out = ops.gemm(g, r.w_proj, bias=r.b_proj, residual=x_mid)
+    saved = (x, mean1, rstd1, h1, qkv, a, lse, x_mid, mean2, rstd2, h2, u, g) if save else None
+    return x_out, saved
+
+
+def block_bwd(dx_out, r, saved, b, L, heads, causal):
+    x, mean1, rstd1, h1, qkv, a, lse, x_mid, mean2, rstd2, h2, u, g = saved
+    # MLP: x_out = x_mid + gelu(h2 Wfc^T + bfc) Wproj^T + bproj
+    weight_grad(dx_out, g, r.g_w_proj)
+    ops.colsum(dx_out, r.g_b_proj)
+    du = ops.gemm(dx_out, r.w_proj, b_kmajor=True, epilogue=EPI_DGELU, aux=u)
+    weight_grad(du, h2, r.g_w_fc)
+    ops.colsum(du, r.g_b_fc)
+    dh2 = ops.gemm(du, r.w_fc, b_kmajor=True)
+    dx_mid = ops.layernorm_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)
+    # attention: x_mid = x + attn(h1) Wout^T + bout
+    weight_grad(dx_mid, a, r.g_w_out)
+    ops.colsum(dx_mid, r.g_b_out)
+    da = ops.gemm(dx_mid, r.w_out, b_kmajor=True)
+    dqkv = ops.attn_bwd(qkv, a, da, lse, b, L, heads, causal)
+    weight_grad(dqkv, h1, r.g_w_in)
+    ops.colsum(dqkv, r.g_b_in)
+    dh1 = ops.gemm(dqkv, r.w_in, b_kmajor=True)
+    return ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
+
+
+def _to_act(t, dtype):
+    if t.dtype == dtype:
+        return t.contiguous()
+    out = torch.empty(t.shape, device=t.device, dtype=dtype)
+    return ops.cast(t.contiguous(), out)
+
+
+# ---------------------------------------------------------------------------------------------
+# vision tower (image_encoder/visual_transformer.py:55-82)
+# ---------------------------------------------------------------------------------------------
+class VisionTowerFn(torch.autograd.Function):
+    """forward(anchor, images, tower, c0, want_dense, want_feature) ->
+         proj [b,E] fp32 (, dense [b,np,width] act dtype)(, feature [b,width] act dtype)"""
+
+    @staticmethod
+    def forward(ctx, anchor, images, tower, c0, want_dense, want_feature):
+        flat = tower._flat()
+        dtype = flat.act_dtype
+        b = images.shape[0]
+        P, width, heads = tower.patch_size, tower.width, tower.heads
+        npatch = (images.shape[2] // P) * (images.shape[3] // P)
+        L = npatch + 1
+        save = bool(ctx.needs_input_grad[0])
+        rows = ops.im2row(images, c0, P, dtype)
+        wconv = flat.wview(tower.conv1.weight).view(width, -1)
+        patches = ops.gemm(rows, wconv)
+        x0 = ops.vit_assemble_fwd(patches, tower.class_embedding.data, tower.positional_embedding.data, b, npatch)
+        x, mean0, rstd0 = ops.layernorm_fwd(x0, tower.ln_pre.weight.data, tower.ln_pre.bias.data, tower.ln_pre.eps)
+        refs = [BlockRefs(flat, blk) for blk in tower.transformer.resblocks]
+        saved_blocks = []
+        for r in refs:
+            x, s = block_fwd(x, r, b, L, heads, False, save=save)
+            saved_blocks.append(s)
+        pooled = ops.pool_rows_fwd(x, None, b, L)
+        feat, mean_p, rstd_p = ops.layernorm_fwd(pooled, tower.ln_post.weight.data, tower.ln_post.bias.data, tower.ln_post.eps)
+        out = ops.gemm(feat, flat.wview(tower.proj), b_kmajor=True, out_dtype=torch.float32)
+        ctx.tower, ctx.refs, ctx.saved_blocks = tower, refs, saved_blocks
+        ctx.misc = (b, L, npatch, rows if tower.conv1.weight.requires_grad else None, x0, mean0, rstd0, pooled, mean_p, rstd_p, feat, x)
+        ctx.want = (want_dense, want_feature)
+        outs = [out]
+        if want_dense:
+            outs.append(x.view(b, L, width)[:, 1:, :])
+        if want_feature:
+            outs.append(feat)
+        return tuple(outs) if len(outs) > 1 else out
+
+    @staticmethod
+    def backward(ctx, *grads):
+        tower = ctx.tower
+        flat = tower._flat()
+        flat.begin_backward()
+        dtype = flat.act_dtype
+        b, L, npatch, rows, x0, mean0, rstd0, pooled, mean_p, rstd_p, feat, x_final = ctx.misc
+        width, heads = tower.width, tower.heads
+        want_dense, want_feature = ctx.want
+        dout = grads[0]
+        gi = 1
+        ddense = dfeat_extra = None
+        if want_dense:
+            ddense = grads[gi]; gi += 1
+        if want_feature:
+            dfeat_extra = grads[gi]; gi += 1
+        g = flat.gview
+        dfeat = None
+        if dout is not None:
+            dout_a = _to_act(dout, dtype)
+            # out = feat @ proj  (proj [width, E])
+            ops.gemm(feat, dout_a, a_kmajor=True, b_kmajor=True, out=g(tower.proj), accumulate=True)
+            dfeat = ops.gemm(dout_a, flat.wview(tower.proj))          # [b,E] x proj[width,E]^T
+        if dfeat_extra is not None:
+            de = _to_act(dfeat_extra, dtype)
+            dfeat = de if dfeat is None else dfeat.add_(de)
+        if dfeat is not None:
+            dpooled = ops.layernorm_bwd(dfeat, pooled, tower.ln_post.weight.data, mean_p, rstd_p, g(tower.ln_post.weight), g(tower.ln_post.bias))
+            dx = ops.pool_rows_bwd(dpooled, None, b, L)
+        else:
+            dx = torch.zeros(b * L, width, device=x_final.device, dtype=dtype)
+        if ddense is not None:
+            dx.view(b, L, width)[:, 1:, :].add_(ddense.to(dtype))
+        flat.grads_ready([tower.proj, tower.ln_post.weight, tower.ln_post.bias])
+        for r, s in zip(reversed(ctx.refs), reversed(ctx.saved_blocks)):
+            dx = block_bwd(dx, r, s, b, L, heads, False)
+            flat.grads_ready(r.params)
+        dx0 = ops.layernorm_bwd(dx, x0, tower.ln_pre.weight.data, mean0, rstd0, g(tower.ln_pre.weight), g(tower.ln_pre.bias))
+        ops.vit_assemble_bwd(dx0, g(tower.class_embedding), g(tower.positional_embedding), b, npatch)
+        if tower.conv1.weight.requires_grad:
+            dpatch = dx0.view(b, L, width)[:, 1:, :].contiguous().view(b * npatch, width)
+            weight_grad(dpatch, rows, g(tower.conv1.weight).view(width, -1))
+        ctx.saved_blocks = ctx.misc = None
+        return (torch.zeros_like(flat.anchor), None, None, None, None, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# text tower (text_encoder/text_transformer.py:183-204)
+# ---------------------------------------------------------------------------------------------
+class TextTowerFn(torch.autograd.Function):
+    """forward(anchor, ids, tower, want_dense) -> proj [b,E] fp32 (, words [b,ctx,width] act dtype)"""
+
+    @staticmethod
+    def forward(ctx, anchor, ids, tower, want_dense):
+        flat = tower._flat()
+        dtype = flat.act_dtype
+        b, L = ids.shape
+        width, heads = tower.width, tower.heads
+        x = ops.text_embed_fwd(ids, tower.token_embedding.weight.data, tower.positional_embedding.data, dtype)
+        refs = [BlockRefs(flat, blk) for blk in tower.transformer.resblocks]
+        saved_blocks = []
+        save = bool(ctx.needs_input_grad[0])
+        for r in refs:
+            x, s = block_fwd(x, r, b, L, heads, True, save=save)
+            saved_blocks.append(s)
+        eot = ids.argmax(dim=-1)                                    # text_transformer.py:203 (index arithmetic)
+        lnw, lnb = tower.ln_final.weight.data, tower.ln_final.bias.data
+        if want_dense:
+            words, mean_f, rstd_f = ops.layernorm_fwd(x, lnw, lnb, tower.ln_final.eps)
+            feat = ops.pool_rows_fwd(words, eot, b, L)
+            pooled = None
+        else:
+            pooled = ops.pool_rows_fwd(x, eot, b, L)
+            feat, mean_f, rstd_f = ops.layernorm_fwd(pooled, lnw, lnb, tower.ln_final.eps)
+            words = None
+        tp = tower.text_projection
+        out = ops.gemm(feat, flat.wview(tp.weight), bias=tp.bias.data, out_dtype=torch.float32)
+        ctx.tower, ctx.refs, ctx.saved_blocks = tower, refs, saved_blocks
+        ctx.misc = (b, L, ids, eot, x, pooled, mean_f, rstd_f, feat, want_dense)
+        if want_dense:
+            return out, words.view(b, L, width)
+        return out
+
+    @staticmethod
+    def backward(ctx, *grads):
+        tower = ctx.tower
+        flat = tower._flat()
+        flat.begin_backward()
+        dtype = flat.act_dtype
+        b, L, ids, eot, x_final, pooled, mean_f, rstd_f, feat, want_dense = ctx.misc
+        width, heads = tower.width, tower.heads
+        g = flat.gview
+        tp = tower.text_projection
+        dout = grads[0]
+        dwords = grads[1] if want_dense else None
+        dfeat = None
+        if dout is not None:
+            dout_a = _to_act(dout, dtype)
+            weight_grad(dout_a, feat, g(tp.weight))
+            ops.colsum(dout_a, g(tp.bias))
+            dfeat = ops.gemm(dout_a, flat.wview(tp.weight), b_kmajor=True)
+        lnw = tower.ln_final.weight.data
+        if want_dense:
+            dw_total = ops.pool_rows_bwd(dfeat, eot, b, L) if dfeat is not None else torch.zeros(b * L, width, device=ids.device, dtype=dtype)
+            if dwords is not None:
+                dw_total.add_(dwords.reshape(b * L, width).to(dtype))
+            dx = ops.layernorm_bwd(dw_total, x_final, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
+        else:
+            dpooled = ops.layernorm_bwd(dfeat, pooled, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
+            dx = ops.pool_rows_bwd(dpooled, eot, b, L)
+        flat.grads_ready([tp.weight, tp.bias, tower.ln_final.weight, tower.ln_final.bias])
+        for r, s in zip(reversed(ctx.refs), reversed(ctx.saved_blocks)):
+            dx = block_bwd(dx, r, s, b, L, heads, True)
+            flat.grads_ready(r.params)
+        te, pe = tower.token_embedding.weight, tower.positional_embedding
+        ops.text_embed_bwd(ids, dx, g(te) if te.requires_grad else None, g(pe) if pe.requires_grad else None)
+        ctx.saved_blocks = ctx.misc = None
+        return (torch.zeros_like(flat.anchor), None, None, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# feature normalisation + fused contrastive loss
+# ---------------------------------------------------------------------------------------------
+class L2NormFn(torch.autograd.Function):
+    """clip.py:129-130: x / (||x|| + eps) -> fp32."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = x.contiguous()
+        y, norm = ops.l2norm_fwd(x, eps)
+        ctx.save_for_backward(x, norm)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, norm = ctx.saved_tensors
+        return ops.l2norm_bwd(x, norm, dy.contiguous().float(), ctx.eps), None
+
+
+class InfoNCEFn(torch.autograd.Function):
+    """Fused multi-pair InfoNCE.  forward(scale[1], label0, n_pairs, Q0, K0, Q1, K1, ...) ->
+    row_loss [P,b], correct1 [P,b], correct5 [P,b] (the last two carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, scale, label0, n_pairs, *feats):
+        pairs = [(feats[2 * i].contiguous(), feats[2 * i + 1].contiguous()) for i in range(n_pairs)]
+        scale = scale.detach().contiguous().float()
+        row_loss, row_lse, c1, c5, _ = ops.infonce_fwd(pairs, scale, label0)
+        ctx.pairs, ctx.scale, ctx.label0, ctx.row_lse = pairs, scale, label0, row_lse
+        ctx.mark_non_differentiable(c1, c5)
+        return row_loss, c1, c5
+
+    @staticmethod
+    def backward(ctx, g_row, _g1, _g5):
+        outs, dscale = ops.infonce_bwd(ctx.pairs, ctx.scale, ctx.label0, ctx.row_lse, g_row.contiguous().float())
+        flat = []
+        for dq, dk in outs:
+            flat += [dq, dk]
+        return (dscale, None, None, *flat)
+
+
+class LogitsFn(torch.autograd.Function):
+    """Materialised logits = scale * Q K^T (clip.py:140-141) for the API surface / parity tests."""
+
+    @staticmethod
+    def forward(ctx, scale, Q, K):
+        Q, K = Q.contiguous(), K.contiguous()
+        raw = ops.gemm(Q, K)                       # fp32 validation-precision kernel
+        ctx.save_for_backward(scale, Q, K, raw)
+        return raw * scale
+
+    @staticmethod
+    def backward(ctx, dl):
+        scale, Q, K, raw = ctx.saved_tensors
+        dl = dl.contiguous()
+        dls = dl * scale
+        dQ = ops.gemm(dls, K, b_kmajor=True)
+        dK = ops.gemm(dls, Q, a_kmajor=True, b_kmajor=True)
+        return (dl * raw).sum().reshape(scale.shape), dQ, dK
+
+
+class RowCEFn(torch.autograd.Function):
+    """F.cross_entropy(reduction='none') on materialised fp32 logits (loss.py:44-45)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits = logits.contiguous().float()
+        row_loss, row_lse, c1, c5 = ops.ce_rows_fwd(logits, labels)
+        ctx.save_for_backward(logits, labels, row_lse)
+        ctx.mark_non_differentiable(c1, c5)
+        return row_loss, c1, c5
+
+    @staticmethod
+    def backward(ctx, g_row, _a, _b):
+        logits, labels, row_lse = ctx.saved_tensors
+        return ops.ce_rows_bwd(logits, labels, row_lse, g_row.contiguous().float()), None

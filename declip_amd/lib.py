@@ -1,0 +1,128 @@
+"""ctypes binding of libdeclip_hip.so (the C-ABI declared in include/declip_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call
+fails, a DeclipHipError is raised (never a silent PyTorch/CPU path).
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdeclip_hip.so")
+
+DH_F32, DH_BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
+MAX_PAIRS = 16
+
+
+class DeclipHipError(RuntimeError):
+    pass
+
+
+class GemmArgs(Structure):
+    _fields_ = [
+        ("dtype", c_int), ("c_dtype", c_int), ("a_kmajor", c_int), ("b_kmajor", c_int),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("A", c_void_p), ("lda", c_int64), ("B", c_void_p), ("ldb", c_int64), ("C", c_void_p), ("ldc", c_int64),
+        ("bias", c_void_p), ("epilogue", c_int), ("residual", c_void_p), ("ldr", c_int64),
+        ("aux", c_void_p), ("ldaux", c_int64), ("accumulate", c_int), ("split_k", c_int), ("alpha", c_float),
+        ("force_generic", c_int),
+    ]
+
+
+class NcePair(Structure):
+    _fields_ = [("Q", c_void_p), ("K", c_void_p), ("dQ", c_void_p), ("dK", c_void_p)]
+
+
+_P = c_void_p
+_PROTOS = {
+    "dh_last_error": (c_char_p, []),
+    "dh_version": (c_int, []),
+    "dh_device_info": (c_int, [c_int, POINTER(c_int)]),
+    "dh_gemm": (c_int, [POINTER(GemmArgs), _P]),
+    "dh_colsum": (c_int, [c_int, _P, c_int64, c_int, c_int, _P, c_int, _P]),
+    "dh_layernorm_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "dh_layernorm_bwd_ws_bytes": (c_int64, [c_int, c_int]),
+    "dh_layernorm_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int64, _P]),
+    "dh_attn_fwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dh_attn_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dh_text_embed_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "dh_text_embed_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "dh_im2row": (c_int, [c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "dh_vit_assemble_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "dh_vit_assemble_bwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "dh_pool_rows_fwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "dh_pool_rows_bwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "dh_l2norm_fwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "dh_l2norm_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "dh_infonce_fwd": (c_int, [POINTER(NcePair), c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]),
+    "dh_infonce_bwd": (c_int, [POINTER(NcePair), c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
+    "dh_ce_rows_fwd": (c_int, [_P, c_int64, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "dh_ce_rows_bwd": (c_int, [_P, c_int64, _P, c_int, c_int, _P, _P, _P, c_int64, _P]),
+    "dh_adamw": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
+    "dh_adamw_segmented": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int, c_float, c_float, c_float, c_int, c_float, _P]),
+    "dh_cast": (c_int, [c_int, _P, c_int, _P, c_int64, _P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_PROTOS)
+
+
+def load():
+    """dlopen the in-tree library (building it is __graft_entry__.build()'s job)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DeclipHipError(
+            "libdeclip_hip.so not found at %s -- run `python -m declip_amd.build` (hipcc, gfx950). "
+            "There is no fallback path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().dh_last_error()
+        raise DeclipHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def dt(t):
+    """torch dtype -> DH dtype enum."""
+    if t.dtype == torch.float32:
+        return DH_F32
+    if t.dtype == torch.bfloat16:
+        return DH_BF16
+    raise DeclipHipError("unsupported dtype %s" % t.dtype)
+
+
+def torch_dtype(d):
+    return torch.float32 if d == DH_F32 else torch.bfloat16
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise DeclipHipError("tensor is not on a HIP device (the HIP path has no CPU fallback)")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def device_info(device=0):
+    out = (c_int * 4)()
+    check(load().dh_device_info(device, out), "dh_device_info")
+    return dict(cus=out[0], clock_khz=out[1], lds_per_cu=out[2], arch=out[3])

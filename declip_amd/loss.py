@@ -1,0 +1,80 @@
+"""Loss functions of the contrastive path on the HIP engine.
+Reference: prototype/loss_functions/loss.py:24-47 (ClipInfoCELoss), utils/misc.py:415-428 (accuracy)."""
+import torch
+from torch import nn
+
+from . import dist as dh_dist
+from . import engine
+
+
+def _is_lazy(x):
+    return hasattr(x, "materialize") and hasattr(x, "Q")
+
+
+class ClipInfoCELoss(nn.Module):
+    """(CE(logits_per_image) + CE(logits_per_text)) / 2 with labels rank*b + arange(b).
+
+    Accepts LazyLogits handles (fused streaming kernel, nothing materialised) or plain
+    tensors (row-wise CE kernel on the materialised logits).  Returns (loss, labels) like the
+    reference; the per-row top-1/top-5 hits of logits_per_image are kept in `.last_correct`
+    so `accuracy()` needs no second pass."""
+
+    def __init__(self):
+        super().__init__()
+        self.last_correct = None
+
+    def forward(self, logits_per_image, logits_per_text):
+        bs, l_bs = logits_per_image.shape
+        dev = logits_per_image.device
+        if _is_lazy(logits_per_image) and _is_lazy(logits_per_text):
+            li, lt = logits_per_image, logits_per_text
+            label0 = li.label0
+            labels = label0 + torch.arange(bs, device=dev, dtype=torch.long)
+            same_scale = li.scale is lt.scale
+            if same_scale:
+                row_loss, c1, c5 = engine.InfoNCEFn.apply(li.scale, label0, 2, li.Q, li.K, lt.Q, lt.K)
+                loss = row_loss.mean()          # mean over 2b rows == (mean_i + mean_t) / 2
+                self.last_correct = (li, c1[0], c5[0])
+            else:
+                rl_i, c1, c5 = engine.InfoNCEFn.apply(li.scale, label0, 1, li.Q, li.K)
+                rl_t, _, _ = engine.InfoNCEFn.apply(lt.scale, label0, 1, lt.Q, lt.K)
+                loss = (rl_i.mean() + rl_t.mean()) / 2
+                self.last_correct = (li, c1[0], c5[0])
+            return loss, labels
+        if _is_lazy(logits_per_image):
+            logits_per_image = logits_per_image.materialize()
+        if _is_lazy(logits_per_text):
+            logits_per_text = logits_per_text.materialize()
+        if l_bs == bs:
+            labels = torch.arange(bs, device=dev, dtype=torch.long)
+        else:
+            labels = dh_dist.get_rank() * bs + torch.arange(bs, device=dev, dtype=torch.long)
+        rl_i, c1, c5 = engine.RowCEFn.apply(logits_per_image, labels)
+        rl_t, _, _ = engine.RowCEFn.apply(logits_per_text, labels)
+        self.last_correct = (logits_per_image, c1, c5)
+        return (rl_i.mean() + rl_t.mean()) / 2, labels
+
+
+def accuracy(output, target, topk=(1,), criterion=None):
+    """utils/misc.py:415-428: precision@k in percent.  For LazyLogits (or when the criterion
+    just saw `output`) the hit flags come from the fused loss kernel; otherwise from the
+    row-CE kernel on the materialised logits.  Only k in {1, 5} exist on the hot path."""
+    c1 = c5 = None
+    if criterion is not None and criterion.last_correct is not None and criterion.last_correct[0] is output:
+        _, c1, c5 = criterion.last_correct
+    elif _is_lazy(output):
+        with torch.no_grad():
+            _, c1, c5 = engine.InfoNCEFn.apply(output.scale.detach(), output.label0, 1, output.Q.detach(), output.K.detach())
+            c1, c5 = c1[0], c5[0]
+    else:
+        with torch.no_grad():
+            _, c1, c5 = engine.RowCEFn.apply(output.detach(), target)
+    res = []
+    for k in topk:
+        if k == 1:
+            res.append(c1.sum().reshape(1) * (100.0 / target.size(0)))
+        elif k == 5:
+            res.append(c5.sum().reshape(1) * (100.0 / target.size(0)))
+        else:
+            raise NotImplementedError("accuracy top-%d (only top-1/top-5 are on the hot path)" % k)
+    return res

@@ -1,0 +1,247 @@
+"""Tensor-level wrappers over the C-ABI (one Python function per entry point).
+
+These only validate shapes, allocate outputs with torch (memory plumbing) and enqueue the
+HIP kernel on torch's current stream.  No arithmetic happens in Python/PyTorch here.
+"""
+import ctypes
+
+import torch
+
+from . import lib as L
+from .lib import DH_BF16, DH_F32, EPI_DGELU, EPI_GELU, EPI_NONE, GemmArgs, NcePair, check, dt, ptr, stream
+
+
+def _contig(t, name):
+    if not t.is_contiguous():
+        raise L.DeclipHipError("%s must be contiguous" % name)
+    return t
+
+
+def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, residual=None, aux=None,
+         out=None, out_dtype=None, accumulate=False, split_k=1, alpha=1.0, force_generic=False):
+    """C[M,N] = epi(alpha * sum_k A(m,k) B(n,k) + bias).  A: [M,K] (or [K,M] if a_kmajor);
+    B: [N,K] (or [K,N] if b_kmajor).  See include/declip_hip.h."""
+    lib = L.load()
+    assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype
+    M, K = (A.shape[1], A.shape[0]) if a_kmajor else (A.shape[0], A.shape[1])
+    N, Kb = (B.shape[1], B.shape[0]) if b_kmajor else (B.shape[0], B.shape[1])
+    assert K == Kb, "contraction mismatch %d vs %d" % (K, Kb)
+    assert A.stride(1) == 1 and B.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=out_dtype or A.dtype)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    a = GemmArgs()
+    a.dtype, a.c_dtype = dt(A), dt(out)
+    a.a_kmajor, a.b_kmajor = int(a_kmajor), int(b_kmajor)
+    a.M, a.N, a.K = M, N, K
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(out), out.stride(0)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+    a.bias = ptr(bias)
+    a.epilogue = epilogue
+    if residual is not None:
+        assert residual.dtype == out.dtype and residual.shape == out.shape
+        a.residual, a.ldr = ptr(residual), residual.stride(0)
+    if aux is not None:
+        assert aux.shape == (M, N)
+        assert aux.dtype == (out.dtype if epilogue == EPI_GELU else A.dtype)
+        a.aux, a.ldaux = ptr(aux), aux.stride(0)
+    a.accumulate, a.split_k, a.alpha, a.force_generic = int(accumulate), int(split_k), float(alpha), int(force_generic)
+    check(lib.dh_gemm(ctypes.byref(a), stream()), "dh_gemm")
+    return out
+
+
+def colsum(X, out, accumulate=True):
+    assert X.dim() == 2 and X.stride(1) == 1 and out.dtype == torch.float32 and out.numel() == X.shape[1]
+    check(L.load().dh_colsum(dt(X), ptr(X), X.stride(0), X.shape[0], X.shape[1], ptr(out), int(accumulate), stream()),
+          "dh_colsum")
+    return out
+
+
+def layernorm_fwd(x, w, b, eps=1e-5, save_stats=True):
+    _contig(x, "x")
+    rows, d = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32) if save_stats else None
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if save_stats else None
+    check(L.load().dh_layernorm_fwd(dt(x), ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, d, eps, stream()),
+          "dh_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None):
+    """dx = LN'(dy) (+ dres); dw/db (fp32) accumulated into."""
+    _contig(dy, "dy"), _contig(x, "x")
+    rows, d = x.shape
+    lib = L.load()
+    dx = torch.empty_like(x)
+    nbytes = lib.dh_layernorm_bwd_ws_bytes(rows, d)
+    ws = torch.empty(max(nbytes, 4) // 4, device=x.device, dtype=torch.float32)
+    check(lib.dh_layernorm_bwd(dt(x), ptr(dy), ptr(x), ptr(w), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dw), ptr(db),
+                               rows, d, ptr(ws), nbytes, stream()), "dh_layernorm_bwd")
+    return dx
+
+
+def attn_fwd(qkv, b, Lq, heads, causal):
+    _contig(qkv, "qkv")
+    d3 = qkv.shape[-1]
+    d = d3 // 3
+    hd = d // heads
+    out = torch.empty(b * Lq, d, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(b, heads, Lq, device=qkv.device, dtype=torch.float32)
+    check(L.load().dh_attn_fwd(dt(qkv), ptr(qkv), ptr(out), ptr(lse), b, Lq, heads, hd, int(causal), stream()), "dh_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, b, Lq, heads, causal):
+    _contig(qkv, "qkv"), _contig(out, "out"), _contig(dout, "dout")
+    d = qkv.shape[-1] // 3
+    hd = d // heads
+    dqkv = torch.empty_like(qkv)
+    check(L.load().dh_attn_bwd(dt(qkv), ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), b, Lq, heads, hd, int(causal),
+                               stream()), "dh_attn_bwd")
+    return dqkv
+
+
+def text_embed_fwd(ids, table, pos, dtype):
+    b, Lq = ids.shape
+    d = table.shape[1]
+    x = torch.empty(b * Lq, d, device=table.device, dtype=dtype)
+    check(L.load().dh_text_embed_fwd(dt(x), ptr(ids), ptr(table), ptr(pos), ptr(x), b, Lq, d, stream()), "dh_text_embed_fwd")
+    return x
+
+
+def text_embed_bwd(ids, dx, dtable, dpos):
+    b, Lq = ids.shape
+    d = dx.shape[-1]
+    check(L.load().dh_text_embed_bwd(dt(dx), ptr(ids), ptr(dx), ptr(dtable), ptr(dpos), b, Lq, d, stream()), "dh_text_embed_bwd")
+
+
+def im2row(images, c0, patch, dtype):
+    _contig(images, "images")
+    assert images.dtype == torch.float32
+    b, ctot, H, W = images.shape
+    rows = torch.empty(b * (H // patch) * (W // patch), 3 * patch * patch, device=images.device, dtype=dtype)
+    check(L.load().dh_im2row(dt(rows), ptr(images), ctot, c0, ptr(rows), b, H, W, patch, stream()), "dh_im2row")
+    return rows
+
+
+def vit_assemble_fwd(patches, cls, pos, b, npatch):
+    d = patches.shape[-1]
+    x = torch.empty(b * (npatch + 1), d, device=patches.device, dtype=patches.dtype)
+    check(L.load().dh_vit_assemble_fwd(dt(x), ptr(patches), ptr(cls), ptr(pos), ptr(x), b, npatch, d, stream()), "dh_vit_assemble_fwd")
+    return x
+
+
+def vit_assemble_bwd(dx, dcls, dpos, b, npatch):
+    d = dx.shape[-1]
+    check(L.load().dh_vit_assemble_bwd(dt(dx), ptr(dx), ptr(dcls), ptr(dpos), b, npatch, d, stream()), "dh_vit_assemble_bwd")
+
+
+def pool_rows_fwd(x, idx, b, Lq):
+    d = x.shape[-1]
+    out = torch.empty(b, d, device=x.device, dtype=x.dtype)
+    check(L.load().dh_pool_rows_fwd(dt(x), ptr(x), ptr(idx), ptr(out), b, Lq, d, stream()), "dh_pool_rows_fwd")
+    return out
+
+
+def pool_rows_bwd(dout, idx, b, Lq):
+    d = dout.shape[-1]
+    dx = torch.empty(b * Lq, d, device=dout.device, dtype=dout.dtype)
+    check(L.load().dh_pool_rows_bwd(dt(dout), ptr(dout), ptr(idx), ptr(dx), b, Lq, d, stream()), "dh_pool_rows_bwd")
+    return dx
+
+
+def l2norm_fwd(x, eps):
+    _contig(x, "x")
+    rows, d = x.shape
+    y = torch.empty(rows, d, device=x.device, dtype=torch.float32)
+    norm = torch.empty(rows, device=x.device, dtype=torch.float32)
+    check(L.load().dh_l2norm_fwd(dt(x), ptr(x), ptr(y), ptr(norm), rows, d, eps, stream()), "dh_l2norm_fwd")
+    return y, norm
+
+
+def l2norm_bwd(x, norm, dy, eps):
+    rows, d = x.shape
+    dx = torch.empty_like(x)
+    check(L.load().dh_l2norm_bwd(dt(x), ptr(x), ptr(norm), ptr(_contig(dy, "dy")), ptr(dx), rows, d, eps, stream()), "dh_l2norm_bwd")
+    return dx
+
+
+def _pair_array(pairs):
+    arr = (NcePair * len(pairs))()
+    for i, p in enumerate(pairs):
+        arr[i].Q, arr[i].K = ptr(p[0]), ptr(p[1])
+        arr[i].dQ = ptr(p[2]) if len(p) > 2 else None
+        arr[i].dK = ptr(p[3]) if len(p) > 3 else None
+    return arr
+
+
+def infonce_fwd(pairs, scale, label0, want_logits=False):
+    """pairs: list of (Q[b,D], K[B,D]) fp32.  scale: 1-element fp32 device tensor.
+    Returns row_loss, row_lse, correct1, correct5 ([P,b] fp32) and optional logits [P,b,B]."""
+    Q0, K0 = pairs[0][0], pairs[0][1]
+    b, D = Q0.shape
+    B = K0.shape[0]
+    for q, k in pairs:
+        assert q.dtype == torch.float32 and k.dtype == torch.float32 and q.shape == (b, D) and k.shape == (B, D)
+        _contig(q, "Q"), _contig(k, "K")
+    P = len(pairs)
+    mk = lambda: torch.empty(P, b, device=Q0.device, dtype=torch.float32)
+    row_loss, row_lse, c1, c5 = mk(), mk(), mk(), mk()
+    logits = torch.empty(P, b, B, device=Q0.device, dtype=torch.float32) if want_logits else None
+    arr = _pair_array(pairs)
+    check(L.load().dh_infonce_fwd(arr, P, b, B, D, ptr(scale), int(label0), ptr(row_loss), ptr(row_lse), ptr(c1), ptr(c5),
+                                  ptr(logits), stream()), "dh_infonce_fwd")
+    return row_loss, row_lse, c1, c5, logits
+
+
+def infonce_bwd(pairs, scale, label0, row_lse, g_row):
+    """pairs: list of (Q, K); returns list of (dQ, dK) and dscale (1-element)."""
+    Q0, K0 = pairs[0]
+    b, D = Q0.shape
+    B = K0.shape[0]
+    outs = [(torch.empty_like(q), torch.empty_like(k)) for q, k in pairs]
+    dscale = torch.zeros(1, device=Q0.device, dtype=torch.float32)
+    arr = _pair_array([(q, k, dq, dk) for (q, k), (dq, dk) in zip(pairs, outs)])
+    check(L.load().dh_infonce_bwd(arr, len(pairs), b, B, D, ptr(scale), int(label0), ptr(_contig(row_lse, "lse")),
+                                  ptr(_contig(g_row, "g")), ptr(dscale), stream()), "dh_infonce_bwd")
+    return outs, dscale
+
+
+def ce_rows_fwd(logits, labels):
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1
+    rows, C = logits.shape
+    mk = lambda: torch.empty(rows, device=logits.device, dtype=torch.float32)
+    row_loss, row_lse, c1, c5 = mk(), mk(), mk(), mk()
+    check(L.load().dh_ce_rows_fwd(ptr(logits), logits.stride(0), ptr(labels), rows, C, ptr(row_loss), ptr(row_lse), ptr(c1),
+                                  ptr(c5), stream()), "dh_ce_rows_fwd")
+    return row_loss, row_lse, c1, c5
+
+
+def ce_rows_bwd(logits, labels, row_lse, g_row):
+    rows, C = logits.shape
+    dlogits = torch.empty(rows, C, device=logits.device, dtype=torch.float32)
+    check(L.load().dh_ce_rows_bwd(ptr(logits), logits.stride(0), ptr(labels), rows, C, ptr(row_lse), ptr(_contig(g_row, "g")),
+                                  ptr(dlogits), C, stream()), "dh_ce_rows_bwd")
+    return dlogits
+
+
+def adamw(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    n = p.numel()
+    check(L.load().dh_adamw(ptr(p), ptr(g), ptr(m), ptr(v), ptr(p_bf16), n, lr, beta1, beta2, eps, wd, step, grad_scale,
+                            stream()), "dh_adamw")
+
+
+def adamw_segmented(p, g, m, v, p_bf16, seg_start, seg_lr, seg_wd, beta1, beta2, eps, step, grad_scale=1.0):
+    """One launch over the whole flat buffer; per-segment (lr, wd) tables live on the device."""
+    n = p.numel()
+    check(L.load().dh_adamw_segmented(ptr(p), ptr(g), ptr(m), ptr(v), ptr(p_bf16), n, ptr(seg_start), ptr(seg_lr),
+                                      ptr(seg_wd), seg_start.numel(), beta1, beta2, eps, step, grad_scale, stream()),
+          "dh_adamw_segmented")
+
+
+def cast(src, dst):
+    assert src.numel() == dst.numel()
+    check(L.load().dh_cast(dt(src), ptr(src), dt(dst), ptr(dst), src.numel(), stream()), "dh_cast")
+    return dst

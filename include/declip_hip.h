@@ -1,0 +1,185 @@
+/* libdeclip_hip.so -- C-ABI of the MI355X (gfx950) contrastive-training hot path.
+ *
+ * The reference (Sense-GVT/DeCLIP) has NO native boundary: its hot path is eager
+ * PyTorch behind a Python plug-in surface (prototype/model/__init__.py:15-21,
+ * prototype/solver/clip_solver.py:413-566).  This header is the boundary a
+ * maintainer would bind instead (ctypes stub in INTEGRATION.md); every entry
+ * point cites the reference code whose arithmetic it replaces (paths relative
+ * to /root/reference/prototype unless noted).
+ *
+ * Conventions
+ *  - extern "C"; every function returns 0 (DH_OK) or a negative error code and
+ *    never throws; dh_last_error() returns a thread-local message.
+ *  - All pointers are BORROWED raw device pointers (row-major, contiguous unless a
+ *    leading dimension is given); the caller keeps them alive until the stream op
+ *    completes.  The library never allocates or frees tensor memory.
+ *  - Every function only ENQUEUES work on `stream` (a hipStream_t passed as void*);
+ *    nothing synchronises the device.
+ *  - dtype: DH_F32 = validation precision (parity <= 1e-3 vs the fp32 reference),
+ *    DH_BF16 = throughput precision (bf16 storage, MFMA bf16, fp32 accumulate,
+ *    fp32 statistics).  Parameters' gradients are always fp32.
+ */
+#ifndef DECLIP_HIP_H
+#define DECLIP_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DH_OK 0
+#define DH_ERR_ARG -1
+#define DH_ERR_LAUNCH -2
+#define DH_ERR_UNSUPPORTED -3
+
+#define DH_F32 0
+#define DH_BF16 1
+
+typedef void* dh_stream_t; /* hipStream_t */
+
+const char* dh_last_error(void);
+int dh_version(void);
+/* device properties the host needs for grid sizing: out[0]=CUs, out[1]=clock kHz, out[2]=LDS bytes/CU, out[3]=gfx arch number */
+int dh_device_info(int device, int* out4);
+
+/* ---------------------------------------------------------------- GEMM ------------------
+ * C[M,N] (+)= epi( alpha * sum_k A(m,k) * B(n,k) + bias[n] )
+ *   a_kmajor = 0: A stored [M][K] (lda)      1: A stored [K][M] (lda)
+ *   b_kmajor = 0: B stored [N][K] (ldb; the nn.Linear weight layout)   1: B stored [K][N] (ldb)
+ * Replaces every dense contraction of the towers: conv1 patch-embed
+ * (model/image_encoder/visual_transformer.py:14-15,56-59), MHA in/out projections and
+ * the MLP (base_transformer.py:33-41,45-53), `x @ proj` (visual_transformer.py:72-73),
+ * text_projection (text_encoder/text_transformer.py:203) and their autograd backward
+ * (dX: b_kmajor=1; dW: a_kmajor=b_kmajor=1 with accumulate).
+ * Epilogues:
+ *   DH_EPI_NONE
+ *   DH_EPI_GELU   aux_out[m,n] = pre-activation, C = QuickGELU(pre)   (base_transformer.py:24-26)
+ *   DH_EPI_DGELU  C = value * QuickGELU'(aux_in[m,n])                 (backward of the above)
+ *   residual != NULL: C += residual[m,n] (type c_dtype)               (base_transformer.py:51-52)
+ *   accumulate = 1: C is fp32 and is atomically accumulated into (split_k > 1 allowed).
+ */
+#define DH_EPI_NONE 0
+#define DH_EPI_GELU 1
+#define DH_EPI_DGELU 2
+
+typedef struct dh_gemm_args {
+  int dtype;   /* element type of A, B, aux (DGELU) */
+  int c_dtype; /* element type of C, residual, aux (GELU) */
+  int a_kmajor, b_kmajor;
+  int M, N, K;
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  void* C; int64_t ldc;
+  const float* bias;     /* [N] fp32 or NULL */
+  int epilogue;
+  const void* residual; int64_t ldr; /* or NULL */
+  void* aux; int64_t ldaux;          /* GELU: out, DGELU: in; or NULL */
+  int accumulate;
+  int split_k;           /* >=1; >1 requires accumulate */
+  float alpha;
+  int force_generic;     /* 1: use the non-MFMA kernel even for bf16 (tests) */
+} dh_gemm_args;
+int dh_gemm(const dh_gemm_args* args, dh_stream_t stream);
+
+/* out[n] (+)= sum_m X[m,n]  (fp32 out; bias gradients).  X: dtype, [M][N] with ldx. */
+int dh_colsum(int dtype, const void* X, int64_t ldx, int M, int N, float* out, int accumulate, dh_stream_t stream);
+
+/* ---------------------------------------------------------------- LayerNorm -------------
+ * base_transformer.py:10-18 (nn.LayerNorm, eps 1e-5): y = (x-mean)*rstd*w + b.
+ * mean/rstd [rows] fp32 are saved for backward.  w,b fp32.
+ * bwd: dx = LN'(dy) (+ dres if non-NULL: the residual-branch gradient, fused add);
+ *      dw[d], db[d] fp32 are ACCUMULATED into; ws: caller scratch of dh_layernorm_bwd_ws_bytes(). */
+int dh_layernorm_fwd(int dtype, const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                     int rows, int d, float eps, dh_stream_t stream);
+int64_t dh_layernorm_bwd_ws_bytes(int rows, int d);
+int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                     const void* dres, void* dx, float* dw, float* db, int rows, int d, void* ws, int64_t ws_bytes,
+                     dh_stream_t stream);
+
+/* ---------------------------------------------------------------- attention -------------
+ * nn.MultiheadAttention(x,x,x, attn_mask) core (base_transformer.py:33,45-48; causal mask
+ * text_encoder/text_transformer.py:136-142): per (batch, head)
+ *   P = softmax(q k^T / sqrt(hd) [+ causal -inf]);  o = P v.
+ * qkv: [b, L, 3*heads*hd] (q | k | v blocks, each heads*hd wide, head-major), out: [b, L, heads*hd],
+ * lse: [b, heads, L] fp32 (log-sum-exp of the scaled scores; saved for backward).
+ * hd must be 64 for DH_BF16 (MFMA path); L <= 128.
+ * bwd recomputes P from q,k,lse: dqkv [b, L, 3*heads*hd]. */
+int dh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, int b, int L, int heads, int hd, int causal,
+                dh_stream_t stream);
+int dh_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int b,
+                int L, int heads, int hd, int causal, dh_stream_t stream);
+
+/* ---------------------------------------------------------------- embeddings ------------
+ * Text: x[b,l,:] = table[ids[b,l],:] + pos[l,:]   (text_transformer.py:188-190); table/pos fp32.
+ * bwd: dtable (fp32, atomic accumulate) and dpos (fp32, atomic accumulate). */
+int dh_text_embed_fwd(int dtype, const int64_t* ids, const float* table, const float* pos, void* x, int b, int L, int d,
+                      dh_stream_t stream);
+int dh_text_embed_bwd(int dtype, const int64_t* ids, const void* dx, float* dtable, float* dpos, int b, int L, int d,
+                      dh_stream_t stream);
+/* Vision: im2row of the stride-P patch conv (visual_transformer.py:14-15,56-59):
+ * images [b,3,H,W] fp32 (channel offset c0 of C_total channels, for channel-stacked views,
+ * data/transforms.py:38-41) -> rows [b*gh*gw, 3*P*P] (dtype), inner order (c,ph,pw). */
+int dh_im2row(int dtype, const float* images, int c_total, int c0, void* rows, int b, int H, int W, int P,
+              dh_stream_t stream);
+/* x[b,0,:] = cls + pos[0]; x[b,1+p,:] = patches[b,p,:] + pos[1+p]  (visual_transformer.py:60-62) */
+int dh_vit_assemble_fwd(int dtype, const void* patches, const float* cls, const float* pos, void* x, int b, int np,
+                        int d, dh_stream_t stream);
+/* dcls[d] += sum_b dx[b,0,:]; dpos[1+np,d] += sum_b dx[b,:,:] (fp32 atomics) */
+int dh_vit_assemble_bwd(int dtype, const void* dx, float* dcls, float* dpos, int b, int np, int d, dh_stream_t stream);
+/* out[i,:] = x[i, idx[i], :] (idx NULL -> position 0): CLS / EOT pooling
+ * (visual_transformer.py:66; text_transformer.py:203).  bwd: dx zero-filled then scattered. */
+int dh_pool_rows_fwd(int dtype, const void* x, const int64_t* idx, void* out, int b, int L, int d, dh_stream_t stream);
+int dh_pool_rows_bwd(int dtype, const void* dout, const int64_t* idx, void* dx, int b, int L, int d, dh_stream_t stream);
+
+/* ---------------------------------------------------------------- features / loss -------
+ * y = x / (||x|| + eps) rows of [rows,d], x of `dtype`, y fp32 (model/clip.py:129-130: eps 0 image, 1e-10 text).
+ * bwd: dx (dtype) from dy (fp32). */
+int dh_l2norm_fwd(int dtype, const void* x, float* y, float* norm, int rows, int d, float eps, dh_stream_t stream);
+int dh_l2norm_bwd(int dtype, const void* x, const float* norm, const float* dy, void* dx, int rows, int d, float eps,
+                  dh_stream_t stream);
+
+/* Fused contrastive loss (model/clip.py:140-141 + loss_functions/loss.py:37-47 + utils/misc.py:415-428):
+ * for each pair p: logits = scale * Q_p[b,D] . K_p[B,D]^T is streamed tile by tile (never written to HBM),
+ * row-wise online log-sum-exp; label of local row i is label0 + i.
+ *   row_loss[p,i] = lse_i - logit_{i,label},  row_lse[p,i], correct1/correct5 [p,i] (0/1: top-1/top-5 hit)
+ * Q,K fp32 (normalised features); scale_dev points to ONE fp32 on the device (exp(logit_scale), clip.py:133-134)
+ * so the step needs no host sync.  logits_out (optional, may be NULL) [p,b,B] fp32 for the API surface.
+ * bwd: given g_row[p,i] = dLoss/d(row_loss[p,i]):
+ *   dQ_p[i,:]  = scale * sum_j g_i (softmax_ij - 1[j=label]) K_p[j,:]
+ *   dK_p[j,:] += scale * sum_i g_i (softmax_ij - 1[j=label]) Q_p[i,:]   (fp32 atomics; zero it first)
+ *   dscale    += sum_ij g_i (softmax_ij - 1[j=label]) <Q_i,K_j>         (fp32 atomic) */
+typedef struct dh_nce_pair {
+  const float* Q; const float* K;   /* [b,D], [B,D] */
+  float* dQ; float* dK;             /* bwd outputs (may be NULL in fwd) */
+} dh_nce_pair;
+int dh_infonce_fwd(const dh_nce_pair* pairs_host, int n_pairs, int b, int B, int D, const float* scale_dev, int label0,
+                   float* row_loss, float* row_lse, float* correct1, float* correct5, float* logits_out,
+                   dh_stream_t stream);
+int dh_infonce_bwd(const dh_nce_pair* pairs_host, int n_pairs, int b, int B, int D, const float* scale_dev, int label0,
+                   const float* row_lse, const float* g_row, float* dscale, dh_stream_t stream);
+
+/* Row-wise softmax cross-entropy on MATERIALISED fp32 logits [rows,C] (leading dim ld): the form
+ * loss_functions/loss.py:44-45 sees when handed tensors, and the MLM head CE (model/declip.py:326-334).
+ * Rows whose label is outside [0,C) (e.g. -100, mask_tokens.py:17) give loss 0 / zero gradient. */
+int dh_ce_rows_fwd(const float* logits, int64_t ld, const int64_t* labels, int rows, int C, float* row_loss,
+                   float* row_lse, float* correct1, float* correct5, dh_stream_t stream);
+int dh_ce_rows_bwd(const float* logits, int64_t ld, const int64_t* labels, int rows, int C, const float* row_lse,
+                   const float* g_row, float* dlogits, int64_t ldd, dh_stream_t stream);
+
+/* ---------------------------------------------------------------- optimizer / casts -----
+ * Fused flat AdamW over a contiguous fp32 range (torch.optim.AdamW semantics, the optimizer of
+ * experiments/clip_experiments/yfcc15m/yfcc15m_vit_clip/config.yaml:26-33), optionally refreshing the
+ * bf16 mirror of the parameters.  step >= 1. */
+int dh_adamw(float* p, const float* g, float* m, float* v, void* p_bf16_or_null, int64_t n, float lr, float beta1,
+             float beta2, float eps, float weight_decay, int step, float grad_scale, dh_stream_t stream);
+/* Same update with per-segment (lr, weight_decay): the parameter groups of utils/misc.py:267-412 laid out
+ * over the flat buffer; seg_start[nseg] ascending element offsets (multiples of 4) in DEVICE memory.
+ * Segments with lr == 0 and wd == 0 are left untouched (frozen parameters, alignment padding). */
+int dh_adamw_segmented(float* p, const float* g, float* m, float* v, void* p_bf16_or_null, int64_t n,
+                       const int64_t* seg_start_dev, const float* seg_lr_dev, const float* seg_wd_dev, int nseg,
+                       float beta1, float beta2, float eps, int step, float grad_scale, dh_stream_t stream);
+int dh_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, dh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,9 @@
+"""Model registry (reference: prototype/model/__init__.py:15-21)."""
+from declip_amd.model.clip import clip_vitb16, clip_vitb32  # noqa: F401
+
+
+def model_entry(config):
+    if config["type"] not in globals():
+        from prototype.spring import PrototypeHelper
+        return PrototypeHelper.external_model_builder[config["type"]](**config["kwargs"])
+    return globals()[config["type"]](**config["kwargs"])

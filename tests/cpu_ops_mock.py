@@ -1,0 +1,228 @@
+"""TEST INFRASTRUCTURE: torch-CPU stand-ins for declip_amd.ops with identical call semantics.
+
+Injected by tests/test_engine_cpu_mock.py ONLY, to exercise the host-side engine (flat parameter
+store, block forward/backward composition, autograd plumbing, optimizer tables) without a GPU.
+The product never imports this file and has no switch to reach it."""
+import torch
+import torch.nn.functional as F
+
+from declip_amd.lib import EPI_DGELU, EPI_GELU, EPI_NONE
+
+
+def _gelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+def _dgelu(x):
+    s = torch.sigmoid(1.702 * x)
+    return s * (1 + 1.702 * x * (1 - s))
+
+
+def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, residual=None, aux=None, out=None,
+         out_dtype=None, accumulate=False, split_k=1, alpha=1.0, force_generic=False):
+    a = A.float().t() if a_kmajor else A.float()
+    b = B.float() if b_kmajor else B.float().t()
+    v = alpha * (a @ b)
+    if accumulate:
+        out += v
+        return out
+    if bias is not None:
+        v = v + bias
+    if epilogue == EPI_GELU:
+        if aux is not None:
+            aux.copy_(v)
+        v = _gelu(v)
+    elif epilogue == EPI_DGELU:
+        v = v * _dgelu(aux.float())
+    if residual is not None:
+        v = v + residual.float()
+    if out is None:
+        return v.to(out_dtype or A.dtype)
+    out.copy_(v)
+    return out
+
+
+def colsum(X, out, accumulate=True):
+    s = X.float().sum(0)
+    if accumulate:
+        out += s
+    else:
+        out.copy_(s)
+    return out
+
+
+def layernorm_fwd(x, w, b, eps=1e-5, save_stats=True):
+    xf = x.float()
+    mean = xf.mean(-1)
+    var = ((xf - mean[:, None]) ** 2).mean(-1)
+    rstd = torch.rsqrt(var + eps)
+    y = (xf - mean[:, None]) * rstd[:, None] * w + b
+    return y.to(x.dtype), mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None):
+    xh = (x.float() - mean[:, None]) * rstd[:, None]
+    g = dy.float() * w
+    dx = rstd[:, None] * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))
+    if dres is not None:
+        dx = dx + dres.float()
+    dw += (dy.float() * xh).sum(0)
+    db += dy.float().sum(0)
+    return dx.to(x.dtype)
+
+
+def _attn(qkv, b, L, heads, causal):
+    d = qkv.shape[-1] // 3
+    hd = d // heads
+    q, k, v = qkv.float().view(b, L, 3 * d).split(d, -1)
+    q = q.reshape(b, L, heads, hd).transpose(1, 2) * hd ** -0.5
+    k = k.reshape(b, L, heads, hd).transpose(1, 2)
+    v = v.reshape(b, L, heads, hd).transpose(1, 2)
+    s = q @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    p = torch.softmax(s, -1)
+    return (p @ v).transpose(1, 2).reshape(b * L, d), torch.logsumexp(s, -1)
+
+
+def attn_fwd(qkv, b, Lq, heads, causal):
+    out, lse = _attn(qkv, b, Lq, heads, causal)
+    return out.to(qkv.dtype), lse
+
+
+def attn_bwd(qkv, out, dout, lse, b, Lq, heads, causal):
+    q = qkv.detach().float().requires_grad_(True)
+    with torch.enable_grad():
+        o, _ = _attn(q, b, Lq, heads, causal)
+        o.backward(dout.float())
+    return q.grad.to(qkv.dtype)
+
+
+def text_embed_fwd(ids, table, pos, dtype):
+    b, L = ids.shape
+    return (table[ids] + pos).reshape(b * L, -1).to(dtype)
+
+
+def text_embed_bwd(ids, dx, dtable, dpos):
+    b, L = ids.shape
+    if dtable is not None:
+        dtable.index_add_(0, ids.reshape(-1), dx.float())
+    if dpos is not None:
+        dpos += dx.float().view(b, L, -1).sum(0)
+
+
+def im2row(images, c0, patch, dtype):
+    x = images[:, c0:c0 + 3]
+    b, c, H, W = x.shape
+    gh, gw = H // patch, W // patch
+    x = x.reshape(b, c, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5)
+    return x.reshape(b * gh * gw, c * patch * patch).to(dtype)
+
+
+def vit_assemble_fwd(patches, cls, pos, b, npatch):
+    d = patches.shape[-1]
+    x = torch.cat([cls.expand(b, 1, d), patches.float().view(b, npatch, d)], 1) + pos
+    return x.reshape(b * (npatch + 1), d).to(patches.dtype)
+
+
+def vit_assemble_bwd(dx, dcls, dpos, b, npatch):
+    d = dx.shape[-1]
+    g = dx.float().view(b, npatch + 1, d)
+    dpos += g.sum(0)
+    if dcls is not None:
+        dcls += g[:, 0].sum(0)
+
+
+def pool_rows_fwd(x, idx, b, Lq):
+    xv = x.view(b, Lq, -1)
+    i = idx if idx is not None else torch.zeros(b, dtype=torch.long)
+    return xv[torch.arange(b), i].contiguous()
+
+
+def pool_rows_bwd(dout, idx, b, Lq):
+    dx = torch.zeros(b, Lq, dout.shape[-1], dtype=dout.dtype)
+    i = idx if idx is not None else torch.zeros(b, dtype=torch.long)
+    dx[torch.arange(b), i] = dout
+    return dx.view(b * Lq, -1)
+
+
+def l2norm_fwd(x, eps):
+    n = x.float().norm(dim=-1)
+    return x.float() / (n[:, None] + eps), n
+
+
+def l2norm_bwd(x, norm, dy, eps):
+    xf = x.float()
+    inv = 1 / (norm + eps)
+    s = (dy * xf).sum(-1)
+    return (dy * inv[:, None] - xf * (s * inv * inv / norm.clamp_min(1e-30))[:, None]).to(x.dtype)
+
+
+def infonce_fwd(pairs, scale, label0, want_logits=False):
+    rl, lse, c1, c5, lg = [], [], [], [], []
+    for q, k in pairs:
+        logits = scale * q @ k.t()
+        labels = label0 + torch.arange(q.shape[0])
+        l = torch.logsumexp(logits, -1)
+        ll = logits[torch.arange(q.shape[0]), labels]
+        cnt = ((logits > ll[:, None]) & (torch.arange(k.shape[0])[None, :] != labels[:, None])).sum(-1)
+        rl.append(l - ll), lse.append(l), c1.append((cnt < 1).float()), c5.append((cnt < 5).float()), lg.append(logits)
+    return torch.stack(rl), torch.stack(lse), torch.stack(c1), torch.stack(c5), (torch.stack(lg) if want_logits else None)
+
+
+def infonce_bwd(pairs, scale, label0, row_lse, g_row):
+    outs, dscale = [], torch.zeros(1)
+    for p, (q, k) in enumerate(pairs):
+        dots = q @ k.t()
+        P = torch.exp(scale * dots - row_lse[p][:, None])
+        labels = label0 + torch.arange(q.shape[0])
+        P[torch.arange(q.shape[0]), labels] -= 1
+        G = P * g_row[p][:, None]
+        outs.append((scale * G @ k, scale * G.t() @ q))
+        dscale += (G * dots).sum()
+    return outs, dscale
+
+
+def ce_rows_fwd(logits, labels):
+    l = torch.logsumexp(logits, -1)
+    valid = labels >= 0
+    safe = labels.clamp_min(0)
+    ll = logits[torch.arange(logits.shape[0]), safe]
+    cnt = ((logits > ll[:, None]) & (torch.arange(logits.shape[1])[None, :] != safe[:, None])).sum(-1)
+    return torch.where(valid, l - ll, torch.zeros_like(l)), l, ((cnt < 1) & valid).float(), ((cnt < 5) & valid).float()
+
+
+def ce_rows_bwd(logits, labels, row_lse, g_row):
+    valid = labels >= 0
+    P = torch.exp(logits - row_lse[:, None])
+    P[torch.arange(logits.shape[0])[valid], labels[valid]] -= 1
+    return P * (g_row * valid)[:, None]
+
+
+def adamw(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    g = g * grad_scale
+    p.mul_(1 - lr * wd)
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    p.addcdiv_(m, v.sqrt() / bc2 ** 0.5 + eps, value=-lr / bc1)
+    if p_bf16 is not None:
+        p_bf16.copy_(p)
+
+
+def cast(src, dst):
+    dst.copy_(src.view(dst.shape))
+    return dst
+
+
+def adamw_segmented(p, g, m, v, p_bf16, seg_start, seg_lr, seg_wd, beta1, beta2, eps, step, grad_scale=1.0):
+    n = p.numel()
+    starts = seg_start.tolist() + [n]
+    for i in range(len(starts) - 1):
+        lo, hi = starts[i], starts[i + 1]
+        lr, wd = float(seg_lr[i]), float(seg_wd[i])
+        if lr == 0.0 and wd == 0.0:
+            continue
+        adamw(p[lo:hi], g[lo:hi], m[lo:hi], v[lo:hi], None, lr, beta1, beta2, eps, wd, step, grad_scale)
+    if p_bf16 is not None:
+        p_bf16.copy_(p)

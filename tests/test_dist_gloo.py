@@ -1,0 +1,111 @@
+"""World-size-2 tests on CPU (gloo): the packed all-gather / reduce-scatter autograd, the flat bucket
+reducer, and the whole data-parallel CLIP step (engine host logic with mocked kernels) against the
+golden produced by TWO reference ranks (tests/golden/clip_tiny_w2.pt)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _w_gather(rank, world, port, out):
+    _init(rank, world, port)
+    from declip_amd import dist as dd
+    torch.manual_seed(rank)
+    a = torch.randn(3, 8, requires_grad=True)
+    b = torch.randn(3, 4, requires_grad=True)
+    ga, gb = dd.all_gather_cat_many([a, b])
+    assert ga.shape == (3 * world, 8) and gb.shape == (3 * world, 4)
+    # every rank weights the gathered rows differently (like the local-rows x global-cols logits)
+    wa = torch.arange(ga.numel(), dtype=torch.float32).view_as(ga) * (rank + 1)
+    wb = torch.ones_like(gb) * (rank + 2)
+    ((ga * wa).sum() + (gb * wb).sum()).backward()
+    # expected (reference AllGather.backward, clip.py:43-49): sum over ranks of the slice belonging to me
+    exp_a = sum(torch.arange(ga.numel(), dtype=torch.float32).view_as(ga)[rank * 3:(rank + 1) * 3] * (r + 1) for r in range(world))
+    exp_b = sum(torch.ones(3, 4) * (r + 2) for r in range(world))
+    assert torch.allclose(a.grad, exp_a) and torch.allclose(b.grad, exp_b)
+    # forward content
+    torch.manual_seed(0)
+    a0 = torch.randn(3, 8)
+    assert torch.allclose(ga[0:3].detach(), a0)
+    if rank == 0:
+        out.put("ok")
+
+
+def _w_reducer(rank, world, port, out):
+    _init(rank, world, port)
+    from declip_amd import dist as dd
+
+    class Flat:
+        total = 1000
+        flat_g = torch.full((1000,), float(rank + 1))
+    red = dd.FlatReducer(Flat, bucket_bytes=4 * 200)
+    red.begin()
+    red.ready(800, 1000)
+    red.ready(600, 790)      # contiguous up to alignment slack -> coalesced
+    red.ready(100, 300)      # disjoint -> separate launch
+    red.finish()             # tail: everything else
+    assert torch.allclose(Flat.flat_g, torch.full((1000,), float(sum(range(1, world + 1)))))
+    if rank == 0:
+        out.put("ok")
+
+
+def _w_clip(rank, world, port, out):
+    _init(rank, world, port)
+    import cpu_ops_mock
+    from declip_amd import dist as dd
+    from declip_amd import engine, ops, synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.testing import build_clip
+    from oracle_util import check_grad_digests, load_golden
+    for name in dir(cpu_ops_mock):
+        if not name.startswith("_") and callable(getattr(cpu_ops_mock, name)) and hasattr(ops, name):
+            setattr(ops, name, getattr(cpu_ops_mock, name))
+    engine._require_gpu = lambda p, name: None
+    g = load_golden("clip_tiny_w2")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_clip(cfg, dtype="fp32", use_allgather=True, seed=seed, device="cpu")
+    wrapped = dd.DistModule(model, sync=False, bucket_bytes=1 << 16)
+    B = b * world
+    images = synth.synth_images(B, res=cfg["res"], seed=seed)[rank * b:(rank + 1) * b]
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])[rank * b:(rank + 1) * b]
+    crit = ClipInfoCELoss()
+    li, lt = wrapped({"images": images, "captions": ids})
+    assert li.shape == (b, B)
+    loss, labels = crit(li, lt)
+    assert labels.tolist() == list(range(rank * b, (rank + 1) * b))
+    loss = loss / world
+    loss.backward()
+    wrapped.sync_gradients()
+    total = loss.detach().clone()
+    torch.distributed.all_reduce(total)
+    if rank == 0:
+        assert abs(float(total) - g["loss"]) <= 1e-4 * abs(g["loss"])
+        assert float((li.materialize().detach() - g["logits_i"]).abs().max()) <= 1e-4 * float(g["logits_i"].abs().max())
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+        check_grad_digests(g["grads"], grads, rtol=5e-4)
+        out.put("ok")
+
+
+@pytest.mark.parametrize("fn,port", [(_w_gather, 29611), (_w_reducer, 29612), (_w_clip, 29613)])
+def test_world2(fn, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=fn, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get() == "ok"

@@ -1,0 +1,140 @@
+"""Host-side engine logic on CPU: declip_amd.ops is replaced by torch-CPU stand-ins (tests/cpu_ops_mock.py)
+so that the flat parameter store, the block forward/backward composition and the autograd plumbing can be
+checked against the golden fixtures without a GPU.  (The HIP kernels themselves are checked by the -m gpu
+tests; this file never claims kernel parity.)"""
+import pytest
+import torch
+
+import cpu_ops_mock
+from oracle_util import check_grad_digests, load_golden
+
+
+@pytest.fixture()
+def mocked_engine(monkeypatch):
+    from declip_amd import engine, ops
+    for name in dir(cpu_ops_mock):
+        if not name.startswith("_") and callable(getattr(cpu_ops_mock, name)) and hasattr(ops, name):
+            monkeypatch.setattr(ops, name, getattr(cpu_ops_mock, name))
+    monkeypatch.setattr(engine, "_require_gpu", lambda p, name: None)
+    return engine
+
+
+def _run(cfg, b, seed, logit_scale, dtype, fused=True):
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss, accuracy
+    from declip_amd.testing import build_clip
+    model = build_clip(cfg, dtype=dtype, seed=seed, logit_scale=logit_scale, fused_loss=fused, device="cpu")
+    images = synth.synth_images(b, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
+    crit = ClipInfoCELoss()
+    li, lt = model({"images": images, "captions": ids})
+    loss, labels = crit(li, lt)
+    p1, p5 = accuracy(li, labels, topk=(1, 5), criterion=crit)
+    loss.backward()
+    grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+    return model, float(loss), li, lt, grads, float(p1), float(p5)
+
+
+@pytest.mark.parametrize("name", ["clip_tiny", "clip_tiny_scale5"])
+def test_engine_composition_matches_golden(mocked_engine, name):
+    g = load_golden(name)
+    model, loss, li, lt, grads, p1, p5 = _run(g["cfg"], g["b"], g["seed"], g["logit_scale"], "fp32")
+    assert abs(loss - g["loss"]) <= 1e-4 * abs(g["loss"])
+    assert float((li.materialize().detach() - g["logits_i"]).abs().max()) <= 1e-4 * float(g["logits_i"].abs().max())
+    check_grad_digests(g["grads"], grads, rtol=5e-4)
+    # conv1 is frozen (visual_transformer.py:45-51): no gradient
+    assert grads["visual.conv1.weight"] is None or float(grads["visual.conv1.weight"].abs().max()) == 0.0
+
+
+def test_flat_store_layout_and_grad_views(mocked_engine):
+    g = load_golden("clip_tiny")
+    model, loss, li, lt, grads, _, _ = _run(g["cfg"], g["b"], g["seed"], None, "fp32")
+    flat = model._flat_store
+    assert flat.attached()
+    for p in flat.params:
+        o, n = flat.index[id(p)]
+        assert o % 64 == 0 and p.data_ptr() == flat.flat_p.data_ptr() + 4 * o
+        if p.requires_grad:
+            assert p.grad.data_ptr() == flat.flat_g.data_ptr() + 4 * o
+    # state_dict keys are the reference's
+    keys = set(model.state_dict().keys())
+    for k in ("logit_scale", "visual.class_embedding", "visual.proj", "visual.conv1.weight",
+              "visual.transformer.resblocks.0.attn.in_proj_weight", "visual.transformer.resblocks.1.mlp.c_proj.bias",
+              "encode_text.token_embedding.weight", "encode_text.text_projection.bias", "encode_text.ln_final.weight"):
+        assert k in keys, k
+
+
+def test_unfused_surface_equals_fused(mocked_engine):
+    g = load_golden("clip_tiny")
+    _, la, _, _, ga, a1, a5 = _run(g["cfg"], g["b"], g["seed"], None, "fp32", fused=True)
+    _, lb, li, lt, gb, b1, b5 = _run(g["cfg"], g["b"], g["seed"], None, "fp32", fused=False)
+    assert torch.is_tensor(li) and li.shape == (g["b"], g["b"])
+    assert abs(la - lb) < 1e-5 and a1 == b1 and a5 == b5
+    for n in ga:
+        if ga[n] is not None:
+            assert float((ga[n] - gb[n]).abs().max()) <= 1e-4 * float(ga[n].abs().max() + 1e-12), n
+
+
+def test_second_backward_accumulates_unless_zeroed(mocked_engine):
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.testing import build_clip
+    cfg = synth.TINY
+    model = build_clip(cfg, dtype="fp32", seed=0, device="cpu")
+    images, ids = synth.synth_images(4, res=cfg["res"]), synth.synth_tokens(4, ctx=cfg["ctx"])
+    crit = ClipInfoCELoss()
+
+    def fb():
+        li, lt = model({"images": images, "captions": ids})
+        crit(li, lt)[0].backward()
+    fb()
+    g1 = model.visual.proj.grad.clone()
+    fb()                                    # no zero_grad: accumulate (torch semantics)
+    assert torch.allclose(model.visual.proj.grad, 2 * g1, rtol=1e-5, atol=1e-7)
+    for p in model.parameters():
+        p.grad = None                       # optimizer.zero_grad(set_to_none=True)
+    fb()
+    assert torch.allclose(model.visual.proj.grad, g1, rtol=1e-5, atol=1e-7)
+
+
+def test_flat_adamw_tables_match_torch_adamw(mocked_engine):
+    """3 steps: engine (mock kernels) + FlatAdamW segment tables vs CPU restatement + torch.optim.AdamW."""
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.optim import build_adamw
+    from declip_amd.testing import build_clip
+    from oracle import restated
+    cfg, b, seed = synth.TINY, 4, 11
+    model = build_clip(cfg, dtype="fp32", seed=seed, device="cpu")
+    opt = build_adamw(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
+    crit = ClipInfoCELoss()
+    sd = synth.synth_state(synth.clip_shapes(cfg), seed=seed)
+    decay = {n for n, p in model.named_parameters() if p.dim() > 1 and "logit_scale" not in n and not n.endswith("bias")}
+    for k, v in sd.items():
+        v.requires_grad_(k != "visual.conv1.weight")
+    train = [k for k in sd if k != "visual.conv1.weight"]
+    ref_opt = torch.optim.AdamW([dict(params=[sd[k] for k in train if k in decay], weight_decay=0.1),
+                                 dict(params=[sd[k] for k in train if k not in decay], weight_decay=0.0)],
+                                lr=1e-3, betas=(0.9, 0.98), eps=1e-8)
+    for step in range(3):
+        images = synth.synth_images(b, res=cfg["res"], seed=seed + step)
+        ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed + step, vocab=cfg["vocab"])
+        opt.zero_grad()
+        li, lt = model({"images": images, "captions": ids})
+        loss, _ = crit(li, lt)
+        loss.backward()
+        opt.step()
+        ref_opt.zero_grad()
+        total, _, _, _ = restated.clip_step_loss(images, ids, sd, cfg, 1)
+        total.backward()
+        ref_opt.step()
+        assert abs(float(loss) - float(total)) <= 1e-4 * abs(float(total))
+    got = dict(model.named_parameters())
+    for k in train:
+        a, r = got[k].detach().cpu(), sd[k].detach()
+        # Adam turns rounding noise on (near-)zero gradients into +-lr steps (e.g. the key bias, whose true
+        # gradient is exactly 0): bound every element by Adam's max step and require the bulk to agree tightly.
+        diff = (a - r).abs()
+        assert float(diff.max()) <= 3 * 1e-3 * 3 + 1e-4 * float(r.abs().max()), k
+        assert float((diff > 1e-4 * float(r.abs().max() + 1e-12)).float().mean()) <= 0.02 or k.endswith("in_proj_bias"), k
+    assert torch.equal(got["visual.conv1.weight"].detach(), synth.synth_state(synth.clip_shapes(cfg), seed=seed)["visual.conv1.weight"])

@@ -1,0 +1,292 @@
+"""Kernel-level parity: every C-ABI entry point against a plain fp32/fp64 torch CPU reference of
+the same op (for floating-point kernels the torch reference is the checker, see oracle/__init__)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+cuda = torch.device("cuda")
+
+
+def _ops():
+    from declip_amd import ops
+    return ops
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def rnd(*shape, seed=0, dtype=torch.float32, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def quick_gelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+def quick_gelu_grad(x):
+    s = torch.sigmoid(1.702 * x)
+    return s * (1 + 1.702 * x * (1 - s))
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype,generic", [(torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)])
+@pytest.mark.parametrize("a_km,b_km", [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K", [(200, 136, 192), (128, 128, 64), (400, 768, 256), (37, 264, 520)])
+def test_gemm_layouts(dtype, generic, a_km, b_km, M, N, K):
+    ops = _ops()
+    A = rnd(M, K, seed=1).to(dtype)
+    B = rnd(N, K, seed=2).to(dtype)
+    ref = A.double() @ B.double().t()
+    Ad = (A.t().contiguous() if a_km else A).to(cuda)
+    Bd = (B.t().contiguous() if b_km else B).to(cuda)
+    out = ops.gemm(Ad, Bd, a_kmajor=a_km, b_kmajor=b_km, out_dtype=torch.float32, force_generic=generic)
+    tol = 2e-5 if dtype == torch.float32 else 2e-3  # bf16 inputs are exact in the reference; fp32 accumulate
+    assert rel_err(out, ref) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(dtype):
+    ops = _ops()
+    from declip_amd.lib import EPI_DGELU, EPI_GELU
+    M, N, K = 264, 384, 128
+    A, B = rnd(M, K, seed=3).to(dtype), rnd(N, K, seed=4, scale=0.1).to(dtype)
+    bias = rnd(N, seed=5)
+    R = rnd(M, N, seed=6).to(dtype)
+    pre = A.double() @ B.double().t() + bias.double()
+    tol = 1e-4 if dtype == torch.float32 else 1.5e-2
+    # bias + residual
+    out = ops.gemm(A.to(cuda), B.to(cuda), bias=bias.to(cuda), residual=R.to(cuda))
+    assert rel_err(out, pre + R.double()) < tol
+    # GELU epilogue with pre-activation side output
+    aux = torch.empty(M, N, device=cuda, dtype=dtype)
+    out = ops.gemm(A.to(cuda), B.to(cuda), bias=bias.to(cuda), epilogue=EPI_GELU, aux=aux)
+    assert rel_err(aux, pre) < tol
+    assert rel_err(out, quick_gelu(pre)) < tol
+    # DGELU epilogue
+    U = rnd(M, N, seed=7).to(dtype)
+    out = ops.gemm(A.to(cuda), B.to(cuda), epilogue=EPI_DGELU, aux=U.to(cuda))
+    assert rel_err(out, (A.double() @ B.double().t()) * quick_gelu_grad(U.double())) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_weight_grad_accumulate_splitk(dtype):
+    ops = _ops()
+    rows, out_f, in_f = 1000, 256, 136
+    dY, X = rnd(rows, out_f, seed=8).to(dtype), rnd(rows, in_f, seed=9).to(dtype)
+    G0 = rnd(out_f, in_f, seed=10)
+    gw = G0.clone().to(cuda)
+    ops.gemm(dY.to(cuda), X.to(cuda), a_kmajor=True, b_kmajor=True, out=gw, accumulate=True, split_k=4)
+    ref = G0.double() + dY.double().t() @ X.double()
+    assert rel_err(gw, ref) < (1e-5 if dtype == torch.float32 else 2e-3)
+
+
+def test_colsum():
+    ops = _ops()
+    for dtype in (torch.float32, torch.bfloat16):
+        X = rnd(1234, 200, seed=11).to(dtype)
+        out = torch.ones(200, device=cuda)
+        ops.colsum(X.to(cuda), out, accumulate=True)
+        assert rel_err(out, 1 + X.double().sum(0)) < 1e-4
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,d", [(50, 768), (77, 512), (13, 128), (9, 100)])
+def test_layernorm(dtype, rows, d):
+    ops = _ops()
+    x = rnd(rows, d, seed=12).to(dtype)
+    w, b = 1 + 0.1 * rnd(d, seed=13), 0.1 * rnd(d, seed=14)
+    dy, dres = rnd(rows, d, seed=15).to(dtype), rnd(rows, d, seed=16).to(dtype)
+    xr = x.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-5)
+    yr.backward(dy.double())
+    y, mean, rstd = ops.layernorm_fwd(x.to(cuda), w.to(cuda), b.to(cuda))
+    tol = 1e-4 if dtype == torch.float32 else 1.5e-2
+    assert rel_err(y, yr.detach()) < tol
+    dw, db = torch.zeros(d, device=cuda), torch.zeros(d, device=cuda)
+    dx = ops.layernorm_bwd(dy.to(cuda), x.to(cuda), w.to(cuda), mean, rstd, dw, db, dres=dres.to(cuda))
+    assert rel_err(dx, xr.grad + dres.double()) < tol
+    assert rel_err(dw, wr.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert rel_err(db, br.grad) < 1e-4
+
+
+# ----------------------------------------------------------------------------- attention
+def attn_ref(qkv, heads, causal):
+    b, L, d3 = qkv.shape
+    d = d3 // 3
+    hd = d // heads
+    q, k, v = qkv.split(d, dim=-1)
+    q = q.reshape(b, L, heads, hd).transpose(1, 2) * hd ** -0.5
+    k = k.reshape(b, L, heads, hd).transpose(1, 2)
+    v = v.reshape(b, L, heads, hd).transpose(1, 2)
+    s = q @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), dtype=s.dtype).triu_(1)
+    p = torch.softmax(s, -1)
+    return (p @ v).transpose(1, 2).reshape(b, L, d), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("b,L,heads,causal", [(3, 50, 12, False), (2, 77, 8, True), (2, 5, 2, False), (1, 16, 2, True), (2, 33, 1, True)])
+def test_attention(dtype, b, L, heads, causal):
+    ops = _ops()
+    d = heads * 64
+    qkv = rnd(b, L, 3 * d, seed=17).to(dtype)
+    dout = rnd(b, L, d, seed=18).to(dtype)
+    qr = qkv.double().requires_grad_(True)
+    out_r, lse_r = attn_ref(qr, heads, causal)
+    out_r.backward(dout.double())
+    out, lse = ops.attn_fwd(qkv.to(cuda).view(b * L, 3 * d), b, L, heads, causal)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert rel_err(out.view(b, L, d), out_r.detach()) < tol
+    assert rel_err(lse, lse_r.detach()) < (1e-5 if dtype == torch.float32 else 5e-3)
+    dqkv = ops.attn_bwd(qkv.to(cuda).view(b * L, 3 * d), out, dout.to(cuda).view(b * L, d), lse, b, L, heads, causal)
+    assert rel_err(dqkv.view(b, L, 3 * d), qr.grad) < (2e-4 if dtype == torch.float32 else 3e-2)
+
+
+# ----------------------------------------------------------------------------- embeddings / pooling
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_text_embed(dtype):
+    ops = _ops()
+    b, L, d, V = 5, 16, 128, 1000
+    g = torch.Generator().manual_seed(19)
+    ids = torch.randint(0, V, (b, L), generator=g)
+    ids[:, 3] = ids[0, 3]                                   # repeated ids exercise the scatter-add
+    table, pos = rnd(V, d, seed=20), rnd(L, d, seed=21)
+    x = ops.text_embed_fwd(ids.to(cuda), table.to(cuda), pos.to(cuda), dtype)
+    ref = table[ids] + pos
+    assert rel_err(x.view(b, L, d), ref) < (1e-6 if dtype == torch.float32 else 1e-2)
+    dx = rnd(b * L, d, seed=22).to(dtype)
+    dt, dp = torch.zeros(V, d, device=cuda), torch.zeros(L, d, device=cuda)
+    ops.text_embed_bwd(ids.to(cuda), dx.to(cuda), dt, dp)
+    rt = torch.zeros(V, d, dtype=torch.float64).index_add_(0, ids.reshape(-1), dx.double())
+    assert rel_err(dt, rt) < 1e-5
+    assert rel_err(dp, dx.double().view(b, L, d).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vision_embed(dtype):
+    ops = _ops()
+    from oracle import restated
+    b, P, res, d = 3, 32, 96, 128
+    images = rnd(b, 6, res, res, seed=23)
+    rows = ops.im2row(images.to(cuda), 3, P, dtype)                       # second channel-stacked view
+    ref = restated.patchify(images[:, 3:6], P).reshape(-1, 3 * P * P)
+    assert rel_err(rows, ref) < (1e-7 if dtype == torch.float32 else 1e-2)
+    npatch = (res // P) ** 2
+    patches, cls, pos = rnd(b * npatch, d, seed=24).to(dtype), rnd(d, seed=25), rnd(npatch + 1, d, seed=26)
+    x = ops.vit_assemble_fwd(patches.to(cuda), cls.to(cuda), pos.to(cuda), b, npatch)
+    refx = torch.cat([cls.expand(b, 1, d), patches.float().view(b, npatch, d)], 1) + pos
+    assert rel_err(x.view(b, npatch + 1, d), refx) < (1e-6 if dtype == torch.float32 else 1e-2)
+    dx = rnd(b * (npatch + 1), d, seed=27).to(dtype)
+    dcls, dpos = torch.zeros(d, device=cuda), torch.zeros(npatch + 1, d, device=cuda)
+    ops.vit_assemble_bwd(dx.to(cuda), dcls, dpos, b, npatch)
+    dxr = dx.double().view(b, npatch + 1, d)
+    assert rel_err(dpos, dxr.sum(0)) < 1e-5 and rel_err(dcls, dxr[:, 0].sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pool_and_l2norm(dtype):
+    ops = _ops()
+    b, L, d = 6, 16, 128
+    x = rnd(b * L, d, seed=28).to(dtype)
+    idx = torch.tensor([0, 3, 15, 7, 7, 1])
+    out = ops.pool_rows_fwd(x.to(cuda), idx.to(cuda), b, L)
+    assert torch.equal(out.cpu(), x.view(b, L, d)[torch.arange(b), idx])
+    out0 = ops.pool_rows_fwd(x.to(cuda), None, b, L)
+    assert torch.equal(out0.cpu(), x.view(b, L, d)[:, 0])
+    dx = ops.pool_rows_bwd(out, idx.to(cuda), b, L).view(b, L, d).cpu()
+    ref = torch.zeros(b, L, d, dtype=dtype)
+    ref[torch.arange(b), idx] = out.cpu()
+    assert torch.equal(dx, ref)
+    for eps in (0.0, 1e-10):
+        f = rnd(b, d, seed=29).to(dtype)
+        fr = f.double().requires_grad_(True)
+        yr = fr / (fr.norm(dim=-1, keepdim=True) + eps)
+        dy = rnd(b, d, seed=30)
+        yr.backward(dy.double())
+        y, norm = ops.l2norm_fwd(f.to(cuda), eps)
+        assert rel_err(y, yr.detach()) < 1e-5
+        dxn = ops.l2norm_bwd(f.to(cuda), norm, dy.to(cuda), eps)
+        assert rel_err(dxn, fr.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+
+
+# ----------------------------------------------------------------------------- losses
+@pytest.mark.parametrize("b,B,D,label0", [(8, 8, 64, 0), (40, 120, 512, 40), (70, 70, 256, 0), (33, 99, 768, 66)])
+def test_infonce(b, B, D, label0):
+    ops = _ops()
+    P = 2
+    scale = torch.tensor([14.3])
+    pairs, refs = [], []
+    for p in range(P):
+        Q = torch.nn.functional.normalize(rnd(b, D, seed=31 + p), dim=-1)
+        K = torch.nn.functional.normalize(rnd(B, D, seed=41 + p), dim=-1)
+        K[label0:label0 + b] += 0.5 * Q
+        K = torch.nn.functional.normalize(K, dim=-1)
+        pairs.append((Q, K))
+    labels = label0 + torch.arange(b)
+    gq = [(q.double().requires_grad_(True), k.double().requires_grad_(True)) for q, k in pairs]
+    sr = scale.double().requires_grad_(True)
+    g_row = rnd(P, b, seed=50).abs()
+    losses, c1r, c5r, logits_r = [], [], [], []
+    for (q, k) in gq:
+        lg = sr * q @ k.t()
+        logits_r.append(lg.detach())
+        losses.append(torch.nn.functional.cross_entropy(lg, labels, reduction="none"))
+        top = lg.topk(min(5, B), 1)[1]
+        c1r.append((top[:, 0] == labels).double())
+        c5r.append((top == labels[:, None]).any(1).double())
+    total = sum((l * g_row[i].double()).sum() for i, l in enumerate(losses))
+    total.backward()
+    dpairs = [(q.to(cuda), k.to(cuda)) for q, k in pairs]
+    row_loss, row_lse, c1, c5, logits = ops.infonce_fwd(dpairs, scale.to(cuda), label0, want_logits=True)
+    assert rel_err(row_loss, torch.stack(losses).detach()) < 1e-5
+    assert rel_err(logits, torch.stack(logits_r)) < 1e-5
+    assert torch.equal(c1.cpu().double(), torch.stack(c1r)) and torch.equal(c5.cpu().double(), torch.stack(c5r))
+    outs, dscale = ops.infonce_bwd(dpairs, scale.to(cuda), label0, row_lse, g_row.to(cuda))
+    for (dq, dk), (q, k) in zip(outs, gq):
+        assert rel_err(dq, q.grad) < 1e-4 and rel_err(dk, k.grad) < 1e-4
+    assert rel_err(dscale, sr.grad) < 1e-4
+
+
+def test_ce_rows():
+    ops = _ops()
+    rows, C = 37, 1001
+    logits = rnd(rows, C, seed=60, scale=3.0)
+    labels = torch.randint(0, C, (rows,), generator=torch.Generator().manual_seed(61))
+    labels[5] = -100
+    lr = logits.double().requires_grad_(True)
+    loss_r = torch.nn.functional.cross_entropy(lr, labels, reduction="none", ignore_index=-100)
+    g = rnd(rows, seed=62).abs()
+    (loss_r * g.double()).sum().backward()
+    row_loss, row_lse, c1, c5 = ops.ce_rows_fwd(logits.to(cuda), labels.to(cuda))
+    assert rel_err(row_loss, loss_r.detach()) < 1e-5
+    dl = ops.ce_rows_bwd(logits.to(cuda), labels.to(cuda), row_lse, g.to(cuda))
+    assert rel_err(dl, lr.grad) < 1e-5
+    top = logits.topk(5, 1)[1]
+    valid = labels >= 0
+    assert torch.equal(c1.cpu().bool() & valid, (top[:, 0] == labels) & valid)
+
+
+# ----------------------------------------------------------------------------- optimizer
+def test_adamw_matches_torch():
+    ops = _ops()
+    n = 4099
+    p0, g1, g2 = rnd(n, seed=70), rnd(n, seed=71), rnd(n, seed=72)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pr], lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
+    p, m, v = p0.clone().to(cuda), torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)
+    pb = torch.empty(n, device=cuda, dtype=torch.bfloat16)
+    for step, g in enumerate((g1, g2), 1):
+        pr.grad = g.clone()
+        opt.step()
+        ops.adamw(p, g.to(cuda), m, v, pb, 1e-2, 0.9, 0.98, 1e-8, 0.1, step)
+    assert rel_err(p, pr.detach()) < 1e-5
+    assert rel_err(pb.float(), pr.detach()) < 1e-2
