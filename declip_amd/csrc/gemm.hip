@@ -313,6 +313,8 @@ int launch_mfma(const dh_gemm_args* a, const EpiParams& e, int split, int kps, h
 
 }  // namespace
 
+bool dh_gemm_try_glds(const dh_gemm_args* a, int split, hipStream_t st);  // gemm_glds.hip
+
 extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   DH_REQUIRE(a && a->A && a->B && a->C, "dh_gemm: null pointer");
@@ -332,8 +334,13 @@ extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
   e.residual = a->residual; e.ldr = a->ldr; e.aux = a->aux; e.ldaux = a->ldaux; e.accumulate = a->accumulate;
   e.alpha = a->alpha;
 
-  // MFMA path: bf16 operands, 16-B aligned rows, dims multiple of 8
-  bool mfma = a->dtype == DH_BF16 && !a->force_generic && (a->lda % 8 == 0) && (a->ldb % 8 == 0) &&
+  // v2 (LDS-DMA + transpose-read) kernel when shapes/alignments allow it
+  if (a->force_generic == 0 && dh_gemm_try_glds(a, split, st)) {
+    DH_CHECK_LAUNCH();
+    return DH_OK;
+  }
+  // v1 MFMA path: bf16 operands, 16-B aligned rows, dims multiple of 8
+  bool mfma = a->dtype == DH_BF16 && a->force_generic != 1 && (a->lda % 8 == 0) && (a->ldb % 8 == 0) &&
               (((uintptr_t)a->A & 15) == 0) && (((uintptr_t)a->B & 15) == 0);
   if (mfma) {
     // contiguous-dimension extents must be multiples of 8 elements (16-B vector loads)

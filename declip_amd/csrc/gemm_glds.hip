@@ -1,0 +1,301 @@
+// GEMM v2 for gfx950: operands go HBM -> LDS by direct LDS-DMA (global_load_lds_dwordx4), never
+// through VGPRs; fragments for v_mfma_f32_32x32x16_bf16 come out of LDS with one ds_read_b128
+// (K-contiguous operands) or two ds_read_b64_tr_b16 (contraction-major operands: the hardware
+// transpose read replaces v1's in-register 8x8 transposes); the epilogue is staged through LDS so
+// every global access of bias / residual / aux / C is a 16-byte vector on a contiguous row segment.
+//
+//   block tile 128 x 128 x 64, 4 waves (2 x 2, 64 x 64 each), 2 LDS stages, one barrier per K-step;
+//   the DMA of K-tile t+1 is in flight while tile t is multiplied.
+//
+// LDS images (both are "lane-linear" for the DMA; the swizzles live on the SOURCE address and on
+// the fragment read, never on the destination -- cdna_hip_programming.md rule 21):
+//   K-contiguous operand : [128 rows][64 k]   128 B rows, 16-B chunk c of row r at slot c ^ ((r>>1)&7)
+//   contraction-major op.: [64 k][128 out]    256 B rows, 16-B chunk c of row k at slot c ^ ((k&3)<<2)
+// ds_read_b64_tr_b16 semantics (measured on MI355X, profiles/r01_hw_probe_trread_glds.txt): inside
+// each 16-lane group, lane i receives element (i&3) of the 8-byte chunks addressed by lanes
+// 4j + (i>>2), j = 0..3.
+#include "dh_common.h"
+
+namespace glds {
+
+struct EpiParams {
+  int M, N;
+  void* C; long ldc;
+  const float* bias;
+  int epilogue;
+  const void* residual; long ldr;
+  void* aux; long ldaux;
+  int accumulate;
+  float alpha;
+};
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;      // 16 KiB per operand per stage
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A | B
+constexpr int CS = 132;                       // epilogue staging row stride (floats)
+constexpr int EPI_BYTES = 128 * CS * 4;
+constexpr int LDS_BYTES = EPI_BYTES > 2 * STAGE_BYTES ? EPI_BYTES : 2 * STAGE_BYTES;
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ void dma16(const bf16_t* src, unsigned char* lds_dst_uniform, int /*unused*/) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+}
+
+// fragment of a K-contiguous tile: rows r0 + (lane&31), k = 16*s + 8*(lane>>5) .. +7
+__device__ __forceinline__ bf16x8_t frag_kcontig(const unsigned char* tile, int r0, int s, int lane) {
+  const int row = r0 + (lane & 31);
+  const int chunk = 2 * s + (lane >> 5);
+  return *reinterpret_cast<const bf16x8_t*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+// fragment of a contraction-major tile via the transpose read: out columns o0 + (lane&31)
+__device__ __forceinline__ bf16x8_t frag_kmajor(const unsigned char* tile, int o0, int s, int lane) {
+  const int t = lane & 15;
+  const int n = o0 + ((lane >> 4) & 1) * 16 + 4 * (t & 3);
+  const int k = 16 * s + 8 * (lane >> 5) + (t >> 2);
+  const int sw = (t >> 2) << 2;                                    // (k & 3) << 2, k & 3 == t >> 2
+  const unsigned char* p = tile + k * 256 + ((((n >> 3) ^ sw)) << 4) + ((n & 7) << 1);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * 256));
+  union { struct { s16x4 a, b; } s; bf16x8_t v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+template <typename TI, typename TO>
+__device__ __forceinline__ void epilogue8(const EpiParams& e, int m, int n, float* v) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
+  if (e.bias) {
+    float bv[8];
+    ld8(e.bias + n, bv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += bv[i];
+  }
+  if (e.epilogue == DH_EPI_GELU) {
+    if (e.aux) st8(reinterpret_cast<TO*>(e.aux) + (long)m * e.ldaux + n, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = quick_gelu_f(v[i]);
+  } else if (e.epilogue == DH_EPI_DGELU) {
+    float u[8];
+    ld8(reinterpret_cast<const TI*>(e.aux) + (long)m * e.ldaux + n, u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= quick_gelu_grad_f(u[i]);
+  }
+  if (e.residual) {
+    float r[8];
+    ld8(reinterpret_cast<const TO*>(e.residual) + (long)m * e.ldr + n, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += r[i];
+  }
+  st8(reinterpret_cast<TO*>(e.C) + (long)m * e.ldc + n, v);
+}
+
+template <bool TA, bool TB, typename TO>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const bf16_t* __restrict__ A, long lda,
+                                                           const bf16_t* __restrict__ B, long ldb, int M, int N, int K,
+                                                           int k_per_split, EpiParams e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * k_per_split;
+  const int kend = min(K, kbeg + k_per_split);
+  const int nk = (kend - kbeg) / BK;                 // host guarantees divisibility
+
+  // ---- per-lane DMA source pointers (4 pieces of 1 KiB per operand per wave per K-step)
+  const bf16_t* asrc[4];
+  const bf16_t* bsrc[4];
+  long astep, bstep;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (TA) {   // image [64 k][128 m]: wave loads k rows wave*16 + 4i + (lane>>4), slot lane&15
+      const int kl = wave * 16 + 4 * i + (lane >> 4);
+      const int c = (lane & 15) ^ (((lane >> 4) & 3) << 2);
+      int m = m0 + c * 8;
+      m = m < M ? m : 0;
+      asrc[i] = A + (long)(kbeg + kl) * lda + m;
+    } else {    // image [128 m][64 k]: wave loads rows wave*32 + 8i + (lane>>3), slot lane&7
+      const int rl = wave * 32 + 8 * i + (lane >> 3);
+      const int c = (lane & 7) ^ ((rl >> 1) & 7);
+      int r = m0 + rl;
+      r = r < M ? r : M - 1;
+      asrc[i] = A + (long)r * lda + kbeg + c * 8;
+    }
+    if (TB) {
+      const int kl = wave * 16 + 4 * i + (lane >> 4);
+      const int c = (lane & 15) ^ (((lane >> 4) & 3) << 2);
+      int n = n0 + c * 8;
+      n = n < N ? n : 0;
+      bsrc[i] = B + (long)(kbeg + kl) * ldb + n;
+    } else {
+      const int rl = wave * 32 + 8 * i + (lane >> 3);
+      const int c = (lane & 7) ^ ((rl >> 1) & 7);
+      int r = n0 + rl;
+      r = r < N ? r : N - 1;
+      bsrc[i] = B + (long)r * ldb + kbeg + c * 8;
+    }
+  }
+  astep = TA ? (long)BK * lda : BK;
+  bstep = TB ? (long)BK * ldb : BK;
+
+  auto issue = [&](int stage) {
+    unsigned char* ta = smem + stage * STAGE_BYTES + wave * 4096;
+    unsigned char* tb = ta + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma16(asrc[i], ta + i * 1024, 0);
+      asrc[i] += astep;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma16(bsrc[i], tb + i * 1024, 0);
+      bsrc[i] += bstep;
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) issue(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt & 1;
+    __syncthreads();                       // drains this wave's DMA (vmcnt) + block barrier: tile kt is in LDS,
+                                           // and every wave is done reading the other stage
+    if (kt + 1 < nk) issue(stage ^ 1);
+    const unsigned char* ta = smem + stage * STAGE_BYTES;
+    const unsigned char* tb = ta + TILE_BYTES;
+    // fragment reads of k16-step s+1 are issued before the MFMAs of step s (register double buffer)
+    bf16x8_t a[2][2], b[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a[0][i] = TA ? frag_kmajor(ta, wm * 64 + i * 32, 0, lane) : frag_kcontig(ta, wm * 64 + i * 32, 0, lane);
+      b[0][i] = TB ? frag_kmajor(tb, wn * 64 + i * 32, 0, lane) : frag_kcontig(tb, wn * 64 + i * 32, 0, lane);
+    }
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      const int cur = s & 1, nxt = cur ^ 1;
+      if (s + 1 < BK / 16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[nxt][i] = TA ? frag_kmajor(ta, wm * 64 + i * 32, s + 1, lane) : frag_kcontig(ta, wm * 64 + i * 32, s + 1, lane);
+          b[nxt][i] = TB ? frag_kmajor(tb, wn * 64 + i * 32, s + 1, lane) : frag_kcontig(tb, wn * 64 + i * 32, s + 1, lane);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  if (e.accumulate) {
+    // split-K partials: atomics straight from the accumulator layout (32 consecutive floats per row)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+          if (m < M && n < N) atomicAdd(reinterpret_cast<float*>(e.C) + (long)m * e.ldc + n, acc[i][j][r] * e.alpha);
+        }
+    return;
+  }
+
+  // ---- epilogue through LDS: Cs[128][CS] fp32
+  __syncthreads();
+  float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = wn * 64 + j * 32 + (lane & 31);
+        Cs[row * CS + col] = acc[i][j][r];
+      }
+  __syncthreads();
+  // thread t: row t>>1, columns (t&1)*64 .. +64 in 8 chunks of 8
+  {
+    const int row = t >> 1;
+    const int m = m0 + row;
+    if (m < M) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int col = (t & 1) * 64 + c * 8;
+        const int n = n0 + col;
+        if (n < N) {
+          float v[8];
+          const float4 x = *reinterpret_cast<const float4*>(Cs + row * CS + col);
+          const float4 y = *reinterpret_cast<const float4*>(Cs + row * CS + col + 4);
+          v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+          epilogue8<bf16_t, TO>(e, m, n, v);
+        }
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB>
+void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, hipStream_t st) {
+  dim3 grid(dh_cdiv(a->N, BN), dh_cdiv(a->M, BM), split);
+  if (a->c_dtype == DH_BF16) {
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)gemm_glds_kernel<TA, TB, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_set = true; }
+    hipLaunchKernelGGL((gemm_glds_kernel<TA, TB, bf16_t>), grid, dim3(256), LDS_BYTES, st, (const bf16_t*)a->A, (long)a->lda,
+                       (const bf16_t*)a->B, (long)a->ldb, a->M, a->N, a->K, kps, e);
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)gemm_glds_kernel<TA, TB, float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_set = true; }
+    hipLaunchKernelGGL((gemm_glds_kernel<TA, TB, float>), grid, dim3(256), LDS_BYTES, st, (const bf16_t*)a->A, (long)a->lda,
+                       (const bf16_t*)a->B, (long)a->ldb, a->M, a->N, a->K, kps, e);
+  }
+}
+
+}  // namespace glds
+
+// Returns true if the v2 kernel took the problem (called from dh_gemm in gemm.hip).
+bool dh_gemm_try_glds(const dh_gemm_args* a, int split, hipStream_t st) {
+  using namespace glds;
+  if (a->dtype != DH_BF16 || a->force_generic) return false;
+  if ((a->lda % 8) || (a->ldb % 8) || ((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15)) return false;
+  if (a->N % 8 || a->M < 1) return false;
+  if (a->a_kmajor && (a->M % 8)) return false;
+  if (a->b_kmajor && (a->N % 8)) return false;
+  if (!a->a_kmajor && a->M < 1) return false;
+  int kps = ((a->K + split - 1) / split + BK - 1) / BK * BK;
+  if (a->K % BK) return false;
+  split = (a->K + kps - 1) / kps;
+  if (!a->accumulate) {
+    // vector epilogue alignment: 16-byte rows for C / residual / aux, 32-byte bias
+    const int esz = a->c_dtype == DH_BF16 ? 2 : 4;
+    if (((uintptr_t)a->C & 15) || ((a->ldc * esz) & 15)) return false;
+    if (a->residual && (((uintptr_t)a->residual & 15) || ((a->ldr * esz) & 15))) return false;
+    if (a->aux) {
+      const int asz = a->epilogue == DH_EPI_DGELU ? 2 : esz;
+      if (((uintptr_t)a->aux & 15) || ((a->ldaux * asz) & 15)) return false;
+    }
+    if (a->bias && ((uintptr_t)a->bias & 15)) return false;
+  }
+  EpiParams e;
+  e.M = a->M; e.N = a->N; e.C = a->C; e.ldc = a->ldc; e.bias = a->bias; e.epilogue = a->epilogue;
+  e.residual = a->residual; e.ldr = a->ldr; e.aux = a->aux; e.ldaux = a->ldaux; e.accumulate = a->accumulate;
+  e.alpha = a->alpha;
+  if (a->a_kmajor && a->b_kmajor) launch<true, true>(a, e, split, kps, st);
+  else if (a->a_kmajor) launch<true, false>(a, e, split, kps, st);
+  else if (a->b_kmajor) launch<false, true>(a, e, split, kps, st);
+  else launch<false, false>(a, e, split, kps, st);
+  return true;
+}

@@ -76,7 +76,7 @@ typedef struct dh_gemm_args {
   int accumulate;
   int split_k;           /* >=1; >1 requires accumulate */
   float alpha;
-  int force_generic;     /* 1: use the non-MFMA kernel even for bf16 (tests) */
+  int force_generic;     /* tests: 1 = VALU fp32-FMA kernel, 2 = v1 register-staged MFMA kernel, 0 = auto */
 } dh_gemm_args;
 int dh_gemm(const dh_gemm_args* args, dh_stream_t stream);
 

@@ -1,0 +1,36 @@
+"""Summarise a rocprofv3 rocpd SQLite database (kernel trace) as a --stats style table.
+    python tools/rocpd_stats.py gpurun_out/prof/xxx_results.db [--csv]
+"""
+import re
+import sqlite3
+import sys
+
+
+def main(path):
+    c = sqlite3.connect(path)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    cols = [r[1] for r in c.execute("pragma table_info(%s)" % kd)]
+    scols = [r[1] for r in c.execute("pragma table_info(%s)" % ks)]
+    name_col = "display_name" if "display_name" in scols else "kernel_name"
+    q = "select s.%s, d.end - d.start from %s d join %s s on d.kernel_id = s.id" % (name_col, kd, ks)
+    agg = {}
+    for name, dur in c.execute(q):
+        name = name.replace("(anonymous namespace)::", "")
+        name = re.sub(r"^void ", "", name)
+        name = re.sub(r"\(.*$", "", name)
+        a = agg.setdefault(name, [0, 0, 10 ** 18, 0])
+        a[0] += 1
+        a[1] += dur
+        a[2] = min(a[2], dur)
+        a[3] = max(a[3], dur)
+    total = sum(a[1] for a in agg.values())
+    print("%-88s %7s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
+    for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("%-88s %7d %12.1f %10.1f %10.1f %10.1f %6.2f" % (name[:88], a[0], a[1] / 1e3, a[1] / a[0] / 1e3, a[2] / 1e3, a[3] / 1e3, 100.0 * a[1] / total))
+    print("TOTAL kernel time: %.3f ms over %d dispatches" % (total / 1e6, sum(a[0] for a in agg.values())))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
