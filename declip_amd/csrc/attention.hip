@@ -4,8 +4,8 @@
 // One workgroup per (batch, head); the whole sequence lives in LDS, the [L,L] score matrix
 // never touches HBM.  bf16 path: v_mfma_f32_16x16x32_bf16, one wave per 16-query block.
 //   fwd:  S^T = K Q^T (so every lane owns ONE query column: softmax is in-lane + 2 shuffles),
-//         P written to LDS as the transpose of the C fragment (8-byte stores), O = P V with V^T
-//         staged in LDS.
+//         P written to LDS as the transpose of the C fragment (8-byte stores), O = P V with the V
+//         operand fetched by the hardware transpose read (ds_read_b64_tr_b16) from the row-major tile.
 //   bwd:  P recomputed from q,k,lse; dP = dO V^T; dS = P o (dP - rowsum(dO o O)) / sqrt(hd);
 //         dV = P^T dO, dK = dS^T Q, dQ = dS K  (all five products on MFMA).
 // fp32 path (validation precision): same math, scalar FMA, any head dim <= 64.
@@ -30,42 +30,57 @@ __device__ __forceinline__ float quad_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
-// stage rows [0,L) x 64 of a q/k/v/do block (global row stride gs elements) into LDS:
-//   rm != null: row-major tile rm[L16][RS]   (rows >= L zero)
-//   tr != null: transposed tile tr[64][TS]   (cols >= L zero up to Lt)
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long gs, int L, int Lrows, bf16_t* rm,
-                                           bf16_t* tr, int TS, int Lt, int tid, int nthr) {
-  const int ntask = (Lrows > Lt ? Lrows : Lt) * 8;  // (row, 16-B chunk)
-  for (int task = tid; task < ntask; task += nthr) {
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+// stage rows [0,L) x 64 of a q/k/v/do block (global row stride gs elements) into a row-major
+// LDS tile rm[Lrows][RS] (rows >= L zero-filled); 16-byte global loads.
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long gs, int L, int Lrows, bf16_t* rm, int tid,
+                                           int nthr) {
+  for (int task = tid; task < Lrows * 8; task += nthr) {
     const int r = task >> 3, c = task & 7;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (r < L) v = *reinterpret_cast<const uint4*>(g + (long)r * gs + c * 8);
-    if (rm && r < Lrows) *reinterpret_cast<uint4*>(rm + r * RS + c * 8) = v;
-    if (tr && r < Lt) {
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        tr[(c * 8 + 2 * i) * TS + r] = (bf16_t)(w[i] & 0xffffu);
-        tr[(c * 8 + 2 * i + 1) * TS + r] = (bf16_t)(w[i] >> 16);
-      }
-    }
+    *reinterpret_cast<uint4*>(rm + r * RS + c * 8) = v;
   }
 }
 
+// MFMA 16x16x32 operand whose contraction index is the ROW of a row-major LDS tile (stride ld
+// elements): lane (t = lane&15, g = lane>>4) needs k = k0 + 8g .. +7 for column c0 + t.  Two hardware
+// transpose reads (ds_read_b64_tr_b16; semantics measured in profiles/r01_hw_probe_trread_glds.txt):
+// lane t supplies the address of row k + (t>>2), columns c0 + 4*(t&3) .. +3 and receives column c0 + t.
+__device__ __forceinline__ bf16x8_t frag_tr(const bf16_t* tile, int ld, int k0, int c0, int lane) {
+  const int t = lane & 15;
+  const bf16_t* p = tile + (k0 + 8 * (lane >> 4) + (t >> 2)) * ld + c0 + 4 * (t & 3);
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 4 * ld));
+  union { struct { s16x4_t a, b; } s; bf16x8_t v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+// zero the k-slots beyond the contraction length (last 32-wide step when L16 % 32 == 16): both
+// operands are cleared so that stale LDS bits (possibly NaN patterns) never reach the MFMA.
+__device__ __forceinline__ bf16x8_t kmask(bf16x8_t f, bool dead) {
+  union { bf16x8_t v; uint4 u; } x;
+  x.v = f;
+  if (dead) x.u = make_uint4(0, 0, 0, 0);
+  return x.v;
+}
+
 // ------------------------------------------------------------------------------------------
-// forward, bf16 / MFMA.  blockDim = 64 * (L16/16); wave w owns queries [16w, 16w+16)
+// forward, bf16 / MFMA.  blockDim = 64 * NKB; wave w owns queries [16w, 16w+16)
 // ------------------------------------------------------------------------------------------
 template <int NKB>  // number of 16-key blocks (L16/16), compile-time so scores stay in registers
 __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
                                      int L, int heads, int causal, float scale) {
   constexpr int L16 = NKB * 16;
-  constexpr int L32 = (L16 + 31) / 32 * 32;
-  constexpr int TS = L32 + 8;
+  constexpr int NKS = (L16 + 31) / 32;          // 32-wide k-steps over the keys
+  constexpr bool KTAIL = (L16 % 32) != 0;
+  constexpr int TS = L16 + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);  // [L16][RS]
   bf16_t* Ks = Qs + L16 * RS;                        // [L16][RS]
-  bf16_t* Vt = Ks + L16 * RS;                        // [64][TS]
-  bf16_t* Ps = Vt + HD * TS;                         // [L16][TS]
+  bf16_t* Vs = Ks + L16 * RS;                        // [L16][RS]
+  bf16_t* Ps = Vs + L16 * RS;                        // [L16][TS]  (+ 32 elements slack for the masked tail read)
 
   const int bh = blockIdx.x;
   const int bi = bh / heads, h = bh % heads;
@@ -75,9 +90,9 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6;
 
-  stage_tile(qg, gs, L, L16, Qs, nullptr, 0, 0, tid, nthr);
-  stage_tile(qg + d_model, gs, L, L16, Ks, nullptr, 0, 0, tid, nthr);
-  stage_tile(qg + 2 * d_model, gs, L, 0, nullptr, Vt, TS, L32, tid, nthr);
+  stage_tile(qg, gs, L, L16, Qs, tid, nthr);
+  stage_tile(qg + d_model, gs, L, L16, Ks, tid, nthr);
+  stage_tile(qg + 2 * d_model, gs, L, L16, Vs, tid, nthr);
   __syncthreads();
 
   const int qb = wave;
@@ -130,19 +145,16 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
     w.y = pack2bf(s[kb][2] * inv, s[kb][3] * inv);
     *reinterpret_cast<uint2*>(Ps + q * TS + kb * 16 + 4 * (lane >> 4)) = w;
   }
-  if (L32 > L16) {  // zero the key padding columns read by the last 32-wide k-step
-    uint2 z = make_uint2(0, 0);
-    *reinterpret_cast<uint2*>(Ps + q * TS + L16 + 4 * (lane >> 4)) = z;
-  }
   __syncthreads();
-  // O[q][d] = sum_key P[q][key] V[key][d]: A = P rows (this wave's queries), B = V^T rows
+  // O[q][d] = sum_key P[q][key] V[key][d]: A = P rows (this wave's queries), B = V via transpose reads
 #pragma unroll
   for (int db = 0; db < 4; ++db) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < L32 / 32; ++ks) {
-      bf16x8_t pf = lds_frag(Ps + (qb * 16 + (lane & 15)) * TS + ks * 32 + 8 * (lane >> 4));
-      bf16x8_t vf = lds_frag(Vt + (db * 16 + (lane & 15)) * TS + ks * 32 + 8 * (lane >> 4));
+    for (int ks = 0; ks < NKS; ++ks) {
+      const bool dead = KTAIL && ks == NKS - 1 && (lane >> 4) >= 2;
+      bf16x8_t pf = kmask(lds_frag(Ps + (qb * 16 + (lane & 15)) * TS + ks * 32 + 8 * (lane >> 4)), dead);
+      bf16x8_t vf = kmask(frag_tr(Vs, RS, ks * 32, db * 16, dead ? (lane & 31) : lane), dead);
       acc = mfma16(pf, vf, acc);
     }
     // C layout: row (query) = 4*(lane>>4)+r, col (d) = lane&15
@@ -162,20 +174,17 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
                                      const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                      bf16_t* __restrict__ dqkv, int L, int heads, int causal, float scale) {
   constexpr int L16 = NKB * 16;
-  constexpr int L32 = (L16 + 31) / 32 * 32;
-  constexpr int TS = L32 + 8;
+  constexpr int NKS = (L16 + 31) / 32;
+  constexpr bool KTAIL = (L16 % 32) != 0;
+  constexpr int TS = L16 + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);  // [L16][RS]
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);  // [L16][RS] row-major tiles
   bf16_t* Ks = Qs + L16 * RS;
   bf16_t* Vs = Ks + L16 * RS;
-  bf16_t* Gs = Vs + L16 * RS;     // dO row-major
-  bf16_t* Qt = Gs + L16 * RS;     // [64][TS]
-  bf16_t* Kt = Qt + HD * TS;
-  bf16_t* Gt = Kt + HD * TS;      // dO^T
-  bf16_t* Pt = Gt + HD * TS;      // P^T  [key][q]   [L16][TS]
-  bf16_t* dSt = Pt + L16 * TS;    // dS^T [key][q]
-  bf16_t* dSs = dSt + L16 * TS;   // dS   [q][key]
-  float* Dq = reinterpret_cast<float*>(dSs + L16 * TS);  // [L16] rowsum(dO o O)
+  bf16_t* Gs = Vs + L16 * RS;     // dO
+  bf16_t* Pt = Gs + L16 * RS;     // P^T  [key][q]   [L16][TS]
+  bf16_t* dSt = Pt + L16 * TS;    // dS^T [key][q]   (+ slack for masked tail reads)
+  float* Dq = reinterpret_cast<float*>(dSt + L16 * TS + 64);  // [L16] rowsum(dO o O)
 
   const int bh = blockIdx.x;
   const int bi = bh / heads, h = bh % heads;
@@ -187,10 +196,10 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6;
 
-  stage_tile(qg, gs, L, L16, Qs, Qt, TS, L32, tid, nthr);
-  stage_tile(qg + d_model, gs, L, L16, Ks, Kt, TS, L32, tid, nthr);
-  stage_tile(qg + 2 * d_model, gs, L, L16, Vs, nullptr, 0, 0, tid, nthr);
-  stage_tile(gg, d_model, L, L16, Gs, Gt, TS, L32, tid, nthr);
+  stage_tile(qg, gs, L, L16, Qs, tid, nthr);
+  stage_tile(qg + d_model, gs, L, L16, Ks, tid, nthr);
+  stage_tile(qg + 2 * d_model, gs, L, L16, Vs, tid, nthr);
+  stage_tile(gg, d_model, L, L16, Gs, tid, nthr);
   // D[q] = sum_d dO[q][d] * O[q][d]   (4 lanes per row, 16 columns each)
   for (int task = tid; task < L16 * 4; task += nthr) {
     const int r = task >> 2, part = task & 3;
@@ -208,13 +217,6 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
     if (part == 0) Dq[r] = acc;
-  }
-  // zero the q-padding columns [L16, L32) of the transposed score tiles
-  if (L32 > L16) {
-    for (int i = tid; i < L16 * (L32 - L16); i += nthr) {
-      const int r = i / (L32 - L16), c = L16 + i % (L32 - L16);
-      Pt[r * TS + c] = 0; dSt[r * TS + c] = 0; dSs[r * TS + c] = 0;
-    }
   }
   __syncthreads();
 
@@ -259,14 +261,11 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
       *reinterpret_cast<uint2*>(Pt + key * TS + qb * 16 + 4 * (lane >> 4)) = w;
       w.x = pack2bf(ds[0], ds[1]); w.y = pack2bf(ds[2], ds[3]);
       *reinterpret_cast<uint2*>(dSt + key * TS + qb * 16 + 4 * (lane >> 4)) = w;
-      // straight stores: dS[q][key]
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dSs[(qb * 16 + 4 * (lane >> 4) + r) * TS + key] = f2bf(ds[r]);
     }
   }
   __syncthreads();
 
-  // ---- phase 2: wave owns row block rb (keys for dV/dK, queries for dQ)
+  // ---- phase 2: wave owns row block rb (keys for dV/dK, queries for dQ); contraction length L16
   {
     const int rb = wave;
     bf16_t* dq_g = dqkv + (long)bi * L * gs + h * HD;
@@ -274,12 +273,19 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
     for (int db = 0; db < 4; ++db) {
       f32x4_t av = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < L32 / 32; ++ks) {
-        const int ro = (rb * 16 + (lane & 15)) * TS + ks * 32 + 8 * (lane >> 4);
-        const int co = (db * 16 + (lane & 15)) * TS + ks * 32 + 8 * (lane >> 4);
-        av = mfma16(lds_frag(Pt + ro), lds_frag(Gt + co), av);   // dV[key][d] = sum_q P^T[key][q] dO[q][d]
-        ak = mfma16(lds_frag(dSt + ro), lds_frag(Qt + co), ak);  // dK[key][d] = sum_q dS^T[key][q] Q[q][d]
-        aq = mfma16(lds_frag(dSs + ro), lds_frag(Kt + co), aq);  // dQ[q][d]  = sum_key dS[q][key] K[key][d]
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bool dead = KTAIL && ks == NKS - 1 && (lane >> 4) >= 2;
+        const int ln = dead ? (lane & 31) : lane;           // dead lanes read in-bounds addresses, then get zeroed
+        const int ro = (rb * 16 + (lane & 15)) * TS + ks * 32 + 8 * (ln >> 4);
+        // dV[key][d] = sum_q P^T[key][q] dO[q][d];  dK[key][d] = sum_q dS^T[key][q] Q[q][d]
+        bf16x8_t gB = kmask(frag_tr(Gs, RS, ks * 32, db * 16, ln), dead);
+        bf16x8_t qB = kmask(frag_tr(Qs, RS, ks * 32, db * 16, ln), dead);
+        av = mfma16(kmask(lds_frag(Pt + ro), dead), gB, av);
+        ak = mfma16(kmask(lds_frag(dSt + ro), dead), qB, ak);
+        // dQ[q][d] = sum_key dS[q][key] K[key][d]: A = dS via transpose read of dS^T, B = K via transpose read
+        bf16x8_t dsA = kmask(frag_tr(dSt, TS, ks * 32, rb * 16, ln), dead);
+        bf16x8_t kB = kmask(frag_tr(Ks, RS, ks * 32, db * 16, ln), dead);
+        aq = mfma16(dsA, kB, aq);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -402,8 +408,8 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const T* __restri
 template <int NKB>
 int launch_fwd_mfma(const bf16_t* qkv, bf16_t* out, float* lse, int b, int L, int heads, int causal, float scale,
                     hipStream_t st) {
-  constexpr int L16 = NKB * 16, L32 = (L16 + 31) / 32 * 32, TS = L32 + 8;
-  size_t lds = (size_t)(2 * L16 * RS + HD * TS + L16 * TS) * sizeof(bf16_t);
+  constexpr int L16 = NKB * 16, TS = L16 + 8;
+  size_t lds = (size_t)(3 * L16 * RS + L16 * TS + 64) * sizeof(bf16_t);
   hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(attn_fwd_mfma_kernel<NKB>, dim3(b * heads), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale);
   return 0;
@@ -411,8 +417,8 @@ int launch_fwd_mfma(const bf16_t* qkv, bf16_t* out, float* lse, int b, int L, in
 template <int NKB>
 int launch_bwd_mfma(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int b,
                     int L, int heads, int causal, float scale, hipStream_t st) {
-  constexpr int L16 = NKB * 16, L32 = (L16 + 31) / 32 * 32, TS = L32 + 8;
-  size_t lds = (size_t)(4 * L16 * RS + 3 * HD * TS + 3 * L16 * TS) * sizeof(bf16_t) + L16 * sizeof(float);
+  constexpr int L16 = NKB * 16, TS = L16 + 8;
+  size_t lds = (size_t)(4 * L16 * RS + 2 * L16 * TS + 64) * sizeof(bf16_t) + L16 * sizeof(float);
   hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(attn_bwd_mfma_kernel<NKB>, dim3(b * heads), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale);
   return 0;
@@ -456,7 +462,7 @@ extern "C" int dh_attn_bwd(int dtype, const void* qkv, const void* out, const vo
                            int b, int L, int heads, int hd, int causal, dh_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   DH_REQUIRE(qkv && out && dout && lse && dqkv && b > 0 && L > 0 && heads > 0, "dh_attn_bwd: bad args");
-  DH_REQUIRE(L <= 96 && hd <= 64, "dh_attn_bwd: L<=96 and hd<=64 required (got %d, %d)", L, hd);
+  DH_REQUIRE(L <= 128 && hd <= 64, "dh_attn_bwd: L<=128 and hd<=64 required (got %d, %d)", L, hd);
   const float scale = 1.0f / sqrtf((float)hd);
   if (dtype == DH_BF16 && hd == 64) {
     const int nkb = (L + 15) / 16;

@@ -22,19 +22,49 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const int64_t* __re
   }
 }
 
+struct HotIds { long id[4]; int n; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dx,
                                                              float* __restrict__ dtable, float* __restrict__ dpos,
-                                                             int rows, int L, int d) {
-  // dtable: scatter-add rows (atomic); dpos handled by vit_assemble-style column reduction below
+                                                             int rows, int L, int d, HotIds hot) {
+  // dtable: scatter-add rows (atomic) for all ids except the "hot" ones (pad / SOT / EOT occur in every
+  // caption: thousands of rows would serialise on the same table row) -- those go through
+  // embed_hot_reduce_kernel.  dpos is a batch reduction (batch_reduce_kernel).
   const int nchunk = d >> 3;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)rows * nchunk; i += (long)gridDim.x * 256) {
     const int row = (int)(i / nchunk), ch = (int)(i % nchunk);
     const long id = ids[row];
+    bool is_hot = false;
+    for (int h = 0; h < hot.n; ++h) is_hot |= (id == hot.id[h]);
+    if (is_hot) continue;
     float g[8];
     ld8(dx + (long)row * d + ch * 8, g);
 #pragma unroll
     for (int k = 0; k < 8; ++k) atomicAdd(dtable + id * d + ch * 8 + k, g[k]);
+  }
+}
+
+// dtable[hot.id[h], :] += sum over rows with ids[row] == hot.id[h] of dx[row, :]
+// grid (ceil(d/64), row chunks, n hot); block 256 = 64 columns x 4 row lanes; one atomic per block column
+template <typename T>
+__global__ __launch_bounds__(256) void embed_hot_reduce_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dx,
+                                                               float* __restrict__ dtable, int rows, int d,
+                                                               int rows_per_block, HotIds hot) {
+  __shared__ float red[4][64];
+  const long id = hot.id[blockIdx.z];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < d)
+    for (int r = r0 + rl; r < r1; r += 4)
+      if (ids[r] == id) s += ld<T>(dx + (long)r * d + c);
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < d) {
+    s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (s != 0.f) atomicAdd(dtable + id * d + c, s);
   }
 }
 
@@ -271,14 +301,26 @@ static int launch_batch_reduce(int dtype, const void* dx, float* out, int b, int
 }
 
 extern "C" int dh_text_embed_bwd(int dtype, const int64_t* ids, const void* dx, float* dtable, float* dpos, int b,
-                                 int L, int d, dh_stream_t stream) {
+                                 int L, int d, const int64_t* hot_ids, int n_hot, dh_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   DH_REQUIRE(ids && dx && d % 8 == 0, "dh_text_embed_bwd: bad args");
   const int rows = b * L;
   if (dtable) {
-    if (dtype == DH_BF16) hipLaunchKernelGGL(text_embed_bwd_kernel<bf16_t>, dim3(grid_for((long)rows * d / 8)), dim3(256), 0, st, ids, (const bf16_t*)dx, dtable, dpos, rows, L, d);
-    else hipLaunchKernelGGL(text_embed_bwd_kernel<float>, dim3(grid_for((long)rows * d / 8)), dim3(256), 0, st, ids, (const float*)dx, dtable, dpos, rows, L, d);
+    HotIds hot;
+    hot.n = 0;
+    for (int h = 0; h < n_hot && h < 4; ++h) hot.id[hot.n++] = hot_ids[h];
+    if (dtype == DH_BF16) hipLaunchKernelGGL(text_embed_bwd_kernel<bf16_t>, dim3(grid_for((long)rows * d / 8)), dim3(256), 0, st, ids, (const bf16_t*)dx, dtable, dpos, rows, L, d, hot);
+    else hipLaunchKernelGGL(text_embed_bwd_kernel<float>, dim3(grid_for((long)rows * d / 8)), dim3(256), 0, st, ids, (const float*)dx, dtable, dpos, rows, L, d, hot);
     DH_CHECK_LAUNCH();
+    if (hot.n > 0) {
+      int chunks = dh_cdiv(rows, 256);
+      if (chunks > 64) chunks = 64;
+      const int rpb = dh_cdiv(rows, chunks);
+      dim3 grid(dh_cdiv(d, 64), dh_cdiv(rows, rpb), hot.n);
+      if (dtype == DH_BF16) hipLaunchKernelGGL(embed_hot_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, ids, (const bf16_t*)dx, dtable, rows, d, rpb, hot);
+      else hipLaunchKernelGGL(embed_hot_reduce_kernel<float>, grid, dim3(256), 0, st, ids, (const float*)dx, dtable, rows, d, rpb, hot);
+      DH_CHECK_LAUNCH();
+    }
   }
   if (dpos) launch_batch_reduce(dtype, dx, dpos, b, L, d, st);
   DH_CHECK_LAUNCH();

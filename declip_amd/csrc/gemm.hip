@@ -334,10 +334,15 @@ extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
   e.residual = a->residual; e.ldr = a->ldr; e.aux = a->aux; e.ldaux = a->ldaux; e.accumulate = a->accumulate;
   e.alpha = a->alpha;
 
-  // v2 (LDS-DMA + transpose-read) kernel when shapes/alignments allow it
+  if (a->a_colsum) DH_REQUIRE(a->a_kmajor, "dh_gemm: a_colsum needs a_kmajor");
+  // v2 (LDS-DMA + transpose-read) kernel when shapes/alignments allow it (fuses a_colsum)
   if (a->force_generic == 0 && dh_gemm_try_glds(a, split, st)) {
     DH_CHECK_LAUNCH();
     return DH_OK;
+  }
+  if (a->a_colsum) {  // other kernels: separate column-sum pass over A = [K][M]
+    int rc = dh_colsum(a->dtype, a->A, a->lda, a->K, a->M, a->a_colsum, 1, stream);
+    if (rc != DH_OK) return rc;
   }
   // v1 MFMA path: bf16 operands, 16-B aligned rows, dims multiple of 8
   bool mfma = a->dtype == DH_BF16 && a->force_generic != 1 && (a->lda % 8 == 0) && (a->ldb % 8 == 0) &&

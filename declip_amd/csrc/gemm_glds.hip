@@ -15,6 +15,7 @@
 // each 16-lane group, lane i receives element (i&3) of the 8-byte chunks addressed by lanes
 // 4j + (i>>2), j = 0..3.
 #include "dh_common.h"
+#include <stdlib.h>
 
 namespace glds {
 
@@ -27,14 +28,22 @@ struct EpiParams {
   void* aux; long ldaux;
   int accumulate;
   float alpha;
+  float* a_colsum;
 };
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;      // 16 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A | B
+constexpr int BN = 128, BK = 64;
 constexpr int CS = 132;                       // epilogue staging row stride (floats)
-constexpr int EPI_BYTES = 128 * CS * 4;
-constexpr int LDS_BYTES = EPI_BYTES > 2 * STAGE_BYTES ? EPI_BYTES : 2 * STAGE_BYTES;
+// block tile (64*WMR) x 128 x 64 with 2*WMR waves (each 64 x 64): WMR = 2 -> 128 x 128 (2 blocks/CU),
+// WMR = 4 -> 256 x 128 (1 block/CU, 85 flop per staged byte: the L2 -> LDS stream stops being the limiter)
+template <int WMR> struct Cfg {
+  static constexpr int BM = 64 * WMR;
+  static constexpr int NW = 2 * WMR;
+  static constexpr int A_BYTES = BM * BK * 2;
+  static constexpr int B_BYTES = BN * BK * 2;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int EPI_BYTES = BM * CS * 4;
+  static constexpr int LDS_BYTES = EPI_BYTES > 2 * STAGE_BYTES ? EPI_BYTES : 2 * STAGE_BYTES;
+};
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -50,14 +59,15 @@ __device__ __forceinline__ bf16x8_t frag_kcontig(const unsigned char* tile, int 
   return *reinterpret_cast<const bf16x8_t*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 // fragment of a contraction-major tile via the transpose read: out columns o0 + (lane&31)
+template <int ROWB>  // bytes per k-row of the image (2 * number of out columns)
 __device__ __forceinline__ bf16x8_t frag_kmajor(const unsigned char* tile, int o0, int s, int lane) {
   const int t = lane & 15;
   const int n = o0 + ((lane >> 4) & 1) * 16 + 4 * (t & 3);
   const int k = 16 * s + 8 * (lane >> 5) + (t >> 2);
   const int sw = (t >> 2) << 2;                                    // (k & 3) << 2, k & 3 == t >> 2
-  const unsigned char* p = tile + k * 256 + ((((n >> 3) ^ sw)) << 4) + ((n & 7) << 1);
+  const unsigned char* p = tile + k * ROWB + ((((n >> 3) ^ sw)) << 4) + ((n & 7) << 1);
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * 256));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * ROWB));
   union { struct { s16x4 a, b; } s; bf16x8_t v; } u;
   u.s.a = lo; u.s.b = hi;
   return u.v;
@@ -92,66 +102,75 @@ __device__ __forceinline__ void epilogue8(const EpiParams& e, int m, int n, floa
   st8(reinterpret_cast<TO*>(e.C) + (long)m * e.ldc + n, v);
 }
 
-template <bool TA, bool TB, typename TO>
-__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const bf16_t* __restrict__ A, long lda,
-                                                           const bf16_t* __restrict__ B, long ldb, int M, int N, int K,
-                                                           int k_per_split, EpiParams e) {
+// DMA source pointer of piece q (1 KiB = 64 lanes x 16 B) of an operand tile, for this lane.
+//   K-contiguous image [R rows][64 k]: piece q = rows 8q .. 8q+7
+//   contraction-major image [64 k][R out]: piece q = (512/R) k-rows x (R/8) slots
+template <bool KM, int R>
+__device__ __forceinline__ const bf16_t* piece_src(const bf16_t* P, long ld, int q, int lane, int o0, int outs, int kbeg) {
+  if (KM) {
+    constexpr int SLOTS = R / 8, RPP = 64 / SLOTS;       // slots per k-row, k-rows per piece
+    const int kl = q * RPP + lane / SLOTS;
+    const int c = (lane % SLOTS) ^ ((kl & 3) << 2);
+    int o = o0 + c * 8;
+    o = o < outs ? o : 0;
+    return P + (long)(kbeg + kl) * ld + o;
+  } else {
+    const int rl = q * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((rl >> 1) & 7);
+    int r = o0 + rl;
+    r = r < outs ? r : outs - 1;
+    return P + (long)r * ld + kbeg + c * 8;
+  }
+}
+
+template <int WMR, bool TA, bool TB, typename TO>
+__global__ __launch_bounds__(128 * WMR, 2) void gemm_glds_kernel(const bf16_t* __restrict__ A, long lda,
+                                                                 const bf16_t* __restrict__ B, long ldb, int M, int N, int K,
+                                                                 int k_per_split, EpiParams e) {
+  using C = Cfg<WMR>;
+  constexpr int BM = C::BM, NW = C::NW;
+  constexpr int APW = (BM / 8) / NW;     // 1-KiB pieces of the A tile per wave (= 4)
+  constexpr int BPW = (BN / 8) / NW;     // pieces of the B tile per wave (4 or 2)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order (MI355X: block b runs on XCD b % 8, each XCD has its own L2): hand every
+  // XCD a contiguous run of logical tiles so that the n-tiles sharing an A row-panel hit one L2.
+  int tile_x = blockIdx.x, tile_y = blockIdx.y;
+  {
+    const int ntx = gridDim.x, nb = gridDim.x * gridDim.y;
+    const int b = blockIdx.y * ntx + blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for any nb
+    tile_y = logical / ntx;
+    tile_x = logical - tile_y * ntx;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
   const int kbeg = blockIdx.z * k_per_split;
   const int kend = min(K, kbeg + k_per_split);
   const int nk = (kend - kbeg) / BK;                 // host guarantees divisibility
 
-  // ---- per-lane DMA source pointers (4 pieces of 1 KiB per operand per wave per K-step)
-  const bf16_t* asrc[4];
-  const bf16_t* bsrc[4];
-  long astep, bstep;
+  const bf16_t* asrc[APW];
+  const bf16_t* bsrc[BPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (TA) {   // image [64 k][128 m]: wave loads k rows wave*16 + 4i + (lane>>4), slot lane&15
-      const int kl = wave * 16 + 4 * i + (lane >> 4);
-      const int c = (lane & 15) ^ (((lane >> 4) & 3) << 2);
-      int m = m0 + c * 8;
-      m = m < M ? m : 0;
-      asrc[i] = A + (long)(kbeg + kl) * lda + m;
-    } else {    // image [128 m][64 k]: wave loads rows wave*32 + 8i + (lane>>3), slot lane&7
-      const int rl = wave * 32 + 8 * i + (lane >> 3);
-      const int c = (lane & 7) ^ ((rl >> 1) & 7);
-      int r = m0 + rl;
-      r = r < M ? r : M - 1;
-      asrc[i] = A + (long)r * lda + kbeg + c * 8;
-    }
-    if (TB) {
-      const int kl = wave * 16 + 4 * i + (lane >> 4);
-      const int c = (lane & 15) ^ (((lane >> 4) & 3) << 2);
-      int n = n0 + c * 8;
-      n = n < N ? n : 0;
-      bsrc[i] = B + (long)(kbeg + kl) * ldb + n;
-    } else {
-      const int rl = wave * 32 + 8 * i + (lane >> 3);
-      const int c = (lane & 7) ^ ((rl >> 1) & 7);
-      int r = n0 + rl;
-      r = r < N ? r : N - 1;
-      bsrc[i] = B + (long)r * ldb + kbeg + c * 8;
-    }
-  }
-  astep = TA ? (long)BK * lda : BK;
-  bstep = TB ? (long)BK * ldb : BK;
+  for (int i = 0; i < APW; ++i) asrc[i] = piece_src<TA, BM>(A, lda, wave * APW + i, lane, m0, M, kbeg);
+#pragma unroll
+  for (int i = 0; i < BPW; ++i) bsrc[i] = piece_src<TB, BN>(B, ldb, wave * BPW + i, lane, n0, N, kbeg);
+  const long astep = TA ? (long)BK * lda : BK;
+  const long bstep = TB ? (long)BK * ldb : BK;
 
   auto issue = [&](int stage) {
-    unsigned char* ta = smem + stage * STAGE_BYTES + wave * 4096;
-    unsigned char* tb = ta + TILE_BYTES;
+    unsigned char* ta = smem + stage * C::STAGE_BYTES + wave * (APW * 1024);
+    unsigned char* tb = smem + stage * C::STAGE_BYTES + C::A_BYTES + wave * (BPW * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < APW; ++i) {
       dma16(asrc[i], ta + i * 1024, 0);
       asrc[i] += astep;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BPW; ++i) {
       dma16(bsrc[i], tb + i * 1024, 0);
       bsrc[i] += bstep;
     }
@@ -165,20 +184,35 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const bf16_t* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // fused bias gradient: the n-tile-0 blocks also column-sum the dY tiles they stage (TA only)
+  const bool do_colsum = TA && e.a_colsum != nullptr && tile_x == 0;
+  float csum = 0.f;
+
   if (nk > 0) issue(0);
   for (int kt = 0; kt < nk; ++kt) {
     const int stage = kt & 1;
     __syncthreads();                       // drains this wave's DMA (vmcnt) + block barrier: tile kt is in LDS,
                                            // and every wave is done reading the other stage
     if (kt + 1 < nk) issue(stage ^ 1);
-    const unsigned char* ta = smem + stage * STAGE_BYTES;
-    const unsigned char* tb = ta + TILE_BYTES;
+    const unsigned char* ta = smem + stage * C::STAGE_BYTES;
+    const unsigned char* tb = ta + C::A_BYTES;
+    if (TA && do_colsum) {
+      // thread -> column m = t % BM, k rows [kh*KR, +KR) with KR = 64 / (threads / BM)
+      constexpr int TPB = 64 * NW, KPARTS = TPB / BM, KR = 64 / KPARTS;
+      const int mcol = t % BM, kh = t / BM;
+#pragma unroll 8
+      for (int kk = 0; kk < KR; ++kk) {
+        const int k = kh * KR + kk;
+        const unsigned char* p = ta + k * (2 * BM) + ((((mcol >> 3) ^ ((k & 3) << 2))) << 4) + ((mcol & 7) << 1);
+        csum += bf2f(*reinterpret_cast<const bf16_t*>(p));
+      }
+    }
     // fragment reads of k16-step s+1 are issued before the MFMAs of step s (register double buffer)
     bf16x8_t a[2][2], b[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      a[0][i] = TA ? frag_kmajor(ta, wm * 64 + i * 32, 0, lane) : frag_kcontig(ta, wm * 64 + i * 32, 0, lane);
-      b[0][i] = TB ? frag_kmajor(tb, wn * 64 + i * 32, 0, lane) : frag_kcontig(tb, wn * 64 + i * 32, 0, lane);
+      a[0][i] = TA ? frag_kmajor<2 * BM>(ta, wm * 64 + i * 32, 0, lane) : frag_kcontig(ta, wm * 64 + i * 32, 0, lane);
+      b[0][i] = TB ? frag_kmajor<2 * BN>(tb, wn * 64 + i * 32, 0, lane) : frag_kcontig(tb, wn * 64 + i * 32, 0, lane);
     }
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
@@ -186,8 +220,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const bf16_t* __restr
       if (s + 1 < BK / 16) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          a[nxt][i] = TA ? frag_kmajor(ta, wm * 64 + i * 32, s + 1, lane) : frag_kcontig(ta, wm * 64 + i * 32, s + 1, lane);
-          b[nxt][i] = TB ? frag_kmajor(tb, wn * 64 + i * 32, s + 1, lane) : frag_kcontig(tb, wn * 64 + i * 32, s + 1, lane);
+          a[nxt][i] = TA ? frag_kmajor<2 * BM>(ta, wm * 64 + i * 32, s + 1, lane) : frag_kcontig(ta, wm * 64 + i * 32, s + 1, lane);
+          b[nxt][i] = TB ? frag_kmajor<2 * BN>(tb, wn * 64 + i * 32, s + 1, lane) : frag_kcontig(tb, wn * 64 + i * 32, s + 1, lane);
         }
       }
 #pragma unroll
@@ -198,6 +232,10 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const bf16_t* __restr
     }
   }
 
+  if (TA && do_colsum) {
+    const int mcol = m0 + (t % BM);
+    if (mcol < M) atomicAdd(e.a_colsum + mcol, csum);
+  }
   if (e.accumulate) {
     // split-K partials: atomics straight from the accumulator layout (32 consecutive floats per row)
 #pragma unroll
@@ -227,19 +265,21 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const bf16_t* __restr
         Cs[row * CS + col] = acc[i][j][r];
       }
   __syncthreads();
-  // thread t: row t>>1, columns (t&1)*64 .. +64 in 8 chunks of 8
+  // 16 consecutive lanes cover one 128-column row (16 B each): every wave store instruction writes
+  // 4 full 256/512-byte row segments -- fully coalesced (the first version had lanes 128 B apart).
   {
-    const int row = t >> 1;
-    const int m = m0 + row;
-    if (m < M) {
+    const int cc = t & 15;
+    constexpr int RSTEP = (64 * NW) / 16;
+    const int n = n0 + cc * 8;
+    if (n < N) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int col = (t & 1) * 64 + c * 8;
-        const int n = n0 + col;
-        if (n < N) {
+      for (int i = 0; i < BM / RSTEP; ++i) {
+        const int row = (t >> 4) + i * RSTEP;
+        const int m = m0 + row;
+        if (m < M) {
           float v[8];
-          const float4 x = *reinterpret_cast<const float4*>(Cs + row * CS + col);
-          const float4 y = *reinterpret_cast<const float4*>(Cs + row * CS + col + 4);
+          const float4 x = *reinterpret_cast<const float4*>(Cs + row * CS + cc * 8);
+          const float4 y = *reinterpret_cast<const float4*>(Cs + row * CS + cc * 8 + 4);
           v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
           epilogue8<bf16_t, TO>(e, m, n, v);
         }
@@ -248,19 +288,25 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const bf16_t* __restr
   }
 }
 
+template <int WMR, bool TA, bool TB, typename TO>
+void launch_cfg(const dh_gemm_args* a, const EpiParams& e, int split, int kps, hipStream_t st) {
+  using C = Cfg<WMR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_glds_kernel<WMR, TA, TB, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    attr_set = true;
+  }
+  dim3 grid(dh_cdiv(a->N, BN), dh_cdiv(a->M, C::BM), split);
+  hipLaunchKernelGGL((gemm_glds_kernel<WMR, TA, TB, TO>), grid, dim3(64 * C::NW), C::LDS_BYTES, st, (const bf16_t*)a->A,
+                     (long)a->lda, (const bf16_t*)a->B, (long)a->ldb, a->M, a->N, a->K, kps, e);
+}
+
 template <bool TA, bool TB>
-void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, hipStream_t st) {
-  dim3 grid(dh_cdiv(a->N, BN), dh_cdiv(a->M, BM), split);
+void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, int wmr, hipStream_t st) {
   if (a->c_dtype == DH_BF16) {
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)gemm_glds_kernel<TA, TB, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_set = true; }
-    hipLaunchKernelGGL((gemm_glds_kernel<TA, TB, bf16_t>), grid, dim3(256), LDS_BYTES, st, (const bf16_t*)a->A, (long)a->lda,
-                       (const bf16_t*)a->B, (long)a->ldb, a->M, a->N, a->K, kps, e);
+    if (wmr == 4) launch_cfg<4, TA, TB, bf16_t>(a, e, split, kps, st); else launch_cfg<2, TA, TB, bf16_t>(a, e, split, kps, st);
   } else {
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)gemm_glds_kernel<TA, TB, float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_set = true; }
-    hipLaunchKernelGGL((gemm_glds_kernel<TA, TB, float>), grid, dim3(256), LDS_BYTES, st, (const bf16_t*)a->A, (long)a->lda,
-                       (const bf16_t*)a->B, (long)a->ldb, a->M, a->N, a->K, kps, e);
+    if (wmr == 4) launch_cfg<4, TA, TB, float>(a, e, split, kps, st); else launch_cfg<2, TA, TB, float>(a, e, split, kps, st);
   }
 }
 
@@ -293,9 +339,15 @@ bool dh_gemm_try_glds(const dh_gemm_args* a, int split, hipStream_t st) {
   e.M = a->M; e.N = a->N; e.C = a->C; e.ldc = a->ldc; e.bias = a->bias; e.epilogue = a->epilogue;
   e.residual = a->residual; e.ldr = a->ldr; e.aux = a->aux; e.ldaux = a->ldaux; e.accumulate = a->accumulate;
   e.alpha = a->alpha;
-  if (a->a_kmajor && a->b_kmajor) launch<true, true>(a, e, split, kps, st);
-  else if (a->a_kmajor) launch<true, false>(a, e, split, kps, st);
-  else if (a->b_kmajor) launch<false, true>(a, e, split, kps, st);
-  else launch<false, false>(a, e, split, kps, st);
+  e.a_colsum = a->a_colsum;
+  // tile choice: 256 x 128 when there is enough work to fill the chip with one block per CU
+  int wmr = 2;
+  const long tiles256 = (long)dh_cdiv(a->M, 256) * dh_cdiv(a->N, BN) * split;
+  (void)tiles256;   // measured: 128 x 128 (2 blocks/CU) beats 256 x 128 (1 block/CU) on every tower shape
+  if (const char* ev = getenv("DH_GEMM_TILE")) { int v = atoi(ev); if (v == 128) wmr = 2; else if (v == 256 && a->M >= 256) wmr = 4; }
+  if (a->a_kmajor && a->b_kmajor) launch<true, true>(a, e, split, kps, wmr, st);
+  else if (a->a_kmajor) launch<true, false>(a, e, split, kps, wmr, st);
+  else if (a->b_kmajor) launch<false, true>(a, e, split, kps, wmr, st);
+  else launch<false, false>(a, e, split, kps, wmr, st);
   return true;
 }

@@ -74,11 +74,21 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2
   m = mm;
 }
 
+// forward partials: block (row tile, pair, column chunk) streams its chunk of K and writes, per row,
+// the online-softmax state (max, sum), the label logit and the count of logits above it; a tiny
+// second kernel merges the chunks.  Column chunking is what gives B = 4096 (8 GPUs) enough blocks.
+// columns per block: chosen on the host so that (row tiles x pairs x chunks) fills the 256 CUs
+static int nce_chunk_cols(int rows, int cols, int n_pairs, int rt) {
+  const int tiles = dh_cdiv(rows, rt) * n_pairs;
+  int want = dh_cdiv(512, tiles);                 // ~2 blocks per CU
+  int chunk = dh_cdiv(dh_cdiv(cols, want), 64) * 64;
+  if (chunk < 64) chunk = 64;
+  return chunk;
+}
+
 template <int RT>
 __global__ __launch_bounds__(256) void nce_fwd_kernel(PairTable pt, int b, int B, int D, const float* __restrict__ scale_p, int label0,
-                                                      float* __restrict__ row_loss, float* __restrict__ row_lse,
-                                                      float* __restrict__ correct1, float* __restrict__ correct5,
-                                                      float* __restrict__ logits_out) {
+                                                      float* __restrict__ part, float* __restrict__ logits_out, int chunk_cols) {
   constexpr int RPT = RT / 16;
   const float scale = *scale_p;
   extern __shared__ float sm[];
@@ -86,6 +96,8 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(PairTable pt, int b, int B
   float* Ys = Xs + RT * (D + 1);       // [64][KC+1]
   float* lab = Ys + CT * (KC + 1);     // [RT] label logits
   const int pair = blockIdx.y;
+  const int nchunk = gridDim.z, chunk = blockIdx.z;
+  const int cbeg = chunk * chunk_cols, cend = min(B, cbeg + chunk_cols);
   const float* Q = pt.Q[pair];
   const float* K = pt.K[pair];
   const int r0 = blockIdx.x * RT;
@@ -94,29 +106,29 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(PairTable pt, int b, int B
   __syncthreads();
   // label logit: 8 threads per row (RT <= 32)
   {
-    const int r = t >> 3, part = t & 7;
+    const int r = t >> 3, part_i = t & 7;
     float a = 0.f;
     if (r < RT && r0 + r < b) {
       const float* kr = K + (long)(label0 + r0 + r) * D;
-      for (int k = part; k < D; k += 8) a = fmaf(Xs[r * (D + 1) + k], kr[k], a);
+      for (int k = part_i; k < D; k += 8) a = fmaf(Xs[r * (D + 1) + k], kr[k], a);
     }
     a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
-    if (r < RT && part == 0) lab[r] = a * scale;
+    if (r < RT && part_i == 0) lab[r] = a * scale;
   }
   __syncthreads();
   float m[RPT], s[RPT], cnt[RPT], ll[RPT];
 #pragma unroll
   for (int r = 0; r < RPT; ++r) { m[r] = -INFINITY; s[r] = 0.f; cnt[r] = 0.f; ll[r] = lab[ty * RPT + r]; }
-  for (int c0 = 0; c0 < B; c0 += CT) {
+  for (int c0 = cbeg; c0 < cend; c0 += CT) {
     float acc[RPT][4];
-    tile_dots<RT>(Xs, D, K, c0, B, Ys, acc);
+    tile_dots<RT>(Xs, D, K, c0, cend, Ys, acc);
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
       const int row = r0 + ty * RPT + r;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int col = c0 + tx * 4 + c;
-        if (col < B) {
+        if (col < cend) {
           const float v = acc[r][c] * scale;
           if (logits_out && row < b) logits_out[((long)pair * b + row) * B + col] = v;
           if (col != label0 + row && v > ll[r]) cnt[r] += 1.f;
@@ -136,14 +148,30 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(PairTable pt, int b, int B
     }
     const int row = r0 + ty * RPT + r;
     if (tx == 0 && row < b) {
-      const float lse = m[r] + __logf(s[r]);
-      const long o = (long)pair * b + row;
-      row_lse[o] = lse;
-      row_loss[o] = lse - ll[r];
-      if (correct1) correct1[o] = cnt[r] < 0.5f ? 1.f : 0.f;
-      if (correct5) correct5[o] = cnt[r] < 4.5f ? 1.f : 0.f;
+      float* o = part + (((long)pair * nchunk + chunk) * b + row) * 4;
+      o[0] = m[r]; o[1] = s[r]; o[2] = cnt[r]; o[3] = ll[r];
     }
   }
+}
+
+__global__ void nce_finalize_kernel(const float* __restrict__ part, int n_pairs, int nchunk, int b,
+                                    float* __restrict__ row_loss, float* __restrict__ row_lse,
+                                    float* __restrict__ correct1, float* __restrict__ correct5) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over pairs * b
+  if (i >= n_pairs * b) return;
+  const int pair = i / b, row = i % b;
+  float m = -INFINITY, s = 0.f, cnt = 0.f, ll = 0.f;
+  for (int c = 0; c < nchunk; ++c) {
+    const float* o = part + (((long)pair * nchunk + c) * b + row) * 4;
+    lse_merge(m, s, o[0], o[1]);
+    cnt += o[2];
+    ll = o[3];
+  }
+  const float lse = m + __logf(s);
+  row_lse[i] = lse;
+  row_loss[i] = lse - ll;
+  if (correct1) correct1[i] = cnt < 0.5f ? 1.f : 0.f;
+  if (correct5) correct5[i] = cnt < 4.5f ? 1.f : 0.f;
 }
 
 // dX_x = scale * sum_y G(x,y) Y_y for a tile of RT rows of X against all rows of Y.
@@ -152,7 +180,7 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(PairTable pt, int b, int B
 template <int RT>
 __global__ __launch_bounds__(256) void nce_bwd_kernel(PairTable pt, int mode, int b, int B, int D, const float* __restrict__ scale_p,
                                                       int label0, const float* __restrict__ row_lse,
-                                                      const float* __restrict__ g_row, float* __restrict__ dscale) {
+                                                      const float* __restrict__ g_row, float* __restrict__ dscale, int chunk_cols) {
   constexpr int RPT = RT / 16;
   const float scale = *scale_p;
   extern __shared__ float sm[];
@@ -165,7 +193,9 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(PairTable pt, int mode, in
   const float* X = mode == 0 ? pt.Q[pair] : pt.K[pair];
   const float* Y = mode == 0 ? pt.K[pair] : pt.Q[pair];
   float* dX = mode == 0 ? pt.dQ[pair] : pt.dK[pair];
-  const int nx = mode == 0 ? b : B, ny = mode == 0 ? B : b;
+  const int nx = mode == 0 ? b : B, ny_all = mode == 0 ? B : b;
+  const int ybeg = blockIdx.z * chunk_cols, ny = min(ny_all, ybeg + chunk_cols);   // column chunk of this block
+  const bool chunked = gridDim.z > 1;
   const int r0 = blockIdx.x * RT;
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   const float* lse_p = row_lse + (long)pair * b;
@@ -173,7 +203,7 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(PairTable pt, int mode, in
   load_rows<RT>(Xs, X, r0, nx, D);
   for (int i = t; i < RT * (D + 1); i += 256) dXs[i] = 0.f;
   float ds_acc = 0.f;
-  for (int c0 = 0; c0 < ny; c0 += CT) {
+  for (int c0 = ybeg; c0 < ny; c0 += CT) {
     float acc[RPT][4];
     tile_dots<RT>(Xs, D, Y, c0, ny, Ys, acc);
 #pragma unroll
@@ -225,7 +255,10 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(PairTable pt, int mode, in
   __syncthreads();
   for (int i = t; i < RT * D; i += 256) {
     int r = i / D, k = i % D;
-    if (r0 + r < nx) dX[(long)(r0 + r) * D + k] = dXs[r * (D + 1) + k] * scale;
+    if (r0 + r < nx) {
+      if (chunked) atomicAdd(dX + (long)(r0 + r) * D + k, dXs[r * (D + 1) + k] * scale);
+      else dX[(long)(r0 + r) * D + k] = dXs[r * (D + 1) + k] * scale;
+    }
   }
   if (mode == 0 && dscale) {
     float tot = block_sum256(ds_acc, red);
@@ -282,25 +315,33 @@ int fill_table(PairTable& pt, const dh_nce_pair* pairs, int n) {
 
 }  // namespace
 
+extern "C" int64_t dh_infonce_ws_bytes(int n_pairs, int b, int B) {
+  const int nchunk = dh_cdiv(B, nce_chunk_cols(b, B, n_pairs, 32));
+  return (int64_t)n_pairs * nchunk * b * 4 * sizeof(float);
+}
+
 extern "C" int dh_infonce_fwd(const dh_nce_pair* pairs, int n_pairs, int b, int B, int D, const float* scale, int label0,
                               float* row_loss, float* row_lse, float* correct1, float* correct5, float* logits_out,
-                              dh_stream_t stream) {
+                              void* ws, int64_t ws_bytes, dh_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   DH_REQUIRE(pairs && n_pairs >= 1 && n_pairs <= DH_MAX_PAIRS, "dh_infonce_fwd: 1..%d pairs", DH_MAX_PAIRS);
   DH_REQUIRE(b > 0 && B >= b && D > 0 && row_loss && row_lse && scale, "dh_infonce_fwd: bad args");
   DH_REQUIRE(label0 >= 0 && label0 + b <= B, "dh_infonce_fwd: labels out of range");
+  DH_REQUIRE(ws && ws_bytes >= dh_infonce_ws_bytes(n_pairs, b, B), "dh_infonce_fwd: workspace too small");
   PairTable pt;
   fill_table(pt, pairs, n_pairs);
   for (int i = 0; i < n_pairs; ++i) DH_REQUIRE(pt.Q[i] && pt.K[i], "dh_infonce_fwd: null feature pointer");
-  if (D <= 1024) {
-    constexpr int RT = 32;
-    size_t lds = (size_t)(RT * (D + 1) + CT * (KC + 1) + RT) * sizeof(float);
-    hipFuncSetAttribute((const void*)nce_fwd_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(nce_fwd_kernel<RT>, dim3(dh_cdiv(b, RT), n_pairs), dim3(256), lds, st, pt, b, B, D, scale, label0,
-                       row_loss, row_lse, correct1, correct5, logits_out);
-  } else {
-    DH_FAIL(DH_ERR_UNSUPPORTED, "dh_infonce_fwd: D=%d > 1024", D);
-  }
+  DH_REQUIRE(D <= 1024, "dh_infonce_fwd: D=%d > 1024", D);
+  constexpr int RT = 32;
+  const int chunk_cols = nce_chunk_cols(b, B, n_pairs, RT);
+  const int nchunk = dh_cdiv(B, chunk_cols);
+  size_t lds = (size_t)(RT * (D + 1) + CT * (KC + 1) + RT) * sizeof(float);
+  hipFuncSetAttribute((const void*)nce_fwd_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(nce_fwd_kernel<RT>, dim3(dh_cdiv(b, RT), n_pairs, nchunk), dim3(256), lds, st, pt, b, B, D, scale, label0,
+                     (float*)ws, logits_out, chunk_cols);
+  DH_CHECK_LAUNCH();
+  hipLaunchKernelGGL(nce_finalize_kernel, dim3(dh_cdiv(n_pairs * b, 256)), dim3(256), 0, st, (const float*)ws, n_pairs, nchunk, b,
+                     row_loss, row_lse, correct1, correct5);
   DH_CHECK_LAUNCH();
   return DH_OK;
 }
@@ -317,9 +358,14 @@ extern "C" int dh_infonce_bwd(const dh_nce_pair* pairs, int n_pairs, int b, int 
     constexpr int RT = decltype(rt_tag)::value;
     size_t lds = (size_t)(2 * RT * (D + 1) + CT * (KC + 1) + RT * (CT + 1) + 8) * sizeof(float);
     hipFuncSetAttribute((const void*)nce_bwd_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int nx = mode == 0 ? b : B;
-    hipLaunchKernelGGL(nce_bwd_kernel<RT>, dim3(dh_cdiv(nx, RT), n_pairs), dim3(256), lds, st, pt, mode, b, B, D, scale,
-                       label0, row_lse, g_row, dscale);
+    const int nx = mode == 0 ? b : B, ny = mode == 0 ? B : b;
+    const int chunk_cols = nce_chunk_cols(nx, ny, n_pairs, RT);
+    const int nz = dh_cdiv(ny, chunk_cols);
+    if (nz > 1)
+      for (int i = 0; i < n_pairs; ++i)
+        hipMemsetAsync(mode == 0 ? (void*)pt.dQ[i] : (void*)pt.dK[i], 0, sizeof(float) * (size_t)nx * D, st);
+    hipLaunchKernelGGL(nce_bwd_kernel<RT>, dim3(dh_cdiv(nx, RT), n_pairs, nz), dim3(256), lds, st, pt, mode, b, B, D, scale,
+                       label0, row_lse, g_row, dscale, chunk_cols);
   };
   if (D <= 512) {
     launch(std::integral_constant<int, 32>{}, 0);

@@ -179,13 +179,23 @@ __global__ __launch_bounds__(256) void ln_bwd_scalar_kernel(const T* __restrict_
   }
 }
 
-__global__ void ln_reduce_kernel(const float* __restrict__ part, int nblocks, int d, float* __restrict__ dw,
-                                 float* __restrict__ db) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 2*d
-  if (i >= 2 * d) return;
+// part[nblocks][2d] -> dw/db: block = 64 columns x 4 row-lanes, coalesced rows of the partial matrix
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ part, int nblocks, int d,
+                                                        float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float red[4][64];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);  // over 2*d
+  const int rl = threadIdx.x >> 6;
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += part[(long)b * 2 * d + i];
-  if (i < d) dw[i] += s; else db[i - d] += s;
+  if (i < 2 * d)
+    for (int b = b0 + rl; b < b1; b += 4) s += part[(long)b * 2 * d + i];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && i < 2 * d) {
+    s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(i < d ? dw + i : db + (i - d), s);
+  }
 }
 
 }  // namespace
@@ -212,9 +222,15 @@ extern "C" int dh_layernorm_fwd(int dtype, const void* x, const float* w, const 
   return DH_OK;
 }
 
+static int ln_bwd_blocks(int rows) {
+  int nb = dh_cdiv(rows, 8);     // >= 2 rows per wave so the register partials amortise
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return nb;
+}
+
 extern "C" int64_t dh_layernorm_bwd_ws_bytes(int rows, int d) {
-  int nb = dh_cdiv(rows, 4);
-  if (nb > 256) nb = 256;
+  int nb = ln_bwd_blocks(rows);
   return (int64_t)nb * 2 * d * sizeof(float);
 }
 
@@ -225,8 +241,7 @@ extern "C" int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const 
   DH_REQUIRE(dy && x && w && mean && rstd && dx && dw && db && rows > 0 && d > 0, "dh_layernorm_bwd: bad args");
   const bool vec = (d % 8 == 0) && d <= 8 * 64 * LN_MAXC && (size_t)(8 * d * sizeof(float)) <= 64 * 1024;
   if (vec) {
-    int nb = dh_cdiv(rows, 4);
-    if (nb > 256) nb = 256;
+    int nb = ln_bwd_blocks(rows);
     DH_REQUIRE(ws && ws_bytes >= (int64_t)nb * 2 * d * (int64_t)sizeof(float), "dh_layernorm_bwd: workspace too small");
     size_t lds = 8 * d * sizeof(float);
     if (dtype == DH_BF16)
@@ -234,7 +249,7 @@ extern "C" int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const 
     else
       hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), lds, st, (const float*)dy, (const float*)x, w, mean, rstd, (const float*)dres, (float*)dx, (float*)ws, rows, d);
     DH_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3(dh_cdiv(2 * d, 256)), dim3(256), 0, st, (const float*)ws, nb, d, dw, db);
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3(dh_cdiv(2 * d, 64), nb >= 64 ? 16 : 1), dim3(256), 0, st, (const float*)ws, nb, d, dw, db);
   } else {
     dim3 grid(ln_grid(rows) > 256 ? 256 : ln_grid(rows));
     if (dtype == DH_BF16)

@@ -118,12 +118,14 @@ class FlatParams:
         if self._in_backward:
             return
         self._in_backward = True
-        none = [p for p in self.params if p.grad is None]
-        if len(none) == len(self.params):
-            self.flat_g.zero_()
-        else:
-            for p in none:
-                self.gview(p).zero_()
+        base, end = self.flat_g.data_ptr(), self.flat_g.data_ptr() + 4 * self.total
+        live = [p for p in self.params if p.grad is not None and base <= p.grad.data_ptr() < end]
+        if not live:
+            self.flat_g.zero_()                  # the common case: optimizer.zero_grad() ran -> one memset
+        else:                                    # accumulate semantics: keep live views, zero the rest
+            for p in self.params:
+                if p.grad is None or not (base <= p.grad.data_ptr() < end):
+                    self.gview(p).zero_()
         if self.reducer is not None:
             self.reducer.begin()
         torch.autograd.Variable._execution_engine.queue_callback(self._end_backward)
@@ -178,9 +180,11 @@ def _split_k(mg, ng, kg):
     return s
 
 
-def weight_grad(dy, x, gw):
-    """gw[out,in] += dy[rows,out]^T x[rows,in]  (contraction over rows: both operands k-major)."""
-    ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=gw, accumulate=True, split_k=_split_k(gw.shape[0], gw.shape[1], dy.shape[0]))
+def weight_grad(dy, x, gw, gb=None):
+    """gw[out,in] += dy[rows,out]^T x[rows,in]  (contraction over rows: both operands k-major);
+    gb[out] += colsum(dy) fused into the same launch (bias gradient)."""
+    ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=gw, accumulate=True,
+             split_k=_split_k(gw.shape[0], gw.shape[1], dy.shape[0]), a_colsum=gb)
 
 
 def block_fwd(x, r, b, L, heads, causal, save):
@@ -200,20 +204,16 @@ def block_fwd(x, r, b, L, heads, causal, save):
 def block_bwd(dx_out, r, saved, b, L, heads, causal):
     x, mean1, rstd1, h1, qkv, a, lse, x_mid, mean2, rstd2, h2, u, g = saved
     # MLP: x_out = x_mid + gelu(h2 Wfc^T + bfc) Wproj^T + bproj
-    weight_grad(dx_out, g, r.g_w_proj)
-    ops.colsum(dx_out, r.g_b_proj)
+    weight_grad(dx_out, g, r.g_w_proj, r.g_b_proj)
     du = ops.gemm(dx_out, r.w_proj, b_kmajor=True, epilogue=EPI_DGELU, aux=u)
-    weight_grad(du, h2, r.g_w_fc)
-    ops.colsum(du, r.g_b_fc)
+    weight_grad(du, h2, r.g_w_fc, r.g_b_fc)
     dh2 = ops.gemm(du, r.w_fc, b_kmajor=True)
     dx_mid = ops.layernorm_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)
     # attention: x_mid = x + attn(h1) Wout^T + bout
-    weight_grad(dx_mid, a, r.g_w_out)
-    ops.colsum(dx_mid, r.g_b_out)
+    weight_grad(dx_mid, a, r.g_w_out, r.g_b_out)
     da = ops.gemm(dx_mid, r.w_out, b_kmajor=True)
     dqkv = ops.attn_bwd(qkv, a, da, lse, b, L, heads, causal)
-    weight_grad(dqkv, h1, r.g_w_in)
-    ops.colsum(dqkv, r.g_b_in)
+    weight_grad(dqkv, h1, r.g_w_in, r.g_b_in)
     dh1 = ops.gemm(dqkv, r.w_in, b_kmajor=True)
     return ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
 
@@ -362,8 +362,7 @@ class TextTowerFn(torch.autograd.Function):
         dfeat = None
         if dout is not None:
             dout_a = _to_act(dout, dtype)
-            weight_grad(dout_a, feat, g(tp.weight))
-            ops.colsum(dout_a, g(tp.bias))
+            weight_grad(dout_a, feat, g(tp.weight), g(tp.bias))
             dfeat = ops.gemm(dout_a, flat.wview(tp.weight), b_kmajor=True)
         lnw = tower.ln_final.weight.data
         if want_dense:
@@ -379,7 +378,9 @@ class TextTowerFn(torch.autograd.Function):
             dx = block_bwd(dx, r, s, b, L, heads, True)
             flat.grads_ready(r.params)
         te, pe = tower.token_embedding.weight, tower.positional_embedding
-        ops.text_embed_bwd(ids, dx, g(te) if te.requires_grad else None, g(pe) if pe.requires_grad else None)
+        V = te.shape[0]
+        ops.text_embed_bwd(ids, dx, g(te) if te.requires_grad else None, g(pe) if pe.requires_grad else None,
+                           hot_ids=(0, V - 2, V - 1))          # pad, <|startoftext|>, <|endoftext|>
         ctx.saved_blocks = ctx.misc = None
         return (torch.zeros_like(flat.anchor), None, None, None)
 

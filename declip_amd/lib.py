@@ -28,7 +28,7 @@ class GemmArgs(Structure):
         ("A", c_void_p), ("lda", c_int64), ("B", c_void_p), ("ldb", c_int64), ("C", c_void_p), ("ldc", c_int64),
         ("bias", c_void_p), ("epilogue", c_int), ("residual", c_void_p), ("ldr", c_int64),
         ("aux", c_void_p), ("ldaux", c_int64), ("accumulate", c_int), ("split_k", c_int), ("alpha", c_float),
-        ("force_generic", c_int),
+        ("force_generic", c_int), ("a_colsum", c_void_p),
     ]
 
 
@@ -49,7 +49,7 @@ _PROTOS = {
     "dh_attn_fwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_text_embed_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
-    "dh_text_embed_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "dh_text_embed_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, POINTER(c_int64), c_int, _P]),
     "dh_im2row": (c_int, [c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "dh_vit_assemble_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "dh_vit_assemble_bwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
@@ -57,7 +57,8 @@ _PROTOS = {
     "dh_pool_rows_bwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
     "dh_l2norm_fwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_float, _P]),
     "dh_l2norm_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
-    "dh_infonce_fwd": (c_int, [POINTER(NcePair), c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]),
+    "dh_infonce_ws_bytes": (c_int64, [c_int, c_int, c_int]),
+    "dh_infonce_fwd": (c_int, [POINTER(NcePair), c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, c_int64, _P]),
     "dh_infonce_bwd": (c_int, [POINTER(NcePair), c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
     "dh_ce_rows_fwd": (c_int, [_P, c_int64, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "dh_ce_rows_bwd": (c_int, [_P, c_int64, _P, c_int, c_int, _P, _P, _P, c_int64, _P]),

@@ -18,7 +18,7 @@ def _contig(t, name):
 
 
 def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, residual=None, aux=None,
-         out=None, out_dtype=None, accumulate=False, split_k=1, alpha=1.0, force_generic=False):
+         out=None, out_dtype=None, accumulate=False, split_k=1, alpha=1.0, force_generic=False, a_colsum=None):
     """C[M,N] = epi(alpha * sum_k A(m,k) B(n,k) + bias).  A: [M,K] (or [K,M] if a_kmajor);
     B: [N,K] (or [K,N] if b_kmajor).  See include/declip_hip.h."""
     lib = L.load()
@@ -47,6 +47,9 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, 
         assert aux.dtype == (out.dtype if epilogue == EPI_GELU else A.dtype)
         a.aux, a.ldaux = ptr(aux), aux.stride(0)
     a.accumulate, a.split_k, a.alpha, a.force_generic = int(accumulate), int(split_k), float(alpha), int(force_generic)
+    if a_colsum is not None:
+        assert a_kmajor and a_colsum.dtype == torch.float32 and a_colsum.numel() == M
+        a.a_colsum = ptr(a_colsum)
     check(lib.dh_gemm(ctypes.byref(a), stream()), "dh_gemm")
     return out
 
@@ -111,10 +114,13 @@ def text_embed_fwd(ids, table, pos, dtype):
     return x
 
 
-def text_embed_bwd(ids, dx, dtable, dpos):
+def text_embed_bwd(ids, dx, dtable, dpos, hot_ids=(0,)):
+    """hot_ids: ids that occur in (almost) every caption (pad, SOT, EOT) -- reduced without atomic contention."""
     b, Lq = ids.shape
     d = dx.shape[-1]
-    check(L.load().dh_text_embed_bwd(dt(dx), ptr(ids), ptr(dx), ptr(dtable), ptr(dpos), b, Lq, d, stream()), "dh_text_embed_bwd")
+    hot = (ctypes.c_int64 * max(1, len(hot_ids)))(*hot_ids)
+    check(L.load().dh_text_embed_bwd(dt(dx), ptr(ids), ptr(dx), ptr(dtable), ptr(dpos), b, Lq, d, hot, len(hot_ids), stream()),
+          "dh_text_embed_bwd")
 
 
 def im2row(images, c0, patch, dtype):
@@ -191,8 +197,11 @@ def infonce_fwd(pairs, scale, label0, want_logits=False):
     row_loss, row_lse, c1, c5 = mk(), mk(), mk(), mk()
     logits = torch.empty(P, b, B, device=Q0.device, dtype=torch.float32) if want_logits else None
     arr = _pair_array(pairs)
-    check(L.load().dh_infonce_fwd(arr, P, b, B, D, ptr(scale), int(label0), ptr(row_loss), ptr(row_lse), ptr(c1), ptr(c5),
-                                  ptr(logits), stream()), "dh_infonce_fwd")
+    lib = L.load()
+    nbytes = lib.dh_infonce_ws_bytes(P, b, B)
+    ws = torch.empty(nbytes // 4, device=Q0.device, dtype=torch.float32)
+    check(lib.dh_infonce_fwd(arr, P, b, B, D, ptr(scale), int(label0), ptr(row_loss), ptr(row_lse), ptr(c1), ptr(c5),
+                             ptr(logits), ptr(ws), nbytes, stream()), "dh_infonce_fwd")
     return row_loss, row_lse, c1, c5, logits
 
 

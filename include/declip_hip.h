@@ -56,6 +56,8 @@ int dh_device_info(int device, int* out4);
  *   DH_EPI_DGELU  C = value * QuickGELU'(aux_in[m,n])                 (backward of the above)
  *   residual != NULL: C += residual[m,n] (type c_dtype)               (base_transformer.py:51-52)
  *   accumulate = 1: C is fp32 and is atomically accumulated into (split_k > 1 allowed).
+ *   a_colsum (with a_kmajor): the weight-gradient call dW = dY^T X also emits db = colsum(dY) from the dY
+ *   tiles it already staged in LDS (nn.Linear bias gradient without re-reading dY from HBM).
  */
 #define DH_EPI_NONE 0
 #define DH_EPI_GELU 1
@@ -77,6 +79,7 @@ typedef struct dh_gemm_args {
   int split_k;           /* >=1; >1 requires accumulate */
   float alpha;
   int force_generic;     /* tests: 1 = VALU fp32-FMA kernel, 2 = v1 register-staged MFMA kernel, 0 = auto */
+  float* a_colsum;       /* optional, a_kmajor only: a_colsum[m] += sum_k A(m,k) (bias gradient fused into dW) */
 } dh_gemm_args;
 int dh_gemm(const dh_gemm_args* args, dh_stream_t stream);
 
@@ -110,11 +113,13 @@ int dh_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, c
 
 /* ---------------------------------------------------------------- embeddings ------------
  * Text: x[b,l,:] = table[ids[b,l],:] + pos[l,:]   (text_transformer.py:188-190); table/pos fp32.
- * bwd: dtable (fp32, atomic accumulate) and dpos (fp32, atomic accumulate). */
+ * bwd: dtable (fp32, atomic accumulate) and dpos (fp32, atomic accumulate).  hot_ids_host (<= 4, HOST array):
+ * ids present in (almost) every caption -- pad 0, SOT, EOT -- which are block-reduced instead of serialising
+ * thousands of atomics on one table row. */
 int dh_text_embed_fwd(int dtype, const int64_t* ids, const float* table, const float* pos, void* x, int b, int L, int d,
                       dh_stream_t stream);
 int dh_text_embed_bwd(int dtype, const int64_t* ids, const void* dx, float* dtable, float* dpos, int b, int L, int d,
-                      dh_stream_t stream);
+                      const int64_t* hot_ids_host, int n_hot, dh_stream_t stream);
 /* Vision: im2row of the stride-P patch conv (visual_transformer.py:14-15,56-59):
  * images [b,3,H,W] fp32 (channel offset c0 of C_total channels, for channel-stacked views,
  * data/transforms.py:38-41) -> rows [b*gh*gw, 3*P*P] (dtype), inner order (c,ph,pw). */
@@ -151,9 +156,10 @@ typedef struct dh_nce_pair {
   const float* Q; const float* K;   /* [b,D], [B,D] */
   float* dQ; float* dK;             /* bwd outputs (may be NULL in fwd) */
 } dh_nce_pair;
+int64_t dh_infonce_ws_bytes(int n_pairs, int b, int B);
 int dh_infonce_fwd(const dh_nce_pair* pairs_host, int n_pairs, int b, int B, int D, const float* scale_dev, int label0,
                    float* row_loss, float* row_lse, float* correct1, float* correct5, float* logits_out,
-                   dh_stream_t stream);
+                   void* ws, int64_t ws_bytes, dh_stream_t stream);
 int dh_infonce_bwd(const dh_nce_pair* pairs_host, int n_pairs, int b, int B, int D, const float* scale_dev, int label0,
                    const float* row_lse, const float* g_row, float* dscale, dh_stream_t stream);
 

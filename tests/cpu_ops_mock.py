@@ -19,7 +19,9 @@ def _dgelu(x):
 
 
 def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, residual=None, aux=None, out=None,
-         out_dtype=None, accumulate=False, split_k=1, alpha=1.0, force_generic=False):
+         out_dtype=None, accumulate=False, split_k=1, alpha=1.0, force_generic=False, a_colsum=None):
+    if a_colsum is not None:
+        a_colsum += A.float().sum(0)
     a = A.float().t() if a_kmajor else A.float()
     b = B.float() if b_kmajor else B.float().t()
     v = alpha * (a @ b)
@@ -103,7 +105,7 @@ def text_embed_fwd(ids, table, pos, dtype):
     return (table[ids] + pos).reshape(b * L, -1).to(dtype)
 
 
-def text_embed_bwd(ids, dx, dtable, dpos):
+def text_embed_bwd(ids, dx, dtable, dpos, hot_ids=(0,)):
     b, L = ids.shape
     if dtable is not None:
         dtable.index_add_(0, ids.reshape(-1), dx.float())

@@ -81,9 +81,18 @@ def test_gemm_weight_grad_accumulate_splitk(dtype):
     dY, X = rnd(rows, out_f, seed=8).to(dtype), rnd(rows, in_f, seed=9).to(dtype)
     G0 = rnd(out_f, in_f, seed=10)
     gw = G0.clone().to(cuda)
-    ops.gemm(dY.to(cuda), X.to(cuda), a_kmajor=True, b_kmajor=True, out=gw, accumulate=True, split_k=4)
+    gb = torch.ones(out_f, device=cuda)
+    ops.gemm(dY.to(cuda), X.to(cuda), a_kmajor=True, b_kmajor=True, out=gw, accumulate=True, split_k=4, a_colsum=gb)
     ref = G0.double() + dY.double().t() @ X.double()
     assert rel_err(gw, ref) < (1e-5 if dtype == torch.float32 else 2e-3)
+    assert rel_err(gb, 1 + dY.double().sum(0)) < 1e-4
+    # MFMA/LDS-DMA path (rows % 64 == 0) with the fused bias gradient
+    rows2 = 1024
+    dY2, X2 = rnd(rows2, out_f, seed=18).to(dtype), rnd(rows2, in_f, seed=19).to(dtype)
+    gw2, gb2 = torch.zeros(out_f, in_f, device=cuda), torch.zeros(out_f, device=cuda)
+    ops.gemm(dY2.to(cuda), X2.to(cuda), a_kmajor=True, b_kmajor=True, out=gw2, accumulate=True, split_k=2, a_colsum=gb2)
+    assert rel_err(gw2, dY2.double().t() @ X2.double()) < (1e-5 if dtype == torch.float32 else 2e-3)
+    assert rel_err(gb2, dY2.double().sum(0)) < 1e-4
 
 
 def test_colsum():
@@ -165,7 +174,7 @@ def test_text_embed(dtype):
     assert rel_err(x.view(b, L, d), ref) < (1e-6 if dtype == torch.float32 else 1e-2)
     dx = rnd(b * L, d, seed=22).to(dtype)
     dt, dp = torch.zeros(V, d, device=cuda), torch.zeros(L, d, device=cuda)
-    ops.text_embed_bwd(ids.to(cuda), dx.to(cuda), dt, dp)
+    ops.text_embed_bwd(ids.to(cuda), dx.to(cuda), dt, dp, hot_ids=(int(ids[0, 3]), 0))
     rt = torch.zeros(V, d, dtype=torch.float64).index_add_(0, ids.reshape(-1), dx.double())
     assert rel_err(dt, rt) < 1e-5
     assert rel_err(dp, dx.double().view(b, L, d).sum(0)) < 1e-5
@@ -219,7 +228,8 @@ def test_pool_and_l2norm(dtype):
 
 
 # ----------------------------------------------------------------------------- losses
-@pytest.mark.parametrize("b,B,D,label0", [(8, 8, 64, 0), (40, 120, 512, 40), (70, 70, 256, 0), (33, 99, 768, 66)])
+@pytest.mark.parametrize("b,B,D,label0", [(8, 8, 64, 0), (40, 120, 512, 40), (70, 70, 256, 0), (33, 99, 768, 66),
+                                          (96, 1160, 128, 1000), (520, 520, 64, 0)])
 def test_infonce(b, B, D, label0):
     ops = _ops()
     P = 2
