@@ -317,9 +317,13 @@ bool dh_gemm_try_glds(const dh_gemm_args* a, int split, hipStream_t st) {
   using namespace glds;
   if (a->dtype != DH_BF16 || a->force_generic) return false;
   if ((a->lda % 8) || (a->ldb % 8) || ((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15)) return false;
-  if (a->N % 8 || a->M < 1) return false;
-  if (a->a_kmajor && (a->M % 8)) return false;
-  if (a->b_kmajor && (a->N % 8)) return false;
+  if (a->M < 1) return false;
+  if (!a->pad_ok) {
+    if (a->N % 8) return false;
+    if (a->a_kmajor && (a->M % 8)) return false;
+  } else if (!a->accumulate && (a->N % 8)) {
+    return false;                                   // the vector epilogue needs whole 8-column chunks
+  }
   if (!a->a_kmajor && a->M < 1) return false;
   int kps = ((a->K + split - 1) / split + BK - 1) / BK * BK;
   if (a->K % BK) return false;

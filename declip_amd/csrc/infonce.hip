@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(PairTable pt, int mode, in
   const float* X = mode == 0 ? pt.Q[pair] : pt.K[pair];
   const float* Y = mode == 0 ? pt.K[pair] : pt.Q[pair];
   float* dX = mode == 0 ? pt.dQ[pair] : pt.dK[pair];
+  if (dX == nullptr && !(mode == 0 && dscale != nullptr)) return;     // gradient not wanted for this operand
   const int nx = mode == 0 ? b : B, ny_all = mode == 0 ? B : b;
   const int ybeg = blockIdx.z * chunk_cols, ny = min(ny_all, ybeg + chunk_cols);   // column chunk of this block
   const bool chunked = gridDim.z > 1;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(PairTable pt, int mode, in
   __syncthreads();
   for (int i = t; i < RT * D; i += 256) {
     int r = i / D, k = i % D;
-    if (r0 + r < nx) {
+    if (dX != nullptr && r0 + r < nx) {
       if (chunked) atomicAdd(dX + (long)(r0 + r) * D + k, dXs[r * (D + 1) + k] * scale);
       else dX[(long)(r0 + r) * D + k] = dXs[r * (D + 1) + k] * scale;
     }
@@ -307,6 +308,25 @@ __global__ __launch_bounds__(256) void ce_rows_bwd_kernel(const float* __restric
   }
 }
 
+// padded / typed variant for the masked-LM head: dlogits [rows_pad][ldd] of type T, zero outside [rows) x [C)
+template <typename T>
+__global__ __launch_bounds__(256) void ce_rows_bwd_pad_kernel(const float* __restrict__ logits, long ld, const int64_t* __restrict__ labels,
+                                                              int rows, int C, const float* __restrict__ row_lse,
+                                                              const float* __restrict__ g_row, T* __restrict__ dlogits, long ldd,
+                                                              int rows_pad, int C_pad) {
+  for (int row = blockIdx.x; row < rows_pad; row += gridDim.x) {
+    const bool live = row < rows;
+    const long lab = live ? labels[row] : -1;
+    const bool valid = lab >= 0 && lab < C;
+    const float g = valid ? g_row[row] : 0.f, lse = live ? row_lse[row] : 0.f;
+    for (int c = threadIdx.x; c < C_pad; c += 256) {
+      float v = 0.f;
+      if (live && c < C && valid) v = g * (__expf(logits[(long)row * ld + c] - lse) - (c == lab ? 1.f : 0.f));
+      st<T>(dlogits + (long)row * ldd + c, v);
+    }
+  }
+}
+
 int fill_table(PairTable& pt, const dh_nce_pair* pairs, int n) {
   for (int i = 0; i < DH_MAX_PAIRS; ++i) { pt.Q[i] = nullptr; pt.K[i] = nullptr; pt.dQ[i] = nullptr; pt.dK[i] = nullptr; }
   for (int i = 0; i < n; ++i) { pt.Q[i] = pairs[i].Q; pt.K[i] = pairs[i].K; pt.dQ[i] = pairs[i].dQ; pt.dK[i] = pairs[i].dK; }
@@ -353,7 +373,7 @@ extern "C" int dh_infonce_bwd(const dh_nce_pair* pairs, int n_pairs, int b, int 
   DH_REQUIRE(b > 0 && B >= b && D > 0 && row_lse && g_row && scale, "dh_infonce_bwd: bad args");
   PairTable pt;
   fill_table(pt, pairs, n_pairs);
-  for (int i = 0; i < n_pairs; ++i) DH_REQUIRE(pt.Q[i] && pt.K[i] && pt.dQ[i] && pt.dK[i], "dh_infonce_bwd: null pointer");
+  for (int i = 0; i < n_pairs; ++i) DH_REQUIRE(pt.Q[i] && pt.K[i], "dh_infonce_bwd: null feature pointer");  // dQ/dK may be NULL: skipped
   auto launch = [&](auto rt_tag, int mode) {
     constexpr int RT = decltype(rt_tag)::value;
     size_t lds = (size_t)(2 * RT * (D + 1) + CT * (KC + 1) + RT * (CT + 1) + 8) * sizeof(float);
@@ -362,8 +382,10 @@ extern "C" int dh_infonce_bwd(const dh_nce_pair* pairs, int n_pairs, int b, int 
     const int chunk_cols = nce_chunk_cols(nx, ny, n_pairs, RT);
     const int nz = dh_cdiv(ny, chunk_cols);
     if (nz > 1)
-      for (int i = 0; i < n_pairs; ++i)
-        hipMemsetAsync(mode == 0 ? (void*)pt.dQ[i] : (void*)pt.dK[i], 0, sizeof(float) * (size_t)nx * D, st);
+      for (int i = 0; i < n_pairs; ++i) {
+        void* dst = mode == 0 ? (void*)pt.dQ[i] : (void*)pt.dK[i];
+        if (dst) hipMemsetAsync(dst, 0, sizeof(float) * (size_t)nx * D, st);
+      }
     hipLaunchKernelGGL(nce_bwd_kernel<RT>, dim3(dh_cdiv(nx, RT), n_pairs, nz), dim3(256), lds, st, pt, mode, b, B, D, scale,
                        label0, row_lse, g_row, dscale, chunk_cols);
   };
@@ -395,6 +417,23 @@ extern "C" int dh_ce_rows_bwd(const float* logits, int64_t ld, const int64_t* la
   DH_REQUIRE(logits && labels && rows > 0 && C > 0 && row_lse && g_row && dlogits, "dh_ce_rows_bwd: bad args");
   hipLaunchKernelGGL(ce_rows_bwd_kernel, dim3(rows > 4096 ? 4096 : rows), dim3(256), 0, st, logits, (long)ld, labels, rows, C,
                      row_lse, g_row, dlogits, (long)ldd);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_ce_rows_bwd_padded(const float* logits, int64_t ld, const int64_t* labels, int rows, int C, const float* row_lse,
+                                     const float* g_row, void* dlogits, int out_dtype, int64_t ldd, int rows_pad, int C_pad,
+                                     dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(logits && labels && rows > 0 && C > 0 && row_lse && g_row && dlogits && rows_pad >= rows && C_pad >= C && ldd >= C_pad,
+             "dh_ce_rows_bwd_padded: bad args");
+  dim3 grid(rows_pad > 4096 ? 4096 : rows_pad);
+  if (out_dtype == DH_BF16)
+    hipLaunchKernelGGL(ce_rows_bwd_pad_kernel<bf16_t>, grid, dim3(256), 0, st, logits, (long)ld, labels, rows, C, row_lse, g_row,
+                       (bf16_t*)dlogits, (long)ldd, rows_pad, C_pad);
+  else
+    hipLaunchKernelGGL(ce_rows_bwd_pad_kernel<float>, grid, dim3(256), 0, st, logits, (long)ld, labels, rows, C, row_lse, g_row,
+                       (float*)dlogits, (long)ldd, rows_pad, C_pad);
   DH_CHECK_LAUNCH();
   return DH_OK;
 }

@@ -15,6 +15,7 @@ from . import ops
 from .lib import DeclipHipError, EPI_DGELU, EPI_GELU, EPI_NONE
 
 ALIGN = 64  # elements; keeps every parameter 256-byte aligned inside the flat buffers
+SLACK = 1 << 16  # zero elements after the last parameter: padded-operand over-reads (MLM head, pad_ok GEMMs) stay in bounds
 
 
 def _require_gpu(p, name):
@@ -57,8 +58,8 @@ class FlatParams:
             off += (n + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
         dev = self.params[0].device
-        self.flat_p = torch.zeros(off, device=dev, dtype=torch.float32)
-        self.flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.flat_p = torch.zeros(off + SLACK, device=dev, dtype=torch.float32)[:off]
+        self.flat_g = torch.zeros(off + SLACK, device=dev, dtype=torch.float32)[:off]
         for p in self.params:
             o, n = self.index[id(p)]
             view = self.flat_p[o:o + n].view(p.shape)
@@ -66,7 +67,7 @@ class FlatParams:
             p.data = view
             p.grad = None
         if self.act_dtype == torch.bfloat16:
-            self.flat_b = torch.empty(off, device=dev, dtype=torch.bfloat16)
+            self.flat_b = torch.zeros(off + SLACK, device=dev, dtype=torch.bfloat16)[:off]
         self.anchor = torch.zeros(1, device=dev, dtype=torch.float32, requires_grad=True)
         self.mirror_fresh = False
         return self
@@ -229,19 +230,27 @@ def _to_act(t, dtype):
 # vision tower (image_encoder/visual_transformer.py:55-82)
 # ---------------------------------------------------------------------------------------------
 class VisionTowerFn(torch.autograd.Function):
-    """forward(anchor, images, tower, c0, want_dense, want_feature) ->
-         proj [b,E] fp32 (, dense [b,np,width] act dtype)(, feature [b,width] act dtype)"""
+    """forward(anchor, images, tower, c0, want_dense, want_feature, n_views) ->
+         proj [V*b,E] fp32 (, dense [V*b,np,width] act dtype)(, feature [V*b,width] act dtype)
+    n_views channel-stacked views (data/transforms.py:38-54) are encoded in ONE pass as a batch of V*b
+    (view-major), which is arithmetically identical to V separate passes (no cross-sample op in the tower)."""
 
     @staticmethod
-    def forward(ctx, anchor, images, tower, c0, want_dense, want_feature):
+    def forward(ctx, anchor, images, tower, c0, want_dense, want_feature, n_views=1):
         flat = tower._flat()
         dtype = flat.act_dtype
-        b = images.shape[0]
+        b0 = images.shape[0]
+        b = b0 * n_views
         P, width, heads = tower.patch_size, tower.width, tower.heads
         npatch = (images.shape[2] // P) * (images.shape[3] // P)
         L = npatch + 1
         save = bool(ctx.needs_input_grad[0])
-        rows = ops.im2row(images, c0, P, dtype)
+        if n_views == 1:
+            rows = ops.im2row(images, c0, P, dtype)
+        else:
+            rows = torch.empty(b * npatch, 3 * P * P, device=images.device, dtype=dtype)
+            for v in range(n_views):
+                ops.im2row(images, c0 + 3 * v, P, dtype, out=rows[v * b0 * npatch:(v + 1) * b0 * npatch])
         wconv = flat.wview(tower.conv1.weight).view(width, -1)
         patches = ops.gemm(rows, wconv)
         x0 = ops.vit_assemble_fwd(patches, tower.class_embedding.data, tower.positional_embedding.data, b, npatch)
@@ -307,7 +316,7 @@ class VisionTowerFn(torch.autograd.Function):
             dpatch = dx0.view(b, L, width)[:, 1:, :].contiguous().view(b * npatch, width)
             weight_grad(dpatch, rows, g(tower.conv1.weight).view(width, -1))
         ctx.saved_blocks = ctx.misc = None
-        return (torch.zeros_like(flat.anchor), None, None, None, None, None)
+        return (torch.zeros_like(flat.anchor), None, None, None, None, None, None)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -415,12 +424,13 @@ class InfoNCEFn(torch.autograd.Function):
         scale = scale.detach().contiguous().float()
         row_loss, row_lse, c1, c5, _ = ops.infonce_fwd(pairs, scale, label0)
         ctx.pairs, ctx.scale, ctx.label0, ctx.row_lse = pairs, scale, label0, row_lse
+        ctx.need = [(bool(ctx.needs_input_grad[3 + 2 * i]), bool(ctx.needs_input_grad[4 + 2 * i])) for i in range(n_pairs)]
         ctx.mark_non_differentiable(c1, c5)
         return row_loss, c1, c5
 
     @staticmethod
     def backward(ctx, g_row, _g1, _g5):
-        outs, dscale = ops.infonce_bwd(ctx.pairs, ctx.scale, ctx.label0, ctx.row_lse, g_row.contiguous().float())
+        outs, dscale = ops.infonce_bwd(ctx.pairs, ctx.scale, ctx.label0, ctx.row_lse, g_row.contiguous().float(), need=ctx.need)
         flat = []
         for dq, dk in outs:
             flat += [dq, dk]

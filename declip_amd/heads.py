@@ -1,0 +1,273 @@
+"""DeCLIP / SLIP heads on the HIP engine: Linear + BatchNorm1d(+ReLU) MLPs (SimSiam projector / predictor,
+SimCLR head), negative-cosine loss, nearest-neighbour feature bank, masked-LM head.
+
+Reference: model/declip.py:33-130 (projection_MLP / prediction_MLP), loss_functions/loss.py:49-81 (D, SimsiamLoss),
+model/utils/nnclr_modules/{memory_bank,nn_memory_bank}.py, model/declip.py:326-334 (MLM CE).
+Parameter containers keep the reference's attribute names (linear1/bn1/.../layer2) so state_dicts match."""
+import torch
+from torch import nn
+
+from . import engine, ops
+from .lib import DeclipHipError
+
+
+def _flat_of(module):
+    root = module.__dict__.get("_engine_root")
+    if root is None:
+        raise DeclipHipError("%s is not attached to an engine model" % type(module).__name__)
+    return root._flat_store.ensure()
+
+
+class CastFn(torch.autograd.Function):
+    """dtype cast with a cast backward (fp32 tower features -> engine activation dtype and back)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        if x.dtype == dtype:
+            return x
+        return ops.cast(x.contiguous(), torch.empty(x.shape, device=x.device, dtype=dtype))
+
+    @staticmethod
+    def backward(ctx, g):
+        if g.dtype == ctx.src:
+            return g, None
+        return ops.cast(g.contiguous(), torch.empty(g.shape, device=g.device, dtype=ctx.src)), None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b through dh_gemm; dW / db accumulate straight into the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, x, lin, flat):
+        x = x.contiguous()
+        y = ops.gemm(x, flat.wview(lin.weight), bias=lin.bias.data if lin.bias is not None else None)
+        ctx.lin, ctx.flat = lin, flat
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        lin, flat = ctx.lin, ctx.flat
+        flat.begin_backward()
+        dy = dy.contiguous()
+        if lin.weight.requires_grad:
+            engine.weight_grad(dy, x, flat.gview(lin.weight), flat.gview(lin.bias) if lin.bias is not None else None)
+        dx = ops.gemm(dy, flat.wview(lin.weight), b_kmajor=True)
+        return dx, None, None
+
+
+class Bn1dFn(torch.autograd.Function):
+    """nn.BatchNorm1d (+ReLU) with batch statistics per group of rows (one group per view)."""
+
+    @staticmethod
+    def forward(ctx, x, bn, flat, groups, relu):
+        x = x.contiguous()
+        training = bn.training or bn.running_mean is None
+        y, mean, invstd = ops.bn1d_fwd(x, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, groups, relu, training,
+                                       eps=bn.eps, momentum=bn.momentum if bn.momentum is not None else 0.1)
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += groups
+        ctx.bn, ctx.flat, ctx.groups, ctx.relu, ctx.training = bn, flat, groups, relu, training
+        ctx.save_for_backward(x, y, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd = ctx.saved_tensors
+        bn, flat = ctx.bn, ctx.flat
+        if not ctx.training:
+            raise DeclipHipError("BatchNorm1d backward in eval mode is not supported")
+        flat.begin_backward()
+        dx = ops.bn1d_bwd(dy.contiguous(), x, y, bn.weight.data, mean, invstd, flat.gview(bn.weight), flat.gview(bn.bias),
+                          ctx.groups, ctx.relu)
+        return dx, None, None, None, None
+
+
+class _HeadBase(nn.Module):
+    def _lin(self, x, lin):
+        return LinearFn.apply(x, lin, _flat_of(self))
+
+    def _bn(self, x, bn, groups, relu):
+        return Bn1dFn.apply(x, bn, _flat_of(self), groups, relu)
+
+
+class projection_MLP(_HeadBase):
+    """model/declip.py:33-90 (DeCLIP; note bn3 = BatchNorm1d(hidden_dim) applied to the out_dim output, quirk 8)
+    and model/slip.py:50-109 (SLIP: out_bn flag)."""
+
+    def __init__(self, in_dim, hidden_dim=1024, out_dim=1024, num_layers=3, out_bn=True):
+        super().__init__()
+        self.num_layers, self.in_dim, self.hidden_dim, self.out_dim, self.out_bn = num_layers, in_dim, hidden_dim, out_dim, out_bn
+        self.linear1 = nn.Linear(in_dim, hidden_dim)
+        self.bn1 = nn.BatchNorm1d(hidden_dim)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.linear2 = nn.Linear(hidden_dim, hidden_dim)
+        self.bn2 = nn.BatchNorm1d(hidden_dim)
+        if num_layers == 3:
+            self.relu2 = nn.ReLU(inplace=True)
+            self.linear3 = nn.Linear(hidden_dim, out_dim)
+            if out_bn:
+                self.bn3 = nn.BatchNorm1d(hidden_dim)
+
+    def forward(self, x, groups=1):
+        """x: [groups*b, in_dim]; BN statistics per group (== calling the reference module once per view)."""
+        flat = _flat_of(self)
+        x = CastFn.apply(x, flat.act_dtype)
+        x = self._bn(self._lin(x, self.linear1), self.bn1, groups, True)
+        x = self._lin(x, self.linear2)
+        if self.num_layers == 3:
+            x = self._bn(x, self.bn2, groups, True)
+            x = self._lin(x, self.linear3)
+            if self.out_bn:
+                x = self._bn(x, self.bn3, groups, False)
+        else:
+            x = self._bn(x, self.bn2, groups, False)
+        return x
+
+
+class prediction_MLP(_HeadBase):
+    """model/declip.py:92-130."""
+
+    def __init__(self, in_dim, hidden_dim=512, out_dim=1024):
+        super().__init__()
+        self.in_dim, self.hidden_dim, self.out_dim = in_dim, hidden_dim, out_dim
+        self.linear1 = nn.Linear(in_dim, hidden_dim)
+        self.bn1 = nn.BatchNorm1d(hidden_dim)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.layer2 = nn.Linear(hidden_dim, out_dim)
+
+    def forward(self, x, groups=1):
+        flat = _flat_of(self)
+        x = CastFn.apply(x, flat.act_dtype)
+        x = self._bn(self._lin(x, self.linear1), self.bn1, groups, True)
+        return self._lin(x, self.layer2)
+
+
+class NegCosFn(torch.autograd.Function):
+    """cos(p_r, stopgrad z_r) per row (loss_functions/loss.py:49-55)."""
+
+    @staticmethod
+    def forward(ctx, p, z):
+        p, z = p.contiguous(), z.detach().contiguous()
+        ctx.save_for_backward(p, z)
+        return ops.cos_rows_fwd(p, z)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, z = ctx.saved_tensors
+        return ops.cos_rows_bwd(p, z, g.contiguous().float()), None
+
+
+class SimsiamLoss(nn.Module):
+    """loss_functions/loss.py:65-81: forward(p1, z1, p2, z2) = -0.5 (D(p1, z2) + D(p2, z1))."""
+
+    def __init__(self, symmetry=True):
+        super().__init__()
+        self.symmetry = symmetry
+
+    def forward(self, p1, z1, p2, z2, minimize_loss=False):
+        if not self.symmetry or minimize_loss:
+            raise NotImplementedError("only the symmetric D(p, stopgrad z) form is on the hot path")
+        return -0.5 * (NegCosFn.apply(p1, z2).mean() + NegCosFn.apply(p2, z1).mean())
+
+
+class NNMemoryBankModule(nn.Module):
+    """Nearest-neighbour feature bank (nnclr_modules/nn_memory_bank.py:10-65, memory_bank.py:40-124).
+
+    MI355X re-design: the bank lives in HBM as [size, D] fp32 (row-major, unit rows) and is searched in
+    place by dh_nn_bank_query; the reference keeps it on the CPU as [D, size] and re-uploads 128 MiB three
+    times per step.  Semantics kept: random unit-vector init on first use, FIFO enqueue that drops the
+    batch tail on wrap and resets the pointer (memory_bank.py:82-87), per-rank bank (not checkpointed)."""
+
+    def __init__(self, size=2 ** 16, topk=1):
+        super().__init__()
+        if size < 0:
+            raise ValueError("Illegal memory bank size %d, must be non-negative." % size)
+        if topk != 1:
+            raise NotImplementedError("topk > 1 (all shipped configs use nn_topk=1)")
+        self.size, self.topk = size, topk
+        self.bank = None
+        self.bank_ptr = 0
+
+    @torch.no_grad()
+    def init_bank(self, dim, device, generator=None):
+        bank = torch.randn(self.size, dim, generator=generator)
+        self.bank = torch.nn.functional.normalize(bank, dim=1).to(device).contiguous()
+        self.bank_ptr = 0
+
+    @torch.no_grad()
+    def _enqueue(self, batch):
+        b, ptr = batch.shape[0], self.bank_ptr
+        if ptr + b >= self.size:
+            self.bank[ptr:] = batch[:self.size - ptr]
+            self.bank_ptr = 0
+        else:
+            self.bank[ptr:ptr + b] = batch
+            self.bank_ptr = ptr + b
+
+    @torch.no_grad()
+    def forward(self, output, update=False, query=True):
+        """returns [nearest neighbours [b, D] fp32]; the search sees the bank BEFORE this call's enqueue
+        (memory_bank.py:117-122).  query=False skips the (discarded) search of an update-only call."""
+        output = output.detach().float().contiguous()
+        if self.bank is None:
+            self.init_bank(output.shape[1], output.device)
+        res = None
+        if query:
+            _, feats = ops.nn_bank_query(output, self.bank)
+            res = [feats]
+        if update:
+            self._enqueue(output)
+        return res
+
+
+class MlmHeadFn(torch.autograd.Function):
+    """text_label_predictor + cross-entropy on the masked positions only (model/declip.py:326-334).
+
+    The reference runs Linear(width -> 49409) on ALL b*77 positions and then selects; here the masked rows
+    are gathered first (same result, ~7x less work).  The vocabulary dimension is handled in a layout padded
+    to a multiple of 64 so that all three GEMMs take the MFMA/LDS-DMA path."""
+
+    @staticmethod
+    def forward(ctx, words, idx, labels_sel, lin, flat):
+        width = words.shape[-1]
+        V = lin.weight.shape[0]
+        Vp = (V + 63) // 64 * 64
+        n = idx.numel()
+        n_pad = max(64, (n + 63) // 64 * 64)
+        wflat = words.reshape(-1, width)
+        rows = ops.gather_rows(wflat, idx, n_pad)
+        logits = torch.empty(n_pad, Vp, device=words.device, dtype=torch.float32)
+        ops.gemm(rows, flat.wview(lin.weight), bias=lin.bias.data, out=logits, pad_ok=True, dims=(n_pad, Vp, width))
+        lview = logits[:n, :V]
+        row_loss, row_lse, _, _ = ops.ce_rows_fwd(lview, labels_sel)
+        ctx.lin, ctx.flat, ctx.meta = lin, flat, (n, n_pad, V, Vp, width, words.shape)
+        ctx.save_for_backward(rows, logits, row_lse, idx, labels_sel)
+        return row_loss
+
+    @staticmethod
+    def backward(ctx, g_row):
+        rows, logits, row_lse, idx, labels_sel = ctx.saved_tensors
+        lin, flat = ctx.lin, ctx.flat
+        n, n_pad, V, Vp, width, wshape = ctx.meta
+        flat.begin_backward()
+        dl = ops.ce_rows_bwd_padded(logits[:n, :V], labels_sel, row_lse, g_row.contiguous().float(), V, rows.dtype, n_pad, Vp)
+        drows = ops.gemm(dl, flat.wview(lin.weight), b_kmajor=True, pad_ok=True, dims=(n_pad, width, Vp))
+        if lin.weight.requires_grad:
+            ops.gemm(dl, rows, a_kmajor=True, b_kmajor=True, out=flat.gview(lin.weight), accumulate=True,
+                     split_k=engine._split_k(V, width, n_pad), a_colsum=flat.gview(lin.bias), pad_ok=True, dims=(V, width, n_pad))
+        dwords = torch.zeros(wshape[0] * wshape[1], width, device=rows.device, dtype=rows.dtype)
+        ops.scatter_rows_add(drows, idx, dwords)
+        return dwords.view(wshape), None, None, None, None
+
+
+def mlm_loss(words, labels, lin, flat):
+    """mean CE over positions with labels != -100 (declip.py:331-334)."""
+    lab = labels.reshape(-1)
+    sel = (lab != -100).nonzero(as_tuple=False).reshape(-1)        # index arithmetic (host sync only if labels live on the GPU)
+    dev = words.device
+    idx = sel.to(dev)
+    labels_sel = lab[sel.to(lab.device)].to(dev)
+    return MlmHeadFn.apply(words, idx, labels_sel, lin, flat).mean()

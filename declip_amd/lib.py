@@ -28,7 +28,7 @@ class GemmArgs(Structure):
         ("A", c_void_p), ("lda", c_int64), ("B", c_void_p), ("ldb", c_int64), ("C", c_void_p), ("ldc", c_int64),
         ("bias", c_void_p), ("epilogue", c_int), ("residual", c_void_p), ("ldr", c_int64),
         ("aux", c_void_p), ("ldaux", c_int64), ("accumulate", c_int), ("split_k", c_int), ("alpha", c_float),
-        ("force_generic", c_int), ("a_colsum", c_void_p),
+        ("force_generic", c_int), ("a_colsum", c_void_p), ("pad_ok", c_int),
     ]
 
 
@@ -62,6 +62,15 @@ _PROTOS = {
     "dh_infonce_bwd": (c_int, [POINTER(NcePair), c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
     "dh_ce_rows_fwd": (c_int, [_P, c_int64, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "dh_ce_rows_bwd": (c_int, [_P, c_int64, _P, c_int, c_int, _P, _P, _P, c_int64, _P]),
+    "dh_ce_rows_bwd_padded": (c_int, [_P, c_int64, _P, c_int, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
+    "dh_bn1d_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, c_int, _P]),
+    "dh_bn1d_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "dh_cos_rows_fwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, _P]),
+    "dh_cos_rows_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, _P]),
+    "dh_nn_bank_ws_bytes": (c_int64, [c_int, c_int]),
+    "dh_nn_bank_query": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_int64, _P]),
+    "dh_gather_rows": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "dh_scatter_rows_add": (c_int, [c_int, _P, _P, _P, c_int, c_int, _P]),
     "dh_adamw": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
     "dh_adamw_segmented": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int, c_float, c_float, c_float, c_int, c_float, _P]),
     "dh_cast": (c_int, [c_int, _P, c_int, _P, c_int64, _P]),

@@ -78,3 +78,20 @@ def accuracy(output, target, topk=(1,), criterion=None):
         else:
             raise NotImplementedError("accuracy top-%d (only top-1/top-5 are on the hot path)" % k)
     return res
+
+
+class NTXentLoss(nn.Module):
+    """ConVIRT-style image-text NT-Xent monitor (reference: loss_functions/nt_xent_ConVIRT.py:4-86):
+    alpha * CE(zi.zj^T / T) + (1 - alpha) * CE(zj.zi^T / T) on the LOCAL [b,b] logits with one-hot targets.
+    Evaluated every step by the declip/filip/defilip solvers for logging (declip_solver.py:486-488)."""
+
+    def __init__(self, batch_size=None, temperature=0.1, use_cosine_similarity=True, alpha_weight=0.75):
+        super().__init__()
+        self.temperature, self.alpha_weight = temperature, alpha_weight
+
+    def forward(self, zis, zjs, norm=True, weights=1.0):
+        if norm:
+            zis, zjs = engine.L2NormFn.apply(zis, 1e-12), engine.L2NormFn.apply(zjs, 1e-12)
+        scale = torch.full((1,), 1.0 / self.temperature, device=zis.device, dtype=torch.float32)
+        rl, _, _ = engine.InfoNCEFn.apply(scale, 0, 2, zis, zjs, zjs, zis)
+        return self.alpha_weight * rl[0].mean() + (1 - self.alpha_weight) * rl[1].mean()

@@ -105,12 +105,13 @@ class VisualTransformer(_Tower):
                 p.requires_grad = False
         return self
 
-    def forward(self, x, return_dense=False, return_feature=False, channel_offset=0):
-        """x: [b, 3*views, H, W] fp32 on the GPU; channel_offset selects a channel-stacked view."""
+    def forward(self, x, return_dense=False, return_feature=False, channel_offset=0, n_views=1):
+        """x: [b, 3*views, H, W] fp32 on the GPU; channel_offset selects a channel-stacked view;
+        n_views > 1 encodes that many consecutive views in one pass (outputs [views*b, ...], view-major)."""
         flat = self._flat()
         if x.dtype != torch.float32:
             x = x.float()
-        return engine.VisionTowerFn.apply(flat.anchor, x.contiguous(), self, channel_offset, return_dense, return_feature)
+        return engine.VisionTowerFn.apply(flat.anchor, x.contiguous(), self, channel_offset, return_dense, return_feature, n_views)
 
 
 class TextTransformer(_Tower):

@@ -18,25 +18,29 @@ def _contig(t, name):
 
 
 def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, residual=None, aux=None,
-         out=None, out_dtype=None, accumulate=False, split_k=1, alpha=1.0, force_generic=False, a_colsum=None):
+         out=None, out_dtype=None, accumulate=False, split_k=1, alpha=1.0, force_generic=False, a_colsum=None,
+         pad_ok=False, dims=None):
     """C[M,N] = epi(alpha * sum_k A(m,k) B(n,k) + bias).  A: [M,K] (or [K,M] if a_kmajor);
     B: [N,K] (or [K,N] if b_kmajor).  See include/declip_hip.h."""
     lib = L.load()
     assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype
     M, K = (A.shape[1], A.shape[0]) if a_kmajor else (A.shape[0], A.shape[1])
     N, Kb = (B.shape[1], B.shape[0]) if b_kmajor else (B.shape[0], B.shape[1])
-    assert K == Kb, "contraction mismatch %d vs %d" % (K, Kb)
+    if dims is not None:            # logical (M, N, K) smaller/larger than the buffers (padded layouts, pad_ok)
+        M, N, K = dims
+    else:
+        assert K == Kb, "contraction mismatch %d vs %d" % (K, Kb)
     assert A.stride(1) == 1 and B.stride(1) == 1
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=out_dtype or A.dtype)
-    assert out.shape == (M, N) and out.stride(1) == 1
+    assert (dims is not None or out.shape == (M, N)) and out.stride(1) == 1
     a = GemmArgs()
     a.dtype, a.c_dtype = dt(A), dt(out)
     a.a_kmajor, a.b_kmajor = int(a_kmajor), int(b_kmajor)
     a.M, a.N, a.K = M, N, K
     a.A, a.lda, a.B, a.ldb, a.C, a.ldc = ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(out), out.stride(0)
     if bias is not None:
-        assert bias.dtype == torch.float32 and bias.numel() == N
+        assert bias.dtype == torch.float32 and (dims is not None or bias.numel() == N)
     a.bias = ptr(bias)
     a.epilogue = epilogue
     if residual is not None:
@@ -50,6 +54,7 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, 
     if a_colsum is not None:
         assert a_kmajor and a_colsum.dtype == torch.float32 and a_colsum.numel() == M
         a.a_colsum = ptr(a_colsum)
+    a.pad_ok = int(pad_ok)
     check(lib.dh_gemm(ctypes.byref(a), stream()), "dh_gemm")
     return out
 
@@ -123,11 +128,12 @@ def text_embed_bwd(ids, dx, dtable, dpos, hot_ids=(0,)):
           "dh_text_embed_bwd")
 
 
-def im2row(images, c0, patch, dtype):
+def im2row(images, c0, patch, dtype, out=None):
     _contig(images, "images")
     assert images.dtype == torch.float32
     b, ctot, H, W = images.shape
-    rows = torch.empty(b * (H // patch) * (W // patch), 3 * patch * patch, device=images.device, dtype=dtype)
+    rows = out if out is not None else torch.empty(b * (H // patch) * (W // patch), 3 * patch * patch, device=images.device, dtype=dtype)
+    assert rows.is_contiguous() and rows.shape == (b * (H // patch) * (W // patch), 3 * patch * patch)
     check(L.load().dh_im2row(dt(rows), ptr(images), ctot, c0, ptr(rows), b, H, W, patch, stream()), "dh_im2row")
     return rows
 
@@ -205,12 +211,14 @@ def infonce_fwd(pairs, scale, label0, want_logits=False):
     return row_loss, row_lse, c1, c5, logits
 
 
-def infonce_bwd(pairs, scale, label0, row_lse, g_row):
-    """pairs: list of (Q, K); returns list of (dQ, dK) and dscale (1-element)."""
+def infonce_bwd(pairs, scale, label0, row_lse, g_row, need=None):
+    """pairs: list of (Q, K); returns list of (dQ, dK) and dscale (1-element).  need: optional list of
+    (need_dQ, need_dK) flags -- unneeded gradients are skipped (None returned)."""
     Q0, K0 = pairs[0]
     b, D = Q0.shape
     B = K0.shape[0]
-    outs = [(torch.empty_like(q), torch.empty_like(k)) for q, k in pairs]
+    need = need or [(True, True)] * len(pairs)
+    outs = [(torch.empty_like(q) if nq else None, torch.empty_like(k) if nk else None) for (q, k), (nq, nk) in zip(pairs, need)]
     dscale = torch.zeros(1, device=Q0.device, dtype=torch.float32)
     arr = _pair_array([(q, k, dq, dk) for (q, k), (dq, dk) in zip(pairs, outs)])
     check(L.load().dh_infonce_bwd(arr, len(pairs), b, B, D, ptr(scale), int(label0), ptr(_contig(row_lse, "lse")),
@@ -254,3 +262,76 @@ def cast(src, dst):
     assert src.numel() == dst.numel()
     check(L.load().dh_cast(dt(src), ptr(src), dt(dst), ptr(dst), src.numel(), stream()), "dh_cast")
     return dst
+
+
+def ce_rows_bwd_padded(logits, labels, row_lse, g_row, C, out_dtype, rows_pad, C_pad):
+    """dlogits [rows_pad, C_pad] (out_dtype), zero outside [rows) x [C) -- padded layout for the MLM GEMMs."""
+    rows = labels.numel()
+    dl = torch.empty(rows_pad, C_pad, device=logits.device, dtype=out_dtype)
+    check(L.load().dh_ce_rows_bwd_padded(ptr(logits), logits.stride(0), ptr(labels), rows, C, ptr(row_lse), ptr(_contig(g_row, "g")),
+                                         ptr(dl), dt(dl), C_pad, rows_pad, C_pad, stream()), "dh_ce_rows_bwd_padded")
+    return dl
+
+
+def bn1d_fwd(x, w, b, running_mean, running_var, groups, relu, training, eps=1e-5, momentum=0.1):
+    _contig(x, "x")
+    rows, C = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(groups, C, device=x.device, dtype=torch.float32)
+    invstd = torch.empty(groups, C, device=x.device, dtype=torch.float32)
+    check(L.load().dh_bn1d_fwd(dt(x), ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(invstd), ptr(running_mean), ptr(running_var),
+                               groups, rows // groups, C, eps, momentum, int(relu), int(training), stream()), "dh_bn1d_fwd")
+    return y, mean, invstd
+
+
+def bn1d_bwd(dy, x, y, w, mean, invstd, dw, db, groups, relu):
+    _contig(dy, "dy")
+    rows, C = x.shape
+    dx = torch.empty_like(x)
+    check(L.load().dh_bn1d_bwd(dt(x), ptr(dy), ptr(x), ptr(y), ptr(w), ptr(mean), ptr(invstd), ptr(dx), ptr(dw), ptr(db), groups,
+                               rows // groups, C, int(relu), stream()), "dh_bn1d_bwd")
+    return dx
+
+
+def cos_rows_fwd(p, z):
+    _contig(p, "p"), _contig(z, "z")
+    rows, d = p.shape
+    out = torch.empty(rows, device=p.device, dtype=torch.float32)
+    check(L.load().dh_cos_rows_fwd(dt(p), ptr(p), ptr(z), ptr(out), rows, d, stream()), "dh_cos_rows_fwd")
+    return out
+
+
+def cos_rows_bwd(p, z, g_row):
+    rows, d = p.shape
+    dp = torch.empty_like(p)
+    check(L.load().dh_cos_rows_bwd(dt(p), ptr(p), ptr(z), ptr(_contig(g_row, "g")), ptr(dp), rows, d, stream()), "dh_cos_rows_bwd")
+    return dp
+
+
+def nn_bank_query(q, bank):
+    """q [rows, D] fp32, bank [size, D] fp32 -> (idx [rows] int64, feats [rows, D] = bank[idx])."""
+    _contig(q, "q"), _contig(bank, "bank")
+    rows, D = q.shape
+    size = bank.shape[0]
+    lib = L.load()
+    nbytes = lib.dh_nn_bank_ws_bytes(rows, size)
+    ws = torch.empty(nbytes // 4, device=q.device, dtype=torch.float32)
+    idx = torch.empty(rows, device=q.device, dtype=torch.int64)
+    feats = torch.empty(rows, D, device=q.device, dtype=torch.float32)
+    check(lib.dh_nn_bank_query(ptr(q), ptr(bank), rows, size, D, ptr(idx), ptr(feats), ptr(ws), nbytes, stream()), "dh_nn_bank_query")
+    return idx, feats
+
+
+def gather_rows(x, idx, n_pad=None):
+    n = idx.numel()
+    n_pad = n_pad or max(n, 1)
+    d = x.shape[-1]
+    out = torch.empty(n_pad, d, device=x.device, dtype=x.dtype)
+    check(L.load().dh_gather_rows(dt(x), ptr(x), ptr(idx), ptr(out), n, n_pad, d, stream()), "dh_gather_rows")
+    return out
+
+
+def scatter_rows_add(dout, idx, dx):
+    n = idx.numel()
+    check(L.load().dh_scatter_rows_add(dt(dx), ptr(dout), ptr(idx), ptr(dx), n, dx.shape[-1], stream()), "dh_scatter_rows_add")
+    return dx

@@ -129,6 +129,46 @@ def clip_shapes(cfg):
     return s
 
 
+def _bn_shapes(s, prefix, c):
+    s[prefix + "weight"] = (c,)
+    s[prefix + "bias"] = (c,)
+    s[prefix + "running_mean"] = (c,)
+    s[prefix + "running_var"] = (c,)
+    s[prefix + "num_batches_tracked"] = ()
+
+
+def declip_shapes(cfg):
+    """DECLIP state_dict (model/declip.py:132-175): CLIP + projector + predictor (+ text_label_predictor)."""
+    s = clip_shapes(cfg)
+    fd, hid = cfg["embed_dim"], cfg.get("simsiam_hidden", 1024)
+    s["projector.linear1.weight"], s["projector.linear1.bias"] = (hid, fd), (hid,)
+    _bn_shapes(s, "projector.bn1.", hid)
+    s["projector.linear2.weight"], s["projector.linear2.bias"] = (hid, hid), (hid,)
+    _bn_shapes(s, "projector.bn2.", hid)
+    s["projector.linear3.weight"], s["projector.linear3.bias"] = (hid, hid), (hid,)
+    _bn_shapes(s, "projector.bn3.", hid)
+    s["predictor.linear1.weight"], s["predictor.linear1.bias"] = (512, 1024), (512,)
+    _bn_shapes(s, "predictor.bn1.", 512)
+    s["predictor.layer2.weight"], s["predictor.layer2.bias"] = (1024, 512), (1024,)
+    if cfg.get("mlm", True):
+        s["text_label_predictor.weight"] = (cfg.get("vocab", VOCAB), cfg["t_width"])
+        s["text_label_predictor.bias"] = (cfg.get("vocab", VOCAB),)
+    return s
+
+
+def synth_bank(size, dim, seed=4):
+    """unit-norm rows [size, dim] (NN bank randn seed 4, normalised, ptr 0)."""
+    g = torch.Generator().manual_seed(4000 + seed)
+    return torch.nn.functional.normalize(torch.randn(size, dim, generator=g), dim=1)
+
+
+def synth_mlm(ids, vocab=VOCAB, seed=3):
+    """deterministic MLM masking of padded id rows -> (masked_ids, labels)"""
+    from .bpe import mask_token_ids
+    g = torch.Generator().manual_seed(3000 + seed)
+    return mask_token_ids(ids, vocab, generator=g)
+
+
 VITB32 = dict(v_width=768, v_layers=12, v_heads=12, patch=32, res=224,
               t_width=512, t_layers=12, t_heads=8, ctx=77, embed_dim=512, vocab=VOCAB)
 TINY = dict(v_width=128, v_layers=2, v_heads=2, patch=32, res=96,

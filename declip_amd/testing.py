@@ -23,3 +23,37 @@ def build_clip(cfg, dtype="bf16", use_allgather=False, seed=0, logit_scale=None,
     model = model.to(device)
     model.train()
     return model
+
+
+def build_declip(cfg, dtype="bf16", seed=0, nn_size=256, fused_loss=True, device="cuda", load_synth=True, mlm=True,
+                 nn_bank=True):
+    from .model.declip import DECLIP
+    vis = VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
+                            layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"])
+    txt = TextTransformer(embed_dim=cfg["embed_dim"], context_length=cfg["ctx"], transformer_width=cfg["t_width"],
+                          transformer_heads=cfg["t_heads"], transformer_layers=cfg["t_layers"],
+                          positional_embedding_flag=True, checkpoint=False, bpe_path=None,
+                          text_encode_type="Transformer", text_model_utils={"random": False, "freeze": False},
+                          vocab_size=cfg.get("vocab", synth.VOCAB))
+    model = DECLIP(vis, txt, True, nn_size=nn_size, nn_topk=1, return_nn_bank=nn_bank,
+                   text_mask_type="MLM" if mlm else None, EDA=True, feature_dim=cfg["embed_dim"], dtype=dtype,
+                   fused_loss=fused_loss)
+    if load_synth:
+        sd = synth.synth_state(synth.declip_shapes(dict(cfg, mlm=mlm)), seed=seed)
+        model.load_state_dict(sd, strict=True)
+    model = model.to(device)
+    model.train()
+    if nn_bank and load_synth:
+        model.nn_replacer_text.bank = synth.synth_bank(nn_size, cfg["embed_dim"], seed=seed).to(device)
+        model.nn_replacer_text.bank_ptr = 0
+    return model
+
+
+def declip_batch(cfg, b, seed=0, device="cuda"):
+    """seeded DeCLIP batch: two channel-stacked views, masked ids + labels, augmented ids."""
+    images = synth.synth_images(b, views=2, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
+    ids_aug = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"])
+    ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+    caps = torch.stack([ids_masked, ids_aug], dim=1)
+    return {"images": images.to(device), "captions": caps.to(device), "mlm_labels": labels}

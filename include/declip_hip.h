@@ -80,6 +80,8 @@ typedef struct dh_gemm_args {
   float alpha;
   int force_generic;     /* tests: 1 = VALU fp32-FMA kernel, 2 = v1 register-staged MFMA kernel, 0 = auto */
   float* a_colsum;       /* optional, a_kmajor only: a_colsum[m] += sum_k A(m,k) (bias gradient fused into dW) */
+  int pad_ok;            /* caller guarantees operand rows are readable (finite) up to the next multiple of 8
+                            elements / 128 rows beyond M,N: lifts the M%8 / N%8 conditions of the MFMA kernels */
 } dh_gemm_args;
 int dh_gemm(const dh_gemm_args* args, dh_stream_t stream);
 
@@ -170,6 +172,38 @@ int dh_ce_rows_fwd(const float* logits, int64_t ld, const int64_t* labels, int r
                    float* row_lse, float* correct1, float* correct5, dh_stream_t stream);
 int dh_ce_rows_bwd(const float* logits, int64_t ld, const int64_t* labels, int rows, int C, const float* row_lse,
                    const float* g_row, float* dlogits, int64_t ldd, dh_stream_t stream);
+
+/* As dh_ce_rows_bwd, writing dlogits [rows_pad][ldd] as `out_dtype` with zeros outside [rows) x [C): the MLM
+ * head's gradient in the padded layout its MFMA GEMMs consume (vocab 49409 padded to a multiple of 64). */
+int dh_ce_rows_bwd_padded(const float* logits, int64_t ld, const int64_t* labels, int rows, int C, const float* row_lse,
+                          const float* g_row, void* dlogits, int out_dtype, int64_t ldd, int rows_pad, int C_pad,
+                          dh_stream_t stream);
+
+/* ---------------------------------------------------------------- DeCLIP / SLIP heads ---
+ * BatchNorm1d (+ optional ReLU) with batch statistics per GROUP of rows (the reference applies the SimSiam
+ * projector / predictor once per view: model/declip.py:33-130,238-241; plain per-rank nn.BatchNorm1d).
+ * x,y [groups*rows_per_group, C]; save_mean/save_invstd [groups, C]; running stats updated group after group
+ * (momentum, unbiased variance) exactly like successive module calls.  training=0 uses the running stats. */
+int dh_bn1d_fwd(int dtype, const void* x, const float* w, const float* b, void* y, float* save_mean, float* save_invstd,
+                float* running_mean, float* running_var, int groups, int rows_per_group, int C, float eps, float momentum,
+                int relu, int training, dh_stream_t stream);
+int dh_bn1d_bwd(int dtype, const void* dy, const void* x, const void* y, const float* w, const float* save_mean,
+                const float* save_invstd, void* dx, float* dw, float* db, int groups, int rows_per_group, int C, int relu,
+                dh_stream_t stream);
+/* cos[r] = <p_r,z_r>/(|p_r||z_r|)  (SimSiam D(p, stopgrad z), loss_functions/loss.py:49-55); bwd w.r.t. p only. */
+int dh_cos_rows_fwd(int dtype, const void* p, const void* z, float* cosv, int rows, int d, dh_stream_t stream);
+int dh_cos_rows_bwd(int dtype, const void* p, const void* z, const float* g_row, void* dp, int rows, int d,
+                    dh_stream_t stream);
+/* Nearest neighbour of every query row in the feature bank (model/utils/nnclr_modules/nn_memory_bank.py:42-65,
+ * topk=1): bank [size][D] fp32 resident in HBM (the reference keeps it on the CPU and re-uploads 128 MiB per
+ * call); exact fp32 dot products, first maximum wins.  idx_out [rows] int64, feat_out [rows][D] = bank[idx]. */
+int64_t dh_nn_bank_ws_bytes(int rows, int size);
+int dh_nn_bank_query(const float* q, const float* bank, int rows, int size, int D, int64_t* idx_out, float* feat_out,
+                     void* ws, int64_t ws_bytes, dh_stream_t stream);
+/* out[r,:] = x[idx[r],:] for r < n, zero rows for n <= r < n_pad (masked-LM rows, model/declip.py:326-334);
+ * scatter_rows_add: dx[idx[r],:] += dout[r,:] (unique indices). */
+int dh_gather_rows(int dtype, const void* x, const int64_t* idx, void* out, int n, int n_pad, int d, dh_stream_t stream);
+int dh_scatter_rows_add(int dtype, const void* dout, const int64_t* idx, void* dx, int n, int d, dh_stream_t stream);
 
 /* ---------------------------------------------------------------- optimizer / casts -----
  * Fused flat AdamW over a contiguous fp32 range (torch.optim.AdamW semantics, the optimizer of

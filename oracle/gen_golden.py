@@ -129,11 +129,77 @@ def gen_clip(name, cfg, b, world=1, seed=0, logit_scale=None):
     print("wrote %s  loss=%.6f  (%d KB)" % (path, ret["loss"], os.path.getsize(path) // 1024))
 
 
+def gen_declip(name, cfg, b, seed=0, nn_size=256):
+    """Reference DECLIP (model/declip.py) + the solver's loss composition (declip_solver.py:435-533), one rank."""
+    import contextlib
+    import io
+    os.environ["SLURM_PROCID"], os.environ["SLURM_NTASKS"] = "0", "1"
+    ref = ref_harness.load_reference()
+    ref_harness.ensure_gloo_group()
+    rd = ref.modules["prototype.model.declip"]
+    vt = ref.modules["prototype.model.image_encoder.visual_transformer"]
+    tt = ref.modules["prototype.model.text_encoder.text_transformer"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        vis = vt.VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
+                                   layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"], checkpoint=False)
+        txt = tt.TextTransformer(embed_dim=cfg["embed_dim"], context_length=cfg["ctx"], transformer_width=cfg["t_width"],
+                                 transformer_heads=cfg["t_heads"], transformer_layers=cfg["t_layers"],
+                                 positional_embedding_flag=True, checkpoint=False, bpe_path=ref_harness.synthetic_bpe_path(),
+                                 text_encode_type="Transformer", text_model_utils={"random": False, "freeze": False})
+        model = rd.DECLIP(vis, txt, True, nn_size=nn_size, nn_topk=1, return_nn_bank=True, text_mask_type="MLM",
+                          EDA=True, feature_dim=cfg["embed_dim"])
+        sd = synth.synth_state(synth.declip_shapes(cfg), seed=seed)
+        model.load_state_dict(sd, strict=True)
+        model.train()
+    images = synth.synth_images(b, views=2, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
+    ids_aug = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"])
+    ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+    bank = synth.synth_bank(nn_size, cfg["embed_dim"], seed=seed)
+    model.nn_replacer_text.bank = bank.t().clone()                       # reference layout [D, size]
+    model.nn_replacer_text.bank_ptr = torch.LongTensor([0])
+    off = ref_harness.AUG_KEY_OFFSET
+
+    def tokenize(texts, context_length=77, return_length=False, mask_type=None):
+        keys = [int(t) for t in texts]
+        if mask_type is not None:
+            return torch.stack([ids_masked[k] for k in keys]), torch.stack([labels[k] for k in keys])
+        return torch.stack([ids_aug[k - off] if k >= off else ids[k] for k in keys])
+    model.encode_text.tokenize = tokenize
+    out = model({"images": images, "captions": [[i] for i in range(b)]}, return_dict=True)
+    L = ref.modules["prototype.loss_functions.loss"]
+    crit, sim_crit = L.ClipInfoCELoss(), L.SimsiamLoss()
+    ntx = ref.modules["prototype.loss_functions.nt_xent_ConVIRT"].NTXentLoss(b)
+    li1, li2, lt1, lt2 = out["logits"]
+    a1, a2, at1, at2 = out["logits_aug"]
+    clip_loss = (crit(li1, lt1)[0] + crit(li2, lt2)[0] + crit(a1, at1)[0] + crit(a2, at2)[0]) / 4
+    n1, n2, n1a, n2a = out["nn_text_logits"]
+    nn_loss = (crit(n1, n1a)[0] + crit(n2, n2a)[0]) / 2
+    p1, p2, z1, z2 = out["simsiam_features"]
+    sim_loss = sim_crit(p1, z1, p2, z2)
+    mlm = out["text_self_supervised"]
+    tf, if1, if2 = out["features"]
+    monitor = ntx(if1, tf) + ntx(if2, tf)
+    total = 0.4 * clip_loss + 0.2 * sim_loss + 0.2 * mlm + 0.2 * nn_loss        # yfcc15m_vit_declip/config.yaml:28-32
+    total.backward()
+    ret = dict(kind="declip", cfg=cfg, b=b, seed=seed, nn_size=nn_size, loss=float(total),
+               parts=dict(clip=float(clip_loss), nn=float(nn_loss), simsiam=float(sim_loss), mlm=float(mlm), convirt=float(monitor)),
+               logits_i1=li1.detach().clone(), nn_logits_i1=n1.detach().clone(),
+               grads=grad_digest([(n, p.grad) for n, p in model.named_parameters()]),
+               bank_ptr=int(model.nn_replacer_text.bank_ptr), bank_sum=float(model.nn_replacer_text.bank.double().sum()),
+               bn1_running_mean=model.projector.bn1.running_mean.clone(), bn1_running_var=model.projector.bn1.running_var.clone(),
+               torch_version=torch.__version__)
+    path = os.path.join(GOLDEN_DIR, name + ".pt")
+    torch.save(ret, path)
+    print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
+
+
 FIXTURES = {
     "clip_tiny": lambda: gen_clip("clip_tiny", synth.TINY, b=4),
     "clip_tiny_scale5": lambda: gen_clip("clip_tiny_scale5", synth.TINY, b=4, seed=3, logit_scale=5.0),
     "clip_tiny_w2": lambda: gen_clip("clip_tiny_w2", synth.TINY, b=3, world=2, seed=5),
     "clip_vitb32_b8": lambda: gen_clip("clip_vitb32_b8", synth.VITB32, b=8, seed=1),
+    "declip_tiny": lambda: gen_declip("declip_tiny", synth.TINY, b=6, seed=2),
 }
 
 

@@ -59,17 +59,25 @@ class _EasyDict(dict):
             raise AttributeError(k)
 
 
+AUG_KEY_OFFSET = 100000
+
+
 class _IdentityEDA:
-    """Deterministic stand-in for textaugment.EDA (reference declip.py:203-212)."""
+    """Deterministic stand-in for textaugment.EDA (reference declip.py:203-212): strings pass through;
+    integer caption KEYS (the oracle feeds row indices instead of strings) map to key + AUG_KEY_OFFSET,
+    which the patched tokenize() resolves to the seeded "augmented" ids."""
+
+    def _aug(self, s):
+        return s + AUG_KEY_OFFSET if isinstance(s, int) else s
 
     def synonym_replacement(self, s):
-        return s
+        return self._aug(s)
 
     def random_swap(self, s):
-        return s
+        return self._aug(s)
 
     def random_deletion(self, s, p=0.1):
-        return s
+        return self._aug(s)
 
 
 def load_reference():

@@ -165,3 +165,103 @@ def clip_step_loss(images, ids, sd, cfg, world=1):
         p1, p5 = accuracy(li.detach(), labels)
         metrics.append(dict(loss=loss.detach(), top1=p1, top5=p5))
     return total, per_rank, feats, metrics
+
+
+# ----------------------------------------------------------------------------- DeCLIP
+def bn_train(x, w, b, eps=1e-5):
+    """nn.BatchNorm1d in training mode (batch statistics, biased variance) -- declip.py:49,54,60."""
+    mu = x.mean(0, keepdim=True)
+    var = ((x - mu) ** 2).mean(0, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
+
+
+def projection_mlp(x, sd, p):
+    """model/declip.py:33-90 (3 layers; bn3 on the output)."""
+    x = torch.relu(bn_train(x @ sd[p + "linear1.weight"].t() + sd[p + "linear1.bias"], sd[p + "bn1.weight"], sd[p + "bn1.bias"]))
+    x = torch.relu(bn_train(x @ sd[p + "linear2.weight"].t() + sd[p + "linear2.bias"], sd[p + "bn2.weight"], sd[p + "bn2.bias"]))
+    return bn_train(x @ sd[p + "linear3.weight"].t() + sd[p + "linear3.bias"], sd[p + "bn3.weight"], sd[p + "bn3.bias"])
+
+
+def prediction_mlp(x, sd, p):
+    """model/declip.py:92-130."""
+    x = torch.relu(bn_train(x @ sd[p + "linear1.weight"].t() + sd[p + "linear1.bias"], sd[p + "bn1.weight"], sd[p + "bn1.bias"]))
+    return x @ sd[p + "layer2.weight"].t() + sd[p + "layer2.bias"]
+
+
+def neg_cos(p, z):
+    """loss_functions/loss.py:49-55 D(p, z)."""
+    z = z.detach()
+    p = p / p.norm(dim=-1, keepdim=True)
+    z = z / z.norm(dim=-1, keepdim=True)
+    return (p * z).sum(dim=1).mean()
+
+
+def simsiam_loss(p1, z1, p2, z2):
+    """loss_functions/loss.py:70-81."""
+    return -0.5 * (neg_cos(p1, z2) + neg_cos(p2, z1))
+
+
+def nn_lookup(q, bank):
+    """nn_memory_bank.py:53-63 with topk=1; bank here is [size, D] (the reference stores [D, size])."""
+    qn = F.normalize(q.detach(), dim=1)
+    bn = F.normalize(bank, dim=1)
+    idx = (qn @ bn.t()).argmax(dim=1)
+    return bank[idx]
+
+
+def bank_enqueue(bank, ptr, batch):
+    """memory_bank.py:71-87 (tail dropped on wrap, pointer reset)."""
+    b, size = batch.shape[0], bank.shape[0]
+    if ptr + b >= size:
+        bank[ptr:] = batch[:size - ptr].detach()
+        return 0
+    bank[ptr:ptr + b] = batch.detach()
+    return ptr + b
+
+
+def convirt_ntxent(zi, zj, temperature=0.1, alpha=0.75):
+    """loss_functions/nt_xent_ConVIRT.py:23-86 (one-hot soft targets == CE on the local [b,b] logits)."""
+    zi, zj = F.normalize(zi, dim=1), F.normalize(zj, dim=1)
+    lab = torch.arange(zi.shape[0])
+    return alpha * F.cross_entropy(zi @ zj.t() / temperature, lab) + (1 - alpha) * F.cross_entropy(zj @ zi.t() / temperature, lab)
+
+
+def declip_step_loss(images, ids_masked, labels, ids_aug, sd, cfg, bank, bank_ptr=0,
+                     weights=(0.4, 0.2, 0.2, 0.2)):
+    """DECLIP.forward (model/declip.py:196-336) + the solver's loss composition
+    (solver/declip_solver.py:435-533, image_text_two_view, weights clip/nn/simsiam/mlm), one rank.
+    images [b,6,H,W]; returns total loss, parts dict, updated (bank, ptr)."""
+    b = images.shape[0]
+    tp = cfg.get("text_prefix", "encode_text.")
+    img1 = vision_tower(images[:, 0:3], sd, cfg)
+    img2 = vision_tower(images[:, 3:6], sd, cfg)
+    txt, words = text_tower(ids_masked, sd, cfg, prefix=tp, return_dense=True)
+    txt_aug = text_tower(ids_aug, sd, cfg, prefix=tp)
+    z1, z2 = projection_mlp(img1, sd, "projector."), projection_mlp(img2, sd, "projector.")
+    p1, p2 = prediction_mlp(z1, sd, "predictor."), prediction_mlp(z2, sd, "predictor.")
+    i1, t = normalize_features(img1, txt)
+    i2, t_aug = normalize_features(img2, txt_aug)
+    s = clamp_scale(sd["logit_scale"], 100.0)
+    ce = lambda q, k: F.cross_entropy(s * q @ k.t(), torch.arange(b))
+    pair = lambda li_q, li_k, lt_q, lt_k: (ce(li_q, li_k) + ce(lt_q, lt_k)) / 2
+    clip_loss = (pair(i1, t, t, i1) + pair(i2, t, t, i2) + pair(i1, t_aug, t_aug, i1) + pair(i2, t_aug, t_aug, i2)) / 4
+    # NN supervision (declip.py:281-300): query(t), query(t_aug)+enqueue, enqueue(t)
+    bank = bank.clone()
+    nn_t = nn_lookup(t, bank)
+    nn_t_aug = nn_lookup(t_aug, bank)
+    ptr = bank_enqueue(bank, bank_ptr, t_aug)
+    ptr = bank_enqueue(bank, ptr, t)
+    nn_t = nn_t / (nn_t.norm(dim=-1, keepdim=True) + 1e-10)
+    nn_t_aug = nn_t_aug / (nn_t_aug.norm(dim=-1, keepdim=True) + 1e-10)
+    nn_loss = (pair(i1, nn_t, i1, nn_t_aug) + pair(i2, nn_t, i2, nn_t_aug)) / 2
+    sim_loss = simsiam_loss(p1, z1, p2, z2)
+    # MLM (declip.py:326-334)
+    sel = labels != -100
+    logits = words[sel] @ sd["text_label_predictor.weight"].t() + sd["text_label_predictor.bias"]
+    mlm = F.cross_entropy(logits, labels[sel])
+    monitor = convirt_ntxent(i1, t) + convirt_ntxent(i2, t)
+    w_clip, w_nn, w_sim, w_mlm = weights
+    total = w_clip * clip_loss + w_sim * sim_loss + w_mlm * mlm + w_nn * nn_loss
+    parts = dict(clip=clip_loss.detach(), nn=nn_loss.detach(), simsiam=sim_loss.detach(), mlm=mlm.detach(),
+                 convirt=monitor.detach())
+    return total, parts, (bank, ptr)

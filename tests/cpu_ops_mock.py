@@ -19,14 +19,26 @@ def _dgelu(x):
 
 
 def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, residual=None, aux=None, out=None,
-         out_dtype=None, accumulate=False, split_k=1, alpha=1.0, force_generic=False, a_colsum=None):
-    if a_colsum is not None:
-        a_colsum += A.float().sum(0)
+         out_dtype=None, accumulate=False, split_k=1, alpha=1.0, force_generic=False, a_colsum=None, pad_ok=False, dims=None):
     a = A.float().t() if a_kmajor else A.float()
     b = B.float() if b_kmajor else B.float().t()
+    if dims is not None:           # logical sizes inside padded buffers: crop / zero-extend like the kernels see them
+        M, N, K = dims
+        def fit(t, r, c):
+            o = torch.zeros(r, c)
+            rr, cc = min(r, t.shape[0]), min(c, t.shape[1])
+            o[:rr, :cc] = t[:rr, :cc]
+            return o
+        a, b = fit(a, M, K), fit(b, K, N)
+        if bias is not None:
+            bb = torch.zeros(N)
+            bb[:min(N, bias.numel())] = bias[:min(N, bias.numel())]
+            bias = bb
+    if a_colsum is not None:
+        a_colsum += a.sum(1)
     v = alpha * (a @ b)
     if accumulate:
-        out += v
+        out += v[:out.shape[0], :out.shape[1]]
         return out
     if bias is not None:
         v = v + bias
@@ -113,12 +125,16 @@ def text_embed_bwd(ids, dx, dtable, dpos, hot_ids=(0,)):
         dpos += dx.float().view(b, L, -1).sum(0)
 
 
-def im2row(images, c0, patch, dtype):
+def im2row(images, c0, patch, dtype, out=None):
     x = images[:, c0:c0 + 3]
     b, c, H, W = x.shape
     gh, gw = H // patch, W // patch
     x = x.reshape(b, c, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5)
-    return x.reshape(b * gh * gw, c * patch * patch).to(dtype)
+    r = x.reshape(b * gh * gw, c * patch * patch).to(dtype)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
 
 
 def vit_assemble_fwd(patches, cls, pos, b, npatch):
@@ -172,7 +188,7 @@ def infonce_fwd(pairs, scale, label0, want_logits=False):
     return torch.stack(rl), torch.stack(lse), torch.stack(c1), torch.stack(c5), (torch.stack(lg) if want_logits else None)
 
 
-def infonce_bwd(pairs, scale, label0, row_lse, g_row):
+def infonce_bwd(pairs, scale, label0, row_lse, g_row, need=None):
     outs, dscale = [], torch.zeros(1)
     for p, (q, k) in enumerate(pairs):
         dots = q @ k.t()
@@ -228,3 +244,75 @@ def adamw_segmented(p, g, m, v, p_bf16, seg_start, seg_lr, seg_wd, beta1, beta2,
         adamw(p[lo:hi], g[lo:hi], m[lo:hi], v[lo:hi], None, lr, beta1, beta2, eps, wd, step, grad_scale)
     if p_bf16 is not None:
         p_bf16.copy_(p)
+
+
+def ce_rows_bwd_padded(logits, labels, row_lse, g_row, C, out_dtype, rows_pad, C_pad):
+    rows = labels.numel()
+    dl = torch.zeros(rows_pad, C_pad, dtype=out_dtype)
+    dl[:rows, :C] = ce_rows_bwd(logits[:rows, :C], labels, row_lse, g_row).to(out_dtype)
+    return dl
+
+
+def bn1d_fwd(x, w, b, running_mean, running_var, groups, relu, training, eps=1e-5, momentum=0.1):
+    rows, C = x.shape
+    R = rows // groups
+    xf = x.float().view(groups, R, C)
+    if training:
+        mean = xf.mean(1)
+        var = xf.var(1, unbiased=False)
+        if running_mean is not None:
+            for g in range(groups):
+                running_mean.mul_(1 - momentum).add_(momentum * mean[g])
+                running_var.mul_(1 - momentum).add_(momentum * var[g] * (R / max(R - 1, 1)))
+    else:
+        mean = running_mean.expand(groups, C)
+        var = running_var.expand(groups, C)
+    invstd = torch.rsqrt(var + eps)
+    y = (xf - mean[:, None]) * invstd[:, None] * w + b
+    if relu:
+        y = y.clamp_min(0)
+    return y.reshape(rows, C).to(x.dtype), mean.contiguous(), invstd.contiguous()
+
+
+def bn1d_bwd(dy, x, y, w, mean, invstd, dw, db, groups, relu):
+    rows, C = x.shape
+    R = rows // groups
+    d = dy.float().view(groups, R, C)
+    if relu:
+        d = d * (y.float().view(groups, R, C) > 0)
+    xh = (x.float().view(groups, R, C) - mean[:, None]) * invstd[:, None]
+    dw += (d * xh).sum((0, 1))
+    db += d.sum((0, 1))
+    dx = w * invstd[:, None] * (d - d.mean(1, keepdim=True) - xh * (d * xh).mean(1, keepdim=True))
+    return dx.reshape(rows, C).to(x.dtype)
+
+
+def cos_rows_fwd(p, z):
+    return F.cosine_similarity(p.float(), z.float(), dim=-1, eps=0)
+
+
+def cos_rows_bwd(p, z, g_row):
+    pf = p.detach().float().requires_grad_(True)
+    with torch.enable_grad():
+        c = (pf * z.float()).sum(-1) / (pf.norm(dim=-1) * z.float().norm(dim=-1))
+        c.backward(g_row)
+    return pf.grad.to(p.dtype)
+
+
+def nn_bank_query(q, bank):
+    sim = q @ bank.t()
+    idx = sim.argmax(dim=1)
+    return idx, bank[idx].clone()
+
+
+def gather_rows(x, idx, n_pad=None):
+    n = idx.numel()
+    n_pad = n_pad or max(n, 1)
+    out = torch.zeros(n_pad, x.shape[-1], dtype=x.dtype)
+    out[:n] = x[idx]
+    return out
+
+
+def scatter_rows_add(dout, idx, dx):
+    dx[idx] += dout[:idx.numel()]
+    return dx

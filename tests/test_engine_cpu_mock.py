@@ -138,3 +138,30 @@ def test_flat_adamw_tables_match_torch_adamw(mocked_engine):
         assert float(diff.max()) <= 3 * 1e-3 * 3 + 1e-4 * float(r.abs().max()), k
         assert float((diff > 1e-4 * float(r.abs().max() + 1e-12)).float().mean()) <= 0.02 or k.endswith("in_proj_bias"), k
     assert torch.equal(got["visual.conv1.weight"].detach(), synth.synth_state(synth.clip_shapes(cfg), seed=seed)["visual.conv1.weight"])
+
+
+def test_declip_engine_composition_matches_golden(mocked_engine):
+    """DECLIP model + solver loss composition on the engine (mock kernels) vs the reference golden."""
+    from declip_amd.heads import SimsiamLoss
+    from declip_amd.loss import ClipInfoCELoss, NTXentLoss
+    from declip_amd.steps import declip_loss
+    from declip_amd.testing import build_declip, declip_batch
+    g = load_golden("declip_tiny")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    model = build_declip(cfg, dtype="fp32", seed=seed, nn_size=g["nn_size"], device="cpu")
+    batch = declip_batch(cfg, b, seed=seed, device="cpu")
+    out = declip_loss(model, batch, ClipInfoCELoss(), SimsiamLoss(), NTXentLoss(b))
+    out["loss"].backward()
+    assert abs(float(out["loss"]) - g["loss"]) <= 1e-4 * abs(g["loss"])
+    for k in ("clip", "nn", "simsiam", "mlm", "convirt"):
+        assert abs(float(out["parts"][k]) - g["parts"][k]) <= 2e-4 * max(1.0, abs(g["parts"][k])), k
+    li1 = out["outputs"]["logits"][0].materialize().detach()
+    assert float((li1 - g["logits_i1"]).abs().max()) <= 1e-4 * float(g["logits_i1"].abs().max())
+    grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+    check_grad_digests(g["grads"], grads, rtol=1e-3)
+    assert model.nn_replacer_text.bank_ptr == g["bank_ptr"]
+    assert abs(float(model.nn_replacer_text.bank.double().sum()) - g["bank_sum"]) <= 1e-3
+    assert torch.allclose(model.projector.bn1.running_mean, g["bn1_running_mean"], rtol=1e-4, atol=1e-6)
+    assert torch.allclose(model.projector.bn1.running_var, g["bn1_running_var"], rtol=1e-4, atol=1e-6)

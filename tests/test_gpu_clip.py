@@ -122,3 +122,31 @@ def test_train_steps_flat_adamw_matches_torch_adamw_on_oracle():
         diff = (a - r).abs()
         assert float(diff.max()) <= 3 * 1e-3 * 3 + 2e-3 * float(r.abs().max()), k
         assert float((diff > 2e-3 * float(r.abs().max() + 1e-12)).float().mean()) <= 0.02 or k.endswith("in_proj_bias"), k
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
+def test_declip_step_matches_reference_golden(dtype, tol):
+    """DECLIP model + declip_solver loss composition on the HIP engine vs the reference golden."""
+    from declip_amd.heads import SimsiamLoss
+    from declip_amd.loss import ClipInfoCELoss, NTXentLoss
+    from declip_amd.steps import declip_loss
+    from declip_amd.testing import build_declip, declip_batch
+    g = load_golden("declip_tiny")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_declip(cfg, dtype=dtype, seed=seed, nn_size=g["nn_size"])
+    batch = declip_batch(cfg, b, seed=seed)
+    out = declip_loss(model, batch, ClipInfoCELoss(), SimsiamLoss(), NTXentLoss(b))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - g["loss"]) <= tol * abs(g["loss"])
+    for k in ("clip", "nn", "mlm", "convirt"):
+        assert abs(float(out["parts"][k]) - g["parts"][k]) <= tol * max(1.0, abs(g["parts"][k])), k
+    assert abs(float(out["parts"]["simsiam"]) - g["parts"]["simsiam"]) <= (1e-4 if dtype == "fp32" else 2e-2)
+    assert model.nn_replacer_text.bank_ptr == g["bank_ptr"]
+    if dtype == "fp32":
+        li1 = out["outputs"]["logits"][0].materialize().detach().cpu()
+        assert float((li1 - g["logits_i1"]).abs().max()) <= 1e-3 * float(g["logits_i1"].abs().max())
+        grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
+        check_grad_digests(g["grads"], grads, rtol=1e-3)
+        assert abs(float(model.nn_replacer_text.bank.double().sum()) - g["bank_sum"]) <= 1e-3
+        assert torch.allclose(model.projector.bn1.running_mean.cpu(), g["bn1_running_mean"], rtol=1e-3, atol=1e-5)

@@ -300,3 +300,95 @@ def test_adamw_matches_torch():
         ops.adamw(p, g.to(cuda), m, v, pb, 1e-2, 0.9, 0.98, 1e-8, 0.1, step)
     assert rel_err(p, pr.detach()) < 1e-5
     assert rel_err(pb.float(), pr.detach()) < 1e-2
+
+
+# ----------------------------------------------------------------------------- DeCLIP heads
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn1d_groups(dtype, relu):
+    ops = _ops()
+    G, R, C = 2, 24, 200
+    x = rnd(G * R, C, seed=80).to(dtype)
+    w, b = 1 + 0.1 * rnd(C, seed=81), 0.1 * rnd(C, seed=82)
+    dy = rnd(G * R, C, seed=83).to(dtype)
+    bn = torch.nn.BatchNorm1d(C).double()
+    bn.weight.data, bn.bias.data = w.double(), b.double()
+    xr = x.double().requires_grad_(True)
+    ys = []
+    for g in range(G):                                     # the reference calls the module once per view
+        y = bn(xr[g * R:(g + 1) * R])
+        ys.append(torch.relu(y) if relu else y)
+    yr = torch.cat(ys)
+    yr.backward(dy.double())
+    rm, rv = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
+    y, mean, invstd = ops.bn1d_fwd(x.to(cuda), w.to(cuda), b.to(cuda), rm, rv, G, relu, True)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert rel_err(y, yr.detach()) < tol
+    assert rel_err(rm, bn.running_mean) < 1e-4 and rel_err(rv, bn.running_var) < 1e-4
+    dw, db = torch.zeros(C, device=cuda), torch.zeros(C, device=cuda)
+    dx = ops.bn1d_bwd(dy.to(cuda), x.to(cuda), y, w.to(cuda), mean, invstd, dw, db, G, relu)
+    assert rel_err(dx, xr.grad) < (2e-4 if dtype == torch.float32 else 3e-2)
+    assert rel_err(dw, bn.weight.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert rel_err(db, bn.bias.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cos_rows(dtype):
+    ops = _ops()
+    p, z = rnd(33, 1024, seed=84).to(dtype), rnd(33, 1024, seed=85).to(dtype)
+    g = rnd(33, seed=86)
+    pr = p.double().requires_grad_(True)
+    cr = torch.nn.functional.cosine_similarity(pr, z.double(), dim=-1)
+    (cr * g.double()).sum().backward()
+    c = ops.cos_rows_fwd(p.to(cuda), z.to(cuda))
+    assert rel_err(c, cr.detach()) < 1e-5
+    dp = ops.cos_rows_bwd(p.to(cuda), z.to(cuda), g.to(cuda))
+    assert rel_err(dp, pr.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("rows,size,D", [(40, 5000, 512), (7, 300, 64), (512, 65536, 512)])
+def test_nn_bank_query_exact(rows, size, D):
+    ops = _ops()
+    bank = torch.nn.functional.normalize(rnd(size, D, seed=87), dim=1)
+    q = torch.nn.functional.normalize(rnd(rows, D, seed=88), dim=1)
+    q[0] = bank[size - 1]                                   # an exact hit in the last chunk
+    idx, feats = ops.nn_bank_query(q.to(cuda), bank.to(cuda))
+    sim = q.double() @ bank.double().t()
+    ref = sim.argmax(1)
+    got = idx.cpu()
+    same = got == ref
+    # fp32 rounding can only flip near-ties: the chosen score must equal the best score to 1e-6
+    chosen = sim[torch.arange(rows), got]
+    assert float((sim.max(1)[0] - chosen).max()) < 2e-6 and same.float().mean() > 0.98
+    assert torch.equal(feats.cpu(), bank[got])
+    assert int(got[0]) == size - 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gather_scatter_rows(dtype):
+    ops = _ops()
+    x = rnd(50, 128, seed=89).to(dtype)
+    idx = torch.tensor([3, 17, 49, 0, 8])
+    out = ops.gather_rows(x.to(cuda), idx.to(cuda), 64)
+    assert torch.equal(out[:5].cpu(), x[idx]) and float(out[5:].abs().max()) == 0.0
+    dx = torch.zeros(50, 128, device=cuda, dtype=dtype)
+    ops.scatter_rows_add(out, idx.to(cuda), dx)
+    ref = torch.zeros(50, 128, dtype=dtype)
+    ref[idx] = x[idx]
+    assert torch.equal(dx.cpu(), ref)
+
+
+def test_ce_rows_bwd_padded_layout():
+    ops = _ops()
+    rows, C, rows_pad, C_pad = 37, 1001, 64, 1024
+    logits = rnd(rows_pad, C_pad, seed=90, scale=2.0).to(cuda)
+    labels = torch.randint(0, C, (rows,), generator=torch.Generator().manual_seed(91)).to(cuda)
+    view = logits[:rows, :C]
+    row_loss, row_lse, _, _ = ops.ce_rows_fwd(view, labels)
+    g = rnd(rows, seed=92).abs().to(cuda)
+    ref = ops.ce_rows_bwd(view.contiguous(), labels, row_lse, g)
+    for dt_ in (torch.float32, torch.bfloat16):
+        dl = ops.ce_rows_bwd_padded(view, labels, row_lse, g, C, dt_, rows_pad, C_pad)
+        assert dl.shape == (rows_pad, C_pad)
+        assert float(dl[rows:].abs().max()) == 0.0 and float(dl[:, C:].abs().max()) == 0.0
+        assert rel_err(dl[:rows, :C].float(), ref) < (1e-6 if dt_ == torch.float32 else 1e-2)
