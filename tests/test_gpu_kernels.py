@@ -392,3 +392,35 @@ def test_ce_rows_bwd_padded_layout():
         assert dl.shape == (rows_pad, C_pad)
         assert float(dl[rows:].abs().max()) == 0.0 and float(dl[:, C:].abs().max()) == 0.0
         assert rel_err(dl[:rows, :C].float(), ref) < (1e-6 if dt_ == torch.float32 else 1e-2)
+
+
+# ----------------------------------------------------------------------------- GEMM v3 (deep pipeline) variants
+@pytest.mark.parametrize("mode", ["1", "2", "3"])                  # 256x128 / 256x256 / 128x128x3 tiles
+@pytest.mark.parametrize("a_km,b_km", [(False, False), (False, True), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(600, 520, 96), (256, 256, 32), (1000, 768, 320), (777, 264, 64)])
+def test_gemm_v3_tiles(monkeypatch, mode, a_km, b_km, M, N, K):
+    ops = _ops()
+    from declip_amd.lib import EPI_GELU
+    monkeypatch.setenv("DH_GEMM_V3_DYN", mode)
+    if a_km and M % 8:
+        M = M // 8 * 8 + 8
+    A = rnd(M, K, seed=1).to(torch.bfloat16)
+    B = rnd(N, K, seed=2, scale=0.2).to(torch.bfloat16)
+    bias = rnd(N, seed=3)
+    ref = A.double() @ B.double().t()
+    Ad = (A.t().contiguous() if a_km else A).to(cuda)
+    Bd = (B.t().contiguous() if b_km else B).to(cuda)
+    if a_km and b_km:                                               # weight-gradient form: fp32 accumulate + fused colsum
+        out = torch.zeros(M, N, device=cuda)
+        cs = torch.zeros(M, device=cuda)
+        ops.gemm(Ad, Bd, a_kmajor=True, b_kmajor=True, out=out, accumulate=True, split_k=2 if K >= 64 else 1, a_colsum=cs)
+        assert rel_err(out, ref) < 2e-3
+        assert rel_err(cs, A.double().sum(1)) < 1e-3
+    else:
+        aux = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+        out = ops.gemm(Ad, Bd, a_kmajor=a_km, b_kmajor=b_km, bias=bias.to(cuda), epilogue=EPI_GELU, aux=aux)
+        pre = ref + bias.double()
+        assert rel_err(aux, pre) < 1.5e-2
+        assert rel_err(out, quick_gelu(pre)) < 1.5e-2
+        out32 = ops.gemm(Ad, Bd, a_kmajor=a_km, b_kmajor=b_km, out_dtype=torch.float32)
+        assert rel_err(out32, ref) < 2e-3
