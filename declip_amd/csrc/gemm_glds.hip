@@ -143,9 +143,18 @@ __global__ __launch_bounds__(128 * WMR, 2) void gemm_glds_kernel(const bf16_t* _
     const int ntx = gridDim.x, nb = gridDim.x * gridDim.y;
     const int b = blockIdx.y * ntx + blockIdx.x;
     const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for any nb
-    tile_y = logical / ntx;
-    tile_x = logical - tile_y * ntx;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    // L2-aware rasterisation: the ~64 tiles an XCD runs concurrently form a GROUP_M x (64/GROUP_M) patch of the
+    // tile grid, so they share GROUP_M A-panels and ~8 B-panels that fit the 4 MiB L2.
+    constexpr int GROUP_M = 8;
+    const int nty = gridDim.y;
+    const int in_group = GROUP_M * ntx;
+    const int gid = logical / in_group;
+    const int first_m = gid * GROUP_M;
+    const int gsz = min(nty - first_m, GROUP_M);
+    const int rem = logical - gid * in_group;
+    tile_y = first_m + rem % gsz;
+    tile_x = rem / gsz;
   }
   const int m0 = tile_y * BM, n0 = tile_x * BN;
   const int kbeg = blockIdx.z * k_per_split;
