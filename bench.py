@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--model", default="clip", choices=["clip", "declip"], help="clip = BASELINE.json metric; declip = configs[2] variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -64,7 +65,7 @@ def main():
     from declip_amd import ops, synth
     from declip_amd.loss import ClipInfoCELoss
     from declip_amd.optim import build_adamw
-    from declip_amd.testing import build_clip
+    from declip_amd.testing import build_clip, build_declip, declip_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -77,19 +78,29 @@ def main():
 
     cfg = synth.VITB32
     b = args.batch
-    model = build_clip(cfg, dtype=args.dtype, use_allgather=(world > 1), seed=0, load_synth=False)
+    crit = ClipInfoCELoss()
+    if args.model == "clip":
+        model = build_clip(cfg, dtype=args.dtype, use_allgather=(world > 1), seed=0, load_synth=False)
+        images = synth.synth_images(b, seed=rank).to(dev)
+        ids = synth.synth_tokens(b, seed=rank).to(dev)
+        batch = {"images": images, "captions": ids}
+    else:
+        from declip_amd.heads import SimsiamLoss
+        from declip_amd.steps import declip_loss
+        model = build_declip(cfg, dtype=args.dtype, seed=0, nn_size=65536, load_synth=False)
+        batch = declip_batch(cfg, b, seed=rank, device=dev)
+        sim_crit = SimsiamLoss()
     wrapped = dh_dist.DistModule(model, sync=False)
     opt = build_adamw(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
-    crit = ClipInfoCELoss()
-    images = synth.synth_images(b, seed=rank).to(dev)
-    ids = synth.synth_tokens(b, seed=rank).to(dev)
-    batch = {"images": images, "captions": ids}
 
     def step():
         opt.zero_grad()
-        li, lt = wrapped(batch)
-        loss, _ = crit(li, lt)
-        loss = loss / world                      # clip_solver.py:418
+        if args.model == "clip":
+            li, lt = wrapped(batch)
+            loss, _ = crit(li, lt)
+            loss = loss / world                  # clip_solver.py:418
+        else:
+            loss = declip_loss(wrapped, batch, crit, sim_crit, None, world_size=world, with_accuracy=False)["loss"]
         loss.backward()                          # gradient all-reduce overlaps inside (dist.FlatReducer)
         wrapped.sync_gradients()
         model.logit_scale.data.clamp_(3, 6)      # grad_clip: logit_scale_param_value (config.yaml:20-23)
@@ -154,13 +165,17 @@ def main():
                         peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
                         launches_per_step=len(records) // nprof, gemm_ms_per_step=round(ms / nprof, 3),
                         gemm_gflop_per_step=round(flops / nprof / 1e9, 1),
-                        step_mfma_frac=round(pairs_per_s * GFLOP_PER_PAIR / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
+                        step_mfma_frac=round(pairs_per_s * (GFLOP_PER_PAIR if args.model == "clip" else 89.9) / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
 
-    out = dict(metric="image-text pairs/sec CLIP ViT-B/32", value=round(pairs_per_s, 2), unit="pairs/s", n_gpus=world,
+    gflop_pair = GFLOP_PER_PAIR if args.model == "clip" else 89.9
+    name = "CLIP" if args.model == "clip" else "DeCLIP"
+    out = dict(metric="image-text pairs/sec %s ViT-B/32" % name, value=round(pairs_per_s, 2), unit="pairs/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
-               config=dict(workload="CLIP ViT-B/32 + 12-layer text transformer, InfoNCE, fwd+bwd+grad-allreduce+AdamW; "
-                                    "per-GPU batch %d, 224x224 images, 77-token captions, random-init weights" % b,
+               config=dict(workload=("CLIP ViT-B/32 + 12-layer text transformer, InfoNCE, fwd+bwd+grad-allreduce+AdamW; "
+                                     "per-GPU batch %d, 224x224 images, 77-token captions, random-init weights" % b) if args.model == "clip" else
+                                    ("DeCLIP ViT-B/32 (2 image views + masked/augmented text, 8+4 InfoNCE pairs, SimSiam, NN bank 65536, MLM), "
+                                     "fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d" % b),
                            global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world),
                loss=round(float(loss) * world, 5))
     if roofline is not None:

@@ -16,6 +16,8 @@ struct PairTable {
   const float* K[DH_MAX_PAIRS];
   float* dQ[DH_MAX_PAIRS];
   float* dK[DH_MAX_PAIRS];
+  int label0[DH_MAX_PAIRS];   // positive column of local row i is label0 + i
+  int excl0[DH_MAX_PAIRS];    // column excl0 + i is removed from row i's softmax (NT-Xent self-pair); < 0: none
 };
 
 constexpr int CT = 64;   // columns per tile
@@ -96,6 +98,8 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(PairTable pt, int b, int B
   float* Ys = Xs + RT * (D + 1);       // [64][KC+1]
   float* lab = Ys + CT * (KC + 1);     // [RT] label logits
   const int pair = blockIdx.y;
+  label0 = pt.label0[pair];
+  const int excl0 = pt.excl0[pair];
   const int nchunk = gridDim.z, chunk = blockIdx.z;
   const int cbeg = chunk * chunk_cols, cend = min(B, cbeg + chunk_cols);
   const float* Q = pt.Q[pair];
@@ -131,6 +135,7 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(PairTable pt, int b, int B
         if (col < cend) {
           const float v = acc[r][c] * scale;
           if (logits_out && row < b) logits_out[((long)pair * b + row) * B + col] = v;
+          if (excl0 >= 0 && col == excl0 + row) continue;             // self-pair removed from the softmax
           if (col != label0 + row && v > ll[r]) cnt[r] += 1.f;
           if (v > m[r]) { s[r] = s[r] * __expf(m[r] - v) + 1.f; m[r] = v; } else s[r] += __expf(v - m[r]);
         }
@@ -190,6 +195,8 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(PairTable pt, int mode, in
   float* Gs = Ys + CT * (KC + 1);        // [RT][65]
   float* red = Gs + RT * (CT + 1);       // [8]
   const int pair = blockIdx.y;
+  label0 = pt.label0[pair];
+  const int excl0 = pt.excl0[pair];
   const float* X = mode == 0 ? pt.Q[pair] : pt.K[pair];
   const float* Y = mode == 0 ? pt.K[pair] : pt.Q[pair];
   float* dX = mode == 0 ? pt.dQ[pair] : pt.dK[pair];
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(PairTable pt, int mode, in
           const int i = mode == 0 ? xr : yc;   // Q row (local)
           const int j = mode == 0 ? yc : xr;   // K row (global)
           const float logit = acc[r][c] * scale;
-          const float p = __expf(logit - lse_p[i]);
+          const float p = (excl0 >= 0 && j == excl0 + i) ? 0.f : __expf(logit - lse_p[i]);
           gval = g_p[i] * (p - (j == label0 + i ? 1.f : 0.f));
           ds_acc += gval * acc[r][c];
         }
@@ -327,9 +334,13 @@ __global__ __launch_bounds__(256) void ce_rows_bwd_pad_kernel(const float* __res
   }
 }
 
-int fill_table(PairTable& pt, const dh_nce_pair* pairs, int n) {
-  for (int i = 0; i < DH_MAX_PAIRS; ++i) { pt.Q[i] = nullptr; pt.K[i] = nullptr; pt.dQ[i] = nullptr; pt.dK[i] = nullptr; }
-  for (int i = 0; i < n; ++i) { pt.Q[i] = pairs[i].Q; pt.K[i] = pairs[i].K; pt.dQ[i] = pairs[i].dQ; pt.dK[i] = pairs[i].dK; }
+int fill_table(PairTable& pt, const dh_nce_pair* pairs, int n, int label0, const int* label0s, const int* excl0s) {
+  for (int i = 0; i < DH_MAX_PAIRS; ++i) { pt.Q[i] = nullptr; pt.K[i] = nullptr; pt.dQ[i] = nullptr; pt.dK[i] = nullptr; pt.label0[i] = label0; pt.excl0[i] = -1; }
+  for (int i = 0; i < n; ++i) {
+    pt.Q[i] = pairs[i].Q; pt.K[i] = pairs[i].K; pt.dQ[i] = pairs[i].dQ; pt.dK[i] = pairs[i].dK;
+    if (label0s) pt.label0[i] = label0s[i];
+    if (excl0s) pt.excl0[i] = excl0s[i];
+  }
   return 0;
 }
 
@@ -341,15 +352,15 @@ extern "C" int64_t dh_infonce_ws_bytes(int n_pairs, int b, int B) {
 }
 
 extern "C" int dh_infonce_fwd(const dh_nce_pair* pairs, int n_pairs, int b, int B, int D, const float* scale, int label0,
-                              float* row_loss, float* row_lse, float* correct1, float* correct5, float* logits_out,
-                              void* ws, int64_t ws_bytes, dh_stream_t stream) {
+                              const int* label0s, const int* excl0s, float* row_loss, float* row_lse, float* correct1,
+                              float* correct5, float* logits_out, void* ws, int64_t ws_bytes, dh_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   DH_REQUIRE(pairs && n_pairs >= 1 && n_pairs <= DH_MAX_PAIRS, "dh_infonce_fwd: 1..%d pairs", DH_MAX_PAIRS);
   DH_REQUIRE(b > 0 && B >= b && D > 0 && row_loss && row_lse && scale, "dh_infonce_fwd: bad args");
-  DH_REQUIRE(label0 >= 0 && label0 + b <= B, "dh_infonce_fwd: labels out of range");
   DH_REQUIRE(ws && ws_bytes >= dh_infonce_ws_bytes(n_pairs, b, B), "dh_infonce_fwd: workspace too small");
   PairTable pt;
-  fill_table(pt, pairs, n_pairs);
+  fill_table(pt, pairs, n_pairs, label0, label0s, excl0s);
+  for (int i = 0; i < n_pairs; ++i) DH_REQUIRE(pt.label0[i] >= 0 && pt.label0[i] + b <= B, "dh_infonce_fwd: labels out of range");
   for (int i = 0; i < n_pairs; ++i) DH_REQUIRE(pt.Q[i] && pt.K[i], "dh_infonce_fwd: null feature pointer");
   DH_REQUIRE(D <= 1024, "dh_infonce_fwd: D=%d > 1024", D);
   constexpr int RT = 32;
@@ -367,12 +378,13 @@ extern "C" int dh_infonce_fwd(const dh_nce_pair* pairs, int n_pairs, int b, int 
 }
 
 extern "C" int dh_infonce_bwd(const dh_nce_pair* pairs, int n_pairs, int b, int B, int D, const float* scale, int label0,
-                              const float* row_lse, const float* g_row, float* dscale, dh_stream_t stream) {
+                              const int* label0s, const int* excl0s, const float* row_lse, const float* g_row, float* dscale,
+                              dh_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   DH_REQUIRE(pairs && n_pairs >= 1 && n_pairs <= DH_MAX_PAIRS, "dh_infonce_bwd: 1..%d pairs", DH_MAX_PAIRS);
   DH_REQUIRE(b > 0 && B >= b && D > 0 && row_lse && g_row && scale, "dh_infonce_bwd: bad args");
   PairTable pt;
-  fill_table(pt, pairs, n_pairs);
+  fill_table(pt, pairs, n_pairs, label0, label0s, excl0s);
   for (int i = 0; i < n_pairs; ++i) DH_REQUIRE(pt.Q[i] && pt.K[i], "dh_infonce_bwd: null feature pointer");  // dQ/dK may be NULL: skipped
   auto launch = [&](auto rt_tag, int mode) {
     constexpr int RT = decltype(rt_tag)::value;

@@ -420,17 +420,24 @@ class InfoNCEFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, scale, label0, n_pairs, *feats):
+        """label0: int, or (label0s, excl0s) per-pair lists (excl0s: self-pair exclusion, NT-Xent)."""
         pairs = [(feats[2 * i].contiguous(), feats[2 * i + 1].contiguous()) for i in range(n_pairs)]
         scale = scale.detach().contiguous().float()
-        row_loss, row_lse, c1, c5, _ = ops.infonce_fwd(pairs, scale, label0)
+        label0s = excl0s = None
+        if isinstance(label0, (tuple, list)):
+            label0s, excl0s = label0
+            label0 = int(label0s[0])
+        row_loss, row_lse, c1, c5, _ = ops.infonce_fwd(pairs, scale, label0, label0s=label0s, excl0s=excl0s)
         ctx.pairs, ctx.scale, ctx.label0, ctx.row_lse = pairs, scale, label0, row_lse
+        ctx.lab = (label0s, excl0s)
         ctx.need = [(bool(ctx.needs_input_grad[3 + 2 * i]), bool(ctx.needs_input_grad[4 + 2 * i])) for i in range(n_pairs)]
         ctx.mark_non_differentiable(c1, c5)
         return row_loss, c1, c5
 
     @staticmethod
     def backward(ctx, g_row, _g1, _g5):
-        outs, dscale = ops.infonce_bwd(ctx.pairs, ctx.scale, ctx.label0, ctx.row_lse, g_row.contiguous().float(), need=ctx.need)
+        outs, dscale = ops.infonce_bwd(ctx.pairs, ctx.scale, ctx.label0, ctx.row_lse, g_row.contiguous().float(), need=ctx.need,
+                                       label0s=ctx.lab[0], excl0s=ctx.lab[1])
         flat = []
         for dq, dk in outs:
             flat += [dq, dk]

@@ -108,8 +108,7 @@ class projection_MLP(_HeadBase):
         if num_layers == 3:
             self.relu2 = nn.ReLU(inplace=True)
             self.linear3 = nn.Linear(hidden_dim, out_dim)
-            if out_bn:
-                self.bn3 = nn.BatchNorm1d(hidden_dim)
+            self.bn3 = nn.BatchNorm1d(hidden_dim)          # always constructed (state_dict), applied only if out_bn
 
     def forward(self, x, groups=1):
         """x: [groups*b, in_dim]; BN statistics per group (== calling the reference module once per view)."""

@@ -95,3 +95,46 @@ class NTXentLoss(nn.Module):
         scale = torch.full((1,), 1.0 / self.temperature, device=zis.device, dtype=torch.float32)
         rl, _, _ = engine.InfoNCEFn.apply(scale, 0, 2, zis, zjs, zjs, zis)
         return self.alpha_weight * rl[0].mean() + (1 - self.alpha_weight) * rl[1].mean()
+
+
+def _ntxent(qs, k, label0s, excl0s, temperature):
+    scale = torch.full((1,), 1.0 / temperature, device=k.device, dtype=torch.float32)
+    rl, _, _ = engine.InfoNCEFn.apply(scale, (label0s, excl0s), len(qs), *[t for q in qs for t in (q, k)])
+    return rl
+
+
+class NT_Xent(nn.Module):
+    """Local SimCLR NT-Xent (reference: loss_functions/nt_xent.py:6-44): rows [z_i; z_j] against themselves,
+    positive of row i is i+b (and vice versa), the row's own entry is excluded; CE(sum) / 2b.  The reference
+    materialises a [2b,2b,D] cosine tensor; here it is two fused InfoNCE pairs with a self-exclusion column."""
+
+    def __init__(self, batch_size, temperature=0.5):
+        super().__init__()
+        self.batch_size, self.temperature = batch_size, temperature
+
+    def forward(self, z_i, z_j):
+        b = z_i.shape[0]
+        qi, qj = engine.L2NormFn.apply(z_i, 1e-8), engine.L2NormFn.apply(z_j, 1e-8)
+        k = torch.cat([qi, qj], dim=0)
+        rl = _ntxent([qi, qj], k, [b, 0], [0, b], self.temperature)
+        return rl.sum() / (2 * b)
+
+
+class NT_Xent_gather(nn.Module):
+    """Cross-rank SimCLR NT-Xent (reference: loss_functions/nt_xent.py:47-97): local rows [z_i; z_j] against the
+    gathered [z_ib; z_jb]; positives at (i, rank*b+i+B) and (i+b, rank*b+i), self-pairs removed; CE(sum) / 2b.
+    The reference builds a [2b, 2B, D] broadcast (2.1 G elements at b=512, B=4096); here nothing above
+    [2B, D] exists."""
+
+    def __init__(self, batch_size, temperature=0.1):
+        super().__init__()
+        self.batch_size, self.temperature = batch_size, temperature
+
+    def forward(self, z_i, z_ib, z_j, z_jb, temperature=None):
+        bs, l_bs = z_i.shape[0], z_ib.shape[0]
+        assert bs == self.batch_size
+        r0 = dh_dist.get_rank() * bs if l_bs != bs else 0
+        qi, qj = engine.L2NormFn.apply(z_i, 1e-8), engine.L2NormFn.apply(z_j, 1e-8)
+        k = torch.cat([engine.L2NormFn.apply(z_ib, 1e-8), engine.L2NormFn.apply(z_jb, 1e-8)], dim=0)
+        rl = _ntxent([qi, qj], k, [r0 + l_bs, r0], [r0, r0 + l_bs], self.temperature)
+        return rl.sum() / (2 * bs)

@@ -189,7 +189,14 @@ def _pair_array(pairs):
     return arr
 
 
-def infonce_fwd(pairs, scale, label0, want_logits=False):
+def _int_array(vals, n):
+    if vals is None:
+        return None
+    assert len(vals) == n
+    return (ctypes.c_int * n)(*[int(v) for v in vals])
+
+
+def infonce_fwd(pairs, scale, label0, want_logits=False, label0s=None, excl0s=None):
     """pairs: list of (Q[b,D], K[B,D]) fp32.  scale: 1-element fp32 device tensor.
     Returns row_loss, row_lse, correct1, correct5 ([P,b] fp32) and optional logits [P,b,B]."""
     Q0, K0 = pairs[0][0], pairs[0][1]
@@ -206,12 +213,12 @@ def infonce_fwd(pairs, scale, label0, want_logits=False):
     lib = L.load()
     nbytes = lib.dh_infonce_ws_bytes(P, b, B)
     ws = torch.empty(nbytes // 4, device=Q0.device, dtype=torch.float32)
-    check(lib.dh_infonce_fwd(arr, P, b, B, D, ptr(scale), int(label0), ptr(row_loss), ptr(row_lse), ptr(c1), ptr(c5),
-                             ptr(logits), ptr(ws), nbytes, stream()), "dh_infonce_fwd")
+    check(lib.dh_infonce_fwd(arr, P, b, B, D, ptr(scale), int(label0), _int_array(label0s, P), _int_array(excl0s, P),
+                             ptr(row_loss), ptr(row_lse), ptr(c1), ptr(c5), ptr(logits), ptr(ws), nbytes, stream()), "dh_infonce_fwd")
     return row_loss, row_lse, c1, c5, logits
 
 
-def infonce_bwd(pairs, scale, label0, row_lse, g_row, need=None):
+def infonce_bwd(pairs, scale, label0, row_lse, g_row, need=None, label0s=None, excl0s=None):
     """pairs: list of (Q, K); returns list of (dQ, dK) and dscale (1-element).  need: optional list of
     (need_dQ, need_dK) flags -- unneeded gradients are skipped (None returned)."""
     Q0, K0 = pairs[0]
@@ -221,8 +228,9 @@ def infonce_bwd(pairs, scale, label0, row_lse, g_row, need=None):
     outs = [(torch.empty_like(q) if nq else None, torch.empty_like(k) if nk else None) for (q, k), (nq, nk) in zip(pairs, need)]
     dscale = torch.zeros(1, device=Q0.device, dtype=torch.float32)
     arr = _pair_array([(q, k, dq, dk) for (q, k), (dq, dk) in zip(pairs, outs)])
-    check(L.load().dh_infonce_bwd(arr, len(pairs), b, B, D, ptr(scale), int(label0), ptr(_contig(row_lse, "lse")),
-                                  ptr(_contig(g_row, "g")), ptr(dscale), stream()), "dh_infonce_bwd")
+    check(L.load().dh_infonce_bwd(arr, len(pairs), b, B, D, ptr(scale), int(label0), _int_array(label0s, len(pairs)),
+                                  _int_array(excl0s, len(pairs)), ptr(_contig(row_lse, "lse")), ptr(_contig(g_row, "g")),
+                                  ptr(dscale), stream()), "dh_infonce_bwd")
     return outs, dscale
 
 

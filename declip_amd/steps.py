@@ -66,3 +66,33 @@ def declip_loss(model, batch, criterion, simsiam_criterion, nt_xent_criterion=No
         n = target.size(0)
         out.update(top1=c1.sum().reshape(1) * (100.0 / n), top5=c5.sum().reshape(1) * (100.0 / n))
     return out
+
+
+SLIP_WEIGHTS = dict(clip_loss=1, simclr_loss=1)                        # yfcc15m_vit_slip/config.yaml:28-30
+
+
+def slip_loss(model, batch, criterion, simclr_criterion, nt_xent_criterion=None, weights=None, world_size=1,
+              with_accuracy=True):
+    """slip_solver.py:438-527 ('slip' model branch)."""
+    w = dict(SLIP_WEIGHTS if weights is None else weights)
+    o = model(batch, return_dict=True)
+    li, lt = o["logits"]
+    tf, imf = o["features"]
+    clip, target = criterion(li, lt)
+    acc_src = criterion.last_correct
+    clip = clip / world_size
+    s1, g1, s2, g2 = o["sim_features"]
+    simclr = simclr_criterion(s1, g1, s2, g2) / world_size
+    parts = dict(clip=clip, simclr=simclr)
+    if nt_xent_criterion is not None:                                   # logged monitor (slip_solver.py:500)
+        with torch.no_grad():
+            parts["nt_xent"] = nt_xent_criterion(imf.detach(), tf.detach()) / world_size
+    loss = clip * w.get("clip_loss", 0)
+    if w.get("simclr_loss", 0):
+        loss = loss + simclr * w["simclr_loss"]
+    out = dict(loss=loss, parts=parts, outputs=o)
+    if with_accuracy and acc_src is not None:
+        _, c1, c5 = acc_src
+        n = target.size(0)
+        out.update(top1=c1.sum().reshape(1) * (100.0 / n), top5=c5.sum().reshape(1) * (100.0 / n))
+    return out

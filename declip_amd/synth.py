@@ -156,6 +156,19 @@ def declip_shapes(cfg):
     return s
 
 
+def slip_shapes(cfg):
+    """SLIP state_dict (model/slip.py:209-217): CLIP (text prefix `text_encoder.`) + predictor_sim."""
+    s = clip_shapes(dict(cfg, text_prefix="text_encoder."))
+    fd, hid, sd = cfg["v_width"], 4096, cfg.get("sim_dim", 256)
+    s["predictor_sim.linear1.weight"], s["predictor_sim.linear1.bias"] = (hid, fd), (hid,)
+    _bn_shapes(s, "predictor_sim.bn1.", hid)
+    s["predictor_sim.linear2.weight"], s["predictor_sim.linear2.bias"] = (hid, hid), (hid,)
+    _bn_shapes(s, "predictor_sim.bn2.", hid)
+    s["predictor_sim.linear3.weight"], s["predictor_sim.linear3.bias"] = (sd, hid), (sd,)
+    _bn_shapes(s, "predictor_sim.bn3.", hid)
+    return s
+
+
 def synth_bank(size, dim, seed=4):
     """unit-norm rows [size, dim] (NN bank randn seed 4, normalised, ptr 0)."""
     g = torch.Generator().manual_seed(4000 + seed)

@@ -57,3 +57,26 @@ def declip_batch(cfg, b, seed=0, device="cuda"):
     ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
     caps = torch.stack([ids_masked, ids_aug], dim=1)
     return {"images": images.to(device), "captions": caps.to(device), "mlm_labels": labels}
+
+
+def build_slip(cfg, dtype="bf16", seed=0, fused_loss=True, device="cuda", load_synth=True):
+    from .model.slip import SLIP
+    vis = VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
+                            layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"])
+    txt = TextTransformer(embed_dim=cfg["embed_dim"], context_length=cfg["ctx"], transformer_width=cfg["t_width"],
+                          transformer_heads=cfg["t_heads"], transformer_layers=cfg["t_layers"],
+                          positional_embedding_flag=True, checkpoint=False, bpe_path=None,
+                          text_encode_type="Transformer", text_model_utils={"random": False, "freeze": False},
+                          vocab_size=cfg.get("vocab", synth.VOCAB))
+    model = SLIP(vis, txt, True, return_sim=True, feature_dim=cfg["v_width"], sim_dim=256, dtype=dtype, fused_loss=fused_loss)
+    if load_synth:
+        model.load_state_dict(synth.synth_state(synth.slip_shapes(cfg), seed=seed), strict=True)
+    model = model.to(device)
+    model.train()
+    return model
+
+
+def slip_batch(cfg, b, seed=0, device="cuda"):
+    images = synth.synth_images(b, views=3, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
+    return {"images": images.to(device), "captions": ids.to(device)}

@@ -159,11 +159,15 @@ typedef struct dh_nce_pair {
   float* dQ; float* dK;             /* bwd outputs (may be NULL in fwd) */
 } dh_nce_pair;
 int64_t dh_infonce_ws_bytes(int n_pairs, int b, int B);
+/* label0s / excl0s (HOST int arrays of n_pairs, or NULL): per-pair label offset, and per-pair offset of a column
+ * removed from row i's softmax (excl0 + i; -1 = none) -- the self-pair of SimCLR NT-Xent
+ * (loss_functions/nt_xent.py:62-97: positives at label0+i, the row's own entry excluded). */
 int dh_infonce_fwd(const dh_nce_pair* pairs_host, int n_pairs, int b, int B, int D, const float* scale_dev, int label0,
-                   float* row_loss, float* row_lse, float* correct1, float* correct5, float* logits_out,
-                   void* ws, int64_t ws_bytes, dh_stream_t stream);
+                   const int* label0s, const int* excl0s, float* row_loss, float* row_lse, float* correct1,
+                   float* correct5, float* logits_out, void* ws, int64_t ws_bytes, dh_stream_t stream);
 int dh_infonce_bwd(const dh_nce_pair* pairs_host, int n_pairs, int b, int B, int D, const float* scale_dev, int label0,
-                   const float* row_lse, const float* g_row, float* dscale, dh_stream_t stream);
+                   const int* label0s, const int* excl0s, const float* row_lse, const float* g_row, float* dscale,
+                   dh_stream_t stream);
 
 /* Row-wise softmax cross-entropy on MATERIALISED fp32 logits [rows,C] (leading dim ld): the form
  * loss_functions/loss.py:44-45 sees when handed tensors, and the MLM head CE (model/declip.py:326-334).

@@ -194,12 +194,58 @@ def gen_declip(name, cfg, b, seed=0, nn_size=256):
     print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
 
 
+def gen_slip(name, cfg, b, seed=0):
+    """Reference SLIP (model/slip.py) + slip_solver.py loss composition, one rank."""
+    import contextlib
+    import io
+    os.environ["SLURM_PROCID"], os.environ["SLURM_NTASKS"] = "0", "1"
+    ref = ref_harness.load_reference()
+    ref_harness.ensure_gloo_group()
+    rs = ref.modules["prototype.model.slip"]
+    vt = ref.modules["prototype.model.image_encoder.visual_transformer"]
+    tt = ref.modules["prototype.model.text_encoder.text_transformer"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        vis = vt.VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
+                                   layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"], checkpoint=False)
+        txt = tt.TextTransformer(embed_dim=cfg["embed_dim"], context_length=cfg["ctx"], transformer_width=cfg["t_width"],
+                                 transformer_heads=cfg["t_heads"], transformer_layers=cfg["t_layers"],
+                                 positional_embedding_flag=True, checkpoint=False, bpe_path=ref_harness.synthetic_bpe_path(),
+                                 text_encode_type="Transformer", text_model_utils={"random": False, "freeze": False})
+        model = rs.SLIP(vis, txt, True, return_sim=True, feature_dim=cfg["v_width"], sim_dim=256)
+        sd = synth.synth_state(synth.slip_shapes(cfg), seed=seed)
+        model.load_state_dict(sd, strict=True)
+        model.train()
+    images = synth.synth_images(b, views=3, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
+    patch_tokenize(model.text_encoder, {i: ids[i] for i in range(b)})
+    out = model({"images": images, "captions": [[i] for i in range(b)]}, return_dict=True)
+    crit = ref.modules["prototype.loss_functions.loss"].ClipInfoCELoss()
+    nx = ref.modules["prototype.loss_functions.nt_xent"]
+    simclr_crit, mon_crit = nx.NT_Xent_gather(b), nx.NT_Xent(b)
+    li, lt = out["logits"]
+    clip_loss, _ = crit(li, lt)
+    s1, g1, s2, g2 = out["sim_features"]
+    simclr = simclr_crit(s1, g1, s2, g2)
+    tf, imf = out["features"]
+    monitor = mon_crit(imf, tf)
+    total = clip_loss + simclr                                           # yfcc15m_vit_slip/config.yaml:28-30
+    total.backward()
+    ret = dict(kind="slip", cfg=cfg, b=b, seed=seed, loss=float(total),
+               parts=dict(clip=float(clip_loss), simclr=float(simclr), nt_xent=float(monitor)),
+               logits_i=li.detach().clone(), sim1=s1.detach().clone(),
+               grads=grad_digest([(n, p.grad) for n, p in model.named_parameters()]), torch_version=torch.__version__)
+    path = os.path.join(GOLDEN_DIR, name + ".pt")
+    torch.save(ret, path)
+    print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
+
+
 FIXTURES = {
     "clip_tiny": lambda: gen_clip("clip_tiny", synth.TINY, b=4),
     "clip_tiny_scale5": lambda: gen_clip("clip_tiny_scale5", synth.TINY, b=4, seed=3, logit_scale=5.0),
     "clip_tiny_w2": lambda: gen_clip("clip_tiny_w2", synth.TINY, b=3, world=2, seed=5),
     "clip_vitb32_b8": lambda: gen_clip("clip_vitb32_b8", synth.VITB32, b=8, seed=1),
     "declip_tiny": lambda: gen_declip("declip_tiny", synth.TINY, b=6, seed=2),
+    "slip_tiny": lambda: gen_slip("slip_tiny", synth.TINY, b=5, seed=4),
 }
 
 

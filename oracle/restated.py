@@ -265,3 +265,40 @@ def declip_step_loss(images, ids_masked, labels, ids_aug, sd, cfg, bank, bank_pt
     parts = dict(clip=clip_loss.detach(), nn=nn_loss.detach(), simsiam=sim_loss.detach(), mlm=mlm.detach(),
                  convirt=monitor.detach())
     return total, parts, (bank, ptr)
+
+
+# ----------------------------------------------------------------------------- SLIP
+def simclr_mlp(x, sd, p):
+    """model/slip.py:50-109 with out_bn=False (bn3 exists but is not applied)."""
+    x = torch.relu(bn_train(x @ sd[p + "linear1.weight"].t() + sd[p + "linear1.bias"], sd[p + "bn1.weight"], sd[p + "bn1.bias"]))
+    x = torch.relu(bn_train(x @ sd[p + "linear2.weight"].t() + sd[p + "linear2.bias"], sd[p + "bn2.weight"], sd[p + "bn2.bias"]))
+    return x @ sd[p + "linear3.weight"].t() + sd[p + "linear3.bias"]
+
+
+def nt_xent(z_i, z_j, temperature):
+    """loss_functions/nt_xent.py:28-44 / :62-97 for one rank (gathered == local): every row's softmax runs over
+    all 2b columns except itself; positives at i <-> i+b; CE(sum) / 2b."""
+    b = z_i.shape[0]
+    p = F.normalize(torch.cat([z_i, z_j]), dim=1, eps=1e-8)
+    sim = p @ p.t() / temperature
+    sim = sim.masked_fill(torch.eye(2 * b, dtype=torch.bool), float("-inf"))
+    labels = torch.cat([torch.arange(b) + b, torch.arange(b)])
+    return F.cross_entropy(sim, labels, reduction="sum") / (2 * b)
+
+
+def slip_step_loss(images, ids, sd, cfg, weights=(1.0, 1.0)):
+    """SLIP.forward (model/slip.py:245-286) + slip_solver.py:438-527, one rank.  images [b,9,H,W]."""
+    b = images.shape[0]
+    img = vision_tower(images[:, 0:3], sd, cfg)
+    _, f1 = vision_tower(images[:, 3:6], sd, cfg, return_feature=True)
+    _, f2 = vision_tower(images[:, 6:9], sd, cfg, return_feature=True)
+    txt = text_tower(ids, sd, cfg, prefix="text_encoder.")
+    s1, s2 = simclr_mlp(f1, sd, "predictor_sim."), simclr_mlp(f2, sd, "predictor_sim.")
+    img_n, txt_n = normalize_features(img, txt)
+    s = sd["logit_scale"].exp()                                        # no clamp (slip.py:265)
+    lab = torch.arange(b)
+    clip = (F.cross_entropy(s * img_n @ txt_n.t(), lab) + F.cross_entropy(s * txt_n @ img_n.t(), lab)) / 2
+    simclr = nt_xent(s1, s2, 0.1)
+    monitor = nt_xent(img_n, txt_n, 0.5)
+    total = weights[0] * clip + weights[1] * simclr
+    return total, dict(clip=clip.detach(), simclr=simclr.detach(), nt_xent=monitor.detach())

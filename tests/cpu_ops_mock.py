@@ -176,11 +176,14 @@ def l2norm_bwd(x, norm, dy, eps):
     return (dy * inv[:, None] - xf * (s * inv * inv / norm.clamp_min(1e-30))[:, None]).to(x.dtype)
 
 
-def infonce_fwd(pairs, scale, label0, want_logits=False):
+def infonce_fwd(pairs, scale, label0, want_logits=False, label0s=None, excl0s=None):
     rl, lse, c1, c5, lg = [], [], [], [], []
-    for q, k in pairs:
+    for p, (q, k) in enumerate(pairs):
         logits = scale * q @ k.t()
-        labels = label0 + torch.arange(q.shape[0])
+        labels = (label0s[p] if label0s is not None else label0) + torch.arange(q.shape[0])
+        if excl0s is not None and excl0s[p] >= 0:
+            logits = logits.clone()
+            logits[torch.arange(q.shape[0]), excl0s[p] + torch.arange(q.shape[0])] = float("-inf")
         l = torch.logsumexp(logits, -1)
         ll = logits[torch.arange(q.shape[0]), labels]
         cnt = ((logits > ll[:, None]) & (torch.arange(k.shape[0])[None, :] != labels[:, None])).sum(-1)
@@ -188,12 +191,14 @@ def infonce_fwd(pairs, scale, label0, want_logits=False):
     return torch.stack(rl), torch.stack(lse), torch.stack(c1), torch.stack(c5), (torch.stack(lg) if want_logits else None)
 
 
-def infonce_bwd(pairs, scale, label0, row_lse, g_row, need=None):
+def infonce_bwd(pairs, scale, label0, row_lse, g_row, need=None, label0s=None, excl0s=None):
     outs, dscale = [], torch.zeros(1)
     for p, (q, k) in enumerate(pairs):
         dots = q @ k.t()
         P = torch.exp(scale * dots - row_lse[p][:, None])
-        labels = label0 + torch.arange(q.shape[0])
+        labels = (label0s[p] if label0s is not None else label0) + torch.arange(q.shape[0])
+        if excl0s is not None and excl0s[p] >= 0:
+            P[torch.arange(q.shape[0]), excl0s[p] + torch.arange(q.shape[0])] = 0
         P[torch.arange(q.shape[0]), labels] -= 1
         G = P * g_row[p][:, None]
         outs.append((scale * G @ k, scale * G.t() @ q))

@@ -165,3 +165,21 @@ def test_declip_engine_composition_matches_golden(mocked_engine):
     assert abs(float(model.nn_replacer_text.bank.double().sum()) - g["bank_sum"]) <= 1e-3
     assert torch.allclose(model.projector.bn1.running_mean, g["bn1_running_mean"], rtol=1e-4, atol=1e-6)
     assert torch.allclose(model.projector.bn1.running_var, g["bn1_running_var"], rtol=1e-4, atol=1e-6)
+
+
+def test_slip_engine_composition_matches_golden(mocked_engine):
+    from declip_amd.loss import ClipInfoCELoss, NT_Xent, NT_Xent_gather
+    from declip_amd.steps import slip_loss
+    from declip_amd.testing import build_slip, slip_batch
+    g = load_golden("slip_tiny")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_slip(cfg, dtype="fp32", seed=seed, device="cpu")
+    assert "text_encoder.ln_final.weight" in model.state_dict() and "predictor_sim.bn3.weight" in model.state_dict()
+    out = slip_loss(model, slip_batch(cfg, b, seed=seed, device="cpu"), ClipInfoCELoss(), NT_Xent_gather(b), NT_Xent(b))
+    out["loss"].backward()
+    assert abs(float(out["loss"]) - g["loss"]) <= 1e-4 * abs(g["loss"])
+    for k in ("clip", "simclr", "nt_xent"):
+        assert abs(float(out["parts"][k]) - g["parts"][k]) <= 2e-4 * max(1.0, abs(g["parts"][k])), k
+    assert float((out["outputs"]["sim_features"][0].detach() - g["sim1"]).abs().max()) <= 1e-4 * float(g["sim1"].abs().max())
+    grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+    check_grad_digests(g["grads"], grads, rtol=1e-3)

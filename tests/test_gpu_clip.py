@@ -150,3 +150,22 @@ def test_declip_step_matches_reference_golden(dtype, tol):
         check_grad_digests(g["grads"], grads, rtol=1e-3)
         assert abs(float(model.nn_replacer_text.bank.double().sum()) - g["bank_sum"]) <= 1e-3
         assert torch.allclose(model.projector.bn1.running_mean.cpu(), g["bn1_running_mean"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
+def test_slip_step_matches_reference_golden(dtype, tol):
+    from declip_amd.loss import ClipInfoCELoss, NT_Xent, NT_Xent_gather
+    from declip_amd.steps import slip_loss
+    from declip_amd.testing import build_slip, slip_batch
+    g = load_golden("slip_tiny")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_slip(cfg, dtype=dtype, seed=seed)
+    out = slip_loss(model, slip_batch(cfg, b, seed=seed), ClipInfoCELoss(), NT_Xent_gather(b), NT_Xent(b))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - g["loss"]) <= tol * abs(g["loss"])
+    for k in ("clip", "simclr", "nt_xent"):
+        assert abs(float(out["parts"][k]) - g["parts"][k]) <= tol * max(1.0, abs(g["parts"][k])), k
+    if dtype == "fp32":
+        grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
+        check_grad_digests(g["grads"], grads, rtol=1e-3)
