@@ -479,3 +479,53 @@ class RowCEFn(torch.autograd.Function):
     def backward(ctx, g_row, _a, _b):
         logits, labels, row_lse = ctx.saved_tensors
         return ops.ce_rows_bwd(logits, labels, row_lse, g_row.contiguous().float()), None
+
+
+# ---------------------------------------------------------------------------------------------
+# FILIP token-wise late interaction (model/filip.py:71-106)
+# ---------------------------------------------------------------------------------------------
+class GatherTokFn(torch.autograd.Function):
+    """rows gather with scatter-add backward (selected top-16 tokens; indices unique)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        x = x.contiguous()
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return ops.gather_rows(x, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        dx = torch.zeros(ctx.shape, device=g.device, dtype=g.dtype)
+        ops.scatter_rows_add(g.contiguous(), idx, dx)
+        return dx, None
+
+
+class MaxSimFn(torch.autograd.Function):
+    """logits[i,l] = scale * mean_j max_m <Q[(i,j)], K[(l,m)]> (filip.py:96-105).
+
+    forward: token-similarity GEMM on MFMA (bf16 operands in bf16 mode, fp32 scores) + dh_maxsim_reduce (arg-max
+    kept as uint8); backward: dh_maxsim_scatter builds the one-hot-weighted G and two GEMMs give dQ / dK."""
+
+    @staticmethod
+    def forward(ctx, scale, Q, K, b, B, J, act_dtype):
+        Qa = _to_act(Q, act_dtype)
+        Ka = _to_act(K, act_dtype)
+        S = ops.gemm(Qa, Ka, out_dtype=torch.float32)                      # [b*J, B*16]
+        sc = scale.detach().reshape(1).float().contiguous()
+        logits, raw, arg = ops.maxsim_reduce(S, b, B, J, sc)
+        ctx.save_for_backward(Qa, Ka, arg, raw, sc)
+        ctx.meta = (b, B, J, act_dtype, scale.shape, Q.dtype, K.dtype)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        Qa, Ka, arg, raw, sc = ctx.saved_tensors
+        b, B, J, act_dtype, sshape, qdt, kdt = ctx.meta
+        dl = dl.contiguous().float()
+        G = ops.maxsim_scatter(dl, arg, sc, b, B, J, act_dtype)
+        dQ = ops.gemm(G, Ka, b_kmajor=True, out_dtype=torch.float32)       # [b*J, D]
+        dK = ops.gemm(G, Qa, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)   # [B*16, D]
+        dscale = (dl * raw).sum().reshape(sshape)
+        return dscale, dQ.to(qdt), dK.to(kdt), None, None, None, None

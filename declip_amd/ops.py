@@ -343,3 +343,32 @@ def scatter_rows_add(dout, idx, dx):
     n = idx.numel()
     check(L.load().dh_scatter_rows_add(dt(dx), ptr(dout), ptr(idx), ptr(dx), n, dx.shape[-1], stream()), "dh_scatter_rows_add")
     return dx
+
+
+def filip_select(img_tok, txt_tok):
+    """img_tok [b,J,D], txt_tok [b,T,D] fp32 normalised -> (idx_img [b,16], idx_txt [b,16]) int64."""
+    _contig(img_tok, "img_tok"), _contig(txt_tok, "txt_tok")
+    b, J, D = img_tok.shape
+    T = txt_tok.shape[1]
+    ia = torch.empty(b, 16, device=img_tok.device, dtype=torch.int64)
+    ib = torch.empty(b, 16, device=img_tok.device, dtype=torch.int64)
+    check(L.load().dh_filip_select(ptr(img_tok), ptr(txt_tok), b, J, T, D, ptr(ia), ptr(ib), stream()), "dh_filip_select")
+    return ia, ib
+
+
+def maxsim_reduce(S, b, B, J, scale):
+    """S [b*J, B*16] -> logits [b,B] (scaled), raw [b,B], argmax [b*J, B] uint8."""
+    assert S.dim() == 2 and S.stride(1) == 1 and S.shape[0] == b * J and S.shape[1] >= B * 16
+    logits = torch.empty(b, B, device=S.device, dtype=torch.float32)
+    raw = torch.empty(b, B, device=S.device, dtype=torch.float32)
+    arg = torch.empty(b * J, B, device=S.device, dtype=torch.uint8)
+    check(L.load().dh_maxsim_reduce(dt(S), ptr(S), S.stride(0), b, B, J, ptr(scale), ptr(logits), ptr(raw), ptr(arg), stream()),
+          "dh_maxsim_reduce")
+    return logits, raw, arg
+
+
+def maxsim_scatter(dlogits, arg, scale, b, B, J, dtype):
+    G = torch.empty(b * J, B * 16, device=dlogits.device, dtype=dtype)
+    check(L.load().dh_maxsim_scatter(dt(G), ptr(_contig(dlogits, "dlogits")), ptr(arg), ptr(scale), ptr(G), G.stride(0), b, B, J,
+                                     stream()), "dh_maxsim_scatter")
+    return G

@@ -96,3 +96,30 @@ def slip_loss(model, batch, criterion, simclr_criterion, nt_xent_criterion=None,
         n = target.size(0)
         out.update(top1=c1.sum().reshape(1) * (100.0 / n), top5=c5.sum().reshape(1) * (100.0 / n))
     return out
+
+
+FILIP_WEIGHTS = dict(clip_loss=0.0, clip_dense_loss=1.0)               # yfcc15m_vit_filip/config.yaml:32-37
+
+
+def filip_loss(model, batch, criterion, weights=None, world_size=1, with_accuracy=True):
+    """filip_solver.py:435-532: global InfoNCE (weight 0.0 in the shipped config) + dense max-sim InfoNCE."""
+    w = dict(FILIP_WEIGHTS if weights is None else weights)
+    o = model(batch, return_dict=True)
+    li, lt = o["logits"]
+    clip, target = criterion(li, lt)
+    acc_src = criterion.last_correct
+    clip = clip / world_size
+    parts = dict(clip=clip)
+    loss = clip * w.get("clip_loss", 0)
+    if "dense_logits" in o:
+        dl_i, dl_t = o["dense_logits"]
+        dense = criterion(dl_i, dl_t)[0] / world_size
+        parts["dense"] = dense
+        if w.get("clip_dense_loss", 0):
+            loss = loss + dense * w["clip_dense_loss"]
+    out = dict(loss=loss, parts=parts, outputs=o)
+    if with_accuracy and acc_src is not None:
+        _, c1, c5 = acc_src
+        n = target.size(0)
+        out.update(top1=c1.sum().reshape(1) * (100.0 / n), top5=c5.sum().reshape(1) * (100.0 / n))
+    return out

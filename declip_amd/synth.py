@@ -169,6 +169,17 @@ def slip_shapes(cfg):
     return s
 
 
+def filip_shapes(cfg):
+    """FILIP state_dict (model/filip.py:27-59): CLIP + image/text mapping + logit_scale_dense + text_label_predictor."""
+    s = clip_shapes(cfg)
+    s["logit_scale_dense"] = ()
+    s["image_mapping.weight"], s["image_mapping.bias"] = (256, cfg["v_width"]), (256,)
+    s["text_mapping.weight"], s["text_mapping.bias"] = (256, cfg["t_width"]), (256,)
+    s["text_label_predictor.weight"] = (cfg.get("vocab", VOCAB), cfg["t_width"])
+    s["text_label_predictor.bias"] = (cfg.get("vocab", VOCAB),)
+    return s
+
+
 def synth_bank(size, dim, seed=4):
     """unit-norm rows [size, dim] (NN bank randn seed 4, normalised, ptr 0)."""
     g = torch.Generator().manual_seed(4000 + seed)
@@ -186,3 +197,7 @@ VITB32 = dict(v_width=768, v_layers=12, v_heads=12, patch=32, res=224,
               t_width=512, t_layers=12, t_heads=8, ctx=77, embed_dim=512, vocab=VOCAB)
 TINY = dict(v_width=128, v_layers=2, v_heads=2, patch=32, res=96,
             t_width=128, t_layers=2, t_heads=2, ctx=16, embed_dim=64, vocab=VOCAB)
+
+# FILIP needs >= 16 image tokens and >= 16 text tokens: 160 px / 32 = 25 patches, 24-token context
+FILIP_SMALL = dict(v_width=128, v_layers=2, v_heads=2, patch=32, res=160,
+                   t_width=128, t_layers=2, t_heads=2, ctx=24, embed_dim=64, vocab=VOCAB)

@@ -80,3 +80,28 @@ def slip_batch(cfg, b, seed=0, device="cuda"):
     images = synth.synth_images(b, views=3, res=cfg["res"], seed=seed)
     ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
     return {"images": images.to(device), "captions": ids.to(device)}
+
+
+def build_filip(cfg, dtype="bf16", seed=0, fused_loss=True, device="cuda", load_synth=True):
+    from .model.filip import FILIP
+    vis = VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
+                            layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"])
+    txt = TextTransformer(embed_dim=cfg["embed_dim"], context_length=cfg["ctx"], transformer_width=cfg["t_width"],
+                          transformer_heads=cfg["t_heads"], transformer_layers=cfg["t_layers"],
+                          positional_embedding_flag=True, checkpoint=False, bpe_path=None,
+                          text_encode_type="Transformer", text_model_utils={"random": False, "freeze": False},
+                          vocab_size=cfg.get("vocab", synth.VOCAB))
+    model = FILIP(vis, txt, True, text_mask_type="MLM", return_dense=True, select_topk=True, feature_dim=cfg["v_width"],
+                  dense_mapping_image=cfg["v_width"], dense_mapping_language=cfg["t_width"], dtype=dtype, fused_loss=fused_loss)
+    if load_synth:
+        model.load_state_dict(synth.synth_state(synth.filip_shapes(cfg), seed=seed), strict=True)
+    model = model.to(device)
+    model.train()
+    return model
+
+
+def filip_batch(cfg, b, seed=0, device="cuda"):
+    images = synth.synth_images(b, views=2, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+    ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+    return {"images": images.to(device), "captions": ids_masked.to(device), "mlm_labels": labels}

@@ -209,6 +209,20 @@ int dh_nn_bank_query(const float* q, const float* bank, int rows, int size, int 
 int dh_gather_rows(int dtype, const void* x, const int64_t* idx, void* out, int n, int n_pad, int d, dh_stream_t stream);
 int dh_scatter_rows_add(int dtype, const void* dout, const int64_t* idx, void* dx, int n, int d, dh_stream_t stream);
 
+/* ---------------------------------------------------------------- FILIP (model/filip.py:71-106) ---
+ * dh_filip_select: per sample the 16 image tokens with the largest summed similarity to the caption's tokens and
+ *   the 16 text tokens with the largest summed similarity to the image's tokens (filip.py:78-87);
+ *   img_tok [b,J,D], txt_tok [b,T,D] fp32 L2-normalised; idx_* [b,16] int64 (token index inside the sample).
+ * dh_maxsim_reduce: S [b*J, B*16] = token-similarity GEMM output (s_dtype) ->
+ *   raw[i,l] = mean_j max_m S[(i,j),(l,m)], logits = scale * raw, argmax [b*J, B] uint8 (filip.py:96-105).
+ * dh_maxsim_scatter: backward of the reduction: G[(i,j),(l,m)] = scale * dlogits[i,l] / J at m = argmax, else 0. */
+int dh_filip_select(const float* img_tok, const float* txt_tok, int b, int J, int T, int D, int64_t* idx_img,
+                    int64_t* idx_txt, dh_stream_t stream);
+int dh_maxsim_reduce(int s_dtype, const void* S, int64_t lds, int b, int B, int J, const float* scale_dev, float* logits,
+                     float* raw, uint8_t* argmax, dh_stream_t stream);
+int dh_maxsim_scatter(int g_dtype, const float* dlogits, const uint8_t* argmax, const float* scale_dev, void* G,
+                      int64_t ldg, int b, int B, int J, dh_stream_t stream);
+
 /* ---------------------------------------------------------------- optimizer / casts -----
  * Fused flat AdamW over a contiguous fp32 range (torch.optim.AdamW semantics, the optimizer of
  * experiments/clip_experiments/yfcc15m/yfcc15m_vit_clip/config.yaml:26-33), optionally refreshing the

@@ -239,6 +239,53 @@ def gen_slip(name, cfg, b, seed=0):
     print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
 
 
+def gen_filip(name, cfg, b, seed=0):
+    """Reference FILIP (model/filip.py) + filip_solver.py loss composition (clip 0.0, dense 1.0), one rank."""
+    import contextlib
+    import io
+    os.environ["SLURM_PROCID"], os.environ["SLURM_NTASKS"] = "0", "1"
+    ref = ref_harness.load_reference()
+    ref_harness.ensure_gloo_group()
+    rf = ref.modules["prototype.model.filip"]
+    vt = ref.modules["prototype.model.image_encoder.visual_transformer"]
+    tt = ref.modules["prototype.model.text_encoder.text_transformer"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        vis = vt.VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
+                                   layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"], checkpoint=False)
+        txt = tt.TextTransformer(embed_dim=cfg["embed_dim"], context_length=cfg["ctx"], transformer_width=cfg["t_width"],
+                                 transformer_heads=cfg["t_heads"], transformer_layers=cfg["t_layers"],
+                                 positional_embedding_flag=True, checkpoint=False, bpe_path=ref_harness.synthetic_bpe_path(),
+                                 text_encode_type="Transformer", text_model_utils={"random": False, "freeze": False})
+        model = rf.FILIP(vis, txt, True, text_mask_type="MLM", return_dense=True, select_topk=True, feature_dim=cfg["v_width"],
+                         dense_mapping_image=cfg["v_width"], dense_mapping_language=cfg["t_width"])
+        sd = synth.synth_state(synth.filip_shapes(cfg), seed=seed)
+        model.load_state_dict(sd, strict=True)
+        model.train()
+    images = synth.synth_images(b, views=2, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+    ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+
+    def tokenize(texts, context_length=77, return_length=False, mask_type=None):
+        keys = [int(t) for t in texts]
+        assert mask_type is not None
+        return torch.stack([ids_masked[k] for k in keys]), torch.stack([labels[k] for k in keys])
+    model.encode_text.tokenize = tokenize
+    out = model({"images": images, "captions": [[i] for i in range(b)]}, return_dict=True)
+    crit = ref.modules["prototype.loss_functions.loss"].ClipInfoCELoss()
+    li, lt = out["logits"]
+    dli, dlt = out["dense_logits"]
+    clip_loss, _ = crit(li, lt)
+    dense_loss, _ = crit(dli, dlt)
+    total = 0.0 * clip_loss + 1.0 * dense_loss                           # yfcc15m_vit_filip/config.yaml:32-37
+    total.backward()
+    ret = dict(kind="filip", cfg=cfg, b=b, seed=seed, loss=float(total), parts=dict(clip=float(clip_loss), dense=float(dense_loss)),
+               dense_logits_i=dli.detach().clone(), dense_logits_t=dlt.detach().clone(),
+               grads=grad_digest([(n, p.grad) for n, p in model.named_parameters()]), torch_version=torch.__version__)
+    path = os.path.join(GOLDEN_DIR, name + ".pt")
+    torch.save(ret, path)
+    print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
+
+
 FIXTURES = {
     "clip_tiny": lambda: gen_clip("clip_tiny", synth.TINY, b=4),
     "clip_tiny_scale5": lambda: gen_clip("clip_tiny_scale5", synth.TINY, b=4, seed=3, logit_scale=5.0),
@@ -246,6 +293,7 @@ FIXTURES = {
     "clip_vitb32_b8": lambda: gen_clip("clip_vitb32_b8", synth.VITB32, b=8, seed=1),
     "declip_tiny": lambda: gen_declip("declip_tiny", synth.TINY, b=6, seed=2),
     "slip_tiny": lambda: gen_slip("slip_tiny", synth.TINY, b=5, seed=4),
+    "filip_small": lambda: gen_filip("filip_small", synth.FILIP_SMALL, b=5, seed=6),
 }
 
 

@@ -302,3 +302,39 @@ def slip_step_loss(images, ids, sd, cfg, weights=(1.0, 1.0)):
     monitor = nt_xent(img_n, txt_n, 0.5)
     total = weights[0] * clip + weights[1] * simclr
     return total, dict(clip=clip.detach(), simclr=simclr.detach(), nt_xent=monitor.detach())
+
+
+# ----------------------------------------------------------------------------- FILIP
+def filip_dense_logits(d1, d2, log_scale_dense, top_k=16):
+    """model/filip.py:71-106 (select_topk=True), one rank.  d1 [b,J,D] image tokens, d2 [b,T,D] text tokens."""
+    d1 = d1 / d1.norm(dim=-1, keepdim=True)
+    d2 = d2 / d2.norm(dim=-1, keepdim=True)
+    s = log_scale_dense.exp()
+    cross = d1 @ d2.transpose(1, 2)
+    id1 = cross.sum(2).topk(top_k, dim=1)[1]
+    id2 = cross.sum(1).topk(top_k, dim=1)[1]
+    b = d1.shape[0]
+    sel1 = d1[torch.arange(b)[:, None], id1]                              # [b,16,D]
+    sel2 = d2[torch.arange(b)[:, None], id2]
+
+    def logits(tok, sel):
+        x = s * torch.einsum("ijk,lmk->iljm", tok, sel)                   # [b, B, J, 16]
+        return x.max(dim=-1)[0].mean(dim=-1)
+    return logits(d1, sel2), logits(d2, sel1)
+
+
+def filip_step_loss(images, ids_masked, sd, cfg, weights=(0.0, 1.0)):
+    """FILIP.forward (model/filip.py:109-142) + filip_solver.py:435-532, one rank; view 1 only."""
+    b = images.shape[0]
+    img, dense = vision_tower(images[:, 0:3], sd, cfg, return_dense=True)
+    txt, words = text_tower(ids_masked, sd, cfg, return_dense=True)
+    img_n, txt_n = normalize_features(img, txt)
+    s = sd["logit_scale"].exp()
+    lab = torch.arange(b)
+    clip = (F.cross_entropy(s * img_n @ txt_n.t(), lab) + F.cross_entropy(s * txt_n @ img_n.t(), lab)) / 2
+    d1 = dense @ sd["image_mapping.weight"].t() + sd["image_mapping.bias"]
+    d2 = words @ sd["text_mapping.weight"].t() + sd["text_mapping.bias"]
+    li, lt = filip_dense_logits(d1, d2, sd["logit_scale_dense"])
+    dense_loss = (F.cross_entropy(li, lab) + F.cross_entropy(lt, lab)) / 2
+    total = weights[0] * clip + weights[1] * dense_loss
+    return total, dict(clip=clip.detach(), dense=dense_loss.detach()), (li.detach(), lt.detach())

@@ -321,3 +321,22 @@ def gather_rows(x, idx, n_pad=None):
 def scatter_rows_add(dout, idx, dx):
     dx[idx] += dout[:idx.numel()]
     return dx
+
+
+def filip_select(img_tok, txt_tok):
+    cross = img_tok @ txt_tok.transpose(1, 2)
+    return cross.sum(2).topk(16, dim=1)[1], cross.sum(1).topk(16, dim=1)[1]
+
+
+def maxsim_reduce(S, b, B, J, scale):
+    v = S[:, :B * 16].float().view(b, J, B, 16)
+    mx, arg = v.max(-1)
+    raw = mx.mean(1)
+    return raw * scale, raw, arg.reshape(b * J, B).to(torch.uint8)
+
+
+def maxsim_scatter(dlogits, arg, scale, b, B, J, dtype):
+    G = torch.zeros(b * J, B, 16)
+    w = (dlogits * scale / J)[:, None, :].expand(b, J, B).reshape(b * J, B)
+    G.scatter_(2, arg.long()[..., None], w[..., None])
+    return G.reshape(b * J, B * 16).to(dtype)

@@ -183,3 +183,22 @@ def test_slip_engine_composition_matches_golden(mocked_engine):
     assert float((out["outputs"]["sim_features"][0].detach() - g["sim1"]).abs().max()) <= 1e-4 * float(g["sim1"].abs().max())
     grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
     check_grad_digests(g["grads"], grads, rtol=1e-3)
+
+
+def test_filip_engine_composition_matches_golden(mocked_engine):
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.steps import filip_loss
+    from declip_amd.testing import build_filip, filip_batch
+    g = load_golden("filip_small")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_filip(cfg, dtype="fp32", seed=seed, device="cpu")
+    assert model.logit_scale_dense.shape == torch.Size([])
+    out = filip_loss(model, filip_batch(cfg, b, seed=seed, device="cpu"), ClipInfoCELoss())
+    out["loss"].backward()
+    assert abs(float(out["loss"]) - g["loss"]) <= 1e-4 * abs(g["loss"])
+    assert abs(float(out["parts"]["clip"]) - g["parts"]["clip"]) <= 2e-4
+    dli, dlt = out["outputs"]["dense_logits"]
+    assert float((dli.detach() - g["dense_logits_i"]).abs().max()) <= 1e-4 * float(g["dense_logits_i"].abs().max())
+    assert float((dlt.detach() - g["dense_logits_t"]).abs().max()) <= 1e-4 * float(g["dense_logits_t"].abs().max())
+    grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+    check_grad_digests(g["grads"], grads, rtol=1e-3)

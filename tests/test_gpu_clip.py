@@ -169,3 +169,22 @@ def test_slip_step_matches_reference_golden(dtype, tol):
     if dtype == "fp32":
         grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
         check_grad_digests(g["grads"], grads, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 3e-2)])
+def test_filip_step_matches_reference_golden(dtype, tol):
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.steps import filip_loss
+    from declip_amd.testing import build_filip, filip_batch
+    g = load_golden("filip_small")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_filip(cfg, dtype=dtype, seed=seed)
+    out = filip_loss(model, filip_batch(cfg, b, seed=seed), ClipInfoCELoss())
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - g["loss"]) <= tol * abs(g["loss"])
+    dli = out["outputs"]["dense_logits"][0].detach().cpu()
+    assert float((dli - g["dense_logits_i"]).abs().max()) <= tol * float(g["dense_logits_i"].abs().max())
+    if dtype == "fp32":
+        grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
+        check_grad_digests(g["grads"], grads, rtol=1e-3)

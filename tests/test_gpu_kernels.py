@@ -424,3 +424,29 @@ def test_gemm_v3_tiles(monkeypatch, mode, a_km, b_km, M, N, K):
         assert rel_err(out, quick_gelu(pre)) < 1.5e-2
         out32 = ops.gemm(Ad, Bd, a_kmajor=a_km, b_kmajor=b_km, out_dtype=torch.float32)
         assert rel_err(out32, ref) < 2e-3
+
+
+# ----------------------------------------------------------------------------- FILIP kernels
+def test_filip_select_and_maxsim():
+    ops = _ops()
+    b, B, J, T, D = 3, 6, 25, 24, 64
+    a = torch.nn.functional.normalize(rnd(b, J, D, seed=100), dim=-1)
+    t = torch.nn.functional.normalize(rnd(b, T, D, seed=101), dim=-1)
+    ia, it = ops.filip_select(a.to(cuda), t.to(cuda))
+    cross = a.double() @ t.double().transpose(1, 2)
+    ra, rt = cross.sum(2).topk(16, dim=1)[1], cross.sum(1).topk(16, dim=1)[1]
+    assert torch.equal(ia.cpu().sort(1)[0], ra.sort(1)[0]) and torch.equal(it.cpu().sort(1)[0], rt.sort(1)[0])
+    K = torch.nn.functional.normalize(rnd(B * 16, D, seed=102), dim=-1)
+    Q = a.reshape(b * J, D)
+    S = (Q @ K.t()).contiguous()
+    scale = torch.tensor([7.5])
+    logits, raw, arg = ops.maxsim_reduce(S.to(cuda), b, B, J, scale.to(cuda))
+    v = S.view(b, J, B, 16)
+    mx, am = v.max(-1)
+    assert rel_err(raw, mx.mean(1)) < 1e-6 and rel_err(logits, 7.5 * mx.mean(1)) < 1e-6
+    assert torch.equal(arg.cpu().view(b, J, B).long(), am)
+    dl = rnd(b, B, seed=103)
+    G = ops.maxsim_scatter(dl.to(cuda), arg, scale.to(cuda), b, B, J, torch.float32)
+    ref = torch.zeros(b, J, B, 16)
+    ref.scatter_(3, am[..., None], (dl * 7.5 / J)[:, None, :, None].expand(b, J, B, 1))
+    assert rel_err(G.view(b, J, B, 16), ref) < 1e-6
