@@ -111,7 +111,9 @@ class DECLIP(CLIP):
         tout = engine.TextTowerFn.apply(flat.anchor, ids_cat, et, want_words)
         txt_cat, words = (tout[0], tout[1]) if want_words else (tout, None)
         # ---- both image views in one pass
-        img_cat = self.visual(images, n_views=2)                                  # [2b, E] fp32, view-major
+        want_dense = bool(getattr(self, "return_filip", False))
+        vout = self.visual(images, n_views=2, return_dense=want_dense)
+        img_cat, dense_cat = (vout[0], vout[1]) if want_dense else (vout, None)   # [2b, E] fp32, view-major
         # ---- SimSiam on the UN-normalised image features (declip.py:238-241), BN statistics per view
         z = self.projector(img_cat, groups=2)
         p = self.predictor(z, groups=2)
@@ -149,11 +151,17 @@ class DECLIP(CLIP):
             ret["nn_text_logits"] = L(i1, g_nn), L(i2, g_nn), L(i1, g_nn_aug), L(i2, g_nn_aug)
         if self.text_mask_type is not None:
             ret["text_self_supervised"] = mlm_loss(words[:b], labels, self.text_label_predictor, flat)
+        self._extra_outputs(ret, dict(b=b, dense=dense_cat, words=words, label0=label0))
         if not self.fused_loss:
             for k in ("logits", "logits_aug", "nn_text_logits"):
                 if k in ret:
                     ret[k] = tuple(x.materialize() for x in ret[k])
         return ret
+
+
+    def _extra_outputs(self, ret, st):
+        """hook for DEFILIP (adds the token-wise 'filip' logits)."""
+        return None
 
 
 def declip_vitb32(**kwargs):

@@ -60,12 +60,24 @@ def declip_loss(model, batch, criterion, simsiam_criterion, nt_xent_criterion=No
         loss = loss + mlm * w["masking_language"]
     if w.get("nn_text", 0):
         loss = loss + nn_loss * w["nn_text"]
+    if "filip" in o:                                                  # defilip_solver.py:462-478,541-542
+        f = criterion(*o["filip"])[0]
+        if "filip_aug" in o:
+            fa = o["filip_aug"]
+            f = (f + criterion(fa[0], fa[1])[0] + criterion(fa[2], fa[3])[0] + criterion(fa[4], fa[5])[0]) / 4
+        f = f / world_size
+        parts["filip"] = f
+        if w.get("filip", 0):
+            loss = loss + f * w["filip"]
     out = dict(loss=loss, parts=parts, outputs=o)
     if with_accuracy and acc_src is not None:
         _, c1, c5 = acc_src
         n = target.size(0)
         out.update(top1=c1.sum().reshape(1) * (100.0 / n), top5=c5.sum().reshape(1) * (100.0 / n))
     return out
+
+
+DEFILIP_WEIGHTS = dict(DECLIP_WEIGHTS, filip=0.2)                    # yfcc15m_vit_defilip/config.yaml:28-34
 
 
 SLIP_WEIGHTS = dict(clip_loss=1, simclr_loss=1)                        # yfcc15m_vit_slip/config.yaml:28-30

@@ -180,6 +180,15 @@ def filip_shapes(cfg):
     return s
 
 
+def defilip_shapes(cfg):
+    """DEFILIP state_dict (model/defilip.py:149-207): DECLIP + logit_scale_dense + image/text mapping."""
+    s = declip_shapes(cfg)
+    s["logit_scale_dense"] = ()
+    s["image_mapping.weight"], s["image_mapping.bias"] = (256, cfg["v_width"]), (256,)
+    s["text_mapping.weight"], s["text_mapping.bias"] = (256, cfg["t_width"]), (256,)
+    return s
+
+
 def synth_bank(size, dim, seed=4):
     """unit-norm rows [size, dim] (NN bank randn seed 4, normalised, ptr 0)."""
     g = torch.Generator().manual_seed(4000 + seed)

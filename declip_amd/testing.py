@@ -105,3 +105,33 @@ def filip_batch(cfg, b, seed=0, device="cuda"):
     ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
     ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
     return {"images": images.to(device), "captions": ids_masked.to(device), "mlm_labels": labels}
+
+
+def build_defilip(cfg, dtype="bf16", seed=0, nn_size=256, device="cuda", load_synth=True, dense_aug=False):
+    from .model.defilip import DEFILIP
+    vis = VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
+                            layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"])
+    txt = TextTransformer(embed_dim=cfg["embed_dim"], context_length=cfg["ctx"], transformer_width=cfg["t_width"],
+                          transformer_heads=cfg["t_heads"], transformer_layers=cfg["t_layers"],
+                          positional_embedding_flag=True, checkpoint=False, bpe_path=None,
+                          text_encode_type="Transformer", text_model_utils={"random": False, "freeze": False},
+                          vocab_size=cfg.get("vocab", synth.VOCAB))
+    model = DEFILIP(vis, txt, True, return_filip=True, dense_mapping_image=cfg["v_width"], dense_mapping_language=cfg["t_width"],
+                    dense_aug=dense_aug, nn_size=nn_size, nn_topk=1, return_nn_bank=True, text_mask_type="MLM", EDA=True,
+                    feature_dim=cfg["embed_dim"], dtype=dtype)
+    if load_synth:
+        model.load_state_dict(synth.synth_state(synth.defilip_shapes(cfg), seed=seed), strict=True)
+    model = model.to(device)
+    model.train()
+    if load_synth:
+        model.nn_replacer_text.bank = synth.synth_bank(nn_size, cfg["embed_dim"], seed=seed).to(device)
+        model.nn_replacer_text.bank_ptr = 0
+    return model
+
+
+def defilip_batch(cfg, b, seed=0, device="cuda"):
+    images = synth.synth_images(b, views=2, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+    ids_aug = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+    ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+    return {"images": images.to(device), "captions": torch.stack([ids_masked, ids_aug], dim=1).to(device), "mlm_labels": labels}

@@ -286,6 +286,67 @@ def gen_filip(name, cfg, b, seed=0):
     print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
 
 
+def gen_defilip(name, cfg, b, seed=0, nn_size=256):
+    """Reference DEFILIP (model/defilip.py) + defilip_solver.py loss composition (declip weights + filip 0.2)."""
+    import contextlib
+    import io
+    os.environ["SLURM_PROCID"], os.environ["SLURM_NTASKS"] = "0", "1"
+    ref = ref_harness.load_reference()
+    ref_harness.ensure_gloo_group()
+    rd = ref.modules["prototype.model.defilip"]
+    vt = ref.modules["prototype.model.image_encoder.visual_transformer"]
+    tt = ref.modules["prototype.model.text_encoder.text_transformer"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        vis = vt.VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
+                                   layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"], checkpoint=False)
+        txt = tt.TextTransformer(embed_dim=cfg["embed_dim"], context_length=cfg["ctx"], transformer_width=cfg["t_width"],
+                                 transformer_heads=cfg["t_heads"], transformer_layers=cfg["t_layers"],
+                                 positional_embedding_flag=True, checkpoint=False, bpe_path=ref_harness.synthetic_bpe_path(),
+                                 text_encode_type="Transformer", text_model_utils={"random": False, "freeze": False})
+        model = rd.DEFILIP(vis, txt, True, nn_size=nn_size, nn_topk=1, return_nn_bank=True, text_mask_type="MLM", EDA=True,
+                           feature_dim=cfg["embed_dim"], return_filip=True, dense_mapping_image=cfg["v_width"],
+                           dense_mapping_language=cfg["t_width"])
+        sd = synth.synth_state(synth.defilip_shapes(cfg), seed=seed)
+        model.load_state_dict(sd, strict=True)
+        model.train()
+    images = synth.synth_images(b, views=2, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+    ids_aug = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+    ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+    model.nn_replacer_text.bank = synth.synth_bank(nn_size, cfg["embed_dim"], seed=seed).t().clone()
+    model.nn_replacer_text.bank_ptr = torch.LongTensor([0])
+    off = ref_harness.AUG_KEY_OFFSET
+
+    def tokenize(texts, context_length=77, return_length=False, mask_type=None):
+        keys = [int(t) for t in texts]
+        if mask_type is not None:
+            return torch.stack([ids_masked[k] for k in keys]), torch.stack([labels[k] for k in keys])
+        return torch.stack([ids_aug[k - off] if k >= off else ids[k] for k in keys])
+    model.encode_text.tokenize = tokenize
+    out = model({"images": images, "captions": [[i] for i in range(b)]}, return_dict=True)
+    L = ref.modules["prototype.loss_functions.loss"]
+    crit, sim_crit = L.ClipInfoCELoss(), L.SimsiamLoss()
+    li1, li2, lt1, lt2 = out["logits"]
+    a1, a2, at1, at2 = out["logits_aug"]
+    clip_loss = (crit(li1, lt1)[0] + crit(li2, lt2)[0] + crit(a1, at1)[0] + crit(a2, at2)[0]) / 4
+    n1, n2, n1a, n2a = out["nn_text_logits"]
+    nn_loss = (crit(n1, n1a)[0] + crit(n2, n2a)[0]) / 2
+    p1, p2, z1, z2 = out["simsiam_features"]
+    sim_loss = sim_crit(p1, z1, p2, z2)
+    mlm = out["text_self_supervised"]
+    fi, ft = out["filip"]
+    filip_loss = crit(fi, ft)[0]
+    total = 0.4 * clip_loss + 0.2 * sim_loss + 0.2 * mlm + 0.2 * nn_loss + 0.2 * filip_loss
+    total.backward()
+    ret = dict(kind="defilip", cfg=cfg, b=b, seed=seed, nn_size=nn_size, loss=float(total),
+               parts=dict(clip=float(clip_loss), nn=float(nn_loss), simsiam=float(sim_loss), mlm=float(mlm), filip=float(filip_loss)),
+               filip_i=fi.detach().clone(), grads=grad_digest([(n, p.grad) for n, p in model.named_parameters()]),
+               torch_version=torch.__version__)
+    path = os.path.join(GOLDEN_DIR, name + ".pt")
+    torch.save(ret, path)
+    print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
+
+
 FIXTURES = {
     "clip_tiny": lambda: gen_clip("clip_tiny", synth.TINY, b=4),
     "clip_tiny_scale5": lambda: gen_clip("clip_tiny_scale5", synth.TINY, b=4, seed=3, logit_scale=5.0),
@@ -294,6 +355,7 @@ FIXTURES = {
     "declip_tiny": lambda: gen_declip("declip_tiny", synth.TINY, b=6, seed=2),
     "slip_tiny": lambda: gen_slip("slip_tiny", synth.TINY, b=5, seed=4),
     "filip_small": lambda: gen_filip("filip_small", synth.FILIP_SMALL, b=5, seed=6),
+    "defilip_small": lambda: gen_defilip("defilip_small", synth.FILIP_SMALL, b=4, seed=7),
 }
 
 

@@ -202,3 +202,23 @@ def test_filip_engine_composition_matches_golden(mocked_engine):
     assert float((dlt.detach() - g["dense_logits_t"]).abs().max()) <= 1e-4 * float(g["dense_logits_t"].abs().max())
     grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
     check_grad_digests(g["grads"], grads, rtol=1e-3)
+
+
+def test_defilip_engine_composition_matches_golden(mocked_engine):
+    from declip_amd.heads import SimsiamLoss
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.steps import DEFILIP_WEIGHTS, declip_loss
+    from declip_amd.testing import build_defilip, defilip_batch
+    g = load_golden("defilip_small")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_defilip(cfg, dtype="fp32", seed=seed, nn_size=g["nn_size"], device="cpu")
+    out = declip_loss(model, defilip_batch(cfg, b, seed=seed, device="cpu"), ClipInfoCELoss(), SimsiamLoss(), None,
+                      weights=DEFILIP_WEIGHTS)
+    out["loss"].backward()
+    assert abs(float(out["loss"]) - g["loss"]) <= 1e-4 * abs(g["loss"])
+    for k in ("clip", "nn", "simsiam", "mlm", "filip"):
+        assert abs(float(out["parts"][k]) - g["parts"][k]) <= 2e-4 * max(1.0, abs(g["parts"][k])), k
+    fi = out["outputs"]["filip"][0].detach()
+    assert float((fi - g["filip_i"]).abs().max()) <= 1e-4 * float(g["filip_i"].abs().max())
+    grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+    check_grad_digests(g["grads"], grads, rtol=1e-3)

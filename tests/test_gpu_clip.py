@@ -188,3 +188,23 @@ def test_filip_step_matches_reference_golden(dtype, tol):
     if dtype == "fp32":
         grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
         check_grad_digests(g["grads"], grads, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-3), ("bf16", 3e-2)])
+def test_defilip_step_matches_reference_golden(dtype, tol):
+    from declip_amd.heads import SimsiamLoss
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.steps import DEFILIP_WEIGHTS, declip_loss
+    from declip_amd.testing import build_defilip, defilip_batch
+    g = load_golden("defilip_small")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_defilip(cfg, dtype=dtype, seed=seed, nn_size=g["nn_size"])
+    out = declip_loss(model, defilip_batch(cfg, b, seed=seed), ClipInfoCELoss(), SimsiamLoss(), None, weights=DEFILIP_WEIGHTS)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - g["loss"]) <= tol * abs(g["loss"])
+    for k in ("clip", "nn", "mlm", "filip"):
+        assert abs(float(out["parts"][k]) - g["parts"][k]) <= tol * max(1.0, abs(g["parts"][k])), k
+    if dtype == "fp32":
+        grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
+        check_grad_digests(g["grads"], grads, rtol=1e-3)
