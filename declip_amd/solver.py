@@ -1,0 +1,370 @@
+"""Training solver for the contrastive step (CLIP / DeCLIP / SLIP / FILIP / DeFILIP) on the HIP engine.
+
+Drop-in for `python -m prototype.solver.{clip,declip,slip,filip,defilip}_solver --config config.yaml`
+(reference: solver/clip_solver.py:89-764 and siblings).  What is kept: the YAML contract (model / dist /
+grad_clip / optimizer(+pconfig) / lr_scheduler / loss weights / saver), the step order
+(lr step -> forward -> losses / world_size -> logit_scale clamp -> backward -> grad sync -> optimizer ->
+clamp), iteration-based training, checkpoint key layout ('model' with 'module.' prefix, 'optimizer', 'last_iter').
+What changes: no per-meter host sync (meters are read every print_freq), no barriers in the step, gradient
+reduction is the engine's bucketed flat all-reduce.  Data: `data.read_from: fake` / `data.type: synthetic`
+produce seeded synthetic batches resident on the GPU (the I/O pipeline is out of scope); any
+iterable of reference-style batch dicts can be injected with `ClsSolver(config, train_loader=...)`.
+"""
+import argparse
+import glob
+import logging
+import math
+import os
+import time
+
+import torch
+import yaml
+
+from . import dist as dh_dist
+from . import steps, synth
+from .heads import SimsiamLoss
+from .loss import ClipInfoCELoss, NT_Xent, NT_Xent_gather, NTXentLoss
+from .meters import AverageMeter
+from .optim import FlatAdamW
+
+
+class AttrDict(dict):
+    """EasyDict stand-in (reference utils/misc.py:65-70 parses YAML into EasyDict)."""
+
+    def __init__(self, d=None):
+        super().__init__()
+        for k, v in (d or {}).items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, AttrDict):
+            v = AttrDict(v)
+        super().__setitem__(k, v)
+
+    __setattr__ = __setitem__
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def parse_config(path):
+    with open(path) as f:
+        return AttrDict(yaml.safe_load(f))
+
+
+# --------------------------------------------------------------------------------------- lr schedule
+class CosineLRScheduler(object):
+    """lr_scheduler/scheduler.py:68-84,200-246: linear warm-up base_lr -> warmup_lr over warmup_steps, then cosine to
+    min_lr at max_iter; every param group is scaled relative to its own initial lr."""
+
+    def __init__(self, optimizer, max_iter, min_lr, base_lr, warmup_lr, warmup_steps, last_iter=0):
+        assert warmup_steps >= 2 or warmup_steps == 0
+        self.optimizer, self.max_iter, self.min_lr = optimizer, max_iter, min_lr
+        self.base_lr, self.warmup_lr, self.warmup_steps, self.last_iter = base_lr, warmup_lr, warmup_steps, last_iter
+        for g in optimizer.param_groups:
+            g.setdefault("initial_lr", g["lr"])
+        self.base_lrs = [g["initial_lr"] for g in optimizer.param_groups]
+
+    def _target(self):
+        it = self.last_iter
+        if self.warmup_steps >= 2 and it < self.warmup_steps:
+            return (self.warmup_lr - self.base_lr) / (self.warmup_steps - 1) * (it - 1) + self.base_lr
+        ratio = (it - self.warmup_steps) / (self.max_iter - self.warmup_steps)
+        return self.min_lr + (self.warmup_lr - self.min_lr) * (1 + math.cos(math.pi * ratio)) / 2
+
+    def step(self, this_iter=None):
+        self.last_iter = self.last_iter + 1 if this_iter is None else this_iter
+        scale = self._target() / self.base_lr
+        for g, b in zip(self.optimizer.param_groups, self.base_lrs):
+            g["lr"] = scale * b
+
+    def get_lr(self):
+        return [g["lr"] for g in self.optimizer.param_groups]
+
+
+def scheduler_entry(cfg):
+    """lr_scheduler/__init__.py:18-22."""
+    if cfg["type"] != "Cosine":
+        raise NotImplementedError("lr_scheduler type %s (shipped configs use Cosine)" % cfg["type"])
+    return CosineLRScheduler(**cfg["kwargs"])
+
+
+# --------------------------------------------------------------------------------------- optimizer groups
+def param_groups(model, opt_cfg):
+    """utils/misc.py:267-400 `param_group_all`, restated: module-type walk puts Conv2d/Linear/BatchNorm/LayerNorm
+    biases into 'bias' when pconfig names it (else conv_b / linear_b / bn_b / ln_b), norm weights into bn_w / ln_w,
+    Linear weights into 'linear_w' only when pconfig names it, parameters whose name contains 'logit_scale' into
+    'logit_scale'; everything else (incl. MultiheadAttention.in_proj_*, embeddings, projections) is the default
+    group.  Groups named in pconfig get its overrides; the others the optimizer defaults."""
+    pconfig = dict(opt_cfg.get("pconfig", {}) or {})
+    keys = ["bn_w", "bn_b", "conv_b", "linear_b", "ln_w", "ln_b"] + [k for k in ("linear_w", "logit_scale", "bias") if k in pconfig]
+    pg, taken = {k: [] for k in keys}, set()
+
+    def put(key, p):
+        if p is not None and id(p) not in taken:
+            taken.add(id(p))
+            pg[key].append(p)
+
+    any_bias = "bias" in pg
+    for _, m in model.named_modules():
+        if isinstance(m, torch.nn.Conv2d):
+            put("bias" if any_bias else "conv_b", m.bias)
+        elif isinstance(m, torch.nn.Linear):
+            put("bias" if any_bias else "linear_b", m.bias)
+            if "linear_w" in pg:
+                put("linear_w", m.weight)
+        elif isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            put("bn_w", m.weight)
+            put("bias" if any_bias else "bn_b", m.bias)
+        elif isinstance(m, torch.nn.LayerNorm):
+            put("ln_w", m.weight)
+            put("bias" if any_bias else "ln_b", m.bias)
+    normal = []
+    for name, p in model.named_parameters():
+        if "logit_scale" in pg and "logit_scale" in name:
+            put("logit_scale", p)
+        if id(p) not in taken:
+            normal.append(p)
+    groups = [dict(params=normal)]
+    for k in keys:
+        if pg[k]:
+            groups.append(dict(params=pg[k], **dict(pconfig.get(k, {}))))
+    return groups
+
+
+def optim_entry(model, opt_cfg):
+    """optimizer/__init__.py:18-26: AdamW -> the engine's fused flat AdamW; other torch optimizers by name."""
+    groups = param_groups(model, opt_cfg)
+    kw = dict(opt_cfg.get("kwargs", {}))
+    if opt_cfg["type"] in ("AdamW", "FusedFP16AdamW"):
+        kw["betas"] = tuple(kw.get("betas", (0.9, 0.999)))
+        return FlatAdamW(groups, model.__dict__["_flat_store"], **kw)
+    return getattr(torch.optim, opt_cfg["type"])(groups, **kw)
+
+
+# --------------------------------------------------------------------------------------- synthetic data
+class SyntheticLoader(object):
+    """Seeded GPU-resident batches with the reference's batch contract (clip_dataloader.py:47-53): `images`
+    [b, 3*views, H, W] fp32, `captions` pre-tokenised ids (+ augmented ids / MLM labels for the DeCLIP family)."""
+
+    def __init__(self, kind, batch_size, rank, device, res=224, ctx=77, n_distinct=4):
+        self.kind, self.b, self.rank, self.device, self.res, self.ctx = kind, batch_size, rank, device, res, ctx
+        self.cache, self.n = {}, n_distinct
+
+    def get(self, step):
+        key = step % self.n
+        if key not in self.cache:
+            seed = 1000 * self.rank + key
+            views = {"clip": 1, "declip": 2, "defilip": 2, "filip": 2, "slip": 3}[self.kind]
+            batch = {"images": synth.synth_images(self.b, views=views, res=self.res, seed=seed).to(self.device)}
+            long_caps = dict(min_len=self.ctx - 6) if self.kind in ("filip", "defilip") else {}
+            ids = synth.synth_tokens(self.b, ctx=self.ctx, seed=seed, **long_caps)
+            if self.kind in ("declip", "defilip"):
+                masked, labels = synth.synth_mlm(ids, seed=seed)
+                aug = synth.synth_tokens(self.b, ctx=self.ctx, seed=seed + 500, **long_caps)
+                batch["captions"] = torch.stack([masked, aug], dim=1).to(self.device)
+                batch["mlm_labels"] = labels
+            elif self.kind == "filip":
+                masked, labels = synth.synth_mlm(ids, seed=seed)
+                batch["captions"], batch["mlm_labels"] = masked.to(self.device), labels
+            else:
+                batch["captions"] = ids.to(self.device)
+            self.cache[key] = batch
+        return self.cache[key]
+
+
+def model_kind(type_name):
+    for k in ("defilip", "declip", "filip", "slip", "clip"):
+        if type_name.startswith(k):
+            return k
+    raise NotImplementedError(type_name)
+
+
+# --------------------------------------------------------------------------------------- solver
+class ClsSolver(object):
+    def __init__(self, config_file, train_loader=None, device="cuda"):
+        self._device_kind = device
+        self.config = parse_config(config_file) if isinstance(config_file, str) else AttrDict(config_file)
+        self.config_file = config_file if isinstance(config_file, str) else None
+        self.kind = model_kind(self.config.model.type)
+        self.setup_env()
+        self.build_model()
+        self.build_optimizer()
+        self.build_lr_scheduler()
+        self.build_data(train_loader)
+        self.build_criteria()
+
+    # ---- clip_solver.py:104-165
+    def setup_env(self):
+        self.rank, self.world_size = dh_dist.get_rank(), dh_dist.get_world_size()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if self._device_kind == "cuda" else torch.device(self._device_kind)
+        saver = self.config.get("saver", AttrDict())
+        base = os.path.dirname(self.config_file) if self.config_file else os.getcwd()
+        self.save_dir = os.path.join(base, "checkpoints")
+        self.print_freq = int(saver.get("print_freq", 10))
+        self.save_freq = int(saver.get("save_freq", 0) or 0)
+        self.logger = logging.getLogger("declip_amd.solver")
+        if not self.logger.handlers:
+            h = logging.StreamHandler()
+            h.setFormatter(logging.Formatter("%(asctime)s %(message)s"))
+            self.logger.addHandler(h)
+        self.logger.setLevel(logging.INFO if self.rank == 0 else logging.WARNING)
+        self.state = {"last_iter": 0}
+        if (saver.get("pretrain", None) or {}).get("auto_resume", False):       # saver.pretrain.auto_resume (clip_solver.py:120-137)
+            cands = sorted(glob.glob(os.path.join(self.save_dir, "ckpt*.pth.tar")), key=os.path.getmtime)
+            if cands:
+                self.state = torch.load(cands[-1], map_location="cpu")
+                self.logger.info("auto-resumed from %s (iter %d)" % (cands[-1], self.state["last_iter"]))
+
+    # ---- clip_solver.py:187-234
+    def build_model(self):
+        from prototype.model import model_entry
+        self.model = model_entry(self.config.model)
+        self.model.to(self.device)
+        self.model.train()
+        if "model" in self.state:
+            sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in self.state["model"].items()}
+            self.model.load_state_dict(sd, strict=False)
+        sync = bool(self.config.get("dist", {}).get("sync", False))
+        self.model = dh_dist.DistModule(self.model, sync)
+
+    def build_optimizer(self):
+        self.optimizer = optim_entry(self.model.module, self.config.optimizer)
+        if "optimizer_flat" in self.state and isinstance(self.optimizer, FlatAdamW):
+            st = self.state["optimizer_flat"]
+            self.optimizer.m.copy_(st["m"]), self.optimizer.v.copy_(st["v"])
+            self.optimizer.step_count = st["step"]
+
+    def build_lr_scheduler(self):
+        cfg = AttrDict(self.config.lr_scheduler)
+        kw = dict(cfg.kwargs)
+        kw["optimizer"] = self.optimizer
+        kw["last_iter"] = self.state["last_iter"]
+        self.max_iter = int(kw["max_iter"])
+        self.lr_scheduler = scheduler_entry(dict(type=cfg.type, kwargs=kw))
+
+    def build_data(self, train_loader):
+        d = self.config.get("data", AttrDict())
+        self.batch_size = int(d.get("batch_size", 128))
+        if train_loader is not None:
+            self.loader = train_loader
+            return
+        if d.get("read_from", "fake") not in ("fake", "synthetic") and d.get("type", "clip") != "synthetic":
+            raise NotImplementedError(
+                "only data.read_from: fake / synthetic is built in (the I/O pipeline is out of scope, DESIGN.md s7); "
+                "pass train_loader= an iterable of {'images','captions'} batch dicts for real data")
+        m = self.model.module
+        ctx = int((m.text_encoder if hasattr(m, "text_encoder") else m.encode_text).context_length)
+        self.loader = SyntheticLoader(self.kind, self.batch_size, self.rank, self.device, res=int(d.get("input_size", 224)), ctx=ctx)
+
+    def build_criteria(self):
+        self.criterion = ClipInfoCELoss()
+        self.simsiam_criterion = SimsiamLoss()
+        self.nt_xent_criterion = NTXentLoss(self.batch_size) if self.kind in ("declip", "defilip", "filip") else NT_Xent(self.batch_size)
+        self.simclr_criterion = NT_Xent_gather(self.batch_size)
+        self.meters = {k: AverageMeter(self.print_freq) for k in ("loss", "top1", "top5", "step_time")}
+
+    # ---- per-model loss composition (steps.py restates the solvers)
+    def _loss(self, batch):
+        W = self.world_size
+        if self.kind == "clip":
+            return steps.clip_loss(self.model, batch, self.criterion, W)
+        if self.kind in ("declip", "defilip"):
+            w = dict(self.config.get("clip_simsiam_loss_weight", steps.DEFILIP_WEIGHTS if self.kind == "defilip" else steps.DECLIP_WEIGHTS))
+            tv = self.config.get("data", {}).get("train", {})
+            return steps.declip_loss(self.model, batch, self.criterion, self.simsiam_criterion, self.nt_xent_criterion, weights=w,
+                                     world_size=W, image_text_two_view=tv.get("image_text_two_view", True),
+                                     only_image_two_view=tv.get("only_image_two_view", False))
+        if self.kind == "slip":
+            return steps.slip_loss(self.model, batch, self.criterion, self.simclr_criterion, self.nt_xent_criterion,
+                                   weights=dict(self.config.get("loss_weight", steps.SLIP_WEIGHTS)), world_size=W)
+        return steps.filip_loss(self.model, batch, self.criterion,
+                                weights=dict(self.config.get("clip_simsiam_loss_weight", steps.FILIP_WEIGHTS)), world_size=W)
+
+    def _clamp_params(self):
+        """grad_clip.type == logit_scale_param_value: clamp the log-space temperature before and after the step
+        (clip_solver.py:507-508,521-522; filip also clamps logit_scale_dense, filip_solver.py:646,661)."""
+        gc = self.config.get("grad_clip", None)
+        if gc and gc.get("type") == "logit_scale_param_value":
+            m = self.model.module
+            m.logit_scale.data.clamp_(min=gc.value, max=gc.max_value)
+            if hasattr(m, "logit_scale_dense"):
+                m.logit_scale_dense.data.clamp_(min=gc.value, max=gc.max_value)
+
+    def train_step(self, curr_step):
+        batch = self.loader.get(curr_step) if hasattr(self.loader, "get") else next(self._iter)
+        self.lr_scheduler.step(curr_step)
+        out = self._loss(batch)
+        self.optimizer.zero_grad()
+        self._clamp_params()
+        out["loss"].backward()
+        self.model.sync_gradients()
+        self.optimizer.step()
+        self._clamp_params()
+        return out
+
+    def train(self, max_steps=None):
+        if not hasattr(self.loader, "get"):
+            self._iter = iter(self.loader)
+        start = self.state["last_iter"] + 1
+        end = self.max_iter if max_steps is None else min(self.max_iter, start + max_steps - 1)
+        t_last = time.time()
+        for curr_step in range(start, end + 1):
+            out = self.train_step(curr_step)
+            self.meters["loss"].reduce_update(out["loss"].detach().clone())
+            if "top1" in out:
+                self.meters["top1"].reduce_update(out["top1"].detach() / self.world_size)
+                self.meters["top5"].reduce_update(out["top5"].detach() / self.world_size)
+            if curr_step % self.print_freq == 0 or curr_step == end:
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize()
+                dt = (time.time() - t_last) / max(1, min(self.print_freq, curr_step - start + 1))
+                t_last = time.time()
+                parts = " ".join("%s %.4f" % (k, float(v.detach())) for k, v in out.get("parts", {}).items())
+                self.logger.info("Iter [%d/%d] loss %.4f (%.4f) top1 %.2f top5 %.2f lr %.6f %.1f ms/step %.0f pairs/s %s" % (
+                    curr_step, self.max_iter, self.meters["loss"].val, self.meters["loss"].avg, self.meters["top1"].avg,
+                    self.meters["top5"].avg, self.lr_scheduler.get_lr()[0], dt * 1e3, self.batch_size * self.world_size / dt, parts))
+            if self.save_freq and curr_step % self.save_freq == 0:
+                self.save(curr_step)
+        self.state["last_iter"] = end
+        return out
+
+    def save(self, curr_step):
+        """clip_solver.py:649-668 key layout ('module.'-prefixed model state, optimizer, last_iter)."""
+        if self.rank != 0:
+            return
+        os.makedirs(self.save_dir, exist_ok=True)
+        st = {"model": {"module." + k: v.detach().cpu() for k, v in self.model.module.state_dict().items()}, "last_iter": curr_step}
+        if isinstance(self.optimizer, FlatAdamW):
+            st["optimizer_flat"] = {"m": self.optimizer.m.cpu(), "v": self.optimizer.v.cpu(), "step": self.optimizer.step_count}
+        else:
+            st["optimizer"] = self.optimizer.state_dict()
+        torch.save(st, os.path.join(self.save_dir, "ckpt.pth.tar"))
+
+    def evaluate(self, *a, **k):
+        raise NotImplementedError("zero-shot evaluation is a 'next' row (SURVEY.md s8(f) #3); encode_image/encode_text are available")
+
+
+def main():
+    """clip_solver.py:740-764."""
+    ap = argparse.ArgumentParser(description="contrastive pre-training solver (MI355X engine)")
+    ap.add_argument("--config", required=True, type=str)
+    ap.add_argument("--evaluate", action="store_true")
+    ap.add_argument("--max-steps", type=int, default=None)
+    args = ap.parse_args()
+    if int(os.environ.get("WORLD_SIZE", os.environ.get("SLURM_NTASKS", "1"))) > 1:
+        dh_dist.initialize("nccl")
+    else:
+        torch.cuda.set_device(0)
+    solver = ClsSolver(args.config)
+    if args.evaluate:
+        solver.evaluate()
+    else:
+        solver.train(args.max_steps)
+
+
+if __name__ == "__main__":
+    main()
