@@ -143,7 +143,9 @@ def main():
             e1.record()
             M, K = (A.shape[1], A.shape[0]) if kw.get("a_kmajor") else (A.shape[0], A.shape[1])
             N = B.shape[1] if kw.get("b_kmajor") else B.shape[0]
-            records.append((e0, e1, 2.0 * M * N * K, A.dtype))
+            records.append((e0, e1, 2.0 * M * N * K, A.dtype,
+                            (M, N, K, int(bool(kw.get("a_kmajor"))), int(bool(kw.get("b_kmajor"))), int(kw.get("epilogue", 0) or 0),
+                             int(kw.get("residual") is not None), int(bool(kw.get("accumulate"))))))
             return out
 
         ops.gemm = timed_gemm
@@ -161,6 +163,15 @@ def main():
         flops = sum(r[2] for r in records if r[3] == torch.bfloat16 or args.dtype != "bf16")
         ms = sum(r[0].elapsed_time(r[1]) for r in records if r[3] == torch.bfloat16 or args.dtype != "bf16")
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        if os.environ.get("DH_BENCH_GEMM_TABLE") and rank == 0:   # per-shape in-step GEMM times (tuning aid)
+            agg = {}
+            for r in records:
+                c, tms, fl = agg.get(r[4], (0, 0.0, 0.0))
+                agg[r[4]] = (c + 1, tms + r[0].elapsed_time(r[1]), fl + r[2])
+            with open(os.environ["DH_BENCH_GEMM_TABLE"], "w") as fh:
+                fh.write("M N K ta tb epi res acc | calls/step  avg_us  TF/s  ms/step\n")
+                for k, (c, tms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    fh.write("%6d %5d %6d %d %d %d %d %d | %4d %8.1f %6.0f %7.3f\n" % (k + (c // nprof, tms / c * 1e3, fl / tms / 1e9, tms / nprof)))
         roofline = dict(bound="mfma", kernel="gemm_mfma_kernel (all tower GEMMs of a step)", achieved=round(achieved, 2),
                         peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
                         launches_per_step=len(records) // nprof, gemm_ms_per_step=round(ms / nprof, 3),

@@ -42,6 +42,19 @@ __device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
+// hardware RNE pack (v_cvt_pk_bf16_f32, gfx950): same rounding as f2bf for finite values, 1 instruction per pair
+typedef __attribute__((ext_vector_type(2))) float dh_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 dh_bf16x2_t;
+__device__ __forceinline__ uint32_t pack2bf_hw(float lo, float hi) {
+  dh_f32x2_t v = {lo, hi};
+  dh_bf16x2_t b = __builtin_convertvector(v, dh_bf16x2_t);
+  return *reinterpret_cast<uint32_t*>(&b);
+}
+__device__ __forceinline__ void st8_hw(bf16_t* p, const float* o) {
+  uint4 v;
+  v.x = pack2bf_hw(o[0], o[1]); v.y = pack2bf_hw(o[2], o[3]); v.z = pack2bf_hw(o[4], o[5]); v.w = pack2bf_hw(o[6], o[7]);
+  *reinterpret_cast<uint4*>(p) = v;
+}
 
 // typed load/store of activation element types (T = float or bf16_t)
 template <typename T> __device__ __forceinline__ float ld(const T* p);

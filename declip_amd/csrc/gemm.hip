@@ -315,6 +315,7 @@ int launch_mfma(const dh_gemm_args* a, const EpiParams& e, int split, int kps, h
 
 bool dh_gemm_try_glds(const dh_gemm_args* a, int split, hipStream_t st);  // gemm_glds.hip
 bool dh_gemm_try_v3(const dh_gemm_args* a, int split, hipStream_t st);    // gemm_v3.hip
+bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st);    // gemm_v4.hip
 
 extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -337,6 +338,11 @@ extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
 
   if (a->a_colsum) DH_REQUIRE(a->a_kmajor, "dh_gemm: a_colsum needs a_kmajor");
   // v2 (LDS-DMA + transpose-read) kernel when shapes/alignments allow it (fuses a_colsum)
+  if ((a->force_generic == 0 || a->force_generic == 4) && dh_gemm_try_v4(a, split, st)) {
+    DH_CHECK_LAUNCH();
+    return DH_OK;
+  }
+  DH_REQUIRE(a->force_generic != 4, "dh_gemm: the v4 kernel does not support this problem");
   if (a->force_generic == 0 && dh_gemm_try_v3(a, split, st)) {
     DH_CHECK_LAUNCH();
     return DH_OK;

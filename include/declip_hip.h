@@ -78,7 +78,7 @@ typedef struct dh_gemm_args {
   int accumulate;
   int split_k;           /* >=1; >1 requires accumulate */
   float alpha;
-  int force_generic;     /* tests: 1 = VALU fp32-FMA kernel, 2 = v1 register-staged MFMA kernel, 3 = v2 LDS-DMA kernel, 0 = auto (v3 deep pipeline first) */
+  int force_generic;     /* tests: 1 = VALU fp32-FMA kernel, 2 = v1 register-staged MFMA kernel, 3 = v2 LDS-DMA kernel, 4 = v4 256x256 ping-pong kernel (error if unsupported), 0 = auto */
   float* a_colsum;       /* optional, a_kmajor only: a_colsum[m] += sum_k A(m,k) (bias gradient fused into dW) */
   int pad_ok;            /* caller guarantees operand rows are readable (finite) up to the next multiple of 8
                             elements / 128 rows beyond M,N: lifts the M%8 / N%8 conditions of the MFMA kernels */

@@ -42,7 +42,7 @@ def main():
     cases.append(("vis.patch.fwd", "NT", 512 * 49, 768, 3072))
     if args.quick:
         cases = [c for c in cases if c[0].startswith("vis.fc") or c[0].startswith("txt.out")]
-    print("%-16s %-3s %7s %6s %6s | %s" % ("case", "lay", "M", "N", "K", "  ".join("%14s" % v for v in ("v2/128 TF", "v3/256x128", "v3/256x256", "v3/128x128x3"))))
+    print("%-16s %-3s %7s %6s %6s | %s" % ("case", "lay", "M", "N", "K", "  ".join("%14s" % v for v in ("v2/128 TF", "v4/256x256"))))
     tot = {}
     for name, lay, M, N, K in cases:
         if lay == "NT":
@@ -58,14 +58,13 @@ def main():
             kw = dict(a_kmajor=True, b_kmajor=True, accumulate=True, split_k=_split_k(M, N, K))
             out = torch.zeros(M, N, device=dev, dtype=torch.float32)
         res = []
-        for variant in ("v2", "v3s", "v3b", "v3c"):
-            os.environ["DH_GEMM_V3_DYN"] = {"v2": "0", "v3s": "1", "v3b": "2", "v3c": "3"}[variant]
-            fn = lambda: ops.gemm(A, B, out=out, **kw)
+        for variant in ("v2", "v4"):
+            fg = {"v2": 3, "v4": 4}[variant]
+            fn = lambda: ops.gemm(A, B, out=out, force_generic=fg, **kw)
             ms = run(fn, args.iters)
             tf = 2.0 * M * N * K / ms / 1e9
             res.append((ms, tf))
             tot[variant] = tot.get(variant, 0.0) + ms
-        os.environ.pop("DH_GEMM_V3_DYN", None)
         print("%-16s %-3s %7d %6d %6d | %s" % (name, lay, M, N, K, "  ".join("%6.3fms %6.0f" % r for r in res)))
     print("sum ms:", {k: round(v, 3) for k, v in tot.items()})
 
