@@ -1,4 +1,4 @@
-// GEMM v4 for gfx950: 256 x 256 x 64 block tile, 8 waves, "ping-pong" phase schedule.
+// GEMM v4 for gfx950: persistent 256 x 256 x 64 tiles, 8 waves, "ping-pong" phase schedule.
 //
 // Why another GEMM: the v2 kernel (128 x 128, one drain-everything barrier per K-step) tops out at
 // ~650-900 TFLOP/s on the tower shapes -- the structure's ceiling (cdna_hip_programming.md s5).  v4 keeps the
@@ -11,19 +11,27 @@
 //     LOAD segment (fragment ds_reads for the quadrant + one 16 KiB half-tile of LDS-DMA for a later K-tile)
 //     and an MFMA segment (8 x v_mfma_f32_32x32x16_bf16), separated by raw s_barriers;
 //   * waves 4-7 run ONE barrier behind waves 0-3, so on every SIMD one wave is in its MFMA segment while its
-//     partner is in its load segment: the matrix pipe and the LDS/DMA path stay busy at the same time;
+//     partner is in its load segment: the matrix pipe and the LDS/DMA path stay busy at the same time
+//     (measured: the main loop alone runs at ~1.7 PFLOP/s on the tower shapes);
 //   * each half-tile (A0/A1/B0/B1 of a K-tile) is consumed in exactly one phase, so it is re-filled two phases
 //     later for K-tile t+2: 4 half-tiles (64 KiB) are always in flight and the waits are COUNTED
 //     (s_waitcnt vmcnt(8): "everything but the 4 youngest half-tiles"), never a drain;
-//   * bf16 outputs: the MFMAs are issued with swapped operands (acc holds C^T fragments: a lane owns 4
-//     consecutive columns of one row), so the accumulators are packed to bf16 and staged in LDS with
-//     ds_write_b64, then written out as 16-byte vectors on full 512-byte row segments; alpha/bias are applied
-//     in fp32 before the packing, GELU / dGELU / residual on the staged value;
-//   * fp32 accumulate (dW, split-K): plain orientation, atomics straight from the accumulators (a lane group
-//     covers 32 consecutive floats of a row).
+//   * PERSISTENT: one workgroup per CU walks a list of tiles.  The first four half-tiles of the NEXT tile are
+//     requested before the epilogue of the current one (into ring buffer 0, the epilogue stages through buffer 1),
+//     and the epilogue's global stores are never waited for: they drain while the next main loop runs (the
+//     counted waits of that tile's first K-tile are widened by the number of stores in flight);
+//   * bf16 outputs (MODE_STORE): MFMAs are issued with swapped operands (acc = C^T fragments: a lane owns 4
+//     consecutive columns of a row), packed with v_cvt_pk_bf16_f32 and staged in LDS with conflict-free
+//     ds_write_b64, then written as 16-byte vectors on full 512-byte row segments; alpha/bias in fp32 before the
+//     packing, GELU / dGELU / residual on the staged value; residual / dGELU operands are PREFETCHED before the
+//     staging so no load ever sits between two stores (a load behind a store waits for the store: in-order vmcnt);
+//   * split-K weight gradients (MODE_PARTIAL): fp32 partial tiles go to a workspace [split][M][N] as fully
+//     coalesced 16-byte stores (LDS-staged, 4 passes) and a small reduce kernel adds them into the gradient --
+//     measured 2x cheaper than fp32 atomics from every split; MODE_ATOMIC (no workspace) keeps the atomics;
+//   * the bias gradient (column sums of the dY operand) rides on the matrix pipe: one extra MFMA per A fragment
+//     against an indicator fragment, spread over the tile columns so every workgroup pays ~1/ntx of it.
 //
-// LDS: 2 stages x {A0, A1, B0, B1} x 16 KiB = 128 KiB (1 block / CU); the epilogue reuses it as the 256 x 256
-// bf16 staging tile.  Half-tile images are exactly the v2 operand tiles:
+// LDS: 2 stages x {A0, A1, B0, B1} x 16 KiB = 128 KiB (1 block / CU).  Half-tile images are the v2 operand tiles:
 //   K-contiguous  [128 rows][64 k]   128-B rows, 16-B chunk c of row r at slot c ^ ((r>>1)&7)
 //   contraction-major [64 k][128 out] 256-B rows, 16-B chunk c of row k at slot c ^ ((k&3)<<2)
 #include "dh_common.h"
@@ -44,21 +52,38 @@ struct EpiParams {
   void* aux; long ldaux;
   float alpha;
   float* a_colsum;
-  int delay;   // experiment: DH_V4_DELAY shader cycles of start-up delay for every other first-round CU
+  float* ws;          // MODE_PARTIAL: [nsplit][M][N] fp32
 };
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;          // 16 KiB
 constexpr int STAGE_BYTES = 4 * HALF_BYTES;       // A0 A1 B0 B1
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;        // 128 KiB; epilogue staging = 256 rows x 512 B = the same 128 KiB
+constexpr int BIAS_OFF = 2 * STAGE_BYTES;         // behind the ring: the whole bias vector (fp32, N <= MAX_BIAS_N), loaded once per workgroup
+constexpr int MAX_BIAS_N = 4096;
+constexpr int LDS_BYTES = 2 * STAGE_BYTES + MAX_BIAS_N * 4; // 144 KiB
+// MODE: what happens to the finished tile.  The bf16 epilogue flavours are separate instantiations (straight-line code:
+// the kernel lives at the 256-VGPR cap, runtime epilogue switches cost spills).
+constexpr int MODE_STORE = 0, MODE_STORE_GELU = 1, MODE_STORE_DGELU = 2, MODE_STORE_RES = 3, MODE_ATOMIC = 4, MODE_PARTIAL = 5;
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+// LDS-DMA of 64 lanes x 16 B (1 KiB) to a wave-uniform LDS address.  INLINE ASM on purpose: when hipcc (ROCm 7.2) can see an
+// LDS-DMA in flight it puts s_waitcnt vmcnt(0) in front of the next LDS access it cannot prove disjoint (every ds_read /
+// ds_write of the epilogue, every transpose read), i.e. it drains the pipeline.  With the DMA (and the transpose reads)
+// issued from asm the compiler sees no VMEM traffic in the main loop at all and every wait there is one of ours.
 __device__ __forceinline__ void dma16(const bf16_t* src, unsigned char* lds_dst_uniform) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+  const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_dst_uniform;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(src) : "memory");
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// "all but the 4 youngest half-tiles and the `s` epilogue stores issued between them" (s is wave-uniform)
+__device__ __forceinline__ void wait_vmcnt_8_plus(int s) {
+  if (s == 0) wait_vmcnt<8>();
+  else if (s == 16) wait_vmcnt<24>();
+  else if (s == 32) wait_vmcnt<40>();
+  else wait_vmcnt<8>();                            // unknown count: conservative
+}
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // fragment of a K-contiguous half-tile: rows r0 + (lane&31), k = 16*s + 8*(lane>>5) .. +7
 __device__ __forceinline__ bf16x8_t frag_kcontig(const unsigned char* tile, int r0, int s, int lane) {
@@ -66,22 +91,39 @@ __device__ __forceinline__ bf16x8_t frag_kcontig(const unsigned char* tile, int 
   const int chunk = 2 * s + (lane >> 5);
   return *reinterpret_cast<const bf16x8_t*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
-// fragment of a contraction-major half-tile via the transpose read: out columns o0 + (lane&31)
-__device__ __forceinline__ bf16x8_t frag_kmajor(const unsigned char* tile, int o0, int s, int lane) {
-  constexpr int ROWB = 256;
+// Fragments of a contraction-major half-tile come out of LDS with the transpose read ds_read_b64_tr_b16, as INLINE ASM on
+// purpose: for the builtin hipcc (ROCm 7.2) inserts s_waitcnt vmcnt(0) in front of every read while an LDS-DMA is in flight
+// (it cannot prove the read does not alias the DMA target), which drains the whole pipeline once per phase.  The asm read is
+// invisible to that pass; the consumer waits lgkmcnt(0) explicitly after the phase barrier (wait_lgkm0 + sched_barrier in
+// the MFMA segments).  Address = per-lane VGPR (ring buffer + kmajor_lane_off) + immediate (region, k16-step).
+// per-lane byte offset (inside a half-tile region, k16-step 0) of the lane's first transpose-read for out columns o0 + ..
+__device__ __forceinline__ uint32_t kmajor_lane_off(int o0, int lane) {
   const int t = lane & 15;
   const int n = o0 + ((lane >> 4) & 1) * 16 + 4 * (t & 3);
-  const int k = 16 * s + 8 * (lane >> 5) + (t >> 2);
+  const int k = 8 * (lane >> 5) + (t >> 2);
   const int sw = (t >> 2) << 2;
-  const unsigned char* p = tile + k * ROWB + ((((n >> 3) ^ sw)) << 4) + ((n & 7) << 1);
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * ROWB));
+  return k * 256 + ((((n >> 3) ^ sw)) << 4) + ((n & 7) << 1);
+}
+template <int OFF> __device__ __forceinline__ bf16x8_t frag_km(uint32_t addr) {
+  s16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 1024));
   union { struct { s16x4 a, b; } s; bf16x8_t v; } u;
   u.s.a = lo; u.s.b = hi;
   return u.v;
 }
-template <bool KM> __device__ __forceinline__ bf16x8_t frag(const unsigned char* tile, int o0, int s, int lane) {
-  return KM ? frag_kmajor(tile, o0, s, lane) : frag_kcontig(tile, o0, s, lane);
+// the 4 k16-step fragments of one 32-row / 32-column group of half-tile REGION (0 A0, 1 A1, 2 B0, 3 B1)
+template <bool KM, int REGION>
+__device__ __forceinline__ void frag4(bf16x8_t* dst, uint32_t km_addr, const unsigned char* tile, int r0, int lane) {
+  if (KM) {
+    dst[0] = frag_km<REGION * 16384>(km_addr);
+    dst[1] = frag_km<REGION * 16384 + 4096>(km_addr);
+    dst[2] = frag_km<REGION * 16384 + 8192>(km_addr);
+    dst[3] = frag_km<REGION * 16384 + 12288>(km_addr);
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dst[s] = frag_kcontig(tile, r0, s, lane);
+  }
 }
 
 // DMA source of 1-KiB piece q (0..15) of a half-tile whose first out-row/column is o0
@@ -109,272 +151,450 @@ __device__ __forceinline__ const bf16_t* piece_src(const bf16_t* P, long ld, int
     __builtin_amdgcn_sched_barrier(0);    \
   } while (0)
 
-// ACC = false: bf16 C with fused epilogue (swapped MFMA operands); ACC = true: fp32 atomic accumulate
-template <bool TA, bool TB, bool ACC>
+// work item w -> (tile_x, tile_y, split z).  Items with the same z are consecutive (they share A/B panels); inside
+// a split the tile order is XCD-aware (workgroup p and all its items w = p + i*grid sit on XCD p % 8 when the grid
+// is a multiple of 8) and grouped so that the tiles an XCD runs concurrently share A and B panels in its 4 MiB L2.
+__device__ __forceinline__ void item_coords(int w, int ntx, int nty, int& tile_x, int& tile_y, int& z) {
+  const int nb = ntx * nty;
+  z = w / nb;
+  const int b = w - z * nb;
+  const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  constexpr int GROUP_M = 8;
+  const int in_group = GROUP_M * ntx;
+  const int gid = logical / in_group;
+  const int first_m = gid * GROUP_M;
+  const int gsz = min(nty - first_m, GROUP_M);
+  const int rem = logical - gid * in_group;
+  tile_y = first_m + rem % gsz;
+  tile_x = rem / gsz;
+}
+
+template <bool TA, bool TB, int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
-                                                         long ldb, int M, int N, int K, int k_per_split, EpiParams e) {
+                                                         long ldb, int M, int N, int K, int k_per_split, int ntx, int nty,
+                                                         int nitems, EpiParams e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool SWAP = MODE != MODE_ATOMIC;
+  constexpr bool STORE = MODE <= MODE_STORE_RES;   // acc holds C^T fragments (lane = row, 4 consecutive columns per register group)
+  // compile-time ablation (tuning aid: -DV4_ABL=mask; 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no epilogue)
+  constexpr bool do_dma = !(V4_ABL & 1), do_mfma = !(V4_ABL & 2), do_frag = !(V4_ABL & 4), do_epi = !(V4_ABL & 8);
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  int tile_x, tile_y;
-  {   // XCD-aware, L2-grouped tile order (block b runs on XCD b % 8; see gemm_glds.hip)
-    const int ntx = gridDim.x, nb = gridDim.x * gridDim.y;
-    const int b = blockIdx.y * ntx + blockIdx.x;
-    const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    constexpr int GROUP_M = 8;
-    const int nty = gridDim.y;
-    const int in_group = GROUP_M * ntx;
-    const int gid = logical / in_group;
-    const int first_m = gid * GROUP_M;
-    const int gsz = min(nty - first_m, GROUP_M);
-    const int rem = logical - gid * in_group;
-    tile_y = first_m + rem % gsz;
-    tile_x = rem / gsz;
-  }
-  if (e.delay > 0) {
-    const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (b < 256 && ((b >> 3) & 1)) {
-      const long t0 = __builtin_readcyclecounter();
-      while (__builtin_readcyclecounter() - t0 < e.delay) __builtin_amdgcn_s_sleep(8);
-    }
-  }
-  const int m0 = tile_y * BM, n0 = tile_x * BN;
-  const int kbeg = blockIdx.z * k_per_split;
-  const int kend = min(K, kbeg + k_per_split);
-  const int nk = (kend - kbeg) / BK;                 // host guarantees divisibility and nk >= 1
-
-  // DMA sources: [half][piece]; wave w stages pieces 2w, 2w+1 of every half-tile
-  const bf16_t* a00 = piece_src<TA>(A, lda, wave * 2 + 0, lane, m0, M, kbeg);
-  const bf16_t* a01 = piece_src<TA>(A, lda, wave * 2 + 1, lane, m0, M, kbeg);
-  const bf16_t* a10 = piece_src<TA>(A, lda, wave * 2 + 0, lane, m0 + 128, M, kbeg);
-  const bf16_t* a11 = piece_src<TA>(A, lda, wave * 2 + 1, lane, m0 + 128, M, kbeg);
-  const bf16_t* b00 = piece_src<TB>(B, ldb, wave * 2 + 0, lane, n0, N, kbeg);
-  const bf16_t* b01 = piece_src<TB>(B, ldb, wave * 2 + 1, lane, n0, N, kbeg);
-  const bf16_t* b10 = piece_src<TB>(B, ldb, wave * 2 + 0, lane, n0 + 128, N, kbeg);
-  const bf16_t* b11 = piece_src<TB>(B, ldb, wave * 2 + 1, lane, n0 + 128, N, kbeg);
+  const int ar = wm * 64, br = wn * 32;             // this wave's rows inside an A half / columns inside a B half
+  unsigned char* const wdst = smem + wave * 2048;   // this wave's 2 KiB slice of a half-tile
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+  const uint32_t akm0 = lds0 + kmajor_lane_off(ar, lane), akm1 = lds0 + kmajor_lane_off(ar + 32, lane), bkm = lds0 + kmajor_lane_off(br, lane);
   const long astep = TA ? (long)BK * lda : BK;
   const long bstep = TB ? (long)BK * ldb : BK;
-  unsigned char* const wdst = smem + wave * 2048;    // this wave's 2 KiB slice of a half-tile
-  // compile-time ablation (tuning aid: -DV4_ABL=mask; 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no epilogue)
-  constexpr bool do_dma = !(V4_ABL & 1), do_mfma = !(V4_ABL & 2), do_frag = !(V4_ABL & 4), do_epi = !(V4_ABL & 8);
 
-#define ISSUE_A0(buf) do { if (!do_dma) break; dma16(a00, wdst + (buf) * STAGE_BYTES);                  dma16(a01, wdst + (buf) * STAGE_BYTES + 1024);                  a00 += astep; a01 += astep; } while (0)
-#define ISSUE_A1(buf) do { if (!do_dma) break; dma16(a10, wdst + (buf) * STAGE_BYTES + HALF_BYTES);     dma16(a11, wdst + (buf) * STAGE_BYTES + HALF_BYTES + 1024);     a10 += astep; a11 += astep; } while (0)
-#define ISSUE_B0(buf) do { if (!do_dma) break; dma16(b00, wdst + (buf) * STAGE_BYTES + 2 * HALF_BYTES); dma16(b01, wdst + (buf) * STAGE_BYTES + 2 * HALF_BYTES + 1024); b00 += bstep; b01 += bstep; } while (0)
-#define ISSUE_B1(buf) do { if (!do_dma) break; dma16(b10, wdst + (buf) * STAGE_BYTES + 3 * HALF_BYTES); dma16(b11, wdst + (buf) * STAGE_BYTES + 3 * HALF_BYTES + 1024); b10 += bstep; b11 += bstep; } while (0)
-
-  f32x16_t acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // ---- prologue: FIFO order matches the steady state (A0 B0 B1 A1 of tile 0, then A0 B0 of tile 1)
-  ISSUE_A0(0); ISSUE_B0(0); ISSUE_B1(0); ISSUE_A1(0);
-  if (nk > 1) { ISSUE_A0(1); ISSUE_B0(1); wait_vmcnt<8>(); } else { wait_vmcnt<4>(); }
-  V4_BARRIER();
-  if (wm == 1) V4_BARRIER();             // waves 4-7 run one barrier behind waves 0-3 from here on
-
-  const int ar = wm * 64, br = wn * 32;  // this wave's rows inside an A half / columns inside a B half
-
+  // DMA sources.  Shapes are whole tiles (host-checked).  Each wave stages pieces 2w, 2w+1 of every half-tile: two per-lane
+  // pointers per operand (the source swizzle of a K-contiguous piece depends on the piece), half +1 = a wave-uniform offset
+  // (128 rows / 128 columns).  ap* / bp* point at K-tile kt+1 while K-tile kt is multiplied (A1, B1 of kt+1 and A0, B0 of kt+2
+  // are issued there).
+  const long a_dh = TA ? 128 : 128 * lda;
+  const long b_dh = TB ? 128 : 128 * ldb;
+  const bf16_t *ap0, *ap1, *bp0, *bp1;
+#define SETUP_SRC(m0_, n0_, kbeg_)                                          \
+  do {                                                                      \
+    ap0 = piece_src<TA>(A, lda, wave * 2 + 0, lane, (m0_), M, (kbeg_));       \
+    ap1 = piece_src<TA>(A, lda, wave * 2 + 1, lane, (m0_), M, (kbeg_));       \
+    bp0 = piece_src<TB>(B, ldb, wave * 2 + 0, lane, (n0_), N, (kbeg_));       \
+    bp1 = piece_src<TB>(B, ldb, wave * 2 + 1, lane, (n0_), N, (kbeg_));       \
+  } while (0)
+#define ISSUE_H(P0, P1, OFF, REGION, buf)                                                     \
+  do {                                                                                        \
+    if (!do_dma) break;                                                                       \
+    dma16((P0) + (OFF), wdst + (buf) * STAGE_BYTES + (REGION) * HALF_BYTES);                  \
+    dma16((P1) + (OFF), wdst + (buf) * STAGE_BYTES + (REGION) * HALF_BYTES + 1024);           \
+  } while (0)
 #define MFMA(ACCV, AF, BF) \
-  if (!do_mfma) { asm volatile("" ::"v"(AF), "v"(BF)); } else ACCV = ACC ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, BF, ACCV, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF, AF, ACCV, 0, 0, 0)
+  if (!do_mfma) { asm volatile("" ::"v"(AF), "v"(BF)); } else ACCV = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF, AF, ACCV, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, BF, ACCV, 0, 0, 0)
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1, nbuf = buf ^ 1;
-    const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
-    const unsigned char* sA0 = smem + buf * STAGE_BYTES;
-    const unsigned char* sA1 = sA0 + HALF_BYTES;
-    const unsigned char* sB0 = sA0 + 2 * HALF_BYTES;
-    const unsigned char* sB1 = sA0 + 3 * HALF_BYTES;
-    bf16x8_t fa0[2][4], fa1[2][4], fb0[4], fb1[4];
-    if (!do_frag) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        fb0[s] = bf16x8_t{}; fb1[s] = bf16x8_t{}; fa0[0][s] = bf16x8_t{}; fa0[1][s] = bf16x8_t{}; fa1[0][s] = bf16x8_t{}; fa1[1][s] = bf16x8_t{};
-        asm volatile("" : "+v"(fb0[s]), "+v"(fb1[s]), "+v"(fa0[0][s]), "+v"(fa0[1][s]), "+v"(fa1[0][s]), "+v"(fa1[1][s]));
-      }
-    }
-
-    // ---- phase 1: quadrant (A0, B0)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) if (do_frag) fb0[s] = frag<TB>(sB0, br, s, lane);
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) if (do_frag) fa0[ii][s] = frag<TA>(sA0, ar + ii * 32, s, lane);
-    if (has1) { ISSUE_B1(nbuf); wait_vmcnt<8>(); } else { wait_vmcnt<2>(); }      // B1(kt) has landed
-    V4_BARRIER();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii) MFMA(acc[ii][0], fa0[ii][s], fb0[s]);
-    __builtin_amdgcn_s_setprio(0);
-    V4_BARRIER();
-
-    // ---- phase 2: quadrant (A0, B1)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) if (do_frag) fb1[s] = frag<TB>(sB1, br, s, lane);
-    if (has1) { ISSUE_A1(nbuf); wait_vmcnt<8>(); } else { wait_vmcnt<0>(); }      // A1(kt) has landed
-    V4_BARRIER();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii) MFMA(acc[ii][1], fa0[ii][s], fb1[s]);
-    __builtin_amdgcn_s_setprio(0);
-    V4_BARRIER();
-
-    // ---- phase 3: quadrant (A1, B1)
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) if (do_frag) fa1[ii][s] = frag<TA>(sA1, ar + ii * 32, s, lane);
-    if (has2) ISSUE_A0(buf);                                                      // A0(kt+2): A0(kt) was read in phase 1
-    V4_BARRIER();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii) MFMA(acc[2 + ii][1], fa1[ii][s], fb1[s]);
-    __builtin_amdgcn_s_setprio(0);
-    V4_BARRIER();
-
-    // ---- phase 4: quadrant (A1, B0); no fragment reads
-    if (has2) { ISSUE_B0(buf); wait_vmcnt<8>(); } else if (has1) { wait_vmcnt<4>(); }   // A0, B0 of tile kt+1 have landed
-    V4_BARRIER();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii) MFMA(acc[2 + ii][0], fa1[ii][s], fb0[s]);
-    __builtin_amdgcn_s_setprio(0);
-    V4_BARRIER();
+  int w = blockIdx.x;
+  int tile_x, tile_y, z;
+  item_coords(w, ntx, nty, tile_x, tile_y, z);
+  {   // first tile: the four half-tiles of its K-tile 0, in steady-state FIFO order
+    SETUP_SRC(tile_y * BM, tile_x * BN, z * k_per_split);
+    ISSUE_H(ap0, ap1, 0, 0, 0); ISSUE_H(bp0, bp1, 0, 2, 0); ISSUE_H(bp0, bp1, b_dh, 3, 0); ISSUE_H(ap0, ap1, a_dh, 1, 0);
   }
-  if (wm == 0) V4_BARRIER();             // re-align the two wave groups
-#undef MFMA
-#undef ISSUE_A0
-#undef ISSUE_A1
-#undef ISSUE_B0
-#undef ISSUE_B1
-
-  if (!do_epi) {
-    if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(e.C)[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7];
-    return;
+  if (STORE) {   // bias -> LDS once (no global load may sit between the epilogue stores of the persistent loop)
+    for (int q = t; q < N / 4; q += 512)
+      *reinterpret_cast<float4*>(smem + BIAS_OFF + 16 * q) = e.bias ? *reinterpret_cast<const float4*>(e.bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  if (ACC) {
-    // split-K / dW: atomics straight from the accumulators (lanes 0..31 = 32 consecutive floats of a row)
-    float* Cf = reinterpret_cast<float*>(e.C);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = m0 + i * 128 + ar + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int n = n0 + j * 128 + br + (lane & 31);
-            if (m < M && n < N) atomicAdd(Cf + (long)m * e.ldc + n, acc[i * 2 + ii][j][r] * e.alpha);
-          }
-    return;
-  }
+  int pend = 0;                      // epilogue stores of the previous tile that may still be in flight (per wave-instruction stream)
 
-  // ---- bf16 epilogue.  acc[i*2+ii][j] holds a C^T fragment: lane -> row m = (lane&31), registers 4*rg .. 4*rg+3
-  // -> 4 consecutive columns n = 8*rg + 4*(lane>>5) + {0..3}.  Staging tile: [256 rows][512 B], 8-byte unit u of
-  // row m stored at unit u ^ (m & 15)  (conflict-free ds_write_b64; ds_read_b128 sees whole 16-B chunks).
-  unsigned char* Cs = smem;
-  float4 bv[2][4];
+  for (; w < nitems; w += gridDim.x) {
+    const int m0 = tile_y * BM, n0 = tile_x * BN;
+    const int kbeg = z * k_per_split;
+    const int nk = (min(K, kbeg + k_per_split) - kbeg) / BK;      // host guarantees divisibility and nk >= 2
+    const int zcur = z;
+    const int txcur = tile_x;
+
+    f32x16_t acc[4][2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      bv[j][rg] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e.bias) {
-        int nb = n0 + j * 128 + br + 8 * rg + 4 * (lane >> 5);
-        nb = nb + 3 < N ? nb : 0;
-        bv[j][rg] = *reinterpret_cast<const float4*>(e.bias + nb);
-      }
-    }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      const int ml = i * 128 + ar + ii * 32 + (lane & 31);
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int nl = j * 128 + br + 8 * rg + 4 * (lane >> 5);
-          uint2 pk;
-          pk.x = pack2bf_hw(acc[i * 2 + ii][j][rg * 4 + 0] * e.alpha + bv[j][rg].x, acc[i * 2 + ii][j][rg * 4 + 1] * e.alpha + bv[j][rg].y);
-          pk.y = pack2bf_hw(acc[i * 2 + ii][j][rg * 4 + 2] * e.alpha + bv[j][rg].z, acc[i * 2 + ii][j][rg * 4 + 3] * e.alpha + bv[j][rg].w);
-          const int u = (nl >> 2) ^ (ml & 15);
-          *reinterpret_cast<uint2*>(Cs + ml * 512 + u * 8) = pk;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x16_t cs;                     // bias-gradient accumulator: column c = row-tile c of this wave (TA only)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cs[r] = 0.f;
+    const bool want_cs = TA && e.a_colsum != nullptr;
+    int cs_ctr = 0;                  // K-tiles with cs_ctr == tile_x contribute (spreads the extra MFMAs over the tile columns)
+
+    // ---- rest of the prologue: A0, B0 of K-tile 1 go to ring buffer 1 (free: every wave is past the epilogue)
+    ap0 += astep; ap1 += astep; bp0 += bstep; bp1 += bstep;
+    ISSUE_H(ap0, ap1, 0, 0, 1); ISSUE_H(bp0, bp1, 0, 2, 1);
+    wait_vmcnt_8_plus(pend);                 // A0, B0 of K-tile 0 have landed
+    V4_BARRIER();
+    if (wm == 1) V4_BARRIER();               // waves 4-7 run one barrier behind waves 0-3 from here on
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1, nbuf = buf ^ 1;
+      const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+      const int pk = kt == 0 ? pend : 0;     // K-tile 0 of a tile: the previous epilogue's stores sit between its loads
+      const unsigned char* sA0 = smem + buf * STAGE_BYTES;
+      const unsigned char* sA1 = sA0 + HALF_BYTES;
+      const unsigned char* sB0 = sA0 + 2 * HALF_BYTES;
+      const unsigned char* sB1 = sA0 + 3 * HALF_BYTES;
+      bf16x8_t fa0[2][4], fa1[2][4], fb0[4], fb1[4];
+      if (!do_frag) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          fb0[s] = bf16x8_t{}; fb1[s] = bf16x8_t{}; fa0[0][s] = bf16x8_t{}; fa0[1][s] = bf16x8_t{}; fa1[0][s] = bf16x8_t{}; fa1[1][s] = bf16x8_t{};
+          asm volatile("" : "+v"(fb0[s]), "+v"(fb1[s]), "+v"(fa0[0][s]), "+v"(fa0[1][s]), "+v"(fa1[0][s]), "+v"(fa1[1][s]));
         }
+      }
+      const bool cs_now = want_cs && cs_ctr == txcur;
+      cs_ctr = cs_ctr + 1 == ntx ? 0 : cs_ctr + 1;
+
+      // ---- phase 1: quadrant (A0, B0)
+      const uint32_t boff = buf * STAGE_BYTES;
+      if (do_frag) {
+        frag4<TB, 2>(fb0, bkm + boff, sB0, br, lane);
+        frag4<TA, 0>(fa0[0], akm0 + boff, sA0, ar, lane);
+        frag4<TA, 0>(fa0[1], akm1 + boff, sA0, ar + 32, lane);
+      }
+      if (has1) { ISSUE_H(bp0, bp1, b_dh, 3, nbuf); wait_vmcnt_8_plus(pk); } else { wait_vmcnt<2>(); }      // B1(kt) has landed
+      V4_BARRIER();
+      wait_lgkm0();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) MFMA(acc[ii][0], fa0[ii][s], fb0[s]);
+      __builtin_amdgcn_s_setprio(0);
+      V4_BARRIER();
+
+      // ---- phase 2: quadrant (A0, B1)
+      if (do_frag) frag4<TB, 3>(fb1, bkm + boff, sB1, br, lane);
+      if (has1) { ISSUE_H(ap0, ap1, a_dh, 1, nbuf); wait_vmcnt_8_plus(pk); } else { wait_vmcnt<0>(); }      // A1(kt) has landed
+      V4_BARRIER();
+      wait_lgkm0();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) MFMA(acc[ii][1], fa0[ii][s], fb1[s]);
+      if (TA && cs_now) {
+        // column sums of A rows (bias gradient): wave wn takes k16-step wn; indicator fragment = ones in column c
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const uint32_t one = ((lane & 31) == ii) ? 0x3f803f80u : 0u;
+          union { uint32_t u[4]; bf16x8_t v; } ind;
+          ind.u[0] = ind.u[1] = ind.u[2] = ind.u[3] = one;
+          const bf16x8_t af = wn == 0 ? fa0[ii][0] : wn == 1 ? fa0[ii][1] : wn == 2 ? fa0[ii][2] : fa0[ii][3];
+          cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ind.v, cs, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      V4_BARRIER();
+
+      // ---- phase 3: quadrant (A1, B1)
+      if (do_frag) {
+        frag4<TA, 1>(fa1[0], akm0 + boff, sA1, ar, lane);
+        frag4<TA, 1>(fa1[1], akm1 + boff, sA1, ar + 32, lane);
+      }
+      if (has2) ISSUE_H(ap0, ap1, astep, 0, buf);                                   // A0(kt+2): A0(kt) was read in phase 1
+      V4_BARRIER();
+      wait_lgkm0();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) MFMA(acc[2 + ii][1], fa1[ii][s], fb1[s]);
+      __builtin_amdgcn_s_setprio(0);
+      V4_BARRIER();
+
+      // ---- phase 4: quadrant (A1, B0); no fragment reads
+      if (has2) { ISSUE_H(bp0, bp1, bstep, 2, buf); wait_vmcnt<8>(); } else if (has1) { wait_vmcnt<4>(); }   // A0, B0 of tile kt+1 have landed
+      ap0 += astep; ap1 += astep; bp0 += bstep; bp1 += bstep;
+      V4_BARRIER();
+      wait_lgkm0();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) MFMA(acc[2 + ii][0], fa1[ii][s], fb0[s]);
+      if (TA && cs_now) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const uint32_t one = ((lane & 31) == 2 + ii) ? 0x3f803f80u : 0u;
+          union { uint32_t u[4]; bf16x8_t v; } ind;
+          ind.u[0] = ind.u[1] = ind.u[2] = ind.u[3] = one;
+          const bf16x8_t af = wn == 0 ? fa1[ii][0] : wn == 1 ? fa1[ii][1] : wn == 2 ? fa1[ii][2] : fa1[ii][3];
+          cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ind.v, cs, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      V4_BARRIER();
     }
-  __syncthreads();
-  {
-    const int cc = t & 31;                 // 16-byte chunk of the row (8 columns)
-    const int r0 = t >> 5;                 // 0..15
-    const int n = n0 + cc * 8;
-    bf16_t* Cb = reinterpret_cast<bf16_t*>(e.C);
-    if (n < N) {
-#pragma unroll 4
-      for (int it = 0; it < 16; ++it) {
-        const int row = r0 + 16 * it;
-        const int m = m0 + row;
-        if (m < M) {
-          const int pc = cc ^ ((row & 15) >> 1);
-          uint4 raw = *reinterpret_cast<const uint4*>(Cs + row * 512 + pc * 16);
-          if (row & 1) { uint32_t tx = raw.x, ty = raw.y; raw.x = raw.z; raw.y = raw.w; raw.z = tx; raw.w = ty; }
-          if (e.epilogue == DH_EPI_NONE && !e.residual) {
-            *reinterpret_cast<uint4*>(Cb + (long)m * e.ldc + n) = raw;
-          } else {
-            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-            float v[8];
+    if (wm == 0) V4_BARRIER();               // re-align the two wave groups; the whole ring is free from here
+
+    // ---- next work item: request the four half-tiles of its K-tile 0 into ring buffer 0 BEFORE the epilogue
+    const int wnext = w + gridDim.x;
+    if (wnext < nitems) {
+      item_coords(wnext, ntx, nty, tile_x, tile_y, z);
+      SETUP_SRC(tile_y * BM, tile_x * BN, z * k_per_split);
+      ISSUE_H(ap0, ap1, 0, 0, 0); ISSUE_H(bp0, bp1, 0, 2, 0); ISSUE_H(bp0, bp1, b_dh, 3, 0); ISSUE_H(ap0, ap1, a_dh, 1, 0);
+    }
+    pend = 0;
+    // the epilogue's per-lane indexing starts from an OPAQUE copy of the thread id: otherwise the compiler hoists ~30 loop-
+    // invariant address registers out of the persistent tile loop and keeps them live across the main loop (spills)
+    int te = t;
+    asm volatile("" : "+v"(te));
+    const int le = te & 63;
+    if (!do_epi) {
+      if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(e.C)[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7] + cs[2];
+      continue;
+    }
+
+    if (TA && want_cs) {
+      // cs: lane -> column c = lane & 31 (row-tile c = i*2+ii of this wave), register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5)
+      const int c = le & 31;
+      if (c < 4) {
+        const int mb = m0 + (c >> 1) * 128 + ar + (c & 1) * 32 + 4 * (le >> 5);
 #pragma unroll
-            for (int x = 0; x < 4; ++x) { v[2 * x] = __uint_as_float(w[x] << 16); v[2 * x + 1] = __uint_as_float(w[x] & 0xffff0000u); }
-            if (e.epilogue == DH_EPI_GELU) {
-              if (e.aux) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.aux) + (long)m * e.ldaux + n) = raw;
-#pragma unroll
-              for (int x = 0; x < 8; ++x) v[x] = quick_gelu_f(v[x]);
-            } else if (e.epilogue == DH_EPI_DGELU) {
-              float uu[8];
-              ld8(reinterpret_cast<const bf16_t*>(e.aux) + (long)m * e.ldaux + n, uu);
-#pragma unroll
-              for (int x = 0; x < 8; ++x) v[x] *= quick_gelu_grad_f(uu[x]);
-            }
-            if (e.residual) {
-              float rr[8];
-              ld8(reinterpret_cast<const bf16_t*>(e.residual) + (long)m * e.ldr + n, rr);
-#pragma unroll
-              for (int x = 0; x < 8; ++x) v[x] += rr[x];
-            }
-            st8_hw(Cb + (long)m * e.ldc + n, v);
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          atomicAdd(e.a_colsum + m, cs[r]);
         }
       }
     }
+
+    if (MODE == MODE_ATOMIC) {
+      // fp32 atomics straight from the accumulators (plain orientation: lanes 0..31 = 32 consecutive floats of a row)
+      float* Cf = reinterpret_cast<float*>(e.C);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = m0 + i * 128 + ar + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (le >> 5);
+              const int n = n0 + j * 128 + br + (le & 31);
+              atomicAdd(Cf + (long)m * e.ldc + n, acc[i * 2 + ii][j][r] * e.alpha);
+            }
+      wait_vmcnt<0>();                       // 128 atomics per lane cannot ride along: drain (also lands the next tile's loads)
+      V4_BARRIER();
+      continue;
+    }
+
+    unsigned char* Cs = smem + STAGE_BYTES;  // ring buffer 1 (buffer 0 is receiving the next tile)
+    if (MODE == MODE_PARTIAL) {
+      // fp32 partial tile -> ws[z][m][n].  4 passes of 64 rows: pass (i, ii) holds rows i*128 + wm*64 + ii*32 + 0..31 of both
+      // wave groups; staging row = wm*32 + (lane&31), 1024 B per row, 16-byte unit u of row r stored at unit u ^ (r & 7).
+      float* Wp = e.ws + (long)zcur * M * N;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int rl = wm * 32 + (le & 31);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int nl = j * 128 + br + 8 * rg + 4 * (le >> 5);
+              f32x4_t v;
+#pragma unroll
+              for (int x = 0; x < 4; ++x) v[x] = acc[i * 2 + ii][j][rg * 4 + x] * e.alpha;
+              *reinterpret_cast<f32x4_t*>(Cs + rl * 1024 + (((nl >> 2) ^ (rl & 7)) << 4)) = v;
+            }
+          wait_lgkm0();
+          V4_BARRIER();
+          {
+            const int c = te & 63;            // 16-byte unit of the row (4 columns)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+              const int rl2 = wave + 8 * it;                                       // staging row 0..63 (wave-uniform)
+              const long m = m0 + i * 128 + (rl2 >> 5) * 64 + ii * 32 + (rl2 & 31);
+              const f32x4_t v = *reinterpret_cast<const f32x4_t*>(Cs + rl2 * 1024 + ((c ^ (rl2 & 7)) << 4));
+              *reinterpret_cast<f32x4_t*>(reinterpret_cast<unsigned char*>(Wp + m * N + n0) + (uint32_t)(c * 16)) = v;
+            }
+          }
+          wait_lgkm0();
+          V4_BARRIER();
+        }
+      pend = 32;
+      continue;
+    }
+
+    // ---- MODE_STORE: bf16 epilogue.  acc[i*2+ii][j] holds a C^T fragment: lane -> row (lane&31), registers 4*rg .. 4*rg+3
+    // -> 4 consecutive columns 8*rg + 4*(lane>>5) + {0..3}.  Two passes (A-half i = rows i*128 ..): staging tile
+    // [128 rows][512 B] in ring buffer 1, 8-byte unit u of row r at unit u ^ (r & 15)  (conflict-free ds_write_b64;
+    // ds_read_b128 sees whole 16-byte chunks, halves swapped on odd rows).
+    {
+      const int cc = te & 31;                 // 16-byte chunk of the row (8 columns)
+      const int r0 = te >> 5;                 // 0..15
+      // every global access of the epilogue = wave-uniform row base (SGPRs) + one 32-bit per-lane byte offset: no
+      // per-row 64-bit address VGPRs (they would not fit beside the accumulators)
+      unsigned char* Cb = reinterpret_cast<unsigned char*>(e.C) + ((long)m0 * e.ldc + n0) * 2;
+      const uint32_t c_off = ((uint32_t)r0 * (uint32_t)e.ldc + cc * 8) * 2;
+      unsigned char* Xb = reinterpret_cast<unsigned char*>(e.aux) + ((long)m0 * e.ldaux + n0) * 2;
+      const uint32_t x_off = ((uint32_t)r0 * (uint32_t)e.ldaux + cc * 8) * 2;
+      const unsigned char* Rb = reinterpret_cast<const unsigned char*>(e.residual) + ((long)m0 * e.ldr + n0) * 2;
+      const uint32_t r_off = ((uint32_t)r0 * (uint32_t)e.ldr + cc * 8) * 2;
+      constexpr bool is_gelu = MODE == MODE_STORE_GELU, is_dgelu = MODE == MODE_STORE_DGELU;
+      // operands of the fused epilogue (dGELU pre-activation, or else the residual) are requested BEFORE any store of
+      // the tile: pass 0's before its staging, pass 1's right after pass 0's staging (its accumulators are dead by then)
+      constexpr bool has_pre = MODE == MODE_STORE_DGELU || MODE == MODE_STORE_RES;
+      const unsigned char* pre_base = is_dgelu ? Xb : Rb;
+      const uint32_t pre_off = is_dgelu ? x_off : r_off;
+      const long pre_ld = is_dgelu ? e.ldaux : e.ldr;
+      uint4 pre0[8], pre1[8];
+      if (has_pre) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pre0[q] = *reinterpret_cast<const uint4*>(pre_base + (long)(16 * q) * pre_ld * 2 + pre_off);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int ml = ar + ii * 32 + (le & 31);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int nl = j * 128 + br + 8 * rg + 4 * (le >> 5);
+              const float4 bq = *reinterpret_cast<const float4*>(smem + BIAS_OFF + 4 * (n0 + nl));
+              uint2 pk;
+              pk.x = pack2bf_hw(acc[i * 2 + ii][j][rg * 4 + 0] * e.alpha + bq.x, acc[i * 2 + ii][j][rg * 4 + 1] * e.alpha + bq.y);
+              pk.y = pack2bf_hw(acc[i * 2 + ii][j][rg * 4 + 2] * e.alpha + bq.z, acc[i * 2 + ii][j][rg * 4 + 3] * e.alpha + bq.w);
+              *reinterpret_cast<uint2*>(Cs + ml * 512 + (((nl >> 2) ^ (ml & 15)) << 3)) = pk;
+            }
+        }
+        if (i == 0 && has_pre) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) pre1[q] = *reinterpret_cast<const uint4*>(pre_base + (long)(128 + 16 * q) * pre_ld * 2 + pre_off);
+        }
+        wait_lgkm0();
+        V4_BARRIER();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = r0 + 16 * it;
+          const long mu = i * 128 + 16 * it;            // wave-uniform part of the row index (relative to m0)
+          const int pc = cc ^ ((row & 15) >> 1);
+          uint4 raw = *reinterpret_cast<const uint4*>(Cs + row * 512 + pc * 16);
+          if (row & 1) { uint32_t tx = raw.x, ty = raw.y; raw.x = raw.z; raw.y = raw.w; raw.z = tx; raw.w = ty; }
+          if (MODE == MODE_STORE) {
+            *reinterpret_cast<uint4*>(Cb + mu * e.ldc * 2 + c_off) = raw;
+          } else {
+            const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
+            float v[8];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { v[2 * x] = __uint_as_float(wv[x] << 16); v[2 * x + 1] = __uint_as_float(wv[x] & 0xffff0000u); }
+            if (is_gelu) {
+              *reinterpret_cast<uint4*>(Xb + mu * e.ldaux * 2 + x_off) = raw;
+#pragma unroll
+              for (int x = 0; x < 8; ++x) v[x] = quick_gelu_f(v[x]);
+            }
+            if (has_pre) {
+              const uint4 pr = i == 0 ? pre0[it] : pre1[it];
+              const uint32_t pw[4] = {pr.x, pr.y, pr.z, pr.w};
+              float pf[8];
+#pragma unroll
+              for (int x = 0; x < 4; ++x) { pf[2 * x] = __uint_as_float(pw[x] << 16); pf[2 * x + 1] = __uint_as_float(pw[x] & 0xffff0000u); }
+              if (is_dgelu) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) v[x] *= quick_gelu_grad_f(pf[x]);
+              } else {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) v[x] += pf[x];
+              }
+            }
+            st8_hw(reinterpret_cast<bf16_t*>(Cb + mu * e.ldc * 2 + c_off), v);
+          }
+        }
+        wait_lgkm0();
+        V4_BARRIER();                        // staging tile free again (next pass / the next tile's K-tile 1)
+      }
+      pend = is_gelu ? 32 : 16;
+    }
+  }
+#undef MFMA
+#undef ISSUE_H
+#undef SETUP_SRC
+}
+
+// out[m][n] (+)= sum_z ws[z][m][n]   (the split-K partial tiles of MODE_PARTIAL)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long ldo, int M,
+                                                            int N, int nsplit, int accumulate) {
+  const long n4 = (long)M * N / 4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long zs = (long)M * N;
+  const int nq = N / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int zz = 0;
+    for (; zz + 4 <= nsplit; zz += 4) {        // 4 independent loads in flight per thread
+      s0 += *reinterpret_cast<const f32x4_t*>(ws + (zz + 0) * zs + i * 4);
+      s1 += *reinterpret_cast<const f32x4_t*>(ws + (zz + 1) * zs + i * 4);
+      s2 += *reinterpret_cast<const f32x4_t*>(ws + (zz + 2) * zs + i * 4);
+      s3 += *reinterpret_cast<const f32x4_t*>(ws + (zz + 3) * zs + i * 4);
+    }
+    for (; zz < nsplit; ++zz) s0 += *reinterpret_cast<const f32x4_t*>(ws + zz * zs + i * 4);
+    f32x4_t s = (s0 + s1) + (s2 + s3);
+    const long m = i / nq, n = (i - m * nq) * 4;
+    f32x4_t* o = reinterpret_cast<f32x4_t*>(out + m * ldo + n);
+    if (accumulate) s += *o;
+    *o = s;
   }
 }
 
-template <bool TA, bool TB, bool ACC>
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    hipDeviceProp_t p;
+    n = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+template <bool TA, bool TB, int MODE>
 void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_v4_kernel<TA, TB, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_v4_kernel<TA, TB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  dim3 grid(dh_cdiv(a->N, BN), dh_cdiv(a->M, BM), split);
-  hipLaunchKernelGGL((gemm_v4_kernel<TA, TB, ACC>), grid, dim3(512), LDS_BYTES, st, (const bf16_t*)a->A, (long)a->lda,
-                     (const bf16_t*)a->B, (long)a->ldb, a->M, a->N, a->K, kps, e);
+  const int ntx = dh_cdiv(a->N, BN), nty = dh_cdiv(a->M, BM);
+  const int nitems = ntx * nty * split;
+  int grid = num_cus();
+  if (grid > nitems) grid = nitems;
+  hipLaunchKernelGGL((gemm_v4_kernel<TA, TB, MODE>), dim3(grid), dim3(512), LDS_BYTES, st, (const bf16_t*)a->A, (long)a->lda,
+                     (const bf16_t*)a->B, (long)a->ldb, a->M, a->N, a->K, kps, ntx, nty, nitems, e);
 }
 
 }  // namespace v4
@@ -386,40 +606,71 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
   if (mode == -2) { const char* ev = getenv("DH_GEMM_V4"); mode = ev ? atoi(ev) : -1; }
   if (mode == 0 && a->force_generic != 4) return false;
   if (a->dtype != DH_BF16) return false;
-  if (a->a_colsum) return false;
   if ((a->lda % 8) || (a->ldb % 8) || ((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15)) return false;
   if (a->K % BK) return false;
   // operand extents: the DMA reads whole 16-byte chunks; out-of-range rows/columns are clamped (their products
   // land in rows/columns that are never stored), but a contraction-major operand needs whole 8-element chunks
   if (a->a_kmajor && (a->M % 8)) return false;
   if (a->b_kmajor && (a->N % 8)) return false;
-  if (a->force_generic != 4 && (a->M < 256 || a->N < 256)) return false;
+  if ((a->M % BM) || (a->N % BN)) return false;   // whole tiles only (every tower shape at b = 256/512 is)
+  if (a->accumulate) {
+    // own split choice (the caller's split_k is sized for the 128 x 128 kernels): one work item per CU if K allows it,
+    // at most 32 slices (reduction traffic), at least 4 K-tiles per slice
+    const int tiles = dh_cdiv(a->N, BN) * dh_cdiv(a->M, BM);
+    int sp = num_cus() / tiles;
+    if (sp > 32) sp = 32;
+    if (sp > a->K / (4 * BK)) sp = a->K / (4 * BK);
+    if (sp < 1) sp = 1;
+    if (a->ws) while (sp > 1 && a->ws_bytes < (int64_t)sp * a->M * a->N * 4) --sp;
+    split = sp;
+  }
   int kps = ((a->K + split - 1) / split + BK - 1) / BK * BK;
+  if (kps < 2 * BK) kps = 2 * BK;                  // the pipeline wants >= 2 K-tiles per work item
+  if (a->K < 2 * BK) return false;
   split = (a->K + kps - 1) / kps;
-  if (!a->accumulate) {
+  if (a->K - (split - 1) * kps < 2 * BK) return false;   // short tail split
+  int md = MODE_STORE;
+  if (a->accumulate) {
+    if (!(a->a_kmajor && a->b_kmajor)) return false;           // only the dW layout is instantiated
+    md = MODE_ATOMIC;
+    // split-K through the workspace: partial tiles + one reduce pass
+    if (a->ws && split > 1 && (a->ldc % 4 == 0) && (((uintptr_t)a->C & 15) == 0) && (((uintptr_t)a->ws & 15) == 0) &&
+        a->ws_bytes >= (int64_t)split * a->M * a->N * 4)
+      md = MODE_PARTIAL;
+  } else {
+    if (a->a_kmajor || a->a_colsum) return false;
     if (a->c_dtype != DH_BF16) return false;
-    if (a->N % 8) return false;
     if (((uintptr_t)a->C & 15) || ((a->ldc * 2) & 15)) return false;
     if (a->residual && (((uintptr_t)a->residual & 15) || ((a->ldr * 2) & 15))) return false;
     if (a->aux && (((uintptr_t)a->aux & 15) || ((a->ldaux * 2) & 15))) return false;
     if (a->bias && ((uintptr_t)a->bias & 15)) return false;
+    if (a->N > MAX_BIAS_N) return false;
+    // instantiated flavours: forward (B = weight [N][K]): plain / GELU+aux / residual; dX (B contraction-major): plain / dGELU
+    if (a->epilogue == DH_EPI_GELU) { if (a->b_kmajor || a->residual || !a->aux) return false; md = MODE_STORE_GELU; }
+    else if (a->epilogue == DH_EPI_DGELU) { if (!a->b_kmajor || a->residual) return false; md = MODE_STORE_DGELU; }
+    else if (a->residual) { if (a->b_kmajor) return false; md = MODE_STORE_RES; }
   }
   EpiParams e;
   e.M = a->M; e.N = a->N; e.C = a->C; e.ldc = a->ldc; e.bias = a->bias; e.epilogue = a->epilogue;
   e.residual = a->residual; e.ldr = a->ldr; e.aux = a->aux; e.ldaux = a->ldaux; e.alpha = a->alpha;
   e.a_colsum = a->a_colsum;
-  static int delay = -1;
-  if (delay < 0) { const char* ev = getenv("DH_V4_DELAY"); delay = ev ? atoi(ev) : 0; }
-  e.delay = delay;
-#define V4_LAUNCH(TA, TB)                                                   \
-  do {                                                                      \
-    if (a->accumulate) launch<TA, TB, true>(a, e, split, kps, st);          \
-    else launch<TA, TB, false>(a, e, split, kps, st);                       \
-  } while (0)
-  if (a->a_kmajor && a->b_kmajor) V4_LAUNCH(true, true);
-  else if (a->a_kmajor) V4_LAUNCH(true, false);
-  else if (a->b_kmajor) V4_LAUNCH(false, true);
-  else V4_LAUNCH(false, false);
-#undef V4_LAUNCH
+  e.ws = (float*)a->ws;
+  switch (md) {
+    case MODE_ATOMIC: launch<true, true, MODE_ATOMIC>(a, e, split, kps, st); break;
+    case MODE_PARTIAL: launch<true, true, MODE_PARTIAL>(a, e, split, kps, st); break;
+    case MODE_STORE_GELU: launch<false, false, MODE_STORE_GELU>(a, e, split, kps, st); break;
+    case MODE_STORE_RES: launch<false, false, MODE_STORE_RES>(a, e, split, kps, st); break;
+    case MODE_STORE_DGELU: launch<false, true, MODE_STORE_DGELU>(a, e, split, kps, st); break;
+    default:
+      if (a->b_kmajor) launch<false, true, MODE_STORE>(a, e, split, kps, st);
+      else launch<false, false, MODE_STORE>(a, e, split, kps, st);
+  }
+  if (md == MODE_PARTIAL) {
+    const long n4 = (long)a->M * a->N / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a->ws, (float*)a->C, (long)a->ldc, a->M,
+                       a->N, split, 1);
+  }
   return true;
 }

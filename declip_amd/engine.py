@@ -181,11 +181,26 @@ def _split_k(mg, ng, kg):
     return s
 
 
+_GEMM_WS = {}
+
+
+def gemm_workspace(device, nbytes=128 << 20):
+    """Scratch for the split-K partial tiles of the weight-gradient GEMMs (one per device and stream; 128 MiB covers
+    32 slices of the largest tower weight)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _GEMM_WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+        _GEMM_WS[key] = ws
+    return ws
+
+
 def weight_grad(dy, x, gw, gb=None):
     """gw[out,in] += dy[rows,out]^T x[rows,in]  (contraction over rows: both operands k-major);
     gb[out] += colsum(dy) fused into the same launch (bias gradient)."""
+    ws = gemm_workspace(dy.device) if dy.is_cuda and dy.dtype == torch.bfloat16 else None
     ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=gw, accumulate=True,
-             split_k=_split_k(gw.shape[0], gw.shape[1], dy.shape[0]), a_colsum=gb)
+             split_k=_split_k(gw.shape[0], gw.shape[1], dy.shape[0]), a_colsum=gb, ws=ws)
 
 
 def block_fwd(x, r, b, L, heads, causal, save):

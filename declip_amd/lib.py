@@ -29,6 +29,7 @@ class GemmArgs(Structure):
         ("bias", c_void_p), ("epilogue", c_int), ("residual", c_void_p), ("ldr", c_int64),
         ("aux", c_void_p), ("ldaux", c_int64), ("accumulate", c_int), ("split_k", c_int), ("alpha", c_float),
         ("force_generic", c_int), ("a_colsum", c_void_p), ("pad_ok", c_int),
+        ("ws", c_void_p), ("ws_bytes", c_int64),
     ]
 
 

@@ -19,7 +19,7 @@ def _contig(t, name):
 
 def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, residual=None, aux=None,
          out=None, out_dtype=None, accumulate=False, split_k=1, alpha=1.0, force_generic=False, a_colsum=None,
-         pad_ok=False, dims=None):
+         pad_ok=False, dims=None, ws=None):
     """C[M,N] = epi(alpha * sum_k A(m,k) B(n,k) + bias).  A: [M,K] (or [K,M] if a_kmajor);
     B: [N,K] (or [K,N] if b_kmajor).  See include/declip_hip.h."""
     lib = L.load()
@@ -55,6 +55,8 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, 
         assert a_kmajor and a_colsum.dtype == torch.float32 and a_colsum.numel() == M
         a.a_colsum = ptr(a_colsum)
     a.pad_ok = int(pad_ok)
+    if ws is not None:              # caller scratch for the split-K partial tiles (v4 kernel)
+        a.ws, a.ws_bytes = ptr(ws), ws.numel() * ws.element_size()
     check(lib.dh_gemm(ctypes.byref(a), stream()), "dh_gemm")
     return out
 

@@ -82,6 +82,9 @@ typedef struct dh_gemm_args {
   float* a_colsum;       /* optional, a_kmajor only: a_colsum[m] += sum_k A(m,k) (bias gradient fused into dW) */
   int pad_ok;            /* caller guarantees operand rows are readable (finite) up to the next multiple of 8
                             elements / 128 rows beyond M,N: lifts the M%8 / N%8 conditions of the MFMA kernels */
+  void* ws; int64_t ws_bytes; /* optional caller scratch (16-B aligned).  With accumulate and split_k > 1 the v4 kernel writes fp32
+                            partial tiles [split][M][N] here and adds them into C with one reduce pass instead of fp32
+                            atomics from every split (needs split*M*N*4 bytes; ignored when too small or NULL) */
 } dh_gemm_args;
 int dh_gemm(const dh_gemm_args* args, dh_stream_t stream);
 

@@ -19,7 +19,7 @@ def _dgelu(x):
 
 
 def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, residual=None, aux=None, out=None,
-         out_dtype=None, accumulate=False, split_k=1, alpha=1.0, force_generic=False, a_colsum=None, pad_ok=False, dims=None):
+         out_dtype=None, accumulate=False, split_k=1, alpha=1.0, force_generic=False, a_colsum=None, pad_ok=False, dims=None, ws=None):
     a = A.float().t() if a_kmajor else A.float()
     b = B.float() if b_kmajor else B.float().t()
     if dims is not None:           # logical sizes inside padded buffers: crop / zero-extend like the kernels see them

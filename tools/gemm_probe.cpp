@@ -33,7 +33,8 @@ static float* rand_f32(size_t n, uint32_t seed) {
   return d;
 }
 
-struct Case { const char* name; int ta, tb, M, N, K; int epi; bool bias, res, acc; int split; };
+struct Case { const char* name; int ta, tb, M, N, K; int epi; bool bias, res, acc; int split; bool ws = false, cs = false; };
+static void* g_ws = nullptr; static size_t g_ws_bytes = 0; static float* g_cs = nullptr;
 
 static int run(const Case& c, int force, void* A, void* B, void* C, float* bias, void* res, void* aux) {
   dh_gemm_args g; memset(&g, 0, sizeof(g));
@@ -43,6 +44,8 @@ static int run(const Case& c, int force, void* A, void* B, void* C, float* bias,
   g.C = C; g.ldc = c.N; g.bias = c.bias ? bias : nullptr; g.epilogue = c.epi;
   g.residual = c.res ? res : nullptr; g.ldr = c.N; g.aux = c.epi ? aux : nullptr; g.ldaux = c.N;
   g.accumulate = c.acc; g.split_k = c.split; g.alpha = 1.f; g.force_generic = force; g.pad_ok = 0;
+  if (c.ws && force != 3) { g.ws = g_ws; g.ws_bytes = (int64_t)g_ws_bytes; }
+  if (c.cs) g.a_colsum = g_cs;
   int rc = dh_gemm(&g, nullptr);
   if (rc != DH_OK) printf("  dh_gemm(force=%d) failed: %s\n", force, dh_last_error());
   return rc;
@@ -79,11 +82,15 @@ int main(int argc, char** argv) {
   int iters = argc > 1 ? atoi(argv[1]) : 20;
   bool quick = argc > 2 && !strcmp(argv[2], "quick");
   // ---------------- correctness: v4 vs the VALU kernel on ragged problems, all layouts / epilogues
+  g_ws_bytes = 512u << 20; g_ws = dalloc(g_ws_bytes); g_cs = (float*)dalloc(8192 * 4);
   std::vector<Case> chk = {
-      {"chk.NT", 0, 0, 512, 512, 256, 0, true, false, false, 1},       {"chk.NT.gelu", 0, 0, 520, 776, 192, 1, true, false, false, 1},
-      {"chk.NT.res", 0, 0, 300, 264, 64, 0, true, true, false, 1},     {"chk.NN.dgelu", 0, 1, 776, 520, 320, 2, false, false, false, 1},
-      {"chk.NN", 0, 1, 1000, 512, 128, 0, false, false, false, 1},      {"chk.TT.acc", 1, 1, 512, 768, 1024, 0, false, false, true, 3},
-      {"chk.TT.acc1", 1, 1, 264, 520, 64, 0, false, false, true, 1},   {"chk.TN.acc", 1, 0, 512, 256, 512, 0, false, false, true, 2},
+      {"chk.NT", 0, 0, 512, 512, 256, 0, true, false, false, 1},       {"chk.NT.gelu", 0, 0, 512, 768, 192, 1, true, false, false, 1},
+      {"chk.NT.res", 0, 0, 256, 256, 128, 0, true, true, false, 1},    {"chk.NN.dgelu", 0, 1, 768, 512, 320, 2, false, false, false, 1},
+      {"chk.NN", 0, 1, 1024, 512, 128, 0, false, false, false, 1},      {"chk.NT.big", 0, 0, 2560, 1280, 704, 0, true, false, false, 1},
+      {"chk.NT.res.big", 0, 0, 2816, 768, 512, 0, true, true, false, 1}, {"chk.NT.gelu.big", 0, 0, 2048, 2048, 512, 1, true, false, false, 1},
+      {"chk.TT.acc", 1, 1, 512, 768, 1024, 0, false, false, true, 3},  {"chk.TT.acc1", 1, 1, 256, 512, 128, 0, false, false, true, 1},
+      {"chk.TT.ws", 1, 1, 512, 768, 1024, 0, false, false, true, 3, true, false}, {"chk.TT.ws.cs", 1, 1, 768, 512, 4096, 0, false, false, true, 5, true, true},
+      {"chk.TT.cs", 1, 1, 512, 1024, 1024, 0, false, false, true, 2, false, true},
   };
   int bad = 0;
   for (auto& c : chk) {
@@ -94,9 +101,20 @@ int main(int argc, char** argv) {
     void *C1 = dalloc(cb), *C2 = dalloc(cb), *X1 = dalloc(cn * 2), *X2 = dalloc(cn * 2);
     hipMemset(C1, 0, cb); hipMemset(C2, 0, cb);
     if (c.epi == 2) { hipMemcpy(X1, aux_in, cn * 2, hipMemcpyDeviceToDevice); hipMemcpy(X2, aux_in, cn * 2, hipMemcpyDeviceToDevice); }
+    std::vector<float> cs1(c.M, 0.f), cs2(c.M, 0.f);
+    hipMemset(g_cs, 0, 8192 * 4);
     int rc1 = run(c, 4, A, B, C1, bias, res, X1);
+    hipDeviceSynchronize();
+    if (c.cs) { hipMemcpy(cs1.data(), g_cs, c.M * 4, hipMemcpyDeviceToHost); hipMemset(g_cs, 0, 8192 * 4); }
     int rc2 = run(c, 1, A, B, C2, bias, res, X2);
     hipDeviceSynchronize();
+    if (c.cs) {
+      hipMemcpy(cs2.data(), g_cs, c.M * 4, hipMemcpyDeviceToHost);
+      double ce = 0, cm = 0;
+      for (int i = 0; i < c.M; ++i) { ce = fmax(ce, fabs((double)cs1[i] - cs2[i])); cm = fmax(cm, fabs((double)cs2[i])); }
+      printf("  colsum err %.3g (max %.3g)%s\n", ce, cm, ce <= 2e-3 * fmax(cm, 1.0) ? "" : "  <-- FAIL");
+      if (ce > 2e-3 * fmax(cm, 1.0)) ++bad;
+    }
     double rm, e = max_err(c, C1, C2, &rm);
     double tol = (c.acc ? 2e-3 : 1.6e-2) * fmax(rm, 1.0);
     bool ok = rc1 == 0 && rc2 == 0 && e <= tol;
@@ -138,8 +156,8 @@ int main(int argc, char** argv) {
       snprintf(names[ni], 32, "%s.%s.fwd", tw.n, l.n); cases.push_back({names[ni++], 0, 0, tw.rows, l.out, l.in, l.epi, true, l.res, false, 1});
       snprintf(names[ni], 32, "%s.%s.dX", tw.n, l.n);  cases.push_back({names[ni++], 0, 1, tw.rows, l.in, l.out, (l.epi == 0 && !strcmp(l.n, "proj")) ? 2 : 0, false, false, false, 1});
       int tiles = ((l.out + 255) / 256) * ((l.in + 255) / 256);
-      int split = 512 / tiles; if (split < 1) split = 1; if (split > tw.rows / 512) split = tw.rows / 512;
-      snprintf(names[ni], 32, "%s.%s.dW", tw.n, l.n);  cases.push_back({names[ni++], 1, 1, l.out, l.in, tw.rows, 0, false, false, true, split});
+      int split = 256 / tiles; if (split < 1) split = 1; if (split > tw.rows / 512) split = tw.rows / 512;
+      snprintf(names[ni], 32, "%s.%s.dW", tw.n, l.n);  cases.push_back({names[ni++], 1, 1, l.out, l.in, tw.rows, 0, false, false, true, split, true, true});
     }
   }
   size_t maxA = 0, maxC = 0;
