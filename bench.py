@@ -134,6 +134,7 @@ def main():
         # dominant kernel = the MFMA GEMM family: bracket every dh_gemm launch of 2 extra steps with
         # events on the launch stream; achieved = algorithmic 2*M*N*K flops / measured kernel time.
         records = []
+        gemm_bytes = []
         orig = ops.gemm
 
         def timed_gemm(A, B, **kw):
@@ -143,6 +144,15 @@ def main():
             e1.record()
             M, K = (A.shape[1], A.shape[0]) if kw.get("a_kmajor") else (A.shape[0], A.shape[1])
             N = B.shape[1] if kw.get("b_kmajor") else B.shape[0]
+            esz = A.element_size()
+            nbytes = (A.numel() + B.numel()) * esz + out.numel() * out.element_size()
+            if kw.get("aux") is not None:
+                nbytes += kw["aux"].numel() * kw["aux"].element_size()
+            if kw.get("residual") is not None:
+                nbytes += kw["residual"].numel() * kw["residual"].element_size()
+            if kw.get("accumulate"):
+                nbytes += out.numel() * out.element_size()          # read-modify-write of the gradient
+            gemm_bytes.append(nbytes)
             records.append((e0, e1, 2.0 * M * N * K, A.dtype,
                             (M, N, K, int(bool(kw.get("a_kmajor"))), int(bool(kw.get("b_kmajor"))), int(kw.get("epilogue", 0) or 0),
                              int(kw.get("residual") is not None), int(bool(kw.get("accumulate"))))))
@@ -172,8 +182,18 @@ def main():
                 fh.write("M N K ta tb epi res acc | calls/step  avg_us  TF/s  ms/step\n")
                 for k, (c, tms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                     fh.write("%6d %5d %6d %d %d %d %d %d | %4d %8.1f %6.0f %7.3f\n" % (k + (c // nprof, tms / c * 1e3, fl / tms / 1e9, tms / nprof)))
-        roofline = dict(bound="mfma", kernel="gemm_mfma_kernel (all tower GEMMs of a step)", achieved=round(achieved, 2),
-                        peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
+        # HBM-side traffic of the same kernels from the rocprofv3 PMC passes of tools/profile_step.sh (committed summary):
+        # per-launch average next to the algorithmic bytes per launch (operands once + outputs once)
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s_b%d.json" % (args.model, b))
+        if os.path.exists(pmc_file):
+            with open(pmc_file) as fh:
+                pm = json.load(fh)
+            traffic = round((pm["gemm_read_bytes_per_step"] + pm["gemm_write_bytes_per_step"]) / max(pm["gemm_launches_per_step"], 1), 1)
+        roofline = dict(bound="mfma", kernel="v4::gemm_v4_kernel family (every tower GEMM of a step: fwd, dX, dW)", achieved=round(achieved, 2),
+                        peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic,
+                        traffic_unit="bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE; profiles/r01_v4_pmc_summary.txt)",
+                        algorithmic_bytes_per_launch=round(sum(gemm_bytes) / max(len(gemm_bytes), 1), 1),
                         launches_per_step=len(records) // nprof, gemm_ms_per_step=round(ms / nprof, 3),
                         gemm_gflop_per_step=round(flops / nprof / 1e9, 1),
                         step_mfma_frac=round(pairs_per_s * (GFLOP_PER_PAIR if args.model == "clip" else 89.9) / 1e3 / (PEAK_BF16_TFLOPS * world), 4))

@@ -41,6 +41,16 @@
 #define V4_ABL 0
 #endif
 
+#ifndef V4_TRACE
+#define V4_TRACE 0
+#endif
+#if V4_TRACE
+// tuning aid (-DV4_TRACE=1): s_memtime stamps of workgroups 0 / 100 / 200, waves 0 and 4, read back with dh_v4_trace_read
+__device__ long v4_trace_buf[6 * 256];
+extern "C" int dh_v4_trace_read(long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(v4_trace_buf), sizeof(long) * n); }
+extern "C" int dh_v4_trace_clear() { static long z[6 * 256]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(v4_trace_buf), z, sizeof(z)); }
+#endif
+
 namespace v4 {
 
 struct EpiParams {
@@ -170,13 +180,19 @@ __device__ __forceinline__ void item_coords(int w, int ntx, int nty, int& tile_x
   tile_x = rem / gsz;
 }
 
-template <bool TA, bool TB, int MODE>
+template <bool TA, bool TB, int MODE, bool ROLES>
 __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                          long ldb, int M, int N, int K, int k_per_split, int ntx, int nty,
                                                          int nitems, EpiParams e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool SWAP = MODE != MODE_ATOMIC;
-  constexpr bool STORE = MODE <= MODE_STORE_RES;   // acc holds C^T fragments (lane = row, 4 consecutive columns per register group)
+  constexpr bool STORE = MODE <= MODE_STORE_RES;
+  // ROLES: waves 4-7 issue ALL LDS-DMA and never store; waves 0-3 do all global stores of the epilogue and never wait on
+  // vmcnt in the main loop.  A wave's vmcnt retires in order, so a wave with epilogue stores in flight cannot wait for a
+  // younger load without also waiting for those stores to reach HBM; with the roles split the stores of tile i drain during
+  // the whole main loop of tile i+1.
+  constexpr int NP = ROLES ? 4 : 2;              // 1-KiB pieces of a half-tile per issuing wave
+  constexpr int WF = ROLES ? 2 : 1;              // vmcnt ops per half-tile relative to the 2-piece scheme   // acc holds C^T fragments (lane = row, 4 consecutive columns per register group)
   // compile-time ablation (tuning aid: -DV4_ABL=mask; 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no epilogue)
   constexpr bool do_dma = !(V4_ABL & 1), do_mfma = !(V4_ABL & 2), do_frag = !(V4_ABL & 4), do_epi = !(V4_ABL & 8);
   const int t = threadIdx.x;
@@ -184,7 +200,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int ar = wm * 64, br = wn * 32;             // this wave's rows inside an A half / columns inside a B half
-  unsigned char* const wdst = smem + wave * 2048;   // this wave's 2 KiB slice of a half-tile
+  const bool issuer = !ROLES || wm == 1;
+  unsigned char* const wdst = smem + (ROLES ? (wave & 3) * 4096 : wave * 2048);   // this wave's slice of a half-tile
   const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
   const uint32_t akm0 = lds0 + kmajor_lane_off(ar, lane), akm1 = lds0 + kmajor_lane_off(ar + 32, lane), bkm = lds0 + kmajor_lane_off(br, lane);
   const long astep = TA ? (long)BK * lda : BK;
@@ -196,29 +213,43 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
   // are issued there).
   const long a_dh = TA ? 128 : 128 * lda;
   const long b_dh = TB ? 128 : 128 * ldb;
-  const bf16_t *ap0, *ap1, *bp0, *bp1;
-#define SETUP_SRC(m0_, n0_, kbeg_)                                          \
-  do {                                                                      \
-    ap0 = piece_src<TA>(A, lda, wave * 2 + 0, lane, (m0_), M, (kbeg_));       \
-    ap1 = piece_src<TA>(A, lda, wave * 2 + 1, lane, (m0_), M, (kbeg_));       \
-    bp0 = piece_src<TB>(B, ldb, wave * 2 + 0, lane, (n0_), N, (kbeg_));       \
-    bp1 = piece_src<TB>(B, ldb, wave * 2 + 1, lane, (n0_), N, (kbeg_));       \
-  } while (0)
-#define ISSUE_H(P0, P1, OFF, REGION, buf)                                                     \
+  const bf16_t *ap[NP], *bp[NP];
+#define SETUP_SRC(m0_, n0_, kbeg_)                                                            \
   do {                                                                                        \
-    if (!do_dma) break;                                                                       \
-    dma16((P0) + (OFF), wdst + (buf) * STAGE_BYTES + (REGION) * HALF_BYTES);                  \
-    dma16((P1) + (OFF), wdst + (buf) * STAGE_BYTES + (REGION) * HALF_BYTES + 1024);           \
+    _Pragma("unroll") for (int q = 0; q < NP; ++q) {                                          \
+      ap[q] = piece_src<TA>(A, lda, (ROLES ? (wave & 3) * 4 : wave * 2) + q, lane, (m0_), M, (kbeg_)); \
+      bp[q] = piece_src<TB>(B, ldb, (ROLES ? (wave & 3) * 4 : wave * 2) + q, lane, (n0_), N, (kbeg_)); \
+    }                                                                                         \
   } while (0)
+#define ISSUE_H(P, OFF, REGION, buf)                                                          \
+  do {                                                                                        \
+    if (!do_dma || !issuer) break;                                                            \
+    _Pragma("unroll") for (int q = 0; q < NP; ++q)                                            \
+      dma16((P)[q] + (OFF), wdst + (buf) * STAGE_BYTES + (REGION) * HALF_BYTES + q * 1024);   \
+  } while (0)
+#define ADVANCE_SRC()                                                                         \
+  do {                                                                                        \
+    _Pragma("unroll") for (int q = 0; q < NP; ++q) { ap[q] += astep; bp[q] += bstep; }        \
+  } while (0)
+#define WAITV(N) do { if (issuer) wait_vmcnt<(N) * WF>(); } while (0)
 #define MFMA(ACCV, AF, BF) \
   if (!do_mfma) { asm volatile("" ::"v"(AF), "v"(BF)); } else ACCV = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF, AF, ACCV, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, BF, ACCV, 0, 0, 0)
 
+#if V4_TRACE
+  const int trace_slot = (blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : blockIdx.x == 200 ? 2 : -1);
+  const bool tracing = trace_slot >= 0 && (t == 0 || t == 256);
+  long* trace_p = v4_trace_buf + (trace_slot * 2 + (t >> 8)) * 256;
+  int trace_n = 0;
+#define TRACE() do { if (tracing && trace_n < 255) trace_p[1 + trace_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TRACE() do { } while (0)
+#endif
   int w = blockIdx.x;
   int tile_x, tile_y, z;
   item_coords(w, ntx, nty, tile_x, tile_y, z);
   {   // first tile: the four half-tiles of its K-tile 0, in steady-state FIFO order
     SETUP_SRC(tile_y * BM, tile_x * BN, z * k_per_split);
-    ISSUE_H(ap0, ap1, 0, 0, 0); ISSUE_H(bp0, bp1, 0, 2, 0); ISSUE_H(bp0, bp1, b_dh, 3, 0); ISSUE_H(ap0, ap1, a_dh, 1, 0);
+    ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, b_dh, 3, 0); ISSUE_H(ap, a_dh, 1, 0);
   }
   if (STORE) {   // bias -> LDS once (no global load may sit between the epilogue stores of the persistent loop)
     for (int q = t; q < N / 4; q += 512)
@@ -247,10 +278,11 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
     int cs_ctr = 0;                  // K-tiles with cs_ctr == tile_x contribute (spreads the extra MFMAs over the tile columns)
 
     // ---- rest of the prologue: A0, B0 of K-tile 1 go to ring buffer 1 (free: every wave is past the epilogue)
-    ap0 += astep; ap1 += astep; bp0 += bstep; bp1 += bstep;
-    ISSUE_H(ap0, ap1, 0, 0, 1); ISSUE_H(bp0, bp1, 0, 2, 1);
-    wait_vmcnt_8_plus(pend);                 // A0, B0 of K-tile 0 have landed
+    ADVANCE_SRC();
+    ISSUE_H(ap, 0, 0, 1); ISSUE_H(bp, 0, 2, 1);
+    if (ROLES) WAITV(8); else wait_vmcnt_8_plus(pend);     // A0, B0 of K-tile 0 have landed
     V4_BARRIER();
+    TRACE();                                 // [0] prologue done
     if (wm == 1) V4_BARRIER();               // waves 4-7 run one barrier behind waves 0-3 from here on
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -279,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
         frag4<TA, 0>(fa0[0], akm0 + boff, sA0, ar, lane);
         frag4<TA, 0>(fa0[1], akm1 + boff, sA0, ar + 32, lane);
       }
-      if (has1) { ISSUE_H(bp0, bp1, b_dh, 3, nbuf); wait_vmcnt_8_plus(pk); } else { wait_vmcnt<2>(); }      // B1(kt) has landed
+      if (has1) { ISSUE_H(bp, b_dh, 3, nbuf); if (ROLES) WAITV(8); else wait_vmcnt_8_plus(pk); } else { WAITV(2); }      // B1(kt) has landed
       V4_BARRIER();
       wait_lgkm0();
       __builtin_amdgcn_sched_barrier(0);
@@ -293,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
 
       // ---- phase 2: quadrant (A0, B1)
       if (do_frag) frag4<TB, 3>(fb1, bkm + boff, sB1, br, lane);
-      if (has1) { ISSUE_H(ap0, ap1, a_dh, 1, nbuf); wait_vmcnt_8_plus(pk); } else { wait_vmcnt<0>(); }      // A1(kt) has landed
+      if (has1) { ISSUE_H(ap, a_dh, 1, nbuf); if (ROLES) WAITV(8); else wait_vmcnt_8_plus(pk); } else { WAITV(0); }      // A1(kt) has landed
       V4_BARRIER();
       wait_lgkm0();
       __builtin_amdgcn_sched_barrier(0);
@@ -321,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
         frag4<TA, 1>(fa1[0], akm0 + boff, sA1, ar, lane);
         frag4<TA, 1>(fa1[1], akm1 + boff, sA1, ar + 32, lane);
       }
-      if (has2) ISSUE_H(ap0, ap1, astep, 0, buf);                                   // A0(kt+2): A0(kt) was read in phase 1
+      if (has2) ISSUE_H(ap, astep, 0, buf);                                   // A0(kt+2): A0(kt) was read in phase 1
       V4_BARRIER();
       wait_lgkm0();
       __builtin_amdgcn_sched_barrier(0);
@@ -334,8 +366,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
       V4_BARRIER();
 
       // ---- phase 4: quadrant (A1, B0); no fragment reads
-      if (has2) { ISSUE_H(bp0, bp1, bstep, 2, buf); wait_vmcnt<8>(); } else if (has1) { wait_vmcnt<4>(); }   // A0, B0 of tile kt+1 have landed
-      ap0 += astep; ap1 += astep; bp0 += bstep; bp1 += bstep;
+      if (has2) { ISSUE_H(bp, bstep, 2, buf); WAITV(8); } else if (has1) { WAITV(4); }   // A0, B0 of tile kt+1 have landed
+      ADVANCE_SRC();
       V4_BARRIER();
       wait_lgkm0();
       __builtin_amdgcn_sched_barrier(0);
@@ -358,14 +390,16 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
       V4_BARRIER();
     }
     if (wm == 0) V4_BARRIER();               // re-align the two wave groups; the whole ring is free from here
+    TRACE();                                 // [1] main loop done
 
     // ---- next work item: request the four half-tiles of its K-tile 0 into ring buffer 0 BEFORE the epilogue
     const int wnext = w + gridDim.x;
     if (wnext < nitems) {
       item_coords(wnext, ntx, nty, tile_x, tile_y, z);
       SETUP_SRC(tile_y * BM, tile_x * BN, z * k_per_split);
-      ISSUE_H(ap0, ap1, 0, 0, 0); ISSUE_H(bp0, bp1, 0, 2, 0); ISSUE_H(bp0, bp1, b_dh, 3, 0); ISSUE_H(ap0, ap1, a_dh, 1, 0);
+      ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, b_dh, 3, 0); ISSUE_H(ap, a_dh, 1, 0);
     }
+    TRACE();                                 // [2] next tile requested
     pend = 0;
     // the epilogue's per-lane indexing starts from an OPAQUE copy of the thread id: otherwise the compiler hoists ~30 loop-
     // invariant address registers out of the persistent tile loop and keeps them live across the main loop (spills)
@@ -454,8 +488,10 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
     // [128 rows][512 B] in ring buffer 1, 8-byte unit u of row r at unit u ^ (r & 15)  (conflict-free ds_write_b64;
     // ds_read_b128 sees whole 16-byte chunks, halves swapped on odd rows).
     {
+      constexpr int RSTEP = ROLES ? 8 : 16, NIT = ROLES ? 16 : 8;   // ROLES: only waves 0-3 read back and store
+      const bool storer = !ROLES || wm == 0;
       const int cc = te & 31;                 // 16-byte chunk of the row (8 columns)
-      const int r0 = te >> 5;                 // 0..15
+      const int r0 = ROLES ? ((te >> 5) & 7) : (te >> 5);
       // every global access of the epilogue = wave-uniform row base (SGPRs) + one 32-bit per-lane byte offset: no
       // per-row 64-bit address VGPRs (they would not fit beside the accumulators)
       unsigned char* Cb = reinterpret_cast<unsigned char*>(e.C) + ((long)m0 * e.ldc + n0) * 2;
@@ -471,6 +507,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
       const unsigned char* pre_base = is_dgelu ? Xb : Rb;
       const uint32_t pre_off = is_dgelu ? x_off : r_off;
       const long pre_ld = is_dgelu ? e.ldaux : e.ldr;
+      static_assert(!(ROLES && (MODE == MODE_STORE_DGELU || MODE == MODE_STORE_RES)), "ROLES: plain / GELU epilogues only");
       uint4 pre0[8], pre1[8];
       if (has_pre) {
 #pragma unroll
@@ -499,10 +536,12 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
         }
         wait_lgkm0();
         V4_BARRIER();
+        TRACE();                             // [3],[5] pass staged
+        if (storer) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-          const int row = r0 + 16 * it;
-          const long mu = i * 128 + 16 * it;            // wave-uniform part of the row index (relative to m0)
+        for (int it = 0; it < NIT; ++it) {
+          const int row = r0 + RSTEP * it;
+          const long mu = i * 128 + RSTEP * it;         // wave-uniform part of the row index (relative to m0)
           const int pc = cc ^ ((row & 15) >> 1);
           uint4 raw = *reinterpret_cast<const uint4*>(Cs + row * 512 + pc * 16);
           if (row & 1) { uint32_t tx = raw.x, ty = raw.y; raw.x = raw.z; raw.y = raw.w; raw.z = tx; raw.w = ty; }
@@ -535,15 +574,23 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
             st8_hw(reinterpret_cast<bf16_t*>(Cb + mu * e.ldc * 2 + c_off), v);
           }
         }
+        }
         wait_lgkm0();
         V4_BARRIER();                        // staging tile free again (next pass / the next tile's K-tile 1)
+        TRACE();                             // [4],[6] pass stored
       }
-      pend = is_gelu ? 32 : 16;
+      pend = ROLES ? 0 : (is_gelu ? 32 : 16);
     }
   }
+#if V4_TRACE
+  if (tracing) trace_p[0] = trace_n;
+#endif
 #undef MFMA
+#undef TRACE
 #undef ISSUE_H
 #undef SETUP_SRC
+#undef ADVANCE_SRC
+#undef WAITV
 }
 
 // out[m][n] (+)= sum_z ws[z][m][n]   (the split-K partial tiles of MODE_PARTIAL)
@@ -582,18 +629,18 @@ static int num_cus() {
   return n;
 }
 
-template <bool TA, bool TB, int MODE>
+template <bool TA, bool TB, int MODE, bool ROLES>
 void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_v4_kernel<TA, TB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_v4_kernel<TA, TB, MODE, ROLES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   const int ntx = dh_cdiv(a->N, BN), nty = dh_cdiv(a->M, BM);
   const int nitems = ntx * nty * split;
   int grid = num_cus();
   if (grid > nitems) grid = nitems;
-  hipLaunchKernelGGL((gemm_v4_kernel<TA, TB, MODE>), dim3(grid), dim3(512), LDS_BYTES, st, (const bf16_t*)a->A, (long)a->lda,
+  hipLaunchKernelGGL((gemm_v4_kernel<TA, TB, MODE, ROLES>), dim3(grid), dim3(512), LDS_BYTES, st, (const bf16_t*)a->A, (long)a->lda,
                      (const bf16_t*)a->B, (long)a->ldb, a->M, a->N, a->K, kps, ntx, nty, nitems, e);
 }
 
@@ -655,15 +702,25 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
   e.residual = a->residual; e.ldr = a->ldr; e.aux = a->aux; e.ldaux = a->ldaux; e.alpha = a->alpha;
   e.a_colsum = a->a_colsum;
   e.ws = (float*)a->ws;
+  static int roles = -1;                         // DH_V4_ROLES=0: every wave loads and stores (the widened-wait scheme)
+  if (roles < 0) { const char* ev = getenv("DH_V4_ROLES"); roles = ev ? atoi(ev) : 1; }
   switch (md) {
-    case MODE_ATOMIC: launch<true, true, MODE_ATOMIC>(a, e, split, kps, st); break;
-    case MODE_PARTIAL: launch<true, true, MODE_PARTIAL>(a, e, split, kps, st); break;
-    case MODE_STORE_GELU: launch<false, false, MODE_STORE_GELU>(a, e, split, kps, st); break;
-    case MODE_STORE_RES: launch<false, false, MODE_STORE_RES>(a, e, split, kps, st); break;
-    case MODE_STORE_DGELU: launch<false, true, MODE_STORE_DGELU>(a, e, split, kps, st); break;
+    case MODE_ATOMIC: launch<true, true, MODE_ATOMIC, false>(a, e, split, kps, st); break;
+    case MODE_PARTIAL: launch<true, true, MODE_PARTIAL, false>(a, e, split, kps, st); break;
+    case MODE_STORE_GELU:
+      if (roles) launch<false, false, MODE_STORE_GELU, true>(a, e, split, kps, st);
+      else launch<false, false, MODE_STORE_GELU, false>(a, e, split, kps, st);
+      break;
+    case MODE_STORE_RES: launch<false, false, MODE_STORE_RES, false>(a, e, split, kps, st); break;
+    case MODE_STORE_DGELU: launch<false, true, MODE_STORE_DGELU, false>(a, e, split, kps, st); break;
     default:
-      if (a->b_kmajor) launch<false, true, MODE_STORE>(a, e, split, kps, st);
-      else launch<false, false, MODE_STORE>(a, e, split, kps, st);
+      if (a->b_kmajor) {
+        if (roles) launch<false, true, MODE_STORE, true>(a, e, split, kps, st);
+        else launch<false, true, MODE_STORE, false>(a, e, split, kps, st);
+      } else {
+        if (roles) launch<false, false, MODE_STORE, true>(a, e, split, kps, st);
+        else launch<false, false, MODE_STORE, false>(a, e, split, kps, st);
+      }
   }
   if (md == MODE_PARTIAL) {
     const long n4 = (long)a->M * a->N / 4;

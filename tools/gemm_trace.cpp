@@ -1,0 +1,47 @@
+// Timeline of one v4 GEMM launch (trace build of the library: tools/build_trace.sh):
+//   LD_LIBRARY_PATH=build/trace tools/gemm_trace M N K epi(0 none,1 gelu)
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "declip_hip.h"
+int main(int argc, char** argv) {
+  int M = argc > 1 ? atoi(argv[1]) : 25600, N = argc > 2 ? atoi(argv[2]) : 2304, K = argc > 3 ? atoi(argv[3]) : 768, epi = argc > 4 ? atoi(argv[4]) : 0;
+  void* h = dlopen("libdeclip_hip.so", RTLD_NOW | RTLD_GLOBAL);
+  auto rd = (int (*)(long*, int))dlsym(h, "dh_v4_trace_read");
+  auto clr = (int (*)())dlsym(h, "dh_v4_trace_clear");
+  if (!rd || !clr) { printf("not a trace build\n"); return 1; }
+  void *A, *B, *C, *X; float* bias;
+  hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 2); hipMalloc(&X, (size_t)M * N * 2); hipMalloc(&bias, N * 4);
+  std::vector<uint16_t> hb((size_t)M * K);
+  uint32_t s = 1; for (auto& v : hb) { s = s * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 + ((s >> 9) & 0x3ff) + ((s >> 31) << 15)); }
+  hipMemcpy(A, hb.data(), (size_t)M * K * 2, hipMemcpyHostToDevice);
+  hipMemcpy(B, hb.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
+  hipMemset(bias, 0, N * 4);
+  dh_gemm_args g; memset(&g, 0, sizeof(g));
+  g.dtype = DH_BF16; g.c_dtype = DH_BF16; g.M = M; g.N = N; g.K = K; g.A = A; g.lda = K; g.B = B; g.ldb = K; g.C = C; g.ldc = N;
+  g.bias = bias; g.epilogue = epi; g.aux = epi ? X : nullptr; g.ldaux = N; g.alpha = 1.f; g.force_generic = 4; g.split_k = 1;
+  for (int i = 0; i < 200; ++i) dh_gemm(&g, nullptr);     // warm clocks
+  hipDeviceSynchronize();
+  clr();
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0); dh_gemm(&g, nullptr); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("M=%d N=%d K=%d epi=%d: %.1f us\n", M, N, K, epi, ms * 1e3);
+  std::vector<long> tb(6 * 256);
+  rd(tb.data(), 6 * 256);
+  const char* names[7] = {"prologue->", "mainloop", "req-next", "stage0", "store0", "stage1", "store1"};
+  for (int slot = 0; slot < 6; ++slot) {
+    long* p = tb.data() + slot * 256; int n = (int)p[0];
+    printf("WG %d wave %d: %d stamps; per tile [cycles]: ", slot / 2 == 0 ? 0 : slot / 2 == 1 ? 100 : 200, (slot & 1) * 4, n);
+    for (int i = 0; i + 6 < n; i += 7) {
+      printf("\n   tile %d: t0=%ld |", i / 7, p[1 + i] - p[1]);
+      for (int j = 1; j < 7; ++j) printf(" %s %ld", names[j], p[1 + i + j] - p[1 + i + j - 1]);
+      if (i + 7 < n) printf(" | next prologue %ld", p[1 + i + 7] - p[1 + i + 6]);
+    }
+    printf("\n");
+  }
+  return 0;
+}
