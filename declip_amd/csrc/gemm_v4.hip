@@ -63,6 +63,7 @@ struct EpiParams {
   float alpha;
   float* a_colsum;
   float* ws;          // MODE_PARTIAL: [nsplit][M][N] fp32
+  float* ws_cs;       // MODE_PARTIAL + a_colsum: [nsplit][ntx][M] fp32 bias-gradient partials
 };
 
 constexpr int BM = 256, BN = 256, BK = 64;
@@ -164,18 +165,21 @@ __device__ __forceinline__ const bf16_t* piece_src(const bf16_t* P, long ld, int
 // work item w -> (tile_x, tile_y, split z).  Items with the same z are consecutive (they share A/B panels); inside
 // a split the tile order is XCD-aware (workgroup p and all its items w = p + i*grid sit on XCD p % 8 when the grid
 // is a multiple of 8) and grouped so that the tiles an XCD runs concurrently share A and B panels in its 4 MiB L2.
-__device__ __forceinline__ void item_coords(int w, int ntx, int nty, int& tile_x, int& tile_y, int& z) {
-  const int nb = ntx * nty;
-  z = w / nb;
-  const int b = w - z * nb;
-  const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+__device__ __forceinline__ void item_coords(int w, int ntx, int nty, int nitems, int& tile_x, int& tile_y, int& z) {
+  // XCD x (workgroups w = x mod 8) walks a CONTIGUOUS chunk of the (split, tile) list: the ~32 items it runs at a time are
+  // (almost) all the tiles of one K-slice, so every A / B panel it streams is shared by several of its CUs through its L2
+  // (with the slices dealt round-robin to the XCDs, PMC showed a 32 % L2 hit rate and ~6 TB/s of fabric reads on the dW calls)
+  const int q = nitems >> 3, r = nitems & 7, xcd = w & 7, idx = w >> 3;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int nb = ntx * nty;
+  z = logical / nb;
+  const int b = logical - z * nb;
   constexpr int GROUP_M = 8;
   const int in_group = GROUP_M * ntx;
-  const int gid = logical / in_group;
+  const int gid = b / in_group;
   const int first_m = gid * GROUP_M;
   const int gsz = min(nty - first_m, GROUP_M);
-  const int rem = logical - gid * in_group;
+  const int rem = b - gid * in_group;
   tile_y = first_m + rem % gsz;
   tile_x = rem / gsz;
 }
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
 #endif
   int w = blockIdx.x;
   int tile_x, tile_y, z;
-  item_coords(w, ntx, nty, tile_x, tile_y, z);
+  item_coords(w, ntx, nty, nitems, tile_x, tile_y, z);
   {   // first tile: the four half-tiles of its K-tile 0, in steady-state FIFO order
     SETUP_SRC(tile_y * BM, tile_x * BN, z * k_per_split);
     ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, b_dh, 3, 0); ISSUE_H(ap, a_dh, 1, 0);
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
     // ---- next work item: request the four half-tiles of its K-tile 0 into ring buffer 0 BEFORE the epilogue
     const int wnext = w + gridDim.x;
     if (wnext < nitems) {
-      item_coords(wnext, ntx, nty, tile_x, tile_y, z);
+      item_coords(wnext, ntx, nty, nitems, tile_x, tile_y, z);
       SETUP_SRC(tile_y * BM, tile_x * BN, z * k_per_split);
       ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, b_dh, 3, 0); ISSUE_H(ap, a_dh, 1, 0);
     }
@@ -412,16 +416,26 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
     }
 
     if (TA && want_cs) {
-      // cs: lane -> column c = lane & 31 (row-tile c = i*2+ii of this wave), register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5)
+      // cs: lane -> column c = lane & 31 (row-tile c = i*2+ii of this wave), register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5).
+      // The four wn-waves of a row hold partial sums over different k16-steps: reduce them through LDS (the bias area, unused
+      // here), then one value per row leaves the workgroup -- to its workspace slot (summed by the reduce pass: no atomics),
+      // or as ONE atomic per row (MODE_ATOMIC).
+      float* csl = reinterpret_cast<float*>(smem + BIAS_OFF);       // [4 wn][256 rows]
       const int c = le & 31;
       if (c < 4) {
-        const int mb = m0 + (c >> 1) * 128 + ar + (c & 1) * 32 + 4 * (le >> 5);
+        const int rb = (c >> 1) * 128 + ar + (c & 1) * 32 + 4 * (le >> 5);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          atomicAdd(e.a_colsum + m, cs[r]);
-        }
+        for (int r = 0; r < 16; ++r) csl[wn * 256 + rb + (r & 3) + 8 * (r >> 2)] = cs[r];
       }
+      wait_lgkm0();
+      V4_BARRIER();
+      if (te < 256) {
+        const float v = (csl[te] + csl[256 + te]) + (csl[512 + te] + csl[768 + te]);
+        if (MODE == MODE_PARTIAL) e.ws_cs[((long)zcur * ntx + txcur) * M + m0 + te] = v;
+        else atomicAdd(e.a_colsum + m0 + te, v);
+      }
+      wait_lgkm0();
+      V4_BARRIER();
     }
 
     if (MODE == MODE_ATOMIC) {
@@ -478,6 +492,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
           }
           wait_lgkm0();
           V4_BARRIER();
+          TRACE();                           // [3..6] partial pass stored
         }
       pend = 32;
       continue;
@@ -595,12 +610,14 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
 
 // out[m][n] (+)= sum_z ws[z][m][n]   (the split-K partial tiles of MODE_PARTIAL)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long ldo, int M,
-                                                            int N, int nsplit, int accumulate) {
+                                                            int N, int nsplit, int accumulate, const float* __restrict__ ws_cs,
+                                                            float* __restrict__ colsum, int ncs) {
   const long n4 = (long)M * N / 4;
   const long stride = (long)gridDim.x * blockDim.x;
   const long zs = (long)M * N;
   const int nq = N / 4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long i = tid; i < n4; i += stride) {
     f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     int zz = 0;
     for (; zz + 4 <= nsplit; zz += 4) {        // 4 independent loads in flight per thread
@@ -615,6 +632,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     f32x4_t* o = reinterpret_cast<f32x4_t*>(out + m * ldo + n);
     if (accumulate) s += *o;
     *o = s;
+  }
+  if (ws_cs) {                                 // bias gradient: colsum[m] += sum over the ncs = nsplit * ntx partial slots
+    for (long m = tid; m < M; m += stride) {
+      float a = 0.f;
+      for (int q = 0; q < ncs; ++q) a += ws_cs[(long)q * M + m];
+      colsum[m] += a;
+    }
   }
 }
 
@@ -668,7 +692,7 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
     if (sp > 32) sp = 32;
     if (sp > a->K / (4 * BK)) sp = a->K / (4 * BK);
     if (sp < 1) sp = 1;
-    if (a->ws) while (sp > 1 && a->ws_bytes < (int64_t)sp * a->M * a->N * 4) --sp;
+    if (a->ws) while (sp > 1 && a->ws_bytes < (int64_t)sp * a->M * a->N * 4 + (int64_t)sp * dh_cdiv(a->N, BN) * a->M * 4) --sp;
     split = sp;
   }
   int kps = ((a->K + split - 1) / split + BK - 1) / BK * BK;
@@ -682,7 +706,7 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
     md = MODE_ATOMIC;
     // split-K through the workspace: partial tiles + one reduce pass
     if (a->ws && split > 1 && (a->ldc % 4 == 0) && (((uintptr_t)a->C & 15) == 0) && (((uintptr_t)a->ws & 15) == 0) &&
-        a->ws_bytes >= (int64_t)split * a->M * a->N * 4)
+        a->ws_bytes >= (int64_t)split * a->M * a->N * 4 + (int64_t)split * dh_cdiv(a->N, BN) * a->M * 4)
       md = MODE_PARTIAL;
   } else {
     if (a->a_kmajor || a->a_colsum) return false;
@@ -702,8 +726,9 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
   e.residual = a->residual; e.ldr = a->ldr; e.aux = a->aux; e.ldaux = a->ldaux; e.alpha = a->alpha;
   e.a_colsum = a->a_colsum;
   e.ws = (float*)a->ws;
-  static int roles = -1;                         // DH_V4_ROLES=0: every wave loads and stores (the widened-wait scheme)
-  if (roles < 0) { const char* ev = getenv("DH_V4_ROLES"); roles = ev ? atoi(ev) : 1; }
+  e.ws_cs = (md == MODE_PARTIAL && a->a_colsum) ? (float*)a->ws + (int64_t)split * a->M * a->N : nullptr;
+  static int roles = -1;                         // DH_V4_ROLES=1: loader / storer wave groups (measured: no gain over the widened waits)
+  if (roles < 0) { const char* ev = getenv("DH_V4_ROLES"); roles = ev ? atoi(ev) : 0; }
   switch (md) {
     case MODE_ATOMIC: launch<true, true, MODE_ATOMIC, false>(a, e, split, kps, st); break;
     case MODE_PARTIAL: launch<true, true, MODE_PARTIAL, false>(a, e, split, kps, st); break;
@@ -727,7 +752,7 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a->ws, (float*)a->C, (long)a->ldc, a->M,
-                       a->N, split, 1);
+                       a->N, split, 1, (const float*)e.ws_cs, a->a_colsum, split * dh_cdiv(a->N, BN));
   }
   return true;
 }

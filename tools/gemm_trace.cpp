@@ -9,13 +9,15 @@
 #include "declip_hip.h"
 int main(int argc, char** argv) {
   int M = argc > 1 ? atoi(argv[1]) : 25600, N = argc > 2 ? atoi(argv[2]) : 2304, K = argc > 3 ? atoi(argv[3]) : 768, epi = argc > 4 ? atoi(argv[4]) : 0;
+  int dw = argc > 5 ? atoi(argv[5]) : 0;   // 1: weight-gradient call (both operands contraction-major, fp32 accumulate, workspace, bias gradient)
   void* h = dlopen("libdeclip_hip.so", RTLD_NOW | RTLD_GLOBAL);
   auto rd = (int (*)(long*, int))dlsym(h, "dh_v4_trace_read");
   auto clr = (int (*)())dlsym(h, "dh_v4_trace_clear");
   if (!rd || !clr) { printf("not a trace build\n"); return 1; }
   void *A, *B, *C, *X; float* bias;
-  hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 2); hipMalloc(&X, (size_t)M * N * 2); hipMalloc(&bias, N * 4);
-  std::vector<uint16_t> hb((size_t)M * K);
+  hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 4); hipMalloc(&X, (size_t)M * N * 2); hipMalloc(&bias, (N + M) * 4);
+  void* ws; hipMalloc(&ws, 256u << 20); hipMemset(C, 0, (size_t)M * N * 4);
+  std::vector<uint16_t> hb((size_t)(M > N ? M : N) * K);
   uint32_t s = 1; for (auto& v : hb) { s = s * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 + ((s >> 9) & 0x3ff) + ((s >> 31) << 15)); }
   hipMemcpy(A, hb.data(), (size_t)M * K * 2, hipMemcpyHostToDevice);
   hipMemcpy(B, hb.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
@@ -23,16 +25,18 @@ int main(int argc, char** argv) {
   dh_gemm_args g; memset(&g, 0, sizeof(g));
   g.dtype = DH_BF16; g.c_dtype = DH_BF16; g.M = M; g.N = N; g.K = K; g.A = A; g.lda = K; g.B = B; g.ldb = K; g.C = C; g.ldc = N;
   g.bias = bias; g.epilogue = epi; g.aux = epi ? X : nullptr; g.ldaux = N; g.alpha = 1.f; g.force_generic = 4; g.split_k = 1;
+  if (dw) { g.a_kmajor = g.b_kmajor = 1; g.lda = M; g.ldb = N; g.c_dtype = DH_F32; g.accumulate = 1; g.bias = nullptr; g.ws = ws; g.ws_bytes = 256u << 20; g.a_colsum = bias; g.split_k = 8; }
   for (int i = 0; i < 200; ++i) dh_gemm(&g, nullptr);     // warm clocks
   hipDeviceSynchronize();
   clr();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0); dh_gemm(&g, nullptr); hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  printf("M=%d N=%d K=%d epi=%d: %.1f us\n", M, N, K, epi, ms * 1e3);
+  printf("M=%d N=%d K=%d epi=%d dw=%d: %.1f us (incl. the reduce pass for dw)\n", M, N, K, epi, dw, ms * 1e3);
   std::vector<long> tb(6 * 256);
   rd(tb.data(), 6 * 256);
   const char* names[7] = {"prologue->", "mainloop", "req-next", "stage0", "store0", "stage1", "store1"};
+  if (dw) { names[3] = "pass0"; names[4] = "pass1"; names[5] = "pass2"; names[6] = "pass3"; }
   for (int slot = 0; slot < 6; ++slot) {
     long* p = tb.data() + slot * 256; int n = (int)p[0];
     printf("WG %d wave %d: %d stamps; per tile [cycles]: ", slot / 2 == 0 ? 0 : slot / 2 == 1 ? 100 : 200, (slot & 1) * 4, n);
