@@ -165,16 +165,8 @@ __device__ __forceinline__ const bf16_t* piece_src(const bf16_t* P, long ld, int
 // work item w -> (tile_x, tile_y, split z).  Items with the same z are consecutive (they share A/B panels); inside
 // a split the tile order is XCD-aware (workgroup p and all its items w = p + i*grid sit on XCD p % 8 when the grid
 // is a multiple of 8) and grouped so that the tiles an XCD runs concurrently share A and B panels in its 4 MiB L2.
-__device__ __forceinline__ void item_coords(int w, int ntx, int nty, int nitems, int& tile_x, int& tile_y, int& z) {
-  // XCD x (workgroups w = x mod 8) walks a CONTIGUOUS chunk of the (split, tile) list: the ~32 items it runs at a time are
-  // (almost) all the tiles of one K-slice, so every A / B panel it streams is shared by several of its CUs through its L2
-  // (with the slices dealt round-robin to the XCDs, PMC showed a 32 % L2 hit rate and ~6 TB/s of fabric reads on the dW calls)
-  const int q = nitems >> 3, r = nitems & 7, xcd = w & 7, idx = w >> 3;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  const int nb = ntx * nty;
-  z = logical / nb;
-  const int b = logical - z * nb;
-  constexpr int GROUP_M = 8;
+__device__ __forceinline__ void tile_from_logical(int b, int ntx, int nty, int& tile_x, int& tile_y) {
+  constexpr int GROUP_M = 8;                       // tiles an XCD runs together share GROUP_M A panels and a few B panels
   const int in_group = GROUP_M * ntx;
   const int gid = b / in_group;
   const int first_m = gid * GROUP_M;
@@ -183,11 +175,42 @@ __device__ __forceinline__ void item_coords(int w, int ntx, int nty, int nitems,
   tile_y = first_m + rem % gsz;
   tile_x = rem / gsz;
 }
+__device__ __forceinline__ void item_coords(int w, int ntx, int nty, int nitems, int& tile_x, int& tile_y, int& z) {
+  // XCD x (workgroups w = x mod 8) walks a CONTIGUOUS chunk of the (split, tile) list: the ~32 items it runs at a time are
+  // (almost) all the tiles of one K-slice, so every A / B panel it streams is shared by several of its CUs through its L2
+  // (with the slices dealt round-robin to the XCDs, PMC showed a 32 % L2 hit rate and ~6 TB/s of fabric reads on the dW calls)
+  const int q = nitems >> 3, r = nitems & 7, xcd = w & 7, idx = w >> 3;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int nb = ntx * nty;
+  z = logical / nb;
+  tile_from_logical(logical - z * nb, ntx, nty, tile_x, tile_y);
+}
+// Work item w of a launch.  Plain launches: nitems = tiles x splits (item_coords).  TAIL-SLICED launches (bf16 outputs whose
+// tile count leaves the last round mostly empty, e.g. 300 tiles on 256 CUs): items [0, n_full) are whole tiles (a multiple of
+// the grid), the remaining `rem` tiles are cut into S K-slices each -- item n_full + lt*S + s computes K-tiles
+// [s*nkt/S, (s+1)*nkt/S) of tile n_full + lt into a private fp32 tile of the workspace, and tail_fixup_kernel sums the
+// slices and applies the epilogue.  The last round then takes ~1/S of a tile time on all CUs instead of a full one on a few.
+struct Item { int tile_x, tile_y, z, kbeg, nk, slice; };
+__device__ __forceinline__ Item decode_item(int w, int ntx, int nty, int nitems, int n_full, int S, int K, int k_per_split) {
+  Item it;
+  if (S == 0 || w < n_full) {
+    item_coords(w, ntx, nty, S ? n_full : nitems, it.tile_x, it.tile_y, it.z);
+    it.kbeg = it.z * k_per_split;
+    it.nk = (min(K, it.kbeg + k_per_split) - it.kbeg) / BK;
+    it.slice = -1;
+  } else {
+    const int j = w - n_full, lt = j / S, sl = j - lt * S, nkt = K / BK;
+    tile_from_logical(n_full + lt, ntx, nty, it.tile_x, it.tile_y);
+    const int k0 = sl * nkt / S, k1 = (sl + 1) * nkt / S;
+    it.z = 0; it.kbeg = k0 * BK; it.nk = k1 - k0; it.slice = j;
+  }
+  return it;
+}
 
 template <bool TA, bool TB, int MODE, bool ROLES>
 __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                          long ldb, int M, int N, int K, int k_per_split, int ntx, int nty,
-                                                         int nitems, EpiParams e) {
+                                                         int nitems, int n_full, int S, EpiParams e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool SWAP = MODE != MODE_ATOMIC;
   constexpr bool STORE = MODE <= MODE_STORE_RES;
@@ -207,7 +230,6 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
   const bool issuer = !ROLES || wm == 1;
   unsigned char* const wdst = smem + (ROLES ? (wave & 3) * 4096 : wave * 2048);   // this wave's slice of a half-tile
   const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
-  const uint32_t akm0 = lds0 + kmajor_lane_off(ar, lane), akm1 = lds0 + kmajor_lane_off(ar + 32, lane), bkm = lds0 + kmajor_lane_off(br, lane);
   const long astep = TA ? (long)BK * lda : BK;
   const long bstep = TB ? (long)BK * ldb : BK;
 
@@ -249,10 +271,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
 #define TRACE() do { } while (0)
 #endif
   int w = blockIdx.x;
-  int tile_x, tile_y, z;
-  item_coords(w, ntx, nty, nitems, tile_x, tile_y, z);
+  Item nxt = decode_item(w, ntx, nty, nitems, n_full, S, K, k_per_split);
   {   // first tile: the four half-tiles of its K-tile 0, in steady-state FIFO order
-    SETUP_SRC(tile_y * BM, tile_x * BN, z * k_per_split);
+    SETUP_SRC(nxt.tile_y * BM, nxt.tile_x * BN, nxt.kbeg);
     ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, b_dh, 3, 0); ISSUE_H(ap, a_dh, 1, 0);
   }
   if (STORE) {   // bias -> LDS once (no global load may sit between the epilogue stores of the persistent loop)
@@ -262,12 +283,17 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
   int pend = 0;                      // epilogue stores of the previous tile that may still be in flight (per wave-instruction stream)
 
   for (; w < nitems; w += gridDim.x) {
-    const int m0 = tile_y * BM, n0 = tile_x * BN;
-    const int kbeg = z * k_per_split;
-    const int nk = (min(K, kbeg + k_per_split) - kbeg) / BK;      // host guarantees divisibility and nk >= 2
-    const int zcur = z;
-    const int txcur = tile_x;
+    const Item cur = nxt;
+    const int m0 = cur.tile_y * BM, n0 = cur.tile_x * BN;
+    const int nk = cur.nk;                                         // host guarantees nk >= 2
+    const int zcur = cur.z;
+    const int txcur = cur.tile_x;
 
+    // fragment addressing restarts from an opaque lane id per tile, so its ~12 address registers are not kept live across
+    // the epilogue of the previous tile (same trick as `te` below)
+    int lm = lane;
+    asm volatile("" : "+v"(lm));
+    const uint32_t akm0 = lds0 + kmajor_lane_off(ar, lm), akm1 = lds0 + kmajor_lane_off(ar + 32, lm), bkm = lds0 + kmajor_lane_off(br, lm);
     f32x16_t acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -311,9 +337,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
       // ---- phase 1: quadrant (A0, B0)
       const uint32_t boff = buf * STAGE_BYTES;
       if (do_frag) {
-        frag4<TB, 2>(fb0, bkm + boff, sB0, br, lane);
-        frag4<TA, 0>(fa0[0], akm0 + boff, sA0, ar, lane);
-        frag4<TA, 0>(fa0[1], akm1 + boff, sA0, ar + 32, lane);
+        frag4<TB, 2>(fb0, bkm + boff, sB0, br, lm);
+        frag4<TA, 0>(fa0[0], akm0 + boff, sA0, ar, lm);
+        frag4<TA, 0>(fa0[1], akm1 + boff, sA0, ar + 32, lm);
       }
       if (has1) { ISSUE_H(bp, b_dh, 3, nbuf); if (ROLES) WAITV(8); else wait_vmcnt_8_plus(pk); } else { WAITV(2); }      // B1(kt) has landed
       V4_BARRIER();
@@ -328,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
       V4_BARRIER();
 
       // ---- phase 2: quadrant (A0, B1)
-      if (do_frag) frag4<TB, 3>(fb1, bkm + boff, sB1, br, lane);
+      if (do_frag) frag4<TB, 3>(fb1, bkm + boff, sB1, br, lm);
       if (has1) { ISSUE_H(ap, a_dh, 1, nbuf); if (ROLES) WAITV(8); else wait_vmcnt_8_plus(pk); } else { WAITV(0); }      // A1(kt) has landed
       V4_BARRIER();
       wait_lgkm0();
@@ -354,8 +380,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
 
       // ---- phase 3: quadrant (A1, B1)
       if (do_frag) {
-        frag4<TA, 1>(fa1[0], akm0 + boff, sA1, ar, lane);
-        frag4<TA, 1>(fa1[1], akm1 + boff, sA1, ar + 32, lane);
+        frag4<TA, 1>(fa1[0], akm0 + boff, sA1, ar, lm);
+        frag4<TA, 1>(fa1[1], akm1 + boff, sA1, ar + 32, lm);
       }
       if (has2) ISSUE_H(ap, astep, 0, buf);                                   // A0(kt+2): A0(kt) was read in phase 1
       V4_BARRIER();
@@ -399,8 +425,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
     // ---- next work item: request the four half-tiles of its K-tile 0 into ring buffer 0 BEFORE the epilogue
     const int wnext = w + gridDim.x;
     if (wnext < nitems) {
-      item_coords(wnext, ntx, nty, nitems, tile_x, tile_y, z);
-      SETUP_SRC(tile_y * BM, tile_x * BN, z * k_per_split);
+      nxt = decode_item(wnext, ntx, nty, nitems, n_full, S, K, k_per_split);
+      SETUP_SRC(nxt.tile_y * BM, nxt.tile_x * BN, nxt.kbeg);
       ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, b_dh, 3, 0); ISSUE_H(ap, a_dh, 1, 0);
     }
     TRACE();                                 // [2] next tile requested
@@ -459,10 +485,15 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
     }
 
     unsigned char* Cs = smem + STAGE_BYTES;  // ring buffer 1 (buffer 0 is receiving the next tile)
-    if (MODE == MODE_PARTIAL) {
-      // fp32 partial tile -> ws[z][m][n].  4 passes of 64 rows: pass (i, ii) holds rows i*128 + wm*64 + ii*32 + 0..31 of both
-      // wave groups; staging row = wm*32 + (lane&31), 1024 B per row, 16-byte unit u of row r stored at unit u ^ (r & 7).
-      float* Wp = e.ws + (long)zcur * M * N;
+    constexpr bool SLICEABLE = MODE == MODE_STORE || MODE == MODE_STORE_RES;   // the N = d GEMMs (few tiles) use these flavours
+    if (MODE == MODE_PARTIAL || (SLICEABLE && cur.slice >= 0)) {
+      // fp32 partial tile: MODE_PARTIAL -> ws[z][m][n]; tail slice -> its private [256][256] tile of the workspace.
+      // 4 passes of 64 rows: pass (i, ii) holds rows i*128 + wm*64 + ii*32 + 0..31 of both wave groups; staging row =
+      // wm*32 + (lane&31), 1024 B per row, 16-byte unit u of row r stored at unit u ^ (r & 7).
+      float* Wp;
+      long wld;
+      if (MODE == MODE_PARTIAL) { Wp = e.ws + (long)zcur * M * N + (long)m0 * N + n0; wld = N; }
+      else { Wp = e.ws + (long)cur.slice * (BM * BN); wld = BN; }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -485,9 +516,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
               const int rl2 = wave + 8 * it;                                       // staging row 0..63 (wave-uniform)
-              const long m = m0 + i * 128 + (rl2 >> 5) * 64 + ii * 32 + (rl2 & 31);
+              const long mr = i * 128 + (rl2 >> 5) * 64 + ii * 32 + (rl2 & 31);    // row inside the tile
               const f32x4_t v = *reinterpret_cast<const f32x4_t*>(Cs + rl2 * 1024 + ((c ^ (rl2 & 7)) << 4));
-              *reinterpret_cast<f32x4_t*>(reinterpret_cast<unsigned char*>(Wp + m * N + n0) + (uint32_t)(c * 16)) = v;
+              *reinterpret_cast<f32x4_t*>(reinterpret_cast<unsigned char*>(Wp + mr * wld) + (uint32_t)(c * 16)) = v;
             }
           }
           wait_lgkm0();
@@ -588,6 +619,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
             }
             st8_hw(reinterpret_cast<bf16_t*>(Cb + mu * e.ldc * 2 + c_off), v);
           }
+          if (it & 1) __builtin_amdgcn_sched_barrier(0);      // keep the unrolled iterations from being interleaved (register pressure)
         }
         }
         wait_lgkm0();
@@ -642,6 +674,52 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// Tail-sliced launches: C tile = epilogue(sum of the S fp32 slice tiles + bias).  One thread = 8 consecutive columns.
+__global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict__ ws, int S, int n_full, int ntx, int nty, EpiParams e) {
+  const int lt = blockIdx.x >> 5;
+  const int id = (blockIdx.x & 31) * 256 + threadIdx.x;
+  const int row = id >> 5, cc = id & 31;
+  int tile_x, tile_y;
+  tile_from_logical(n_full + lt, ntx, nty, tile_x, tile_y);
+  const long m = (long)tile_y * BM + row;
+  const int n = tile_x * BN + cc * 8;
+  float v[8];
+  {
+    const float* p = ws + (long)lt * S * (BM * BN) + row * BN + cc * 8;
+    ld8(p, v);
+    for (int sl = 1; sl < S; ++sl) {
+      float u[8];
+      ld8(p + (long)sl * (BM * BN), u);
+#pragma unroll
+      for (int x = 0; x < 8; ++x) v[x] += u[x];
+    }
+  }
+  if (e.bias) {
+    float b[8];
+    ld8(e.bias + n, b);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] += b[x];
+  }
+  bf16_t* C = reinterpret_cast<bf16_t*>(e.C);
+  if (e.epilogue == DH_EPI_GELU) {
+    if (e.aux) st8_hw(reinterpret_cast<bf16_t*>(e.aux) + m * e.ldaux + n, v);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] = quick_gelu_f(bf2f(f2bf(v[x])));      // like the in-kernel path: GELU of the stored pre-activation
+  } else if (e.epilogue == DH_EPI_DGELU) {
+    float u[8];
+    ld8(reinterpret_cast<const bf16_t*>(e.aux) + m * e.ldaux + n, u);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] *= quick_gelu_grad_f(u[x]);
+  }
+  if (e.residual) {
+    float r[8];
+    ld8(reinterpret_cast<const bf16_t*>(e.residual) + m * e.ldr + n, r);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] += r[x];
+  }
+  st8_hw(C + m * e.ldc + n, v);
+}
+
 static int num_cus() {
   static int n = 0;
   if (!n) {
@@ -654,18 +732,18 @@ static int num_cus() {
 }
 
 template <bool TA, bool TB, int MODE, bool ROLES>
-void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, hipStream_t st) {
+void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, int n_full, int S, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)gemm_v4_kernel<TA, TB, MODE, ROLES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   const int ntx = dh_cdiv(a->N, BN), nty = dh_cdiv(a->M, BM);
-  const int nitems = ntx * nty * split;
+  const int nitems = S ? n_full + (ntx * nty - n_full) * S : ntx * nty * split;
   int grid = num_cus();
   if (grid > nitems) grid = nitems;
   hipLaunchKernelGGL((gemm_v4_kernel<TA, TB, MODE, ROLES>), dim3(grid), dim3(512), LDS_BYTES, st, (const bf16_t*)a->A, (long)a->lda,
-                     (const bf16_t*)a->B, (long)a->ldb, a->M, a->N, a->K, kps, ntx, nty, nitems, e);
+                     (const bf16_t*)a->B, (long)a->ldb, a->M, a->N, a->K, kps, ntx, nty, nitems, n_full, S, e);
 }
 
 }  // namespace v4
@@ -727,26 +805,41 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
   e.a_colsum = a->a_colsum;
   e.ws = (float*)a->ws;
   e.ws_cs = (md == MODE_PARTIAL && a->a_colsum) ? (float*)a->ws + (int64_t)split * a->M * a->N : nullptr;
+  // tail slicing (bf16 outputs): when the last round of whole tiles would use at most half of the CUs, cut those tiles in K
+  int n_full = 0, S = 0;
+  if ((md == MODE_STORE || md == MODE_STORE_RES) && a->ws && (((uintptr_t)a->ws & 15) == 0)) {
+    static int tail = -1;
+    if (tail < 0) { const char* ev = getenv("DH_V4_TAIL"); tail = ev ? atoi(ev) : 1; }
+    const int T = dh_cdiv(a->N, BN) * dh_cdiv(a->M, BM), G = num_cus(), rem = T % G, nkt = a->K / BK;
+    if (tail && T > G && rem > 0 && rem <= G / 2 && nkt >= 24) {   // short-K tiles: the slice overheads eat the gain (measured)
+      int s_ = G / rem;
+      if (s_ > 8) s_ = 8;
+      if (s_ > nkt / 2) s_ = nkt / 2;
+      if (s_ >= 2 && a->ws_bytes >= (int64_t)rem * s_ * BM * BN * 4) { S = s_; n_full = T - rem; }
+    }
+  }
   static int roles = -1;                         // DH_V4_ROLES=1: loader / storer wave groups (measured: no gain over the widened waits)
   if (roles < 0) { const char* ev = getenv("DH_V4_ROLES"); roles = ev ? atoi(ev) : 0; }
   switch (md) {
-    case MODE_ATOMIC: launch<true, true, MODE_ATOMIC, false>(a, e, split, kps, st); break;
-    case MODE_PARTIAL: launch<true, true, MODE_PARTIAL, false>(a, e, split, kps, st); break;
+    case MODE_ATOMIC: launch<true, true, MODE_ATOMIC, false>(a, e, split, kps, n_full, S, st); break;
+    case MODE_PARTIAL: launch<true, true, MODE_PARTIAL, false>(a, e, split, kps, n_full, S, st); break;
     case MODE_STORE_GELU:
-      if (roles) launch<false, false, MODE_STORE_GELU, true>(a, e, split, kps, st);
-      else launch<false, false, MODE_STORE_GELU, false>(a, e, split, kps, st);
+      if (roles) launch<false, false, MODE_STORE_GELU, true>(a, e, split, kps, n_full, S, st);
+      else launch<false, false, MODE_STORE_GELU, false>(a, e, split, kps, n_full, S, st);
       break;
-    case MODE_STORE_RES: launch<false, false, MODE_STORE_RES, false>(a, e, split, kps, st); break;
-    case MODE_STORE_DGELU: launch<false, true, MODE_STORE_DGELU, false>(a, e, split, kps, st); break;
+    case MODE_STORE_RES: launch<false, false, MODE_STORE_RES, false>(a, e, split, kps, n_full, S, st); break;
+    case MODE_STORE_DGELU: launch<false, true, MODE_STORE_DGELU, false>(a, e, split, kps, n_full, S, st); break;
     default:
       if (a->b_kmajor) {
-        if (roles) launch<false, true, MODE_STORE, true>(a, e, split, kps, st);
-        else launch<false, true, MODE_STORE, false>(a, e, split, kps, st);
+        if (roles) launch<false, true, MODE_STORE, true>(a, e, split, kps, n_full, S, st);
+        else launch<false, true, MODE_STORE, false>(a, e, split, kps, n_full, S, st);
       } else {
-        if (roles) launch<false, false, MODE_STORE, true>(a, e, split, kps, st);
-        else launch<false, false, MODE_STORE, false>(a, e, split, kps, st);
+        if (roles) launch<false, false, MODE_STORE, true>(a, e, split, kps, n_full, S, st);
+        else launch<false, false, MODE_STORE, false>(a, e, split, kps, n_full, S, st);
       }
   }
+  if (S) hipLaunchKernelGGL(tail_fixup_kernel, dim3((dh_cdiv(a->N, BN) * dh_cdiv(a->M, BM) - n_full) * 32), dim3(256), 0, st,
+                            (const float*)a->ws, S, n_full, dh_cdiv(a->N, BN), dh_cdiv(a->M, BM), e);
   if (md == MODE_PARTIAL) {
     const long n4 = (long)a->M * a->N / 4;
     int blocks = (int)((n4 + 255) / 256);

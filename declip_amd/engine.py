@@ -208,11 +208,12 @@ def block_fwd(x, r, b, L, heads, causal, save):
     h1, mean1, rstd1 = ops.layernorm_fwd(x, r.ln1_w, r.ln1_b, r.eps1)
     qkv = ops.gemm(h1, r.w_in, bias=r.b_in)
     a, lse = ops.attn_fwd(qkv, b, L, heads, causal)
-    x_mid = ops.gemm(a, r.w_out, bias=r.b_out, residual=x)
+    ws = gemm_workspace(x.device) if x.is_cuda and x.dtype == torch.bfloat16 else None   # tail-sliced tiles (v4 GEMM)
+    x_mid = ops.gemm(a, r.w_out, bias=r.b_out, residual=x, ws=ws)
     h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, r.ln2_w, r.ln2_b, r.eps2)
     u = torch.empty(x.shape[0], r.w_fc.shape[0], device=x.device, dtype=x.dtype) if save else None
     g = ops.gemm(h2, r.w_fc, bias=r.b_fc, epilogue=EPI_GELU, aux=u)
-    x_out = ops.gemm(g, r.w_proj, bias=r.b_proj, residual=x_mid)
+    x_out = ops.gemm(g, r.w_proj, bias=r.b_proj, residual=x_mid, ws=ws)
     saved = (x, mean1, rstd1, h1, qkv, a, lse, x_mid, mean2, rstd2, h2, u, g) if save else None
     return x_out, saved
 
@@ -223,14 +224,15 @@ def block_bwd(dx_out, r, saved, b, L, heads, causal):
     weight_grad(dx_out, g, r.g_w_proj, r.g_b_proj)
     du = ops.gemm(dx_out, r.w_proj, b_kmajor=True, epilogue=EPI_DGELU, aux=u)
     weight_grad(du, h2, r.g_w_fc, r.g_b_fc)
-    dh2 = ops.gemm(du, r.w_fc, b_kmajor=True)
+    ws = gemm_workspace(du.device) if du.is_cuda and du.dtype == torch.bfloat16 else None
+    dh2 = ops.gemm(du, r.w_fc, b_kmajor=True, ws=ws)
     dx_mid = ops.layernorm_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)
     # attention: x_mid = x + attn(h1) Wout^T + bout
     weight_grad(dx_mid, a, r.g_w_out, r.g_b_out)
-    da = ops.gemm(dx_mid, r.w_out, b_kmajor=True)
+    da = ops.gemm(dx_mid, r.w_out, b_kmajor=True, ws=ws)
     dqkv = ops.attn_bwd(qkv, a, da, lse, b, L, heads, causal)
     weight_grad(dqkv, h1, r.g_w_in, r.g_b_in)
-    dh1 = ops.gemm(dqkv, r.w_in, b_kmajor=True)
+    dh1 = ops.gemm(dqkv, r.w_in, b_kmajor=True, ws=ws)
     return ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
 
 

@@ -44,7 +44,7 @@ static int run(const Case& c, int force, void* A, void* B, void* C, float* bias,
   g.C = C; g.ldc = c.N; g.bias = c.bias ? bias : nullptr; g.epilogue = c.epi;
   g.residual = c.res ? res : nullptr; g.ldr = c.N; g.aux = c.epi ? aux : nullptr; g.ldaux = c.N;
   g.accumulate = c.acc; g.split_k = c.split; g.alpha = 1.f; g.force_generic = force; g.pad_ok = 0;
-  if (c.ws && force != 3) { g.ws = g_ws; g.ws_bytes = (int64_t)g_ws_bytes; }
+  if ((c.ws || !c.acc) && force != 3) { g.ws = g_ws; g.ws_bytes = (int64_t)g_ws_bytes; }
   if (c.cs) g.a_colsum = g_cs;
   int rc = dh_gemm(&g, nullptr);
   if (rc != DH_OK) printf("  dh_gemm(force=%d) failed: %s\n", force, dh_last_error());
