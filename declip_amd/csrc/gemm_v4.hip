@@ -666,10 +666,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *o = s;
   }
   if (ws_cs) {                                 // bias gradient: colsum[m] += sum over the ncs = nsplit * ntx partial slots
-    for (long m = tid; m < M; m += stride) {
-      float a = 0.f;
-      for (int q = 0; q < ncs; ++q) a += ws_cs[(long)q * M + m];
-      colsum[m] += a;
+    // 8 threads per row, each over a strided subset of the slots with 4 loads in flight; combined by lane shuffles
+    const long gt = (long)gridDim.x * blockDim.x - 1 - tid;      // the LAST threads of the grid take this (short) job
+    const int part = (int)(gt & 7);
+    for (long m = gt >> 3; m < M; m += stride >> 3) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int q = part;
+      for (; q + 24 < ncs; q += 32) {
+        a0 += ws_cs[(long)q * M + m];
+        a1 += ws_cs[(long)(q + 8) * M + m];
+        a2 += ws_cs[(long)(q + 16) * M + m];
+        a3 += ws_cs[(long)(q + 24) * M + m];
+      }
+      for (; q < ncs; q += 8) a0 += ws_cs[(long)q * M + m];
+      float a = (a0 + a1) + (a2 + a3);
+      a += __shfl_xor(a, 1, 64);
+      a += __shfl_xor(a, 2, 64);
+      a += __shfl_xor(a, 4, 64);
+      if (part == 0) colsum[m] += a;
     }
   }
 }
