@@ -141,8 +141,8 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
     uint2 w;
-    w.x = pack2bf(s[kb][0] * inv, s[kb][1] * inv);
-    w.y = pack2bf(s[kb][2] * inv, s[kb][3] * inv);
+    w.x = pack2bf_hw(s[kb][0] * inv, s[kb][1] * inv);
+    w.y = pack2bf_hw(s[kb][2] * inv, s[kb][3] * inv);
     *reinterpret_cast<uint2*>(Ps + q * TS + kb * 16 + 4 * (lane >> 4)) = w;
   }
   __syncthreads();
@@ -155,13 +155,14 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
       const bool dead = KTAIL && ks == NKS - 1 && (lane >> 4) >= 2;
       bf16x8_t pf = kmask(lds_frag(Ps + (qb * 16 + (lane & 15)) * TS + ks * 32 + 8 * (lane >> 4)), dead);
       bf16x8_t vf = kmask(frag_tr(Vs, RS, ks * 32, db * 16, dead ? (lane & 31) : lane), dead);
-      acc = mfma16(pf, vf, acc);
+      acc = mfma16(vf, pf, acc);            // swapped operands: the fragment comes out transposed
     }
-    // C layout: row (query) = 4*(lane>>4)+r, col (d) = lane&15
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qq = qb * 16 + 4 * (lane >> 4) + r;
-      if (qq < L) out[((long)bi * L + qq) * d_model + h * HD + db * 16 + (lane & 15)] = f2bf(acc[r]);
+    // C^T layout: lane&15 = query row, registers = 4 consecutive head-dim columns 4*(lane>>4)+r -> one 8-byte store
+    const int qq = qb * 16 + (lane & 15);
+    if (qq < L) {
+      uint2 w;
+      w.x = pack2bf_hw(acc[0], acc[1]); w.y = pack2bf_hw(acc[2], acc[3]);
+      *reinterpret_cast<uint2*>(out + ((long)bi * L + qq) * d_model + h * HD + db * 16 + 4 * (lane >> 4)) = w;
     }
   }
 }
@@ -257,9 +258,9 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
       }
       // transposed fragment stores: [key][q..q+3], 8 bytes
       uint2 w;
-      w.x = pack2bf(p[0], p[1]); w.y = pack2bf(p[2], p[3]);
+      w.x = pack2bf_hw(p[0], p[1]); w.y = pack2bf_hw(p[2], p[3]);
       *reinterpret_cast<uint2*>(Pt + key * TS + qb * 16 + 4 * (lane >> 4)) = w;
-      w.x = pack2bf(ds[0], ds[1]); w.y = pack2bf(ds[2], ds[3]);
+      w.x = pack2bf_hw(ds[0], ds[1]); w.y = pack2bf_hw(ds[2], ds[3]);
       *reinterpret_cast<uint2*>(dSt + key * TS + qb * 16 + 4 * (lane >> 4)) = w;
     }
   }
@@ -280,22 +281,24 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
         // dV[key][d] = sum_q P^T[key][q] dO[q][d];  dK[key][d] = sum_q dS^T[key][q] Q[q][d]
         bf16x8_t gB = kmask(frag_tr(Gs, RS, ks * 32, db * 16, ln), dead);
         bf16x8_t qB = kmask(frag_tr(Qs, RS, ks * 32, db * 16, ln), dead);
-        av = mfma16(kmask(lds_frag(Pt + ro), dead), gB, av);
-        ak = mfma16(kmask(lds_frag(dSt + ro), dead), qB, ak);
+        av = mfma16(gB, kmask(lds_frag(Pt + ro), dead), av);      // operands swapped: transposed fragments (see the stores below)
+        ak = mfma16(qB, kmask(lds_frag(dSt + ro), dead), ak);
         // dQ[q][d] = sum_key dS[q][key] K[key][d]: A = dS via transpose read of dS^T, B = K via transpose read
         bf16x8_t dsA = kmask(frag_tr(dSt, TS, ks * 32, rb * 16, ln), dead);
         bf16x8_t kB = kmask(frag_tr(Ks, RS, ks * 32, db * 16, ln), dead);
-        aq = mfma16(dsA, kB, aq);
+        aq = mfma16(kB, dsA, aq);
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rb * 16 + 4 * (lane >> 4) + r;
-        if (row < L) {
-          const long o = (long)row * gs + db * 16 + (lane & 15);
-          dq_g[o] = f2bf(aq[r]);
-          dq_g[o + d_model] = f2bf(ak[r]);
-          dq_g[o + 2 * d_model] = f2bf(av[r]);
-        }
+      // transposed fragments: lane&15 = row (query / key), registers = 4 consecutive head-dim columns -> 8-byte stores
+      const int row = rb * 16 + (lane & 15);
+      if (row < L) {
+        const long o = (long)row * gs + db * 16 + 4 * (lane >> 4);
+        uint2 w;
+        w.x = pack2bf_hw(aq[0], aq[1]); w.y = pack2bf_hw(aq[2], aq[3]);
+        *reinterpret_cast<uint2*>(dq_g + o) = w;
+        w.x = pack2bf_hw(ak[0], ak[1]); w.y = pack2bf_hw(ak[2], ak[3]);
+        *reinterpret_cast<uint2*>(dq_g + o + d_model) = w;
+        w.x = pack2bf_hw(av[0], av[1]); w.y = pack2bf_hw(av[2], av[3]);
+        *reinterpret_cast<uint2*>(dq_g + o + 2 * d_model) = w;
       }
     }
   }

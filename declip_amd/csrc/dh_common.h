@@ -89,6 +89,10 @@ __device__ __forceinline__ void st8(float* p, const float* o) {
   *reinterpret_cast<float4*>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
 }
 
+// st8 with the hardware bf16 pack where the output is bf16
+__device__ __forceinline__ void st8_fast(bf16_t* p, const float* o) { st8_hw(p, o); }
+__device__ __forceinline__ void st8_fast(float* p, const float* o) { st8(p, o); }
+
 // ----------------------------------------------------------------------------- reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -8,51 +8,74 @@ namespace {
 
 constexpr int LN_MAXC = 4;  // up to 4 chunks of 8 per lane -> d <= 2048 on the vector path
 
-template <typename T>
+// NCH = 16-byte chunks per lane (d <= 512 * NCH); two rows per wave are in flight at a time (the kernel is latency-bound:
+// a wave that loads, reduces and stores one row at a time leaves HBM idle most of the time)
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                      int d, float eps) {
+  constexpr int R = 2;
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
   const int nchunk = d >> 3;
-  for (int row = wave_global; row < rows; row += nwaves) {
-    const T* xr = x + (long)row * d;
-    float v[LN_MAXC][8];
-    float s = 0.f;
+  float wv[NCH][8], bv[NCH][8];
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-      int ch = lane + 64 * c;
-      if (ch < nchunk) {
-        ld8(xr + ch * 8, v[c]);
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunk) { ld8(w + ch * 8, wv[c]); ld8(b + ch * 8, bv[c]); }
+  }
+  for (int row0 = wave_global * R; row0 < rows; row0 += nwaves * R) {
+    float v[R][NCH][8];
+    float s[R];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += v[c][i];
+    for (int r = 0; r < R; ++r) {
+      s[r] = 0.f;
+      const int row = row0 + r < rows ? row0 + r : rows - 1;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) ld8(x + (long)row * d + ch * 8, v[r][c]);
       }
     }
-    const float mu = wave_sum(s) / d;
-    float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-      int ch = lane + 64 * c;
-      if (ch < nchunk) {
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { float t = v[c][i] - mu; q += t * t; }
-      }
+      for (int c = 0; c < NCH; ++c)
+        if (lane + 64 * c < nchunk) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) s[r] += v[r][c][i];
+        }
+    float mu[R], rs[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) mu[r] = wave_sum(s[r]) / d;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (lane + 64 * c < nchunk) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { float t = v[r][c][i] - mu[r]; q += t * t; }
+        }
+      rs[r] = rsqrtf(wave_sum(q) / d + eps);
     }
-    const float rs = rsqrtf(wave_sum(q) / d + eps);
-    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
-    T* yr = y + (long)row * d;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-      int ch = lane + 64 * c;
-      if (ch < nchunk) {
-        float wv[8], bv[8], o[8];
-        ld8(w + ch * 8, wv);
-        ld8(b + ch * 8, bv);
+    for (int r = 0; r < R; ++r) {
+      const int row = row0 + r;
+      if (row < rows) {
+        if (lane == 0) { if (mean) mean[row] = mu[r]; if (rstd) rstd[row] = rs[r]; }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mu) * rs * wv[i] + bv[i];
-        st8(yr + ch * 8, o);
+        for (int c = 0; c < NCH; ++c) {
+          const int ch = lane + 64 * c;
+          if (ch < nchunk) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (v[r][c][i] - mu[r]) * rs[r] * wv[c][i] + bv[c][i];
+            st8_fast(y + (long)row * d + ch * 8, o);
+          }
+        }
       }
     }
   }
@@ -80,8 +103,9 @@ __global__ __launch_bounds__(256) void ln_fwd_scalar_kernel(const T* __restrict_
 }
 
 // backward: wave per row (grid-stride); per-lane register partials for dw/db of the
-// lane's own columns; block partial written to part[block][2][d].
-template <typename T>
+// lane's own columns; block partial written to part[block][2][d].  NCH as in the forward kernel (register budget ->
+// occupancy: the d = 768 / 512 towers need 2 / 1 chunk slots, not 4).
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dres,
@@ -90,57 +114,63 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwaves = gridDim.x * 4;
   const int nchunk = d >> 3;
-  float aw[LN_MAXC][8], ab[LN_MAXC][8];
+  float aw[NCH][8], ab[NCH][8], wv[NCH][8];
 #pragma unroll
-  for (int c = 0; c < LN_MAXC; ++c)
+  for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { aw[c][i] = 0.f; ab[c][i] = 0.f; }
+    for (int i = 0; i < 8; ++i) { aw[c][i] = 0.f; ab[c][i] = 0.f; wv[c][i] = 0.f; }
+    if (lane + 64 * c < nchunk) ld8(w + (lane + 64 * c) * 8, wv[c]);
+  }
 
   for (int row = blockIdx.x * 4 + wave; row < rows; row += nwaves) {
+    float xv[NCH][8], dv[NCH][8], rv[NCH][8];
+    // all loads of the row first (x, dy, residual-branch gradient), then the statistics
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        ld8(x + (long)row * d + ch * 8, xv[c]);
+        ld8(dy + (long)row * d + ch * 8, dv[c]);
+        if (dres) ld8(dres + (long)row * d + ch * 8, rv[c]);
+      }
+    }
     const float mu = mean[row], rs = rstd[row];
-    float xh[LN_MAXC][8], g[LN_MAXC][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-      int ch = lane + 64 * c;
-      if (ch < nchunk) {
-        float xv[8], dv[8], wv[8];
-        ld8(x + (long)row * d + ch * 8, xv);
-        ld8(dy + (long)row * d + ch * 8, dv);
-        ld8(w + ch * 8, wv);
+    for (int c = 0; c < NCH; ++c) {
+      if (lane + 64 * c < nchunk) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          xh[c][i] = (xv[i] - mu) * rs;
-          g[c][i] = dv[i] * wv[i];
-          s1 += g[c][i];
-          s2 += g[c][i] * xh[c][i];
-          aw[c][i] += dv[i] * xh[c][i];
-          ab[c][i] += dv[i];
+          const float xh = (xv[c][i] - mu) * rs, g = dv[c][i] * wv[c][i];
+          s1 += g;
+          s2 += g * xh;
+          aw[c][i] += dv[c][i] * xh;
+          ab[c][i] += dv[c][i];
+          xv[c][i] = xh;
+          dv[c][i] = g;
         }
       }
     }
     const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-      int ch = lane + 64 * c;
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
       if (ch < nchunk) {
         float o[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = rs * (g[c][i] - c1 - xh[c][i] * c2);
+        for (int i = 0; i < 8; ++i) o[i] = rs * (dv[c][i] - c1 - xv[c][i] * c2);
         if (dres) {
-          float r[8];
-          ld8(dres + (long)row * d + ch * 8, r);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] += r[i];
+          for (int i = 0; i < 8; ++i) o[i] += rv[c][i];
         }
-        st8(dx + (long)row * d + ch * 8, o);
+        st8_fast(dx + (long)row * d + ch * 8, o);
       }
     }
   }
   // block reduce of the 4 waves' partials through LDS
   float* my = sm + wave * 2 * d;
 #pragma unroll
-  for (int c = 0; c < LN_MAXC; ++c) {
+  for (int c = 0; c < NCH; ++c) {
     int ch = lane + 64 * c;
     if (ch < nchunk) {
 #pragma unroll
@@ -211,11 +241,18 @@ extern "C" int dh_layernorm_fwd(int dtype, const void* x, const float* w, const 
   DH_REQUIRE(x && w && b && y && rows > 0 && d > 0, "dh_layernorm_fwd: bad args");
   const bool vec = (d % 8 == 0) && d <= 8 * 64 * LN_MAXC;
   dim3 grid(ln_grid(rows));
+  const int nch = dh_cdiv(d / 8, 64);
+#define LN_FWD(TT)                                                                                                                       \
+  {                                                                                                                                      \
+    if (nch <= 1) hipLaunchKernelGGL((ln_fwd_kernel<TT, 1>), grid, dim3(256), 0, st, (const TT*)x, w, b, (TT*)y, mean, rstd, rows, d, eps);       \
+    else if (nch == 2) hipLaunchKernelGGL((ln_fwd_kernel<TT, 2>), grid, dim3(256), 0, st, (const TT*)x, w, b, (TT*)y, mean, rstd, rows, d, eps);  \
+    else hipLaunchKernelGGL((ln_fwd_kernel<TT, LN_MAXC>), grid, dim3(256), 0, st, (const TT*)x, w, b, (TT*)y, mean, rstd, rows, d, eps);          \
+  }
   if (dtype == DH_BF16) {
-    if (vec) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, w, b, (bf16_t*)y, mean, rstd, rows, d, eps);
+    if (vec) LN_FWD(bf16_t)
     else hipLaunchKernelGGL(ln_fwd_scalar_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, w, b, (bf16_t*)y, mean, rstd, rows, d, eps);
   } else {
-    if (vec) hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, w, b, (float*)y, mean, rstd, rows, d, eps);
+    if (vec) LN_FWD(float)
     else hipLaunchKernelGGL(ln_fwd_scalar_kernel<float>, grid, dim3(256), 0, st, (const float*)x, w, b, (float*)y, mean, rstd, rows, d, eps);
   }
   DH_CHECK_LAUNCH();
@@ -244,10 +281,14 @@ extern "C" int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const 
     int nb = ln_bwd_blocks(rows);
     DH_REQUIRE(ws && ws_bytes >= (int64_t)nb * 2 * d * (int64_t)sizeof(float), "dh_layernorm_bwd: workspace too small");
     size_t lds = 8 * d * sizeof(float);
-    if (dtype == DH_BF16)
-      hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, st, (const bf16_t*)dy, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)ws, rows, d);
-    else
-      hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), lds, st, (const float*)dy, (const float*)x, w, mean, rstd, (const float*)dres, (float*)dx, (float*)ws, rows, d);
+    const int nch = dh_cdiv(d / 8, 64);
+#define LN_BWD(TT)                                                                                                                                             \
+  {                                                                                                                                                            \
+    if (nch <= 1) hipLaunchKernelGGL((ln_bwd_kernel<TT, 1>), dim3(nb), dim3(256), lds, st, (const TT*)dy, (const TT*)x, w, mean, rstd, (const TT*)dres, (TT*)dx, (float*)ws, rows, d);      \
+    else if (nch == 2) hipLaunchKernelGGL((ln_bwd_kernel<TT, 2>), dim3(nb), dim3(256), lds, st, (const TT*)dy, (const TT*)x, w, mean, rstd, (const TT*)dres, (TT*)dx, (float*)ws, rows, d); \
+    else hipLaunchKernelGGL((ln_bwd_kernel<TT, LN_MAXC>), dim3(nb), dim3(256), lds, st, (const TT*)dy, (const TT*)x, w, mean, rstd, (const TT*)dres, (TT*)dx, (float*)ws, rows, d);         \
+  }
+    if (dtype == DH_BF16) LN_BWD(bf16_t) else LN_BWD(float)
     DH_CHECK_LAUNCH();
     hipLaunchKernelGGL(ln_reduce_kernel, dim3(dh_cdiv(2 * d, 64), nb >= 64 ? 16 : 1), dim3(256), 0, st, (const float*)ws, nb, d, dw, db);
   } else {
