@@ -44,6 +44,9 @@
 #ifndef V4_TRACE
 #define V4_TRACE 0
 #endif
+#ifndef V4_TWO_PHASE
+#define V4_TWO_PHASE 1   // K-tile schedule: 1 = two phases of 16 MFMAs (4 barriers per K-tile), 0 = four phases of 8 (8 barriers)
+#endif
 #if V4_TRACE
 // tuning aid (-DV4_TRACE=1): s_memtime stamps of workgroups 0 / 100 / 200, waves 0 and 4, read back with dh_v4_trace_read
 __device__ long v4_trace_buf[6 * 256];
@@ -88,6 +91,12 @@ __device__ __forceinline__ void dma16(const bf16_t* src, unsigned char* lds_dst_
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // "all but the 4 youngest half-tiles and the `s` epilogue stores issued between them" (s is wave-uniform)
+template <int N> __device__ __forceinline__ void wait_vmcnt_plus(int s) {   // "all but the N youngest loads and the s stores between them"
+  if (s == 0) wait_vmcnt<N>();
+  else if (s == 16) wait_vmcnt<N + 16>();
+  else if (s == 32) wait_vmcnt<N + 32>();
+  else wait_vmcnt<N>();                            // unknown count: conservative
+}
 __device__ __forceinline__ void wait_vmcnt_8_plus(int s) {
   if (s == 0) wait_vmcnt<8>();
   else if (s == 16) wait_vmcnt<24>();
@@ -310,7 +319,11 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
     // ---- rest of the prologue: A0, B0 of K-tile 1 go to ring buffer 1 (free: every wave is past the epilogue)
     ADVANCE_SRC();
     ISSUE_H(ap, 0, 0, 1); ISSUE_H(bp, 0, 2, 1);
+#if V4_TWO_PHASE
+    if (ROLES) WAITV(6); else wait_vmcnt_plus<6>(pend);    // A0, B0, B1 of K-tile 0 have landed (A1 and K-tile 1's A0, B0 may fly)
+#else
     if (ROLES) WAITV(8); else wait_vmcnt_8_plus(pend);     // A0, B0 of K-tile 0 have landed
+#endif
     V4_BARRIER();
     TRACE();                                 // [0] prologue done
     if (wm == 1) V4_BARRIER();               // waves 4-7 run one barrier behind waves 0-3 from here on
@@ -334,6 +347,68 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
       const bool cs_now = want_cs && cs_ctr == txcur;
       cs_ctr = cs_ctr + 1 == ntx ? 0 : cs_ctr + 1;
 
+#if V4_TWO_PHASE
+      // Two phases per K-tile.  Phase A: fragments of A0, B0, B1 (16 reads), 16 MFMAs (quadrants A0B0, A0B1); phase B:
+      // fragments of A1 (8 reads), 16 MFMAs (A1B1, A1B0).  Every load segment ends with lgkmcnt(0) BEFORE its barrier, so a
+      // half-tile can be refilled in the very next phase: phase B requests A0, B0 of K-tile kt+2 (read in phase A), phase A
+      // of the next K-tile requests B1, A1 of kt+2.  Waits: phase A for A1(kt) = all but the 4 youngest half-tiles; phase B
+      // for A0, B0, B1 of kt+1 = all but the 3 youngest.
+      const uint32_t boff = buf * STAGE_BYTES;
+      if (do_frag) {
+        frag4<TB, 2>(fb0, bkm + boff, sB0, br, lm);
+        frag4<TB, 3>(fb1, bkm + boff, sB1, br, lm);
+        frag4<TA, 0>(fa0[0], akm0 + boff, sA0, ar, lm);
+        frag4<TA, 0>(fa0[1], akm1 + boff, sA0, ar + 32, lm);
+      }
+      if (has1) { ISSUE_H(bp, b_dh, 3, nbuf); ISSUE_H(ap, a_dh, 1, nbuf); if (ROLES) WAITV(8); else wait_vmcnt_plus<8>(pk); } else { WAITV(0); }   // A1(kt) has landed
+      wait_lgkm0();
+      V4_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) { MFMA(acc[ii][0], fa0[ii][s], fb0[s]); MFMA(acc[ii][1], fa0[ii][s], fb1[s]); }
+      if (TA && cs_now) {
+        // column sums of A rows (bias gradient): wave wn takes k16-step wn; indicator fragment = ones in column c
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const uint32_t one = ((lane & 31) == ii) ? 0x3f803f80u : 0u;
+          union { uint32_t u[4]; bf16x8_t v; } ind;
+          ind.u[0] = ind.u[1] = ind.u[2] = ind.u[3] = one;
+          const bf16x8_t af = wn == 0 ? fa0[ii][0] : wn == 1 ? fa0[ii][1] : wn == 2 ? fa0[ii][2] : fa0[ii][3];
+          cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ind.v, cs, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      V4_BARRIER();
+
+      if (do_frag) {
+        frag4<TA, 1>(fa1[0], akm0 + boff, sA1, ar, lm);
+        frag4<TA, 1>(fa1[1], akm1 + boff, sA1, ar + 32, lm);
+      }
+      if (has2) { ISSUE_H(ap, astep, 0, buf); ISSUE_H(bp, bstep, 2, buf); WAITV(6); } else if (has1) { WAITV(2); }   // A0, B0, B1 of kt+1 have landed
+      ADVANCE_SRC();
+      wait_lgkm0();
+      V4_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) { MFMA(acc[2 + ii][1], fa1[ii][s], fb1[s]); MFMA(acc[2 + ii][0], fa1[ii][s], fb0[s]); }
+      if (TA && cs_now) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const uint32_t one = ((lane & 31) == 2 + ii) ? 0x3f803f80u : 0u;
+          union { uint32_t u[4]; bf16x8_t v; } ind;
+          ind.u[0] = ind.u[1] = ind.u[2] = ind.u[3] = one;
+          const bf16x8_t af = wn == 0 ? fa1[ii][0] : wn == 1 ? fa1[ii][1] : wn == 2 ? fa1[ii][2] : fa1[ii][3];
+          cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ind.v, cs, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      V4_BARRIER();
+    }
+#else
       // ---- phase 1: quadrant (A0, B0)
       const uint32_t boff = buf * STAGE_BYTES;
       if (do_frag) {
@@ -419,6 +494,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
       __builtin_amdgcn_s_setprio(0);
       V4_BARRIER();
     }
+#endif
     if (wm == 0) V4_BARRIER();               // re-align the two wave groups; the whole ring is free from here
     TRACE();                                 // [1] main loop done
 
