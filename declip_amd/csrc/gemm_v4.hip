@@ -87,7 +87,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // issued from asm the compiler sees no VMEM traffic in the main loop at all and every wait there is one of ours.
 __device__ __forceinline__ void dma16(const bf16_t* src, unsigned char* lds_dst_uniform) {
   const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_dst_uniform;
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(src) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(src) : "memory", "m0");
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // "all but the 4 youngest half-tiles and the `s` epilogue stores issued between them" (s is wave-uniform)
