@@ -69,12 +69,31 @@ struct EpiParams {
   float* ws_cs;       // MODE_PARTIAL + a_colsum: [nsplit][ntx][M] fp32 bias-gradient partials
 };
 
+// The kernel's ONLY parameter: the kernarg segment is exactly this struct, and the kernel reads most of it LATE, through an
+// opaque pointer to the kernarg segment, right where a value is needed (prologue of the launch, start of each epilogue).
+// Passed as ordinary by-value arguments, these ~45 scalars were preloaded and kept (then spilled: 150-280 SGPR spills, with
+// v_readlane reloads inside the K loop of the dW kernel) across the main loop, which itself needs only four strides.
+struct KArgs {
+  const bf16_t* A; long lda;
+  const bf16_t* B; long ldb;
+  int M, N, K, k_per_split, ntx, nty, nitems, n_full, S, dyn;   // dyn: 0 static partition, 1 dynamic after the first item, 2 fully dynamic + stealing
+  int* sched;
+  EpiParams e;
+};
+typedef const __attribute__((address_space(4))) unsigned char* kargp_t;
+template <typename T> __device__ __forceinline__ T karg_load(kargp_t kp, int off) {
+  typedef const __attribute__((address_space(4))) T* P;
+  return *(P)(kp + off);
+}
+#define KARG(kp, T, field) karg_load<T>((kp), (int)offsetof(KArgs, field))
+
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;          // 16 KiB
 constexpr int STAGE_BYTES = 4 * HALF_BYTES;       // A0 A1 B0 B1
 constexpr int BIAS_OFF = 2 * STAGE_BYTES;         // behind the ring: the whole bias vector (fp32, N <= MAX_BIAS_N), loaded once per workgroup
 constexpr int MAX_BIAS_N = 4096;
-constexpr int LDS_BYTES = 2 * STAGE_BYTES + MAX_BIAS_N * 4; // 144 KiB
+constexpr int SCHED_OFF = BIAS_OFF + MAX_BIAS_N * 4;   // one word: the work item after next (dynamic scheduling)
+constexpr int LDS_BYTES = SCHED_OFF + 16;            // 144 KiB + 16 B
 // MODE: what happens to the finished tile.  The bf16 epilogue flavours are separate instantiations (straight-line code:
 // the kernel lives at the 256-VGPR cap, runtime epilogue switches cost spills).
 constexpr int MODE_STORE = 0, MODE_STORE_GELU = 1, MODE_STORE_DGELU = 2, MODE_STORE_RES = 3, MODE_ATOMIC = 4, MODE_PARTIAL = 5;
@@ -184,42 +203,66 @@ __device__ __forceinline__ void tile_from_logical(int b, int ntx, int nty, int& 
   tile_y = first_m + rem % gsz;
   tile_x = rem / gsz;
 }
-__device__ __forceinline__ void item_coords(int w, int ntx, int nty, int nitems, int& tile_x, int& tile_y, int& z) {
-  // XCD x (workgroups w = x mod 8) walks a CONTIGUOUS chunk of the (split, tile) list: the ~32 items it runs at a time are
-  // (almost) all the tiles of one K-slice, so every A / B panel it streams is shared by several of its CUs through its L2
-  // (with the slices dealt round-robin to the XCDs, PMC showed a 32 % L2 hit rate and ~6 TB/s of fabric reads on the dW calls)
-  const int q = nitems >> 3, r = nitems & 7, xcd = w & 7, idx = w >> 3;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  const int nb = ntx * nty;
-  z = logical / nb;
-  tile_from_logical(logical - z * nb, ntx, nty, tile_x, tile_y);
-}
-// Work item w of a launch.  Plain launches: nitems = tiles x splits (item_coords).  TAIL-SLICED launches (bf16 outputs whose
-// tile count leaves the last round mostly empty, e.g. 300 tiles on 256 CUs): items [0, n_full) are whole tiles (a multiple of
-// the grid), the remaining `rem` tiles are cut into S K-slices each -- item n_full + lt*S + s computes K-tiles
-// [s*nkt/S, (s+1)*nkt/S) of tile n_full + lt into a private fp32 tile of the workspace, and tail_fixup_kernel sums the
-// slices and applies the epilogue.  The last round then takes ~1/S of a tile time on all CUs instead of a full one on a few.
+// Work items of a launch.  Plain launches: n_fullitems = tiles x splits whole items.  TAIL-SLICED launches (bf16 outputs
+// whose tile count leaves the last round mostly empty, e.g. 300 tiles on 256 CUs): n_fullitems = n_full whole tiles (a
+// multiple of the grid) and the remaining `rem` tiles are cut into S K-slices each -- slice j = lt*S + s computes K-tiles
+// [s*nkt/S, (s+1)*nkt/S) of tile n_full + lt into a private fp32 tile of the workspace, and tail_fixup_kernel sums the slices
+// and applies the epilogue.  The last round then takes ~1/S of a tile time on all CUs instead of a full one on a few.
+//
+// Distribution: XCD x (workgroups p = x mod 8) owns a CONTIGUOUS chunk of the whole-item list and a contiguous chunk of the
+// slice list; its list = whole items first, slices last.  A workgroup is identified by (x, position l in that list).  The
+// first position of a workgroup is static (l = p / 8); every further one comes from a per-XCD atomic counter (DYNAMIC
+// scheduling: when other kernels -- RCCL during the overlapped gradient all-reduce -- hold some CUs, the workgroups that do
+// run simply take more tiles; with a static partition a 4-CU hog slowed this GEMM by 39 %), with stealing from the other
+// XCDs' lists once the own one is exhausted.  Without a scheduler buffer the partition is static (l += workgroups on x).
 struct Item { int tile_x, tile_y, z, kbeg, nk, slice; };
-__device__ __forceinline__ Item decode_item(int w, int ntx, int nty, int nitems, int n_full, int S, int K, int k_per_split) {
-  Item it;
-  if (S == 0 || w < n_full) {
-    item_coords(w, ntx, nty, S ? n_full : nitems, it.tile_x, it.tile_y, it.z);
+__device__ __forceinline__ void chunk_of(int n, int x, int& start, int& len) {
+  const int q = n >> 3, r = n & 7;
+  len = q + (x < r ? 1 : 0);
+  start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+}
+__device__ __forceinline__ bool decode_pos(int x, int l, int ntx, int nty, int n_fullitems, int n_full, int S, int K, int k_per_split,
+                                           Item& it) {
+  int sf, lf;
+  chunk_of(n_fullitems, x, sf, lf);
+  if (l < lf) {
+    const int logical = sf + l, nb = ntx * nty;
+    it.z = logical / nb;
+    tile_from_logical(logical - it.z * nb, ntx, nty, it.tile_x, it.tile_y);
     it.kbeg = it.z * k_per_split;
     it.nk = (min(K, it.kbeg + k_per_split) - it.kbeg) / BK;
     it.slice = -1;
-  } else {
-    const int j = w - n_full, lt = j / S, sl = j - lt * S, nkt = K / BK;
-    tile_from_logical(n_full + lt, ntx, nty, it.tile_x, it.tile_y);
-    const int k0 = sl * nkt / S, k1 = (sl + 1) * nkt / S;
-    it.z = 0; it.kbeg = k0 * BK; it.nk = k1 - k0; it.slice = j;
+    return true;
   }
-  return it;
+  if (S == 0) return false;
+  const int rem = ntx * nty - n_full;
+  int ss, ls;
+  chunk_of(rem * S, x, ss, ls);
+  const int j0 = l - lf;
+  if (j0 >= ls) return false;
+  const int j = ss + j0, lt = j / S, sl = j - lt * S, nkt = K / BK;
+  tile_from_logical(n_full + lt, ntx, nty, it.tile_x, it.tile_y);
+  const int k0 = sl * nkt / S, k1 = (sl + 1) * nkt / S;
+  it.z = 0; it.kbeg = k0 * BK; it.nk = k1 - k0; it.slice = j;
+  return true;
 }
+__device__ __forceinline__ int wgs_on_xcd(int x, int grid) { return x < grid ? ((grid - 1 - x) >> 3) + 1 : 0; }
 
 template <bool TA, bool TB, int MODE, bool ROLES>
-__global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
-                                                         long ldb, int M, int N, int K, int k_per_split, int ntx, int nty,
-                                                         int nitems, int n_full, int S, EpiParams e) {
+__global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) {
+  // launch-time view of the arguments (prologue); the epilogues re-read what they need (see KArgs)
+  kargp_t kp = (kargp_t)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  const bf16_t* A = KARG(kp, const bf16_t*, A);
+  const bf16_t* B = KARG(kp, const bf16_t*, B);
+  long lda = KARG(kp, long, lda), ldb = KARG(kp, long, ldb);
+  EpiParams e;
+  e.bias = KARG(kp, const float*, e.bias);
+  e.a_colsum = KARG(kp, float*, e.a_colsum);
+  int M = KARG(kp, int, M), N = KARG(kp, int, N), K = KARG(kp, int, K), k_per_split = KARG(kp, int, k_per_split);
+  int ntx = KARG(kp, int, ntx), nty = KARG(kp, int, nty), nitems = KARG(kp, int, nitems), n_full = KARG(kp, int, n_full), S = KARG(kp, int, S);
+  int* sched = KARG(kp, int*, sched);
+  const int dyn = sched ? KARG(kp, int, dyn) : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool SWAP = MODE != MODE_ATOMIC;
   constexpr bool STORE = MODE <= MODE_STORE_RES;
@@ -279,9 +322,94 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
 #else
 #define TRACE() do { } while (0)
 #endif
-  int w = blockIdx.x;
-  Item nxt = decode_item(w, ntx, nty, nitems, n_full, S, K, k_per_split);
-  {   // first tile: the four half-tiles of its K-tile 0, in steady-state FIFO order
+  // ---- work distribution state (see decode_pos)
+  const int xcd = blockIdx.x & 7, grid = gridDim.x;
+  int n_fullitems = S ? n_full : nitems;
+  int* const sched_lds = reinterpret_cast<int*>(smem + SCHED_OFF);      // [0] = packed (x << 24 | l) of the item after next, or -1
+  // first_of(x): positions of XCD x's list that are handed out statically (one per workgroup; none when fully dynamic)
+  auto first_of = [&](int x) { return dyn == 2 ? 0 : wgs_on_xcd(x, grid); };
+  auto list_len = [&](int x) {
+    int sf, lf, ss = 0, ls = 0;
+    chunk_of(n_fullitems, x, sf, lf);
+    if (S) chunk_of((ntx * nty - n_full) * S, x, ss, ls);
+    return lf + ls;
+  };
+  // thread 0 only.  fetch_raw: the non-blocking part -- one returning atomic on the own XCD's counter (plus, when stealing
+  // is enabled, a snapshot of all eight counters), results read much later.  INLINE ASM: inside the exec-masked
+  // `if (t == 0)` hipcc would wait for a visible returning atomic right at the end of the branch (vmcnt(0): the next
+  // tile's loads were just requested).  The result registers are read only after wait_vmcnt_plus<8>() at the end of the
+  // epilogue (these requests are older than everything issued after them: in-order vmcnt).
+  // The asynchronous results live in PLAIN variables written by the issuing asm and "re-defined" by the asm that waits for
+  // them (FETCH_WAIT ties them to the s_waitcnt as in/out operands): the compiler must not copy them in between, because a
+  // copy made before the wait would carry the stale register contents (checked in the ISA: no moves, no spills).
+#define FETCH_ISSUE(RAW, SN)                                                                                   \
+  do {                                                                                                        \
+    RAW = 1 << 22;                                                                                            \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) SN[q_] = 1 << 22;                                        \
+    if (first_of(xcd) < list_len(xcd)) {                                                                      \
+      const int one_ = 1;                                                                                     \
+      int* p_ = sched + xcd;                                                                                  \
+      asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(RAW) : "v"(p_), "v"(one_) : "memory");      \
+    }                                                                                                         \
+    if (dyn == 2) {                                                                                           \
+      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(SN[0]) : "v"(sched) : "memory");                \
+      asm volatile("global_load_dword %0, %1, off offset:4 sc1" : "=v"(SN[1]) : "v"(sched) : "memory");       \
+      asm volatile("global_load_dword %0, %1, off offset:8 sc1" : "=v"(SN[2]) : "v"(sched) : "memory");       \
+      asm volatile("global_load_dword %0, %1, off offset:12 sc1" : "=v"(SN[3]) : "v"(sched) : "memory");      \
+      asm volatile("global_load_dword %0, %1, off offset:16 sc1" : "=v"(SN[4]) : "v"(sched) : "memory");      \
+      asm volatile("global_load_dword %0, %1, off offset:20 sc1" : "=v"(SN[5]) : "v"(sched) : "memory");      \
+      asm volatile("global_load_dword %0, %1, off offset:24 sc1" : "=v"(SN[6]) : "v"(sched) : "memory");      \
+      asm volatile("global_load_dword %0, %1, off offset:28 sc1" : "=v"(SN[7]) : "v"(sched) : "memory");      \
+    }                                                                                                         \
+  } while (0)
+#define FETCH_WAIT(N, RAW, SN)                                                                                                    \
+  asm volatile("s_waitcnt vmcnt(%9)" : "+v"(RAW), "+v"(SN[0]), "+v"(SN[1]), "+v"(SN[2]), "+v"(SN[3]), "+v"(SN[4]), "+v"(SN[5]), \
+               "+v"(SN[6]), "+v"(SN[7]) : "n"(N) : "memory")
+  // fetch_finish: packed position of the next item, or -1.  Stealing (dyn == 2): only lists whose counter snapshot says
+  // something is left are tried (a blocking atomic each: this is the end of the kernel)
+  auto fetch_finish = [&](int raw, const int* snap) -> int {
+    const int l0 = first_of(xcd) + raw;
+    if (l0 < list_len(xcd)) return (xcd << 24) | l0;
+    if (dyn != 2) return -1;
+    for (int k = 1; k < 8; ++k) {
+      const int x = (xcd + k) & 7;
+      const int total = list_len(x);
+      int sn = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sn = q == x ? snap[q] : sn;
+      if (sn >= total) continue;
+      const int l = atomicAdd(sched + x, 1);
+      if (l < total) return (x << 24) | l;
+    }
+    return -1;
+  };
+  Item nxt;
+  bool have;
+  if (dyn == 2) {
+    // fully dynamic: the first TWO positions come from the counters (a late-starting workgroup owns nothing)
+    if (t == 0) {
+      int r0, r1, sa[8], sb[8];
+      FETCH_ISSUE(r0, sa);
+      FETCH_ISSUE(r1, sb);
+      FETCH_WAIT(0, r0, sa);
+      FETCH_WAIT(0, r1, sb);
+      sched_lds[1] = fetch_finish(r0, sa);
+      sched_lds[0] = fetch_finish(r1, sb);
+    }
+    __syncthreads();
+    const int p0 = __builtin_amdgcn_readfirstlane(sched_lds[1]);
+    have = p0 >= 0 && decode_pos(p0 >> 24, p0 & 0xffffff, ntx, nty, n_fullitems, n_full, S, K, k_per_split, nxt);
+  } else {
+    const int my_l = blockIdx.x >> 3;                                    // position in XCD `xcd`'s list
+    have = decode_pos(xcd, my_l, ntx, nty, n_fullitems, n_full, S, K, k_per_split, nxt);   // grid <= items: always true
+    if (t == 0) {
+      int v;
+      if (dyn) { int r0, sa[8]; FETCH_ISSUE(r0, sa); FETCH_WAIT(0, r0, sa); v = fetch_finish(r0, sa); }
+      else { const int l = my_l + wgs_on_xcd(xcd, grid); v = (xcd << 24) | l; }     // static partition (validity checked at decode)
+      sched_lds[0] = v;
+    }
+  }
+  if (have) {   // first tile: the four half-tiles of its K-tile 0, in steady-state FIFO order
     SETUP_SRC(nxt.tile_y * BM, nxt.tile_x * BN, nxt.kbeg);
     ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, b_dh, 3, 0); ISSUE_H(ap, a_dh, 1, 0);
   }
@@ -291,12 +419,29 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
   }
   int pend = 0;                      // epilogue stores of the previous tile that may still be in flight (per wave-instruction stream)
 
-  for (; w < nitems; w += gridDim.x) {
-    const Item cur = nxt;
-    const int m0 = cur.tile_y * BM, n0 = cur.tile_x * BN;
-    const int nk = cur.nk;                                         // host guarantees nk >= 2
-    const int zcur = cur.z;
-    const int txcur = cur.tile_x;
+  // everything the epilogue / the choice of the next item needs, re-read from the kernarg segment (see KArgs)
+#define RELOAD_ARGS()                                                                                   \
+  do {                                                                                                  \
+    kargp_t kq = (kargp_t)__builtin_amdgcn_kernarg_segment_ptr();                     \
+    asm volatile("" : "+s"(kq));                                                                        \
+    A = KARG(kq, const bf16_t*, A); B = KARG(kq, const bf16_t*, B);                                     \
+    lda = KARG(kq, long, lda); ldb = KARG(kq, long, ldb);                                               \
+    M = KARG(kq, int, M); N = KARG(kq, int, N); K = KARG(kq, int, K); k_per_split = KARG(kq, int, k_per_split); \
+    ntx = KARG(kq, int, ntx); nty = KARG(kq, int, nty); nitems = KARG(kq, int, nitems);                 \
+    n_full = KARG(kq, int, n_full); S = KARG(kq, int, S); sched = KARG(kq, int*, sched);                \
+    e.M = M; e.N = N; e.C = KARG(kq, void*, e.C); e.ldc = KARG(kq, long, e.ldc);                        \
+    e.bias = KARG(kq, const float*, e.bias); e.epilogue = KARG(kq, int, e.epilogue);                    \
+    e.residual = KARG(kq, const void*, e.residual); e.ldr = KARG(kq, long, e.ldr);                      \
+    e.aux = KARG(kq, void*, e.aux); e.ldaux = KARG(kq, long, e.ldaux); e.alpha = KARG(kq, float, e.alpha); \
+    e.a_colsum = KARG(kq, float*, e.a_colsum); e.ws = KARG(kq, float*, e.ws); e.ws_cs = KARG(kq, float*, e.ws_cs); \
+  } while (0)
+  while (have) {
+    const int m0 = nxt.tile_y * BM, n0 = nxt.tile_x * BN;
+    const int nk = nxt.nk;                                         // host guarantees nk >= 2
+    const int zcur = nxt.z;
+    const int txcur = nxt.tile_x;
+    const int cur_slice = nxt.slice;
+    const int ntx_cs = ntx;
 
     // fragment addressing restarts from an opaque lane id per tile, so its ~12 address registers are not kept live across
     // the epilogue of the previous tile (same trick as `te` below)
@@ -345,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
         }
       }
       const bool cs_now = want_cs && cs_ctr == txcur;
-      cs_ctr = cs_ctr + 1 == ntx ? 0 : cs_ctr + 1;
+      cs_ctr = cs_ctr + 1 == ntx_cs ? 0 : cs_ctr + 1;
 
 #if V4_TWO_PHASE
       // Two phases per K-tile.  Phase A: fragments of A0, B0, B1 (16 reads), 16 MFMAs (quadrants A0B0, A0B1); phase B:
@@ -499,14 +644,23 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
     TRACE();                                 // [1] main loop done
 
     // ---- next work item: request the four half-tiles of its K-tile 0 into ring buffer 0 BEFORE the epilogue
-    const int wnext = w + gridDim.x;
-    if (wnext < nitems) {
-      nxt = decode_item(wnext, ntx, nty, nitems, n_full, S, K, k_per_split);
+    RELOAD_ARGS();
+    n_fullitems = S ? n_full : nitems;
+    const int packed = __builtin_amdgcn_readfirstlane(sched_lds[0]);       // published before this tile's prologue barrier
+    have = packed >= 0 && decode_pos(packed >> 24, packed & 0xffffff, ntx, nty, n_fullitems, n_full, S, K, k_per_split, nxt);
+    int fut = -1;                                // thread 0: the item after that (published at the end of this epilogue)
+    int fut_raw = 1 << 22, fut_sn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (have) {
+      if (t == 0) {
+        if (dyn) FETCH_ISSUE(fut_raw, fut_sn);   // no control flow depends on it until the end of the epilogue
+        else { const int x = packed >> 24, l = (packed & 0xffffff) + wgs_on_xcd(x, grid); fut = (x << 24) | l; }
+      }
       SETUP_SRC(nxt.tile_y * BM, nxt.tile_x * BN, nxt.kbeg);
       ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, b_dh, 3, 0); ISSUE_H(ap, a_dh, 1, 0);
     }
     TRACE();                                 // [2] next tile requested
     pend = 0;
+    do {   // the epilogue flavours leave with `break`
     // the epilogue's per-lane indexing starts from an OPAQUE copy of the thread id: otherwise the compiler hoists ~30 loop-
     // invariant address registers out of the persistent tile loop and keeps them live across the main loop (spills)
     int te = t;
@@ -514,7 +668,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
     const int le = te & 63;
     if (!do_epi) {
       if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(e.C)[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7] + cs[2];
-      continue;
+      V4_BARRIER();
+      break;
     }
 
     if (TA && want_cs) {
@@ -557,19 +712,19 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
             }
       wait_vmcnt<0>();                       // 128 atomics per lane cannot ride along: drain (also lands the next tile's loads)
       V4_BARRIER();
-      continue;
+      break;
     }
 
     unsigned char* Cs = smem + STAGE_BYTES;  // ring buffer 1 (buffer 0 is receiving the next tile)
     constexpr bool SLICEABLE = MODE == MODE_STORE || MODE == MODE_STORE_RES;   // the N = d GEMMs (few tiles) use these flavours
-    if (MODE == MODE_PARTIAL || (SLICEABLE && cur.slice >= 0)) {
+    if (MODE == MODE_PARTIAL || (SLICEABLE && cur_slice >= 0)) {
       // fp32 partial tile: MODE_PARTIAL -> ws[z][m][n]; tail slice -> its private [256][256] tile of the workspace.
       // 4 passes of 64 rows: pass (i, ii) holds rows i*128 + wm*64 + ii*32 + 0..31 of both wave groups; staging row =
       // wm*32 + (lane&31), 1024 B per row, 16-byte unit u of row r stored at unit u ^ (r & 7).
       float* Wp;
       long wld;
       if (MODE == MODE_PARTIAL) { Wp = e.ws + (long)zcur * M * N + (long)m0 * N + n0; wld = N; }
-      else { Wp = e.ws + (long)cur.slice * (BM * BN); wld = BN; }
+      else { Wp = e.ws + (long)cur_slice * (BM * BN); wld = BN; }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -602,7 +757,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
           TRACE();                           // [3..6] partial pass stored
         }
       pend = 32;
-      continue;
+      break;
     }
 
     // ---- MODE_STORE: bf16 epilogue.  acc[i*2+ii][j] holds a C^T fragment: lane -> row (lane&31), registers 4*rg .. 4*rg+3
@@ -704,6 +859,26 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
       }
       pend = ROLES ? 0 : (is_gelu ? 32 : 16);
     }
+      } while (0);
+    if (t == 0) {
+      if (dyn && have) {
+        // the raw counter value was requested before this epilogue's P4 loads (8), prefetch loads and stores: it is older
+        // than the `8 + pend` operations that may still be in flight, so this wait does not touch the stores
+        if (pend == 32) FETCH_WAIT(40, fut_raw, fut_sn);
+        else if (pend == 16) FETCH_WAIT(24, fut_raw, fut_sn);
+        else FETCH_WAIT(8, fut_raw, fut_sn);
+        fut = fetch_finish(fut_raw, fut_sn);
+      }
+      sched_lds[0] = fut;                        // read by every wave at the start of the NEXT epilogue (barriers in between)
+    }
+  }
+  if (dyn && t == 0) {
+    // self-resetting scheduler state: the last workgroup to leave zeroes the counters for the next launch on this stream
+    const int d = atomicAdd(sched + 8, 1);
+    if (d == grid - 1) {
+#pragma unroll
+      for (int x = 0; x < 9; ++x) sched[x] = 0;
+    }
   }
 #if V4_TRACE
   if (tracing) trace_p[0] = trace_n;
@@ -712,6 +887,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const bf16_t* __restric
 #undef TRACE
 #undef ISSUE_H
 #undef SETUP_SRC
+#undef RELOAD_ARGS
+#undef FETCH_ISSUE
+#undef FETCH_WAIT
 #undef ADVANCE_SRC
 #undef WAITV
 }
@@ -821,6 +999,32 @@ static int num_cus() {
   return n;
 }
 
+// Scheduler state for the dynamic tile distribution: 16 launch slots x 16 ints (8 per-XCD counters, 1 exit counter), one
+// slot per stream that launches v4 GEMMs (two launches on different streams may overlap in time; launches on one stream do
+// not).  Library-internal, allocated once, zero at rest (the kernel restores the zeros on its way out).
+static int* sched_slot(hipStream_t st, int* dyn) {
+  // DH_V4_DYNAMIC: 0 (default) static partition; 1 dynamic after each workgroup's first item -- declip_amd.dist sets it for
+  // multi-GPU jobs, where RCCL kernels hold CUs during the overlapped gradient all-reduce (measured with a 16-CU hog:
+  // static 83 -> 119 us, dynamic 83 -> 101 us; costs ~1.5 % when nothing else runs); 2 fully dynamic + stealing (experimental)
+  static int mode = -1;
+  if (mode < 0) { const char* ev = getenv("DH_V4_DYNAMIC"); mode = ev ? atoi(ev) : 0; }
+  *dyn = mode;
+  if (!mode) return nullptr;
+  constexpr int NSLOT = 16;
+  static int* buf = nullptr;
+  static hipStream_t owner[NSLOT];
+  static int nown = 0;
+  if (!buf) {
+    if (hipMalloc(&buf, NSLOT * 16 * sizeof(int)) != hipSuccess) { buf = nullptr; *dyn = 0; return nullptr; }
+    hipMemset(buf, 0, NSLOT * 16 * sizeof(int));
+  }
+  for (int i = 0; i < nown; ++i)
+    if (owner[i] == st) return buf + i * 16;
+  if (nown == NSLOT) { *dyn = 0; return nullptr; }   // more streams than slots: static partition for the extra ones
+  owner[nown] = st;
+  return buf + (nown++) * 16;
+}
+
 template <bool TA, bool TB, int MODE, bool ROLES>
 void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, int n_full, int S, hipStream_t st) {
   static bool attr_set = false;
@@ -832,8 +1036,11 @@ void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, int n
   const int nitems = S ? n_full + (ntx * nty - n_full) * S : ntx * nty * split;
   int grid = num_cus();
   if (grid > nitems) grid = nitems;
-  hipLaunchKernelGGL((gemm_v4_kernel<TA, TB, MODE, ROLES>), dim3(grid), dim3(512), LDS_BYTES, st, (const bf16_t*)a->A, (long)a->lda,
-                     (const bf16_t*)a->B, (long)a->ldb, a->M, a->N, a->K, kps, ntx, nty, nitems, n_full, S, e);
+  KArgs ka;
+  ka.A = (const bf16_t*)a->A; ka.lda = a->lda; ka.B = (const bf16_t*)a->B; ka.ldb = a->ldb;
+  ka.M = a->M; ka.N = a->N; ka.K = a->K; ka.k_per_split = kps; ka.ntx = ntx; ka.nty = nty; ka.nitems = nitems; ka.n_full = n_full; ka.S = S;
+  ka.sched = sched_slot(st, &ka.dyn); ka.e = e;
+  hipLaunchKernelGGL((gemm_v4_kernel<TA, TB, MODE, ROLES>), dim3(grid), dim3(512), LDS_BYTES, st, ka);
 }
 
 }  // namespace v4

@@ -48,6 +48,10 @@ def initialize(backend="nccl"):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "12345")
     os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+    if world > 1:
+        # RCCL kernels hold some CUs while the gradient all-reduce overlaps the backward pass: let the persistent GEMM hand
+        # out its tiles dynamically (a static partition loses a whole tile time per occupied CU; gemm_v4.hip / probe_contention)
+        os.environ.setdefault("DH_V4_DYNAMIC", "1")
     if torch.cuda.is_available():
         torch.cuda.set_device(get_local_rank())
     else:
