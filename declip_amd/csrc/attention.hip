@@ -44,6 +44,28 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long gs
   }
 }
 
+// The MFMA kernels are PERSISTENT: a workgroup walks (batch, head) pairs and fetches the tiles of the NEXT pair into registers
+// (2 x 16 bytes per thread and tile) while it multiplies the current one -- with 2-4 workgroups per CU (LDS-bound) the
+// one-shot version spent about half of its time waiting for its own loads.
+struct TileRegs { uint4 v[2]; };
+__device__ __forceinline__ TileRegs tile_load(const bf16_t* __restrict__ g, long gs, int L, int tid, int nthr) {
+  TileRegs r;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int task = tid + k * nthr, row = task >> 3, c = task & 7;
+    r.v[k] = make_uint4(0, 0, 0, 0);
+    if (row < L) r.v[k] = *reinterpret_cast<const uint4*>(g + (long)row * gs + c * 8);
+  }
+  return r;
+}
+__device__ __forceinline__ void tile_store(const TileRegs& r, bf16_t* rm, int tid, int nthr) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int task = tid + k * nthr, row = task >> 3, c = task & 7;
+    *reinterpret_cast<uint4*>(rm + row * RS + c * 8) = r.v[k];
+  }
+}
+
 // MFMA 16x16x32 operand whose contraction index is the ROW of a row-major LDS tile (stride ld
 // elements): lane (t = lane&15, g = lane>>4) needs k = k0 + 8g .. +7 for column c0 + t.  Two hardware
 // transpose reads (ds_read_b64_tr_b16; semantics measured in profiles/r01_hw_probe_trread_glds.txt):
@@ -71,7 +93,7 @@ __device__ __forceinline__ bf16x8_t kmask(bf16x8_t f, bool dead) {
 // ------------------------------------------------------------------------------------------
 template <int NKB>  // number of 16-key blocks (L16/16), compile-time so scores stay in registers
 __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
-                                     int L, int heads, int causal, float scale) {
+                                     int L, int heads, int causal, float scale, int nbh) {
   constexpr int L16 = NKB * 16;
   constexpr int NKS = (L16 + 31) / 32;          // 32-wide k-steps over the keys
   constexpr bool KTAIL = (L16 % 32) != 0;
@@ -82,18 +104,25 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
   bf16_t* Vs = Ks + L16 * RS;                        // [L16][RS]
   bf16_t* Ps = Vs + L16 * RS;                        // [L16][TS]  (+ 32 elements slack for the masked tail read)
 
-  const int bh = blockIdx.x;
-  const int bi = bh / heads, h = bh % heads;
   const int d_model = heads * HD;
   const long gs = 3L * d_model;
-  const bf16_t* qg = qkv + (long)bi * L * gs + h * HD;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6;
-
-  stage_tile(qg, gs, L, L16, Qs, tid, nthr);
-  stage_tile(qg + d_model, gs, L, L16, Ks, tid, nthr);
-  stage_tile(qg + 2 * d_model, gs, L, L16, Vs, tid, nthr);
+  TileRegs rq, rk, rv;
+  {
+    const int bh0 = blockIdx.x;
+    const bf16_t* qg0 = qkv + (long)(bh0 / heads) * L * gs + (bh0 % heads) * HD;
+    rq = tile_load(qg0, gs, L, tid, nthr); rk = tile_load(qg0 + d_model, gs, L, tid, nthr); rv = tile_load(qg0 + 2 * d_model, gs, L, tid, nthr);
+  }
+  for (int bh = blockIdx.x; bh < nbh; bh += gridDim.x) {
+  const int bi = bh / heads, h = bh % heads;
+  tile_store(rq, Qs, tid, nthr); tile_store(rk, Ks, tid, nthr); tile_store(rv, Vs, tid, nthr);
   __syncthreads();
+  if (bh + (int)gridDim.x < nbh) {         // next pair's tiles: in flight during this pair's arithmetic
+    const int bn = bh + gridDim.x;
+    const bf16_t* qn = qkv + (long)(bn / heads) * L * gs + (bn % heads) * HD;
+    rq = tile_load(qn, gs, L, tid, nthr); rk = tile_load(qn + d_model, gs, L, tid, nthr); rv = tile_load(qn + 2 * d_model, gs, L, tid, nthr);
+  }
 
   const int qb = wave;
   const int q = qb * 16 + (lane & 15);  // this lane's query (column of S^T)
@@ -165,6 +194,8 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
       *reinterpret_cast<uint2*>(out + ((long)bi * L + qq) * d_model + h * HD + db * 16 + 4 * (lane >> 4)) = w;
     }
   }
+  __syncthreads();                         // every wave is done with the tiles before the next pair overwrites them
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -173,7 +204,7 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
 template <int NKB>
 __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                      const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                     bf16_t* __restrict__ dqkv, int L, int heads, int causal, float scale) {
+                                     bf16_t* __restrict__ dqkv, int L, int heads, int causal, float scale, int nbh) {
   constexpr int L16 = NKB * 16;
   constexpr int NKS = (L16 + 31) / 32;
   constexpr bool KTAIL = (L16 % 32) != 0;
@@ -187,39 +218,66 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
   bf16_t* dSt = Pt + L16 * TS;    // dS^T [key][q]   (+ slack for masked tail reads)
   float* Dq = reinterpret_cast<float*>(dSt + L16 * TS + 64);  // [L16] rowsum(dO o O)
 
-  const int bh = blockIdx.x;
-  const int bi = bh / heads, h = bh % heads;
   const int d_model = heads * HD;
   const long gs = 3L * d_model;
-  const bf16_t* qg = qkv + (long)bi * L * gs + h * HD;
-  const bf16_t* og = out + (long)bi * L * d_model + h * HD;
-  const bf16_t* gg = dout + (long)bi * L * d_model + h * HD;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6;
-
-  stage_tile(qg, gs, L, L16, Qs, tid, nthr);
-  stage_tile(qg + d_model, gs, L, L16, Ks, tid, nthr);
-  stage_tile(qg + 2 * d_model, gs, L, L16, Vs, tid, nthr);
-  stage_tile(gg, d_model, L, L16, Gs, tid, nthr);
-  // D[q] = sum_d dO[q][d] * O[q][d]   (4 lanes per row, 16 columns each)
-  for (int task = tid; task < L16 * 4; task += nthr) {
-    const int r = task >> 2, part = task & 3;
-    float acc = 0.f;
-    if (r < L) {
-      float a[8], b[8];
+  // D[q] = sum_d dO[q][d] * O[q][d]: thread -> row tid >> 2, 16 columns (tid & 3) * 16 .. +15 (two 16-byte pieces each of O, dO)
+  struct DRegs { uint4 o[2], g[2]; };
+  auto d_load = [&](const bf16_t* og, const bf16_t* gg) {
+    DRegs r;
+    const int row = tid >> 2, part = tid & 3;
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        ld8(og + (long)r * d_model + part * 16 + c * 8, a);
-        ld8(gg + (long)r * d_model + part * 16 + c * 8, b);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc += a[i] * b[i];
+    for (int c = 0; c < 2; ++c) {
+      r.o[c] = make_uint4(0, 0, 0, 0); r.g[c] = make_uint4(0, 0, 0, 0);
+      if (row < L) {
+        r.o[c] = *reinterpret_cast<const uint4*>(og + (long)row * d_model + part * 16 + c * 8);
+        r.g[c] = *reinterpret_cast<const uint4*>(gg + (long)row * d_model + part * 16 + c * 8);
       }
     }
+    return r;
+  };
+  TileRegs rq, rk, rv, rg;
+  DRegs rd;
+  {
+    const int bh0 = blockIdx.x, b0 = bh0 / heads, h0 = bh0 % heads;
+    const bf16_t* qg0 = qkv + (long)b0 * L * gs + h0 * HD;
+    const bf16_t* gg0 = dout + (long)b0 * L * d_model + h0 * HD;
+    rq = tile_load(qg0, gs, L, tid, nthr); rk = tile_load(qg0 + d_model, gs, L, tid, nthr); rv = tile_load(qg0 + 2 * d_model, gs, L, tid, nthr);
+    rg = tile_load(gg0, d_model, L, tid, nthr);
+    rd = d_load(out + (long)b0 * L * d_model + h0 * HD, gg0);
+  }
+  for (int bh = blockIdx.x; bh < nbh; bh += gridDim.x) {
+  const int bi = bh / heads, h = bh % heads;
+  tile_store(rq, Qs, tid, nthr); tile_store(rk, Ks, tid, nthr); tile_store(rv, Vs, tid, nthr); tile_store(rg, Gs, tid, nthr);
+  {
+    const uint32_t* ow = reinterpret_cast<const uint32_t*>(rd.o);
+    const uint32_t* gw = reinterpret_cast<const uint32_t*>(rd.g);
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      acc += __uint_as_float(ow[i] << 16) * __uint_as_float(gw[i] << 16) + __uint_as_float(ow[i] & 0xffff0000u) * __uint_as_float(gw[i] & 0xffff0000u);
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
-    if (part == 0) Dq[r] = acc;
+    if ((tid & 3) == 0) Dq[tid >> 2] = acc;
   }
   __syncthreads();
+  // this pair's log-sum-exp values are requested BEFORE the prefetch: a load issued behind the prefetch would have to wait
+  // for all of it (vmcnt retires in order)
+  float lse_r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qq = wave * 16 + 4 * (lane >> 4) + r;
+    lse_r[r] = qq < L ? lse[((long)bi * heads + h) * L + qq] : 0.f;
+  }
+  if (bh + (int)gridDim.x < nbh) {         // next pair's tiles: in flight during this pair's arithmetic
+    const int bn = bh + gridDim.x, b1 = bn / heads, h1 = bn % heads;
+    const bf16_t* qn = qkv + (long)b1 * L * gs + h1 * HD;
+    const bf16_t* gn = dout + (long)b1 * L * d_model + h1 * HD;
+    rq = tile_load(qn, gs, L, tid, nthr); rk = tile_load(qn + d_model, gs, L, tid, nthr); rv = tile_load(qn + 2 * d_model, gs, L, tid, nthr);
+    rg = tile_load(gn, d_model, L, tid, nthr);
+    rd = d_load(out + (long)b1 * L * d_model + h1 * HD, gn);
+  }
 
   // ---- phase 1: wave owns query block qb: S[q][key] (rows q), dP[q][key]
   {
@@ -230,13 +288,9 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
       qf[ks] = lds_frag(Qs + (qb * 16 + (lane & 15)) * RS + ks * 32 + 8 * (lane >> 4));
       gf[ks] = lds_frag(Gs + (qb * 16 + (lane & 15)) * RS + ks * 32 + 8 * (lane >> 4));
     }
-    float lse_r[4], d_r[4];
+    float d_r[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qq = qb * 16 + 4 * (lane >> 4) + r;
-      lse_r[r] = qq < L ? lse[((long)bi * heads + h) * L + qq] : 0.f;
-      d_r[r] = Dq[qq];
-    }
+    for (int r = 0; r < 4; ++r) d_r[r] = Dq[qb * 16 + 4 * (lane >> 4) + r];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
@@ -301,6 +355,8 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
         *reinterpret_cast<uint2*>(dq_g + o + 2 * d_model) = w;
       }
     }
+  }
+  __syncthreads();                         // every wave is done with the tiles before the next pair overwrites them
   }
 }
 
@@ -408,13 +464,27 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const T* __restri
   }
 }
 
+static int attn_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    hipDeviceProp_t p;
+    n = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return n;
+}
+
 template <int NKB>
 int launch_fwd_mfma(const bf16_t* qkv, bf16_t* out, float* lse, int b, int L, int heads, int causal, float scale,
                     hipStream_t st) {
   constexpr int L16 = NKB * 16, TS = L16 + 8;
   size_t lds = (size_t)(3 * L16 * RS + L16 * TS + 64) * sizeof(bf16_t);
   hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(attn_fwd_mfma_kernel<NKB>, dim3(b * heads), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale);
+  const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
+  int grid = attn_cus() * (per_cu < 1 ? 1 : per_cu);
+  if (grid > b * heads) grid = b * heads;
+  hipLaunchKernelGGL(attn_fwd_mfma_kernel<NKB>, dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads);
   return 0;
 }
 template <int NKB>
@@ -423,7 +493,10 @@ int launch_bwd_mfma(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
   constexpr int L16 = NKB * 16, TS = L16 + 8;
   size_t lds = (size_t)(4 * L16 * RS + 2 * L16 * TS + 64) * sizeof(bf16_t) + L16 * sizeof(float);
   hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(attn_bwd_mfma_kernel<NKB>, dim3(b * heads), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale);
+  const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
+  int grid = attn_cus() * (per_cu < 1 ? 1 : per_cu);
+  if (grid > b * heads) grid = b * heads;
+  hipLaunchKernelGGL(attn_bwd_mfma_kernel<NKB>, dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads);
   return 0;
 }
 
