@@ -1046,10 +1046,17 @@ void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, int n
 }  // namespace v4
 
 // Returns true if the v4 kernel took the problem (called from dh_gemm first).  DH_GEMM_V4=0 disables it.
+static int g_v4_mode = -2;   // -2 unread, -1 default (on), 0 off, 1 on
+extern "C" int dh_gemm_v4_enable(int on) {
+  if (g_v4_mode == -2) { const char* ev = getenv("DH_GEMM_V4"); g_v4_mode = ev ? atoi(ev) : -1; }
+  const int prev = g_v4_mode;
+  g_v4_mode = on;
+  return prev;
+}
 bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
   using namespace v4;
-  static int mode = -2;
-  if (mode == -2) { const char* ev = getenv("DH_GEMM_V4"); mode = ev ? atoi(ev) : -1; }
+  if (g_v4_mode == -2) { const char* ev = getenv("DH_GEMM_V4"); g_v4_mode = ev ? atoi(ev) : -1; }
+  const int mode = g_v4_mode;
   if (mode == 0 && a->force_generic != 4) return false;
   if (a->dtype != DH_BF16) return false;
   if ((a->lda % 8) || (a->ldb % 8) || ((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15)) return false;

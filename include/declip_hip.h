@@ -87,6 +87,9 @@ typedef struct dh_gemm_args {
                             atomics from every split (needs split*M*N*4 bytes; ignored when too small or NULL) */
 } dh_gemm_args;
 int dh_gemm(const dh_gemm_args* args, dh_stream_t stream);
+/* Auto-dispatch switch for the 256 x 256 persistent kernel (on by default; DH_GEMM_V4=0 in the environment turns it off).
+ * Returns the previous setting (-1 = default).  Used by the parity tests to run one model through both GEMM families. */
+int dh_gemm_v4_enable(int on);
 
 /* out[n] (+)= sum_m X[m,n]  (fp32 out; bias gradients).  X: dtype, [M][N] with ldx. */
 int dh_colsum(int dtype, const void* X, int64_t ldx, int M, int N, float* out, int accumulate, dh_stream_t stream);
