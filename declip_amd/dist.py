@@ -133,18 +133,30 @@ class FlatReducer:
         self.done = []       # launched [lo, hi)
         self.runs = []       # coalesced ready-but-not-launched [lo, hi)
         self.works = []
+        self.events = []     # (lo, hi, stream id, event): ranges finished on a tower side stream (FlatParams.side_stream)
 
     def begin(self):
-        self.done, self.runs, self.works = [], [], []
+        self.done, self.runs, self.works, self.events = [], [], [], []
 
     def _launch(self, lo, hi):
         if hi <= lo:
             return
         self.done.append((lo, hi))
+        if self.events:
+            # the collective is ordered after the CURRENT stream only: wait for pieces of this run produced on another one
+            cur = torch.cuda.current_stream(self.flat.flat_g.device)
+            for a, b, sid, ev in self.events:
+                if sid != cur.cuda_stream and a < hi and b > lo:
+                    cur.wait_event(ev)
         if is_dist():
             self.works.append(tdist.all_reduce(self.flat.flat_g[lo:hi], op=tdist.ReduceOp.SUM, async_op=True))
 
     def ready(self, lo, hi):
+        if getattr(self.flat, "side_streams", None):
+            cur = torch.cuda.current_stream(self.flat.flat_g.device)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self.events.append((lo, hi, cur.cuda_stream, ev))
         runs = sorted(self.runs + [(lo, hi)])
         merged = [list(runs[0])]
         for a, b in runs[1:]:

@@ -38,6 +38,8 @@ class FlatParams:
         self.mirror_fresh = False
         self.reducer = None          # set by dist.DistModule
         self.names = {}
+        self.side_streams = []       # extra HIP streams that towers run on (see side_stream); joined wherever params/grads are consumed
+        self._zero_event = None
 
     # ------------------------------------------------------------------ construction
     def attach(self):
@@ -102,6 +104,24 @@ class FlatParams:
         hi = max(self.index[id(p)][0] + self.index[id(p)][1] for p in params)
         return lo, hi
 
+    # ------------------------------------------------------------------ tower streams
+    def side_stream(self, i=0):
+        """The i-th extra stream of this store.  Independent towers (image / text) are enqueued on different streams so that
+        the ragged last round of one tower's persistent GEMMs, its HBM-bound LayerNorm / attention launches and the other
+        tower's MFMA work fill each other's idle CUs (one 256x256 workgroup owns a CU; the hardware queues interleave at
+        workgroup granularity)."""
+        while len(self.side_streams) <= i:
+            self.side_streams.append(torch.cuda.Stream(device=self.flat_p.device))
+        return self.side_streams[i]
+
+    def join_streams(self):
+        """The current stream waits for everything enqueued on the side streams (stream-ordered, no host sync)."""
+        if self.side_streams:
+            cur = torch.cuda.current_stream(self.flat_p.device)
+            for s in self.side_streams:
+                if s != cur:
+                    cur.wait_stream(s)
+
     def refresh_mirror(self):
         if self.flat_b is not None and not self.mirror_fresh:
             ops.cast(self.flat_p, self.flat_b)
@@ -110,6 +130,7 @@ class FlatParams:
     def begin_step(self):
         """Call at the start of every forward in training: parameters may have changed."""
         self.ensure()
+        self.join_streams()
         self.mirror_fresh = False
         self.refresh_mirror()
 
@@ -117,6 +138,8 @@ class FlatParams:
     def begin_backward(self):
         """First engine backward of an autograd pass: establish the accumulate-into contract."""
         if self._in_backward:
+            if self._zero_event is not None:     # a tower on another stream: its gradient writes must follow the zeroing
+                torch.cuda.current_stream(self.flat_p.device).wait_event(self._zero_event)
             return
         self._in_backward = True
         base, end = self.flat_g.data_ptr(), self.flat_g.data_ptr() + 4 * self.total
@@ -127,12 +150,17 @@ class FlatParams:
             for p in self.params:
                 if p.grad is None or not (base <= p.grad.data_ptr() < end):
                     self.gview(p).zero_()
+        if self.side_streams:
+            self._zero_event = torch.cuda.Event()
+            self._zero_event.record(torch.cuda.current_stream(self.flat_p.device))
         if self.reducer is not None:
             self.reducer.begin()
         torch.autograd.Variable._execution_engine.queue_callback(self._end_backward)
 
     def _end_backward(self):
         self._in_backward = False
+        self._zero_event = None
+        self.join_streams()                      # gradients written on the side streams are final from here on
         for p in self.params:
             if not p.requires_grad:
                 continue

@@ -7,6 +7,8 @@ matrices are never materialised: `ClipInfoCELoss` / `accuracy` consume the handl
 the fused InfoNCE kernel.  `.materialize()` (or engine kwarg fused_loss=False) yields real
 tensors for code that wants them.
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -104,9 +106,31 @@ class CLIP(nn.Module):
 
     def features(self, images, texts):
         """normalised (image, text) features, fp32 [b,E] (clip.py:123-130)."""
-        img = self.visual(images)
-        txt = self.encode_text(texts)
-        return engine.L2NormFn.apply(img, 0.0), engine.L2NormFn.apply(txt, 1e-10)
+        if not self._two_streams(images):
+            img = self.visual(images)
+            txt = self.encode_text(texts)
+            return engine.L2NormFn.apply(img, 0.0), engine.L2NormFn.apply(txt, 1e-10)
+        # the towers are independent until the loss: text on a side stream, image on the caller's.  autograd replays each
+        # tower's backward on its forward stream, so the two backward passes overlap the same way.
+        main = torch.cuda.current_stream(images.device)
+        side = self._flat_store.ensure().side_stream(0)
+        side.wait_stream(main)                              # inputs + the refreshed bf16 mirror
+        with torch.cuda.stream(side):
+            txt = engine.L2NormFn.apply(self.encode_text(texts), 1e-10)
+        img = engine.L2NormFn.apply(self.visual(images), 0.0)
+        main.wait_stream(side)
+        txt.record_stream(main)
+        return img, txt
+
+    def _two_streams(self, images):
+        """DH_TOWER_STREAMS: 1 = image and text tower on two HIP streams, 0 = one stream.  Default: on for a single process,
+        off under torch.distributed (the bucketed gradient all-reduce then orders against both streams, FlatReducer)."""
+        if not images.is_cuda:
+            return False
+        v = os.environ.get("DH_TOWER_STREAMS")
+        if v is None:
+            return not dh_dist.is_dist()
+        return v == "1"
 
     def forward(self, input, all_gather=False):
         self._flat_store.begin_step()

@@ -73,8 +73,11 @@ class _Tower(nn.Module):
             if st is None:
                 st = engine.FlatParams(self, self.__dict__.get("_act_dtype", torch.bfloat16))
                 self.__dict__["_own_flat"] = st
-            return st.ensure()
-        return root._flat_store.ensure()
+            st = st.ensure()
+        else:
+            st = root._flat_store.ensure()
+        st.refresh_mirror()          # a tower called directly (encode_text / encode_image) must never see an unwritten bf16 mirror
+        return st
 
 
 class VisualTransformer(_Tower):

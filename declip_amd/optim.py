@@ -59,6 +59,7 @@ class FlatAdamW(torch.optim.Optimizer):
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None
         flat = self.flat
+        flat.join_streams()
         self._refresh_table()
         self.step_count += 1
         g0 = self.param_groups[0]

@@ -344,8 +344,47 @@ class ClsSolver(object):
             st["optimizer"] = self.optimizer.state_dict()
         torch.save(st, os.path.join(self.save_dir, "ckpt.pth.tar"))
 
-    def evaluate(self, *a, **k):
-        raise NotImplementedError("zero-shot evaluation is a 'next' row (SURVEY.md s8(f) #3); encode_image/encode_text are available")
+    @torch.no_grad()
+    def evaluate(self, val_data=None):
+        """Zero-shot classification (clip_solver.py:675-737).  val_data: {'loader': iterable of {'images', 'labels'} batches whose
+        `.dataset` (or the loader itself) has get_label_texts() -> (prompts class-major, ensemble matrix)}; None builds the
+        synthetic set from `data.test` (label_num / prompts_num / batch_size / batches).  Every rank evaluates its own batches;
+        the hit counters are summed over ranks, so every rank returns the same metrics (the reference broadcasts rank 0's)."""
+        from . import zeroshot
+        m = self.model.module
+        if val_data is None:
+            t = self.config.get("data", AttrDict()).get("test", AttrDict())
+            ctx = int((m.text_encoder if hasattr(m, "text_encoder") else m.encode_text).context_length)
+            loader = zeroshot.SyntheticZeroShotData(
+                label_num=int(t.get("label_num", 1000)), prompts_num=int(t.get("prompts_num", 1)),
+                batch_size=int(t.get("batch_size", self.batch_size)), batches=int(t.get("batches", 4)),
+                res=int(self.config.get("data", {}).get("input_size", 224)), ctx=ctx, rank=self.rank, world=self.world_size)
+        else:
+            loader = val_data["loader"] if isinstance(val_data, dict) else val_data
+        source = getattr(loader, "dataset", loader)
+        texts, ensemble = source.get_label_texts()
+        label_num = ensemble.shape[1]
+        n_texts = texts.shape[0] if torch.is_tensor(texts) else len(texts)
+        self.logger.info("Use %d prompts" % (n_texts // label_num))
+        was_training = self.model.training
+        self.model.eval()
+        class_emb = zeroshot.class_embeddings(m, texts, label_num, text_chunk=int(self.config.get("eval_text_chunk", 2048)))
+        meter = zeroshot.ZeroShotMeter(self.device)
+        t0, n_img = time.time(), 0
+        for batch in loader:
+            images = batch["images"].to(self.device, non_blocking=True)
+            out = zeroshot.classify(m, images, class_emb, ensemble, return_dense=bool(self.config.get("return_dense", False)))
+            labels = batch["labels"] if "labels" in batch else batch["label"]
+            meter.update(out["topk"], labels.view(-1).long())
+            n_img += images.shape[0]
+        metrics = meter.result()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+        metrics["images_per_s"] = n_img * self.world_size / max(time.time() - t0, 1e-9)
+        self.logger.info("zero-shot: " + " ".join("%s %.4g" % kv for kv in metrics.items()))
+        if was_training:
+            self.model.train()
+        return metrics
 
 
 def main():

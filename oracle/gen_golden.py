@@ -347,6 +347,71 @@ def gen_defilip(name, cfg, b, seed=0, nn_size=256):
     print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
 
 
+def gen_zeroshot(name, cfg, label_num, prompts_num, b, batches=2, seed=0):
+    """The reference's own ClsSolver.evaluate (solver/clip_solver.py:675-737), called unbound on a stand-in solver object that
+    carries exactly the attributes it reads (model.module, path.result_path, dist.rank, logger, fp16, config) and a stand-in
+    val loader/dataset (get_label_texts / dump / evaluate).  Records scores + predictions per batch."""
+    import contextlib
+    import io
+    import tempfile
+    import types
+    ref = ref_harness.load_reference()
+    sys.modules.update(ref.modules)
+    data_stub = types.ModuleType("prototype.data")           # prototype.data pulls torchvision (absent); evaluate() does not use it
+    for n in ("build_imagenet_train_dataloader", "build_imagenet_test_dataloader", "build_clip_dataloader"):
+        setattr(data_stub, n, None)
+    sys.modules["prototype.data"] = data_stub
+    sys.path.insert(0, ref_harness.REFERENCE_ROOT)
+    try:
+        import prototype.solver.clip_solver as ref_solver
+    finally:
+        sys.path.remove(ref_harness.REFERENCE_ROOT)
+        for k in [k for k in sys.modules if k == "prototype" or k.startswith("prototype.") or k == "linklink" or k.startswith("linklink.")]:
+            del sys.modules[k]
+    ref_solver.broadcast_object = lambda obj, *a, **k: obj
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = build_ref_clip(ref, cfg, use_allgather=False)
+        model.load_state_dict(synth.synth_state(synth.clip_shapes(cfg), seed=seed), strict=True)
+    class_ids = synth.synth_tokens(label_num * prompts_num, ctx=cfg["ctx"], seed=seed + 77, vocab=cfg["vocab"], max_len=6)
+    patch_tokenize(model.encode_text, {i: class_ids[i] for i in range(class_ids.shape[0])})
+    dumped = []
+
+    class Dataset:
+        def get_label_texts(self):
+            return list(range(label_num * prompts_num)), torch.eye(label_num)
+
+        def dump(self, writer, batch):
+            dumped.append(dict(prediction=batch["prediction"].clone(), score=batch["score"].clone()))
+
+        def evaluate(self, res_file):
+            return types.SimpleNamespace(metric={})
+
+    class Loader:
+        dataset = Dataset()
+
+        def __iter__(self):
+            for i in range(batches):
+                yield {"images": synth.synth_images(b, res=cfg["res"], seed=seed * 1000 + i)}
+
+    class Log:
+        def info(self, *a):
+            pass
+        critical = info
+
+    tmp = tempfile.mkdtemp()
+    fake = types.SimpleNamespace(model=types.SimpleNamespace(module=model, eval=model.eval, train=model.train),
+                                 path=types.SimpleNamespace(result_path=tmp), dist=types.SimpleNamespace(rank=0),
+                                 logger=Log(), fp16=False, config={})
+    ref_solver.ClsSolver.evaluate(fake, {"loader": Loader()})
+    ret = dict(kind="zeroshot", cfg=cfg, label_num=label_num, prompts_num=prompts_num, b=b, batches=batches, seed=seed,
+               scores=[d["score"] for d in dumped], predictions=[d["prediction"] for d in dumped],
+               torch_version=torch.__version__)
+    path = os.path.join(GOLDEN_DIR, name + ".pt")
+    torch.save(ret, path)
+    print("wrote %s  batches=%d preds0=%s (%d KB)" % (path, len(dumped), dumped[0]["prediction"].tolist(), os.path.getsize(path) // 1024))
+
+
 FIXTURES = {
     "clip_tiny": lambda: gen_clip("clip_tiny", synth.TINY, b=4),
     "clip_tiny_scale5": lambda: gen_clip("clip_tiny_scale5", synth.TINY, b=4, seed=3, logit_scale=5.0),
@@ -356,6 +421,7 @@ FIXTURES = {
     "slip_tiny": lambda: gen_slip("slip_tiny", synth.TINY, b=5, seed=4),
     "filip_small": lambda: gen_filip("filip_small", synth.FILIP_SMALL, b=5, seed=6),
     "defilip_small": lambda: gen_defilip("defilip_small", synth.FILIP_SMALL, b=4, seed=7),
+    "zeroshot_tiny": lambda: gen_zeroshot("zeroshot_tiny", synth.TINY, label_num=7, prompts_num=3, b=5, batches=2, seed=8),
 }
 
 

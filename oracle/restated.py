@@ -137,6 +137,26 @@ def clip_forward(images, ids, sd, cfg, world=1):
     return out, (img, txt)
 
 
+def zero_shot(images, class_ids, label_num, sd, cfg):
+    """solver/clip_solver.py:687-719 (evaluate): per class, encode its prompts, normalise each, mean, normalise; per image,
+    encode, normalise, logits = img @ class_emb^T (no logit scale), scores = softmax(logits) @ I, prediction = top-1.
+    class_ids [label_num*prompts_num, ctx], class-major (clip_dataset.py:270-276).  One class at a time, as the reference does."""
+    prompts_num = class_ids.shape[0] // label_num
+    prefix = cfg.get("text_prefix", "encode_text.")
+    embs = []
+    for i in range(label_num):
+        t = text_tower(class_ids[i * prompts_num:(i + 1) * prompts_num], sd, cfg, prefix=prefix)
+        t = t / t.norm(dim=-1, keepdim=True)
+        t = t.mean(dim=0)
+        embs.append(t / t.norm())
+    class_emb = torch.stack(embs, dim=0)
+    img = vision_tower(images, sd, cfg)
+    img = img / img.norm(dim=-1, keepdim=True)
+    logits = img @ class_emb.t()
+    scores = F.softmax(logits, dim=1) @ torch.eye(label_num, dtype=logits.dtype)
+    return class_emb, logits, scores, logits.topk(k=1, dim=1)[1].view(-1)
+
+
 def info_nce(logits_i, logits_t, rank=0):
     """loss_functions/loss.py:37-47."""
     bs, l_bs = logits_i.shape

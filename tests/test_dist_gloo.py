@@ -98,7 +98,41 @@ def _w_clip(rank, world, port, out):
         out.put("ok")
 
 
-@pytest.mark.parametrize("fn,port", [(_w_gather, 29611), (_w_reducer, 29612), (_w_clip, 29613)])
+def _w_zero_shot(rank, world, port, out):
+    """Zero-shot evaluate sharded over two ranks: each rank classifies its own batches, the hit counters are summed, and
+    every rank reports the metrics of the whole set (== a one-rank run over all batches)."""
+    _init(rank, world, port)
+    import cpu_ops_mock
+    from declip_amd import engine, ops, zeroshot
+    from declip_amd.testing import build_clip
+    from oracle_util import load_golden
+    for name in dir(cpu_ops_mock):
+        if not name.startswith("_") and callable(getattr(cpu_ops_mock, name)) and hasattr(ops, name):
+            setattr(ops, name, getattr(cpu_ops_mock, name))
+    engine._require_gpu = lambda p, name: None
+    g = load_golden("zeroshot_tiny")
+    cfg = g["cfg"]
+    model = build_clip(cfg, dtype="fp32", seed=g["seed"], device="cpu").eval()
+
+    def run(rk, wd, reduce):
+        data = zeroshot.SyntheticZeroShotData(label_num=6, prompts_num=2, batch_size=5, batches=4, res=cfg["res"], ctx=cfg["ctx"],
+                                              seed=3, rank=rk, world=wd)
+        texts, mat = data.get_label_texts()
+        emb = zeroshot.class_embeddings(model, texts, 6)
+        meter = zeroshot.ZeroShotMeter("cpu")
+        for batch in data:
+            # labels = the model's own 2nd choice: top-1 misses, top-5 hits (a non-trivial, deterministic count)
+            top = zeroshot.classify(model, batch["images"], emb, mat)["topk"]
+            meter.update(top, torch.where(batch["labels"] % 2 == 0, top[:, 0], top[:, 1]))
+        return meter.result(reduce=reduce)
+    sharded = run(rank, world, True)
+    whole = run(0, 1, False)
+    assert sharded == whole and whole["count"] == 20 and whole["top5"] == 100.0 and 0 < whole["top1"] < 100.0
+    if rank == 0:
+        out.put("ok")
+
+
+@pytest.mark.parametrize("fn,port", [(_w_gather, 29611), (_w_reducer, 29612), (_w_clip, 29613), (_w_zero_shot, 29614)])
 def test_world2(fn, port):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()

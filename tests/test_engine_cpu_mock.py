@@ -222,3 +222,44 @@ def test_defilip_engine_composition_matches_golden(mocked_engine):
     assert float((fi - g["filip_i"]).abs().max()) <= 1e-4 * float(g["filip_i"].abs().max())
     grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
     check_grad_digests(g["grads"], grads, rtol=1e-3)
+
+
+def _zero_shot_inputs(g):
+    from declip_amd import synth
+    cfg, seed = g["cfg"], g["seed"]
+    ids = synth.synth_tokens(g["label_num"] * g["prompts_num"], ctx=cfg["ctx"], seed=seed + 77, vocab=cfg["vocab"], max_len=6)
+    return ids, [synth.synth_images(g["b"], res=cfg["res"], seed=seed * 1000 + i) for i in range(g["batches"])]
+
+
+@pytest.mark.parametrize("chunk", [2048, 4])
+def test_zero_shot_composition_matches_reference_evaluate(mocked_engine, chunk):
+    """Chunked prompt encoding + segmented per-class mean == the reference's class-at-a-time loop (clip_solver.py:692-719)."""
+    from declip_amd import zeroshot
+    from declip_amd.testing import build_clip
+    g = load_golden("zeroshot_tiny")
+    model = build_clip(g["cfg"], dtype="fp32", seed=g["seed"], device="cpu").eval()
+    ids, batches = _zero_shot_inputs(g)
+    emb = zeroshot.class_embeddings(model, ids, g["label_num"], text_chunk=chunk)
+    assert emb.shape == (g["label_num"], g["cfg"]["embed_dim"])
+    meter = zeroshot.ZeroShotMeter("cpu")
+    for i, images in enumerate(batches):
+        out = zeroshot.classify(model, images, emb, torch.eye(g["label_num"]))
+        assert float((out["scores"] - g["scores"][i]).abs().max()) <= 1e-5
+        assert torch.equal(out["prediction"], g["predictions"][i])
+        meter.update(out["topk"], g["predictions"][i])
+    res = meter.result()
+    assert res["top1"] == 100.0 and res["top5"] == 100.0 and res["count"] == g["b"] * g["batches"]
+    with pytest.raises(ValueError):
+        zeroshot.class_embeddings(model, ids[:-1], g["label_num"])
+
+
+def test_zero_shot_prompt_templates(tmp_path):
+    from declip_amd import zeroshot
+    texts, mat = zeroshot.label_texts({3: "dog", 1: "cat"}, "prompt6")
+    assert len(texts) == 12 and texts[0] == "a photo of a cat." and texts[6] == "a photo of a dog." and torch.equal(mat, torch.eye(2))
+    assert zeroshot.prompts_for("tabby cat", "cc") == ["tabby cat"]
+    f = tmp_path / "tpl"
+    f.write_text("itap of a {0}.\n a {0} in the wild. \n")
+    assert zeroshot.prompts_for("fox", "file:%s" % f) == ["itap of a fox.", "a fox in the wild."]
+    with pytest.raises(NotImplementedError):
+        zeroshot.prompts_for("x", "prompt7")

@@ -243,3 +243,47 @@ def test_clip_bf16_vitb32_b256_v4_gemm_matches_v2_gemm():
         cos = float((ga.double().flatten() @ g.double().flatten()) / (ga.double().norm() * g.double().norm() + 1e-30))
         assert cos > 0.98, (n, cos)
     assert worst < 5e-2, worst
+
+
+def test_clip_two_tower_streams_match_one_stream(monkeypatch):
+    """Image and text tower on two HIP streams (CLIP.features, DH_TOWER_STREAMS) against the one-stream order, ViT-B/32
+    b = 256, three optimizer steps each.  Same kernels on the same data: the forward (features, first loss) is bit-identical.
+    Gradients are compared at the run-to-run noise of ONE mode (the float atomics of the InfoNCE backward perturb d(features)
+    by ~1e-7, which bf16 rounding inside the towers amplifies to <= 3e-3 of a parameter's largest gradient -- measured with
+    tools/stream_ab.py); a missing stream dependency (a lost or half-written gradient) is orders of magnitude above that."""
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.optim import build_adamw
+    from declip_amd.testing import build_clip
+    cfg, b, seed = synth.VITB32, 256, 5
+    images = synth.synth_images(b, res=cfg["res"], seed=seed).cuda()
+    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"]).cuda()
+
+    def run(mode):
+        monkeypatch.setenv("DH_TOWER_STREAMS", mode)
+        model = build_clip(cfg, dtype="bf16", seed=seed)
+        opt = build_adamw(model, lr=1e-4, weight_decay=0.1)
+        crit = ClipInfoCELoss()
+        losses, first = [], None
+        for i in range(3):
+            li, lt = model({"images": images, "captions": ids})
+            loss, _ = crit(li, lt)
+            opt.zero_grad()
+            loss.backward()
+            if i == 0:
+                torch.cuda.synchronize()
+                first = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}
+                first["~img"], first["~txt"] = li.Q.detach().float().cpu(), lt.Q.detach().float().cpu()
+            opt.step()
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        assert (len(model._flat_store.side_streams) == 1) == (mode == "1")
+        return losses, first
+
+    l1, g1 = run("1")
+    l0, g0 = run("0")
+    assert l1[0] == l0[0] and torch.equal(g1["~img"], g0["~img"]) and torch.equal(g1["~txt"], g0["~txt"])
+    for a, c in zip(l1, l0):
+        assert abs(a - c) <= 3e-3 * abs(c)
+    for n, g in g0.items():
+        assert float((g1[n] - g).abs().max()) <= 1e-2 * float(g.abs().max()) + 1e-12, n

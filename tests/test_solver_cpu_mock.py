@@ -88,3 +88,21 @@ def test_solver_trains_saves_and_resumes(mocked, tmp_path, kind):
     assert torch.equal(s2.model.module.visual.proj.detach().cpu(), w1)
     s2.train()
     assert s2.state["last_iter"] == 6
+
+
+def test_solver_zero_shot_evaluate_synthetic(mocked, tmp_path):
+    """--evaluate on the built-in synthetic set: forward only, metrics are chance-level but well formed, mode restored."""
+    import yaml
+    from declip_amd.solver import ClsSolver
+    cfg = _config("clip")
+    cfg["data"]["test"] = dict(type="synthetic", label_num=10, prompts_num=3, batch_size=6, batches=3)
+    cfg["saver"]["pretrain"] = dict(auto_resume=False)
+    cfgp = tmp_path / "config.yaml"
+    cfgp.write_text(yaml.safe_dump(cfg))
+    s = ClsSolver(str(cfgp), device="cpu")
+    before = {k: v.clone() for k, v in s.model.module.state_dict().items()}
+    m = s.evaluate()
+    assert m["count"] == 18 and 0.0 <= m["top1"] <= m["top5"] <= 100.0 and m["images_per_s"] > 0
+    assert s.model.training
+    for k, v in s.model.module.state_dict().items():
+        assert torch.equal(v, before[k]), k
