@@ -161,6 +161,10 @@ def main():
         ops.gemm = timed_gemm
         import declip_amd.engine as eng
         eng.ops.gemm = timed_gemm
+        # kernel durations are taken with the towers on ONE stream: with two streams (the timed region above) a GEMM shares
+        # the chip with the other tower's launches and its event-bracketed duration measures the overlap, not the kernel
+        streams_env = os.environ.get("DH_TOWER_STREAMS")
+        os.environ["DH_TOWER_STREAMS"] = "0"
         sync()
         nprof = 2
         tp0 = time.perf_counter()
@@ -170,6 +174,10 @@ def main():
         tprof = time.perf_counter() - tp0
         ops.gemm = orig
         eng.ops.gemm = orig
+        if streams_env is None:
+            del os.environ["DH_TOWER_STREAMS"]
+        else:
+            os.environ["DH_TOWER_STREAMS"] = streams_env
         flops = sum(r[2] for r in records if r[3] == torch.bfloat16 or args.dtype != "bf16")
         ms = sum(r[0].elapsed_time(r[1]) for r in records if r[3] == torch.bfloat16 or args.dtype != "bf16")
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -195,6 +203,7 @@ def main():
                         traffic_unit="bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE; profiles/r01_v4_pmc_summary.txt)",
                         algorithmic_bytes_per_launch=round(sum(gemm_bytes) / max(len(gemm_bytes), 1), 1),
                         launches_per_step=len(records) // nprof, gemm_ms_per_step=round(ms / nprof, 3),
+                        note="kernel durations measured with both towers on one stream (no co-running launches)",
                         gemm_gflop_per_step=round(flops / nprof / 1e9, 1),
                         step_mfma_frac=round(pairs_per_s * (GFLOP_PER_PAIR if args.model == "clip" else 89.9) / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
 
@@ -207,7 +216,8 @@ def main():
                                      "per-GPU batch %d, 224x224 images, 77-token captions, random-init weights" % b) if args.model == "clip" else
                                     ("DeCLIP ViT-B/32 (2 image views + masked/augmented text, 8+4 InfoNCE pairs, SimSiam, NN bank 65536, MLM), "
                                      "fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d" % b),
-                           global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world),
+                           global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world,
+                           tower_streams=1 + len(model.__dict__["_flat_store"].side_streams)),
                loss=round(float(loss) * world, 5))
     if roofline is not None:
         out["roofline"] = roofline

@@ -123,14 +123,9 @@ class CLIP(nn.Module):
         return img, txt
 
     def _two_streams(self, images):
-        """DH_TOWER_STREAMS: 1 = image and text tower on two HIP streams, 0 = one stream.  Default: on for a single process,
-        off under torch.distributed (the bucketed gradient all-reduce then orders against both streams, FlatReducer)."""
-        if not images.is_cuda:
-            return False
-        v = os.environ.get("DH_TOWER_STREAMS")
-        if v is None:
-            return not dh_dist.is_dist()
-        return v == "1"
+        """DH_TOWER_STREAMS: 1 (default) = image and text tower on two HIP streams, 0 = one stream.  Under torch.distributed
+        the bucketed gradient all-reduce orders every bucket against both streams (dist.FlatReducer; tests/test_gpu_dist.py)."""
+        return images.is_cuda and os.environ.get("DH_TOWER_STREAMS", "1") == "1"
 
     def forward(self, input, all_gather=False):
         self._flat_store.begin_step()

@@ -1,0 +1,75 @@
+"""Data-parallel CLIP step with TWO ranks sharing the one GPU of the test box (gloo backend on CUDA tensors: RCCL refuses two
+ranks on one device, and the driver's 8-GPU node is not available to the tests).  What it checks on the real HIP path: the
+packed all-gather / its backward, the bucketed flat gradient all-reduce launched as backward progresses -- with the image and
+text tower on two HIP streams (events order every bucket against both streams) and on one -- against the golden produced by
+two reference ranks (tests/golden/clip_tiny_w2.pt, fp32, 1e-3)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, streams, bucket_bytes, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      DH_TOWER_STREAMS=streams, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from declip_amd import dist as dd
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.testing import build_clip
+    from oracle_util import check_grad_digests, load_golden
+    g = load_golden("clip_tiny_w2")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_clip(cfg, dtype="fp32", use_allgather=True, seed=seed)
+    wrapped = dd.DistModule(model, sync=False, bucket_bytes=bucket_bytes)
+    B = b * world
+    images = synth.synth_images(B, res=cfg["res"], seed=seed)[rank * b:(rank + 1) * b].cuda()
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])[rank * b:(rank + 1) * b].cuda()
+    crit = ClipInfoCELoss()
+    for it in range(2):                       # second pass: the zero-event / bucket state of the first must not leak
+        for p in model.parameters():
+            p.grad = None
+        li, lt = wrapped({"images": images, "captions": ids})
+        loss, labels = crit(li, lt)
+        loss = loss / world
+        loss.backward()
+        wrapped.sync_gradients()
+        torch.cuda.synchronize()
+        assert (len(model._flat_store.side_streams) == 1) == (streams == "1")
+        total = loss.detach().clone()
+        dist.all_reduce(total)
+        if rank == 0:
+            assert abs(float(total) - g["loss"]) <= 1e-3 * abs(g["loss"])
+            assert float((li.materialize().detach().cpu() - g["logits_i"]).abs().max()) <= 1e-3 * float(g["logits_i"].abs().max())
+            grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
+            check_grad_digests(g["grads"], grads, rtol=1e-3)
+    dist.barrier()
+    if rank == 0:
+        out.put("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("streams,bucket_bytes,port", [("1", 1 << 14, 29711), ("0", 1 << 14, 29712), ("1", 48 << 20, 29713)])
+def test_two_ranks_on_one_gpu_match_two_reference_ranks(streams, bucket_bytes, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, streams, bucket_bytes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        if p.is_alive():
+            p.terminate()
+            p.join(10)
+            pytest.fail("rank timed out")
+        assert p.exitcode == 0
+    assert q.get() == "ok"

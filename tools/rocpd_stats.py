@@ -30,6 +30,21 @@ def main(path):
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print("%-88s %7d %12.1f %10.1f %10.1f %10.1f %6.2f" % (name[:88], a[0], a[1] / 1e3, a[1] / a[0] / 1e3, a[2] / 1e3, a[3] / 1e3, 100.0 * a[1] / total))
     print("TOTAL kernel time: %.3f ms over %d dispatches" % (total / 1e6, sum(a[0] for a in agg.values())))
+    # how much of the wall clock had at least one kernel resident (union of the dispatch intervals), and how often two
+    # overlapped (streams): gaps = launch latency / host stalls, overlap = concurrent streams
+    iv = sorted(c.execute("select d.start, d.end from %s d" % kd))
+    if iv:
+        busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+        for a, b in iv[1:]:
+            if a > cur_e:
+                busy += cur_e - cur_s
+                cur_s, cur_e = a, b
+            else:
+                cur_e = max(cur_e, b)
+        busy += cur_e - cur_s
+        span = max(b for _, b in iv) - iv[0][0]
+        print("first-to-last dispatch span %.3f ms; >=1 kernel resident %.3f ms (%.1f %%); sum of durations / resident time = %.3f" % (
+            span / 1e6, busy / 1e6, 100.0 * busy / span, total / busy))
 
 
 if __name__ == "__main__":
