@@ -7,6 +7,7 @@ matrices are never materialised: `ClipInfoCELoss` / `accuracy` consume the handl
 the fused InfoNCE kernel.  `.materialize()` (or engine kwarg fused_loss=False) yields real
 tensors for code that wants them.
 """
+import contextlib
 import os
 
 import numpy as np
@@ -106,21 +107,36 @@ class CLIP(nn.Module):
 
     def features(self, images, texts):
         """normalised (image, text) features, fp32 [b,E] (clip.py:123-130)."""
-        if not self._two_streams(images):
-            img = self.visual(images)
-            txt = self.encode_text(texts)
-            return engine.L2NormFn.apply(img, 0.0), engine.L2NormFn.apply(txt, 1e-10)
         # the towers are independent until the loss: text on a side stream, image on the caller's.  autograd replays each
         # tower's backward on its forward stream, so the two backward passes overlap the same way.
-        main = torch.cuda.current_stream(images.device)
-        side = self._flat_store.ensure().side_stream(0)
-        side.wait_stream(main)                              # inputs + the refreshed bf16 mirror
-        with torch.cuda.stream(side):
+        side = self._fork(images)
+        with self._on(side):
             txt = engine.L2NormFn.apply(self.encode_text(texts), 1e-10)
         img = engine.L2NormFn.apply(self.visual(images), 0.0)
-        main.wait_stream(side)
-        txt.record_stream(main)
+        self._join(side, txt)
         return img, txt
+
+    # ---- two tower streams (FlatParams.side_stream): fork before the text tower, join after the image tower is enqueued
+    def _fork(self, images):
+        if not self._two_streams(images):
+            return None
+        side = self._flat_store.ensure().side_stream(0)
+        side.wait_stream(torch.cuda.current_stream(images.device))      # inputs + the refreshed bf16 mirror
+        return side
+
+    @staticmethod
+    def _on(side):
+        return torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+
+    @staticmethod
+    def _join(side, *outs):
+        if side is None:
+            return
+        main = torch.cuda.current_stream(side.device)
+        main.wait_stream(side)
+        for t in outs:
+            if torch.is_tensor(t):
+                t.record_stream(main)                                   # allocated on the side stream, consumed on this one
 
     def _two_streams(self, images):
         """DH_TOWER_STREAMS: 1 (default) = image and text tower on two HIP streams, 0 = one stream.  Under torch.distributed

@@ -108,22 +108,14 @@ class DECLIP(CLIP):
         b = images.shape[0]
         ids_cat = torch.cat([ids.to(dev), ids_aug.to(dev)], dim=0).long().contiguous()
         want_words = self.text_mask_type is not None
-        two = self._two_streams(images)          # text tower on the side stream, both image views on the caller's (clip.py features)
-        if two:
-            main, side = torch.cuda.current_stream(dev), flat.side_stream(0)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                tout = engine.TextTowerFn.apply(flat.anchor, ids_cat, et, want_words)
-        else:
+        side = self._fork(images)                # text tower on the side stream, both image views on the caller's (clip.py)
+        with self._on(side):
             tout = engine.TextTowerFn.apply(flat.anchor, ids_cat, et, want_words)
         txt_cat, words = (tout[0], tout[1]) if want_words else (tout, None)
         # ---- both image views in one pass
         want_dense = bool(getattr(self, "return_filip", False))
         vout = self.visual(images, n_views=2, return_dense=want_dense)
-        if two:
-            main.wait_stream(side)
-            for t_out in (tout if isinstance(tout, (tuple, list)) else (tout,)):
-                t_out.record_stream(main)
+        self._join(side, *(tout if isinstance(tout, (tuple, list)) else (tout,)))
         img_cat, dense_cat = (vout[0], vout[1]) if want_dense else (vout, None)   # [2b, E] fp32, view-major
         # ---- SimSiam on the UN-normalised image features (declip.py:238-241), BN statistics per view
         z = self.projector(img_cat, groups=2)

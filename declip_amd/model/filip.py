@@ -98,8 +98,11 @@ class FILIP(CLIP):
         dev = flat.flat_p.device
         ids = ids.to(dev).long().contiguous()
         b = images.shape[0]
-        txt, words = engine.TextTowerFn.apply(flat.anchor, ids, et, True)
+        side = self._fork(images)                                               # text tower on the side stream (clip.py)
+        with self._on(side):
+            txt, words = engine.TextTowerFn.apply(flat.anchor, ids, et, True)
         img, dense = self.visual(images, return_dense=True)                     # view 1 only (channels 0..2)
+        self._join(side, txt, words)
         img_n = engine.L2NormFn.apply(img, 0.0)
         txt_n = engine.L2NormFn.apply(txt, 1e-10)
         scale = self.logit_scale_value()

@@ -61,8 +61,11 @@ class SLIP(CLIP):
         images = input["images"]                                            # [b, 9, H, W]: base, aug1, aug2
         texts = self.sample_captions(input["captions"])
         b = images.shape[0]
-        txt = self.text_encoder(texts)
+        side = self._fork(images)                                           # text tower on the side stream (clip.py)
+        with self._on(side):
+            txt = self.text_encoder(texts)
         proj, feat = self.visual(images, return_feature=True, n_views=3)    # [3b, E] fp32, [3b, width]
+        self._join(side, txt)
         sim = self.predictor_sim(feat[b:], groups=2)                        # BN statistics per view
         sim1, sim2 = sim[:b], sim[b:]
         img_n = engine.L2NormFn.apply(proj[:b], 0.0)
