@@ -8,8 +8,26 @@ namespace {
 
 constexpr int LN_MAXC = 4;  // up to 4 chunks of 8 per lane -> d <= 2048 on the vector path
 
-// NCH = 16-byte chunks per lane (d <= 512 * NCH); two rows per wave are in flight at a time (the kernel is latency-bound:
-// a wave that loads, reduces and stores one row at a time leaves HBM idle most of the time)
+// 8 consecutive elements as they come from memory (bf16: one 16-byte register quad) -- rows are PREFETCHED in this form
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  uint4 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void unpack(float* o) const {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+};
+template <> struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void unpack(float* o) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
+};
+
+// NCH = 16-byte chunks per lane (d <= 512 * NCH); two rows per wave per iteration, and the NEXT iteration's two rows are
+// requested (packed, 4 registers per chunk) before the current ones are reduced: the kernel is latency-bound (load ->
+// two dependent wave reductions -> store), a wave that handles one iteration at a time leaves HBM idle most of the time
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, T* __restrict__ y,
@@ -26,27 +44,35 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     const int ch = lane + 64 * c;
     if (ch < nchunk) { ld8(w + ch * 8, wv[c]); ld8(b + ch * 8, bv[c]); }
   }
-  for (int row0 = wave_global * R; row0 < rows; row0 += nwaves * R) {
+  Raw8<T> nxt[R][NCH];
+  auto fetch = [&](int row0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = row0 + r < rows ? row0 + r : rows - 1;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) nxt[r][c].load(x + (long)row * d + ch * 8);
+      }
+    }
+  };
+  int row0 = wave_global * R;
+  if (row0 < rows) fetch(row0);
+  for (; row0 < rows; row0 += nwaves * R) {
     float v[R][NCH][8];
     float s[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       s[r] = 0.f;
-      const int row = row0 + r < rows ? row0 + r : rows - 1;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int ch = lane + 64 * c;
-        if (ch < nchunk) ld8(x + (long)row * d + ch * 8, v[r][c]);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int c = 0; c < NCH; ++c)
         if (lane + 64 * c < nchunk) {
+          nxt[r][c].unpack(v[r][c]);
 #pragma unroll
           for (int i = 0; i < 8; ++i) s[r] += v[r][c][i];
         }
+    }
+    if (row0 + nwaves * R < rows) fetch(row0 + nwaves * R);
     float mu[R], rs[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) mu[r] = wave_sum(s[r]) / d;
@@ -182,6 +208,103 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     part[(long)blockIdx.x * 2 * d + i] = sm[i] + sm[2 * d + i] + sm[4 * d + i] + sm[6 * d + i];
 }
 
+// bf16 specialisation of the backward: the three row operands stay PACKED in registers (4 instead of 8 registers per chunk
+// each) and are unpacked twice (statistics pass, output pass).  The generic kernel above keeps them as floats: 148 VGPRs at
+// d = 768 -> 3 waves per SIMD, and its 1024-block grid then runs as 768 + 256 blocks (a second, third-full round).  This
+// one fits 4 waves per SIMD; the grid is sized from the occupancy the runtime reports so every block is resident at once.
+__device__ __forceinline__ void unpack8(const uint4& v, float* o) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[2 * i] = __uint_as_float(w[i] << 16);
+    o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256, NCH <= 2 ? 4 : 2) void ln_bwd_bf16_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                             const float* __restrict__ w, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
+                                                             bf16_t* __restrict__ dx, float* __restrict__ part, int rows, int d) {
+  extern __shared__ float sm[];  // [4 waves][2][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwaves = gridDim.x * 4;
+  const int nchunk = d >> 3;
+  float aw[NCH][8], ab[NCH][8], wv[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { aw[c][i] = 0.f; ab[c][i] = 0.f; wv[c][i] = 0.f; }
+    if (lane + 64 * c < nchunk) ld8(w + (lane + 64 * c) * 8, wv[c]);
+  }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += nwaves) {
+    uint4 xr[NCH], dr[NCH], rr[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        xr[c] = *reinterpret_cast<const uint4*>(x + (long)row * d + ch * 8);
+        dr[c] = *reinterpret_cast<const uint4*>(dy + (long)row * d + ch * 8);
+        if (dres) rr[c] = *reinterpret_cast<const uint4*>(dres + (long)row * d + ch * 8);
+      }
+    }
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (lane + 64 * c < nchunk) {
+        float xv[8], dv[8];
+        unpack8(xr[c], xv);
+        unpack8(dr[c], dv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xh = (xv[i] - mu) * rs, g = dv[i] * wv[c][i];
+          s1 += g;
+          s2 += g * xh;
+          aw[c][i] += dv[i] * xh;
+          ab[c][i] += dv[i];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      // opaque to the optimiser: the unpacked floats of the statistics pass must die there, not be carried to this pass
+      asm volatile("" : "+v"(xr[c].x), "+v"(xr[c].y), "+v"(xr[c].z), "+v"(xr[c].w), "+v"(dr[c].x), "+v"(dr[c].y), "+v"(dr[c].z), "+v"(dr[c].w));
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        float xv[8], dv[8], o[8];
+        unpack8(xr[c], xv);
+        unpack8(dr[c], dv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = rs * (dv[i] * wv[c][i] - c1 - (xv[i] - mu) * rs * c2);
+        if (dres) {
+          float rv[8];
+          unpack8(rr[c], rv);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += rv[i];
+        }
+        st8_hw(dx + (long)row * d + ch * 8, o);
+      }
+    }
+  }
+  float* my = sm + wave * 2 * d;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    int ch = lane + 64 * c;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { my[ch * 8 + i] = aw[c][i]; my[d + ch * 8 + i] = ab[c][i]; }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * d; i += 256)
+    part[(long)blockIdx.x * 2 * d + i] = sm[i] + sm[2 * d + i] + sm[4 * d + i] + sm[6 * d + i];
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_scalar_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ w, const float* __restrict__ mean,
@@ -235,12 +358,20 @@ static int ln_grid(int rows) {
   return g > 1024 ? 1024 : g;
 }
 
+// grid <= cap whose waves all run the same number of loop iterations (rows_per_block rows per block and iteration): 25600
+// rows on 1024 blocks of 8 rows is 3.1 iterations -> a quarter of the waves run a 4th one while the rest idle
+static int ln_balanced_grid(int rows, int rows_per_block, int cap) {
+  const int iters = dh_cdiv(rows, rows_per_block * cap);
+  int g = dh_cdiv(rows, rows_per_block * iters);
+  return g < 1 ? 1 : g;
+}
+
 extern "C" int dh_layernorm_fwd(int dtype, const void* x, const float* w, const float* b, void* y, float* mean,
                                 float* rstd, int rows, int d, float eps, dh_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   DH_REQUIRE(x && w && b && y && rows > 0 && d > 0, "dh_layernorm_fwd: bad args");
   const bool vec = (d % 8 == 0) && d <= 8 * 64 * LN_MAXC;
-  dim3 grid(ln_grid(rows));
+  dim3 grid(vec ? ln_balanced_grid(rows, 8, 1024) : ln_grid(rows));      // vector kernel: 4 waves x 2 rows per iteration
   const int nch = dh_cdiv(d / 8, 64);
 #define LN_FWD(TT)                                                                                                                       \
   {                                                                                                                                      \
@@ -282,13 +413,29 @@ extern "C" int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const 
     DH_REQUIRE(ws && ws_bytes >= (int64_t)nb * 2 * d * (int64_t)sizeof(float), "dh_layernorm_bwd: workspace too small");
     size_t lds = 8 * d * sizeof(float);
     const int nch = dh_cdiv(d / 8, 64);
-#define LN_BWD(TT)                                                                                                                                             \
-  {                                                                                                                                                            \
-    if (nch <= 1) hipLaunchKernelGGL((ln_bwd_kernel<TT, 1>), dim3(nb), dim3(256), lds, st, (const TT*)dy, (const TT*)x, w, mean, rstd, (const TT*)dres, (TT*)dx, (float*)ws, rows, d);      \
-    else if (nch == 2) hipLaunchKernelGGL((ln_bwd_kernel<TT, 2>), dim3(nb), dim3(256), lds, st, (const TT*)dy, (const TT*)x, w, mean, rstd, (const TT*)dres, (TT*)dx, (float*)ws, rows, d); \
-    else hipLaunchKernelGGL((ln_bwd_kernel<TT, LN_MAXC>), dim3(nb), dim3(256), lds, st, (const TT*)dy, (const TT*)x, w, mean, rstd, (const TT*)dres, (TT*)dx, (float*)ws, rows, d);         \
-  }
-    if (dtype == DH_BF16) LN_BWD(bf16_t) else LN_BWD(float)
+    if (dtype == DH_BF16) {
+      // all blocks resident at once: blocks per CU from the runtime's occupancy query (registers + the LDS of this d)
+      static int cus = 0;
+      if (!cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+      }
+      int per_cu = 0;
+#define LN_OCC(N) hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ln_bwd_bf16_kernel<N>, 256, lds)
+      hipError_t oe = nch <= 1 ? LN_OCC(1) : nch == 2 ? LN_OCC(2) : LN_OCC(LN_MAXC);
+#undef LN_OCC
+      int cap = (oe == hipSuccess && per_cu > 0 && per_cu * cus < 1024) ? per_cu * cus : 1024;
+      if (cap > nb) cap = nb;                                  // never more blocks than the workspace was sized for
+      nb = ln_balanced_grid(rows, 4, cap);
+#define LN_BWD16(N) hipLaunchKernelGGL((ln_bwd_bf16_kernel<N>), dim3(nb), dim3(256), lds, st, (const bf16_t*)dy, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, (float*)ws, rows, d)
+      if (nch <= 1) LN_BWD16(1); else if (nch == 2) LN_BWD16(2); else LN_BWD16(LN_MAXC);
+#undef LN_BWD16
+    } else {
+#define LN_BWD32(N) hipLaunchKernelGGL((ln_bwd_kernel<float, N>), dim3(nb), dim3(256), lds, st, (const float*)dy, (const float*)x, w, mean, rstd, (const float*)dres, (float*)dx, (float*)ws, rows, d)
+      if (nch <= 1) LN_BWD32(1); else if (nch == 2) LN_BWD32(2); else LN_BWD32(LN_MAXC);
+#undef LN_BWD32
+    }
     DH_CHECK_LAUNCH();
     hipLaunchKernelGGL(ln_reduce_kernel, dim3(dh_cdiv(2 * d, 64), nb >= 64 ? 16 : 1), dim3(256), 0, st, (const float*)ws, nb, d, dw, db);
   } else {
