@@ -28,14 +28,21 @@ def _byte_table():
     return {b: chr(c) for b, c in zip(keep, chars)}
 
 
+try:                                   # resolved once: a failing `import` inside the per-caption path costs ~45 us each time
+    import ftfy as _ftfy
+except ImportError:
+    _ftfy = None
+
+
+def _unescape(text):
+    """basic_clean of the reference (simple_tokenizer.py:50-53): ftfy.fix_text when available, html.unescape twice."""
+    if _ftfy is not None:
+        text = _ftfy.fix_text(text)
+    return html.unescape(html.unescape(text))
+
+
 def _clean(text):
-    try:
-        import ftfy
-        text = ftfy.fix_text(text)
-    except ImportError:
-        pass
-    text = html.unescape(html.unescape(text)).strip()
-    return re.sub(r"\s+", " ", text).strip()
+    return re.sub(r"\s+", " ", _unescape(text).strip()).strip()
 
 
 class SimpleTokenizer(object):
@@ -89,6 +96,62 @@ class SimpleTokenizer(object):
         return bytearray(self.byte_decoder[c] for c in text).decode("utf-8", errors="replace").replace("</w>", " ")
 
 
+class NativeTokenizer(SimpleTokenizer):
+    """Same vocabulary and results as SimpleTokenizer; batches go through the host-thread tokeniser of the C-ABI library
+    (`dh_bpe_encode`, declip_amd/csrc/bpe_host.hip).  Cleaning and lower-casing stay here (C-implemented builtins); captions
+    that are not pure ASCII after cleaning come back flagged and take the Python path, so results never differ."""
+
+    def __init__(self, bpe_path, threads=None):
+        super().__init__(bpe_path)
+        import os
+        from . import lib as L
+        self._L = L
+        text = gzip.open(bpe_path).read()
+        n_merges = 49152 - 256 - 2
+        self._handle = L.load().dh_bpe_create(text, len(text), n_merges)
+        if not self._handle:
+            msg = L.load().dh_last_error()
+            raise L.DeclipHipError("dh_bpe_create failed: %s" % (msg.decode() if msg else "?"))
+        assert L.load().dh_bpe_vocab_size(self._handle) == len(self.encoder)
+        self.threads = threads or max(1, min(8, (os.cpu_count() or 2) // 2))     # used for batches of >= 2048 captions
+
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            try:
+                self._L.load().dh_bpe_destroy(h)
+            except Exception:
+                pass
+
+    def encode_batch(self, texts, context_length=77):
+        """list[str] -> LongTensor [n, context_length] (SOT, ids, EOT, zero pad; over-long keeps the final EOT)."""
+        import ctypes
+        import numpy as np
+        n = len(texts)
+        out = torch.zeros(n, context_length, dtype=torch.long)
+        if n == 0:
+            return out
+        # ASCII captions: whitespace only separates tokens, so the whitespace collapse of whitespace_clean() cannot change
+        # the ids and is skipped; anything else is left empty here, comes back flagged and takes the Python path below
+        blobs = []
+        for t in texts:
+            u = _unescape(t)
+            blobs.append(u.lower().encode("ascii") if u.isascii() else b"\xff")
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(b) for b in blobs], out=offsets[1:])
+        status = np.zeros(n, dtype=np.int32)
+        blob = b"".join(blobs)
+        self._L.check(self._L.load().dh_bpe_encode(self._handle, blob, offsets.ctypes.data, n, context_length, out.data_ptr(),
+                                                   status.ctypes.data, self.threads if n >= 2048 else 1), "dh_bpe_encode")
+        sot, eot = self.encoder["<|startoftext|>"], self.encoder["<|endoftext|>"]
+        for i in np.nonzero(status)[0]:
+            toks = [sot] + self.encode(texts[i]) + [eot]
+            if len(toks) > context_length:
+                toks = toks[:context_length - 1] + [toks[-1]]
+            out[i, :len(toks)] = torch.tensor(toks, dtype=torch.long)
+        return out
+
+
 def mask_token_ids(ids, vocab_size, mlm_probability=0.15, generator=None):
     """BERT-style masking on padded id rows [b, ctx] (mask_tokens.py:5-29): 15 % of the non-special,
     non-pad tokens are selected; 80 % -> <|mask|>, 10 % -> random id, 10 % unchanged; labels = -100
@@ -116,13 +179,16 @@ def tokenize(tokenizer, texts, context_length=77, mask_type=None):
     first context_length-1 tokens and the final EOT."""
     if isinstance(texts, str):
         texts = [texts]
-    sot, eot = tokenizer.encoder["<|startoftext|>"], tokenizer.encoder["<|endoftext|>"]
-    out = torch.zeros(len(texts), context_length, dtype=torch.long)
-    for i, t in enumerate(texts):
-        toks = [sot] + tokenizer.encode(t) + [eot]
-        if len(toks) > context_length:
-            toks = toks[:context_length - 1] + [toks[-1]]
-        out[i, :len(toks)] = torch.tensor(toks, dtype=torch.long)
+    if hasattr(tokenizer, "encode_batch"):
+        out = tokenizer.encode_batch(list(texts), context_length)
+    else:
+        sot, eot = tokenizer.encoder["<|startoftext|>"], tokenizer.encoder["<|endoftext|>"]
+        out = torch.zeros(len(texts), context_length, dtype=torch.long)
+        for i, t in enumerate(texts):
+            toks = [sot] + tokenizer.encode(t) + [eot]
+            if len(toks) > context_length:
+                toks = toks[:context_length - 1] + [toks[-1]]
+            out[i, :len(toks)] = torch.tensor(toks, dtype=torch.long)
     if mask_type is not None:
         if mask_type != "MLM":
             raise NotImplementedError(mask_type)

@@ -39,6 +39,10 @@ class NcePair(Structure):
 
 _P = c_void_p
 _PROTOS = {
+    "dh_bpe_create": (c_void_p, [c_char_p, c_int64, c_int]),
+    "dh_bpe_destroy": (None, [c_void_p]),
+    "dh_bpe_vocab_size": (c_int, [c_void_p]),
+    "dh_bpe_encode": (c_int, [c_void_p, c_char_p, _P, c_int, c_int, _P, _P, c_int]),
     "dh_last_error": (c_char_p, []),
     "dh_version": (c_int, []),
     "dh_device_info": (c_int, [c_int, POINTER(c_int)]),

@@ -153,11 +153,11 @@ class TextTransformer(_Tower):
 
     def _get_tokenizer(self):
         if self.tokenizer is None:
-            from ..bpe import SimpleTokenizer
+            from ..bpe import NativeTokenizer
             if not self._bpe_path or not os.path.exists(self._bpe_path):
                 raise DeclipHipError("captions were given as strings but bpe_path %r does not exist; pass pre-tokenised "
                                      "LongTensor ids [b,%d] instead" % (self._bpe_path, self.context_length))
-            self.tokenizer = SimpleTokenizer(self._bpe_path)
+            self.tokenizer = NativeTokenizer(self._bpe_path)       # host-thread BPE of the C-ABI library (bpe_host.hip)
             assert len(self.tokenizer.encoder) == self.vocab_size
         return self.tokenizer
 

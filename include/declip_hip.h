@@ -243,6 +243,20 @@ int dh_adamw_segmented(float* p, const float* g, float* m, float* v, void* p_bf1
                        float beta1, float beta2, float eps, int step, float grad_scale, dh_stream_t stream);
 int dh_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, dh_stream_t stream);
 
+/* ---- host side: caption tokeniser (no device work) ----------------------------------------------
+ * Byte-level BPE of model/utils/text_utils/simple_tokenizer.py:62-134 + the [SOT] ids [EOT] / zero-pad /
+ * truncate-keeping-EOT layout of text_encoder/text_transformer.py:144-180, batch-parallel on host threads.
+ * `merges` = decompressed text of the vocabulary file (header line + "left right" per line), the first n_merges
+ * lines are used (49152 - 256 - 2 in the reference).  Captions must already be cleaned and lower-cased
+ * (ftfy / html.unescape / whitespace collapse are the caller's); a caption containing a non-ASCII byte is not
+ * tokenised (status 1, row zeroed): the caller runs its Unicode-aware tokeniser for that row.
+ * dh_bpe_create returns NULL on error (dh_last_error()).  Thread-safe per handle. */
+void* dh_bpe_create(const char* merges, int64_t nbytes, int n_merges);
+void dh_bpe_destroy(void* handle);
+int dh_bpe_vocab_size(void* handle);
+int dh_bpe_encode(void* handle, const char* texts, const int64_t* offsets /* n + 1 */, int n, int ctx,
+                  int64_t* out /* [n][ctx] */, int32_t* status /* [n] */, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif
