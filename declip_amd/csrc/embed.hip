@@ -338,6 +338,52 @@ extern "C" int dh_im2row(int dtype, const float* images, int c_total, int c0, vo
   return DH_OK;
 }
 
+// uint8 HWC images (what a decoder / the host hands over: 4x fewer PCIe and HBM bytes than fp32 CHW) -> the fp32 CHW
+// batch contract of the towers: crop window, optional horizontal mirror, (x / 255 - mean[c]) / std[c]  (ToTensor + Normalize
+// + crop + flip of the reference's pipelines, data/nvidia_dali_dataloader.py crop_mirror_normalize / data/transforms.py).
+// One thread = 4 consecutive output pixels of a row, all 3 channels.
+__global__ __launch_bounds__(256) void image_prep_u8_kernel(const uint8_t* __restrict__ src, int src_h, int src_w,
+                                                            const int* __restrict__ crop_xy, const uint8_t* __restrict__ flip,
+                                                            float m0, float m1, float m2, float s0, float s1, float s2,
+                                                            float* __restrict__ dst, int c_total, int c0, int b, int H, int W) {
+  const long n = (long)b * H * (W / 4);
+  const float mean[3] = {m0, m1, m2}, inv[3] = {1.f / s0, 1.f / s1, 1.f / s2};
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+    const int xg = (int)(t % (W / 4));
+    const int y = (int)((t / (W / 4)) % H);
+    const int bi = (int)(t / ((long)(W / 4) * H));
+    const int x0 = crop_xy ? crop_xy[2 * bi] : 0, y0 = crop_xy ? crop_xy[2 * bi + 1] : 0;
+    const bool mir = flip && flip[bi];
+    const uint8_t* row = src + ((long)bi * src_h + (y0 + y)) * src_w * 3;
+    float o[3][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int x = xg * 4 + i;
+      const uint8_t* px = row + (long)(x0 + (mir ? W - 1 - x : x)) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c][i] = ((float)px[c] / 255.f - mean[c]) * inv[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      *reinterpret_cast<float4*>(dst + (((long)bi * c_total + c0 + c) * H + y) * W + xg * 4) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+  }
+}
+
+extern "C" int dh_image_prep_u8(const uint8_t* src, int b, int src_h, int src_w, const int* crop_xy_dev, const uint8_t* flip_dev,
+                                const float* mean3, const float* std3, float* dst, int c_total, int c0, int H, int W,
+                                dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(src && dst && mean3 && std3 && b > 0 && H > 0 && W > 0 && W % 4 == 0 && src_h >= H && src_w >= W && c0 >= 0 && c0 + 3 <= c_total,
+             "dh_image_prep_u8: bad args");
+  DH_REQUIRE(crop_xy_dev || (src_h == H && src_w == W), "dh_image_prep_u8: a crop table is required when the source is larger than the output");
+  DH_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "dh_image_prep_u8: zero std");
+  const long n = (long)b * H * (W / 4);
+  hipLaunchKernelGGL(image_prep_u8_kernel, dim3(grid_for(n)), dim3(256), 0, st, src, src_h, src_w, crop_xy_dev, flip_dev, mean3[0], mean3[1],
+                     mean3[2], std3[0], std3[1], std3[2], dst, c_total, c0, b, H, W);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
 extern "C" int dh_vit_assemble_fwd(int dtype, const void* patches, const float* cls, const float* pos, void* x, int b,
                                    int np, int d, dh_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;

@@ -112,6 +112,8 @@ class VisualTransformer(_Tower):
         """x: [b, 3*views, H, W] fp32 on the GPU; channel_offset selects a channel-stacked view;
         n_views > 1 encodes that many consecutive views in one pass (outputs [views*b, ...], view-major)."""
         flat = self._flat()
+        if x.dtype == torch.uint8:           # decoded images as bytes [b, H, W, 3]: normalised on the GPU (4x less PCIe / HBM input)
+            x = engine.ops.image_prep_u8(x.contiguous(), (self.input_resolution, self.input_resolution))
         if x.dtype != torch.float32:
             x = x.float()
         return engine.VisionTowerFn.apply(flat.anchor, x.contiguous(), self, channel_offset, return_dense, return_feature, n_views)

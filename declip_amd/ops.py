@@ -130,6 +130,29 @@ def text_embed_bwd(ids, dx, dtable, dpos, hot_ids=(0,)):
           "dh_text_embed_bwd")
 
 
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)     # transforms.Normalize of the reference pipelines
+
+
+def image_prep_u8(src, out_hw, crop_xy=None, flip=None, mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None, c0=0):
+    """uint8 [b, Hs, Ws, 3] on the GPU -> fp32 [b, C, H, W] channels c0..c0+2 (crop window, optional mirror, normalise).
+    crop_xy: int32 [b, 2] (x0, y0) device tensor or None; flip: uint8/bool [b] device tensor or None."""
+    assert src.dtype == torch.uint8 and src.dim() == 4 and src.shape[3] == 3 and src.is_contiguous()
+    b, Hs, Ws, _ = src.shape
+    H, W = out_hw
+    if out is None:
+        out = torch.empty(b, 3, H, W, device=src.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == b and tuple(out.shape[2:]) == (H, W)
+    if crop_xy is not None:
+        assert crop_xy.dtype == torch.int32 and crop_xy.shape == (b, 2) and crop_xy.is_contiguous()
+    if flip is not None:
+        flip = flip.to(torch.uint8).contiguous()
+        assert flip.shape == (b,)
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    check(L.load().dh_image_prep_u8(ptr(src), b, Hs, Ws, ptr(crop_xy), ptr(flip), m3, s3, ptr(out), out.shape[1], c0, H, W, stream()),
+          "dh_image_prep_u8")
+    return out
+
+
 def im2row(images, c0, patch, dtype, out=None):
     _contig(images, "images")
     assert images.dtype == torch.float32

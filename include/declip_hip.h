@@ -133,6 +133,14 @@ int dh_text_embed_bwd(int dtype, const int64_t* ids, const void* dx, float* dtab
  * data/transforms.py:38-41) -> rows [b*gh*gw, 3*P*P] (dtype), inner order (c,ph,pw). */
 int dh_im2row(int dtype, const float* images, int c_total, int c0, void* rows, int b, int H, int W, int P,
               dh_stream_t stream);
+/* uint8 HWC images [b][src_h][src_w][3] -> fp32 CHW channels c0..c0+2 of dst [b][c_total][H][W]:
+ * dst = (src / 255 - mean[c]) / std[c] over the window at crop_xy_dev[b][2] = (x0, y0) (NULL: src is H x W), mirrored
+ * horizontally where flip_dev[b] != 0 (NULL: never).  ToTensor + Normalize + crop + flip of the reference's input
+ * pipelines (data/transforms.py, data/nvidia_dali_dataloader.py crop_mirror_normalize); resizing stays with the
+ * decoder.  mean3 / std3 are HOST pointers; the crop window must lie inside the source (caller's contract). */
+int dh_image_prep_u8(const uint8_t* src, int b, int src_h, int src_w, const int* crop_xy_dev, const uint8_t* flip_dev,
+                     const float* mean3, const float* std3, float* dst, int c_total, int c0, int H, int W,
+                     dh_stream_t stream);
 /* x[b,0,:] = cls + pos[0]; x[b,1+p,:] = patches[b,p,:] + pos[1+p]  (visual_transformer.py:60-62) */
 int dh_vit_assemble_fwd(int dtype, const void* patches, const float* cls, const float* pos, void* x, int b, int np,
                         int d, dh_stream_t stream);

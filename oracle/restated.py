@@ -102,6 +102,23 @@ def text_tower(ids, sd, cfg, prefix="encode_text.", return_dense=False):
     return (out, x) if return_dense else out
 
 
+def image_prep_u8(src, out_hw, crop_xy=None, flip=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """uint8 HWC -> normalised fp32 CHW: crop window (x0, y0), horizontal flip, ToTensor (x / 255), Normalize ((x - mean) / std)
+    -- the tail of the reference's input pipelines (data/transforms.py + torchvision ToTensor / Normalize as composed in
+    data/clip_dataloader.py; data/nvidia_dali_dataloader.py crop_mirror_normalize does the same in one op)."""
+    b = src.shape[0]
+    H, W = out_hw
+    out = torch.empty(b, 3, H, W, dtype=torch.float32)
+    m, s = torch.tensor(mean).view(3, 1, 1), torch.tensor(std).view(3, 1, 1)
+    for i in range(b):
+        x0, y0 = (int(crop_xy[i, 0]), int(crop_xy[i, 1])) if crop_xy is not None else (0, 0)
+        win = src[i, y0:y0 + H, x0:x0 + W, :]
+        if flip is not None and bool(flip[i]):
+            win = win.flip(1)
+        out[i] = (win.permute(2, 0, 1).float() / 255.0 - m) / s
+    return out
+
+
 # ----------------------------------------------------------------------------- CLIP
 def clamp_scale(log_scale, clamp_max=100.0):
     """clip.py:133-134: exp() then a `.data` clamp -- the forward value is clamped,

