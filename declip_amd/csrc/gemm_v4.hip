@@ -44,6 +44,13 @@
 #ifndef V4_TRACE
 #define V4_TRACE 0
 #endif
+// Cache policy of the epilogue traffic (measured in-step, CLIP b=512): 0 none; 1 output tiles stored non-temporal (+1.2 %: a
+// 128 KB tile per CU per epilogue otherwise displaces the A/B panels the XCD's 4 MB L2 is holding for the next tiles; the 4d-wide
+// GELU / dGELU calls gain 7-12 %); 2 only the GELU / dGELU outputs (+1.1 %); 3 = 1 + read-once epilogue operands (residual, dGELU
+// pre-activation) loaded non-temporal (+0.3 % more); 4 = 3 + the split-K partial tiles (-1.6 %: the reduce pass wants them cached).
+#ifndef V4_NT_STORE
+#define V4_NT_STORE 3
+#endif
 #ifndef V4_TWO_PHASE
 #define V4_TWO_PHASE 1   // K-tile schedule: 1 = two phases of 16 MFMAs (4 barriers per K-tile), 0 = four phases of 8 (8 barriers)
 #endif
@@ -55,6 +62,30 @@ extern "C" int dh_v4_trace_clear() { static long z[6 * 256]; return (int)hipMemc
 #endif
 
 namespace v4 {
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+// 16-byte store of an output tile row piece; V4_NT_STORE: non-temporal (the tile is not read again by this kernel: keep it
+// from displacing the operand panels in the XCD's L2)
+// 16-byte load of an epilogue operand that is read exactly once (residual / dGELU pre-activation)
+template <bool NT>
+__device__ __forceinline__ uint4 load_once16(const unsigned char* p) {
+  if (NT) {
+    const u32x4_t w = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(w.x, w.y, w.z, w.w);
+  }
+  return *reinterpret_cast<const uint4*>(p);
+}
+
+template <bool NT>
+__device__ __forceinline__ void store_c16(unsigned char* p, const uint4& v) {
+  if (NT) {
+    u32x4_t w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t*>(p));
+  } else {
+    *reinterpret_cast<uint4*>(p) = v;
+  }
+}
+
 
 struct EpiParams {
   int M, N;
@@ -749,7 +780,11 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
               const int rl2 = wave + 8 * it;                                       // staging row 0..63 (wave-uniform)
               const long mr = i * 128 + (rl2 >> 5) * 64 + ii * 32 + (rl2 & 31);    // row inside the tile
               const f32x4_t v = *reinterpret_cast<const f32x4_t*>(Cs + rl2 * 1024 + ((c ^ (rl2 & 7)) << 4));
+#if V4_NT_STORE >= 4
+              __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(reinterpret_cast<unsigned char*>(Wp + mr * wld) + (uint32_t)(c * 16)));
+#else
               *reinterpret_cast<f32x4_t*>(reinterpret_cast<unsigned char*>(Wp + mr * wld) + (uint32_t)(c * 16)) = v;
+#endif
             }
           }
           wait_lgkm0();
@@ -778,6 +813,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       const unsigned char* Rb = reinterpret_cast<const unsigned char*>(e.residual) + ((long)m0 * e.ldr + n0) * 2;
       const uint32_t r_off = ((uint32_t)r0 * (uint32_t)e.ldr + cc * 8) * 2;
       constexpr bool is_gelu = MODE == MODE_STORE_GELU, is_dgelu = MODE == MODE_STORE_DGELU;
+      // output stores: V4_NT_STORE 1 = all non-temporal, 2 = only the 4d-wide GELU / dGELU outputs, 0 = none
+      constexpr bool NT_OUT = V4_NT_STORE == 1 || V4_NT_STORE >= 3 || (V4_NT_STORE == 2 && (is_gelu || is_dgelu));
+      constexpr bool NT_IN = V4_NT_STORE >= 3;          // 3: also the read-once epilogue operands
       // operands of the fused epilogue (dGELU pre-activation, or else the residual) are requested BEFORE any store of
       // the tile: pass 0's before its staging, pass 1's right after pass 0's staging (its accumulators are dead by then)
       constexpr bool has_pre = MODE == MODE_STORE_DGELU || MODE == MODE_STORE_RES;
@@ -788,7 +826,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       uint4 pre0[8], pre1[8];
       if (has_pre) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) pre0[q] = *reinterpret_cast<const uint4*>(pre_base + (long)(16 * q) * pre_ld * 2 + pre_off);
+        for (int q = 0; q < 8; ++q) pre0[q] = load_once16<NT_IN>(pre_base + (long)(16 * q) * pre_ld * 2 + pre_off);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -809,7 +847,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
         }
         if (i == 0 && has_pre) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) pre1[q] = *reinterpret_cast<const uint4*>(pre_base + (long)(128 + 16 * q) * pre_ld * 2 + pre_off);
+          for (int q = 0; q < 8; ++q) pre1[q] = load_once16<NT_IN>(pre_base + (long)(128 + 16 * q) * pre_ld * 2 + pre_off);
         }
         wait_lgkm0();
         V4_BARRIER();
@@ -823,14 +861,14 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
           uint4 raw = *reinterpret_cast<const uint4*>(Cs + row * 512 + pc * 16);
           if (row & 1) { uint32_t tx = raw.x, ty = raw.y; raw.x = raw.z; raw.y = raw.w; raw.z = tx; raw.w = ty; }
           if (MODE == MODE_STORE) {
-            *reinterpret_cast<uint4*>(Cb + mu * e.ldc * 2 + c_off) = raw;
+            store_c16<NT_OUT>(Cb + mu * e.ldc * 2 + c_off, raw);
           } else {
             const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
             float v[8];
 #pragma unroll
             for (int x = 0; x < 4; ++x) { v[2 * x] = __uint_as_float(wv[x] << 16); v[2 * x + 1] = __uint_as_float(wv[x] & 0xffff0000u); }
             if (is_gelu) {
-              *reinterpret_cast<uint4*>(Xb + mu * e.ldaux * 2 + x_off) = raw;
+              store_c16<NT_OUT>(Xb + mu * e.ldaux * 2 + x_off, raw);
 #pragma unroll
               for (int x = 0; x < 8; ++x) v[x] = quick_gelu_f(v[x]);
             }
@@ -848,7 +886,11 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
                 for (int x = 0; x < 8; ++x) v[x] += pf[x];
               }
             }
-            st8_hw(reinterpret_cast<bf16_t*>(Cb + mu * e.ldc * 2 + c_off), v);
+            {
+              uint4 pk;
+              pk.x = pack2bf_hw(v[0], v[1]); pk.y = pack2bf_hw(v[2], v[3]); pk.z = pack2bf_hw(v[4], v[5]); pk.w = pack2bf_hw(v[6], v[7]);
+              store_c16<NT_OUT>(Cb + mu * e.ldc * 2 + c_off, pk);
+            }
           }
           if (it & 1) __builtin_amdgcn_sched_barrier(0);      // keep the unrolled iterations from being interleaved (register pressure)
         }

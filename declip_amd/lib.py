@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdeclip_hip.so")
+LIB_PATH = os.environ.get("DECLIP_HIP_LIB") or os.path.join(HERE, "libdeclip_hip.so")    # override: ablation builds (tools/build_abl.sh)
 
 DH_F32, DH_BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
