@@ -204,6 +204,104 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float* __restrict_
     if (tx == 0 && row < rows) { pval[(long)blockIdx.y * rows + row] = best[r]; pidx[(long)blockIdx.y * rows + row] = bidx[r]; }
   }
 }
+// The same search on the matrix pipe: v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain at the fp32 vector peak (157 TF),
+// ~12x what the VALU tile kernel above reaches.  Block = 4 waves: 64 query rows (whole rows in LDS) x one chunk of the bank,
+// streamed as tiles of 128 bank rows x 32 k (register-prefetched, one LDS stage).  Wave w multiplies bank rows w*32.. of
+// the tile with both 32-row query blocks; operands are issued swapped (A = bank, B = queries) so a LANE owns one query row
+// and its 16 accumulator registers are 16 bank rows: the running arg-max is in-lane, ascending bank index, strict '>'
+// (first maximum wins, as torch.topk's tie order on ascending indices).  k pairing: lane (r, h) feeds k = 8g + 4h + j to
+// MFMA j of group g for BOTH operands, so one 16-byte LDS read per operand feeds 4 MFMAs.
+constexpr int NM_QT = 64, NM_BT = 128, NM_KC = 32;
+__global__ __launch_bounds__(256) void nn_search_mfma_kernel(const float* __restrict__ Q, const float* __restrict__ bank, int rows,
+                                                             int size, int D, int chunk, float* __restrict__ pval, int* __restrict__ pidx) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int QS = D + 4, BS = NM_KC + 4;                      // row strides: = 4 (mod 32) words -> conflict-free 16-byte reads
+  float* Xs = sm;                                            // [64][QS]
+  float* Ys = Xs + NM_QT * QS;                               // [128][BS]
+  float* redv = Ys + NM_BT * BS;                             // [4 waves][64]
+  int* redi = reinterpret_cast<int*>(redv + 4 * NM_QT);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int r0 = blockIdx.x * NM_QT;
+  const int cbeg = blockIdx.y * chunk, cend = min(size, cbeg + chunk);
+  for (int i = t; i < NM_QT * (D / 4); i += 256) {
+    const int rr = i / (D / 4), k4 = i % (D / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + rr < rows) v = *reinterpret_cast<const float4*>(Q + (long)(r0 + rr) * D + k4 * 4);
+    *reinterpret_cast<float4*>(Xs + rr * QS + k4 * 4) = v;
+  }
+  float best[2] = {-INFINITY, -INFINITY};
+  int bidx[2] = {0x7fffffff, 0x7fffffff};
+  // stage loader: thread -> bank row t >> 1 of the tile, 16 consecutive k (t & 1) * 16 .. +15  (4 float4)
+  const int srow = t >> 1, sk = (t & 1) * 16;
+  float4 pre[4];
+  auto fetch = [&](int c0, int k0) {
+    const int y = c0 + srow;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (y < cend) pre[q] = *reinterpret_cast<const float4*>(bank + (long)y * D + k0 + sk + 4 * q);
+    }
+  };
+  const int nk = D / NM_KC;
+  fetch(cbeg, 0);
+  for (int c0 = cbeg; c0 < cend; c0 += NM_BT) {
+    f32x16_t acc[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[qb][x] = 0.f;
+    for (int kc = 0; kc < nk; ++kc) {
+      __syncthreads();                                       // the previous stage has been consumed
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(Ys + srow * BS + sk + 4 * q) = pre[q];
+      __syncthreads();
+      // next stage in flight during this stage's MFMAs
+      if (kc + 1 < nk) fetch(c0, (kc + 1) * NM_KC);
+      else if (c0 + NM_BT < cend) fetch(c0 + NM_BT, 0);
+#pragma unroll
+      for (int g = 0; g < NM_KC / 8; ++g) {
+        const float4 a = *reinterpret_cast<const float4*>(Ys + (wave * 32 + r) * BS + 8 * g + 4 * h);
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          const float4 b = *reinterpret_cast<const float4*>(Xs + (qb * 32 + r) * QS + kc * NM_KC + 8 * g + 4 * h);
+          const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[qb], 0, 0, 0);
+        }
+      }
+    }
+    // acc[qb][x] of lane (r, h): query row qb*32 + r, bank row c0 + wave*32 + (x/4)*8 + h*4 + x%4  (ascending in x)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int col = c0 + wave * 32 + (x >> 2) * 8 + h * 4 + (x & 3);
+        if (col < cend && acc[qb][x] > best[qb]) { best[qb] = acc[qb][x]; bidx[qb] = col; }
+      }
+  }
+  // lanes r and r + 32 hold the same query row; then the four waves (different bank rows) through LDS
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float v2 = __shfl_xor(best[qb], 32, 64);
+    const int i2 = __shfl_xor(bidx[qb], 32, 64);
+    if (v2 > best[qb] || (v2 == best[qb] && i2 < bidx[qb])) { best[qb] = v2; bidx[qb] = i2; }
+    if (h == 0) { redv[wave * NM_QT + qb * 32 + r] = best[qb]; redi[wave * NM_QT + qb * 32 + r] = bidx[qb]; }
+  }
+  __syncthreads();
+  if (t < NM_QT && r0 + t < rows) {
+    float bv = redv[t]; int bi = redi[t];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float v = redv[w * NM_QT + t]; const int i = redi[w * NM_QT + t];
+      if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+    pval[(long)blockIdx.y * rows + r0 + t] = bv;
+    pidx[(long)blockIdx.y * rows + r0 + t] = bi;
+  }
+}
+
 __global__ void nn_merge_gather_kernel(const float* __restrict__ pval, const int* __restrict__ pidx, int nchunk, int rows,
                                        const float* __restrict__ bank, int D, int64_t* __restrict__ idx_out, float* __restrict__ feat_out) {
   const int row = blockIdx.x;
@@ -334,9 +432,15 @@ extern "C" int dh_nn_bank_query(const float* q, const float* bank, int rows, int
   DH_REQUIRE(ws && ws_bytes >= (int64_t)nchunk * rows * 8, "dh_nn_bank_query: workspace too small");
   float* pval = (float*)ws;
   int* pidx = (int*)(pval + (long)nchunk * rows);
-  size_t lds = (size_t)(NN_RT * (D + 1) + NN_CT * (NN_KC + 1)) * sizeof(float);
-  hipFuncSetAttribute((const void*)nn_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(nn_search_kernel, dim3(dh_cdiv(rows, NN_RT), nchunk), dim3(256), lds, st, q, bank, rows, size, D, chunk, pval, pidx);
+  const size_t lds_m = (size_t)(NM_QT * (D + 4) + NM_BT * (NM_KC + 4) + 8 * NM_QT) * sizeof(float);
+  if (D % NM_KC == 0 && lds_m <= 160 * 1024) {                 // matrix-pipe search (D <= 512: whole query rows fit LDS)
+    hipFuncSetAttribute((const void*)nn_search_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+    hipLaunchKernelGGL(nn_search_mfma_kernel, dim3(dh_cdiv(rows, NM_QT), nchunk), dim3(256), lds_m, st, q, bank, rows, size, D, chunk, pval, pidx);
+  } else {
+    size_t lds = (size_t)(NN_RT * (D + 1) + NN_CT * (NN_KC + 1)) * sizeof(float);
+    hipFuncSetAttribute((const void*)nn_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nn_search_kernel, dim3(dh_cdiv(rows, NN_RT), nchunk), dim3(256), lds, st, q, bank, rows, size, D, chunk, pval, pidx);
+  }
   DH_CHECK_LAUNCH();
   hipLaunchKernelGGL(nn_merge_gather_kernel, dim3(rows), dim3(128), 0, st, (const float*)pval, (const int*)pidx, nchunk, rows, bank, D, idx_out, feat_out);
   DH_CHECK_LAUNCH();

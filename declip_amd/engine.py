@@ -264,6 +264,15 @@ def block_bwd(dx_out, r, saved, b, L, heads, causal):
     return ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
 
 
+def to_device_async(t, dev):
+    """Host -> device without stalling the host: a pageable `.to(device)` waits for everything already enqueued on the stream
+    (in the DeCLIP step: the whole text tower, ~35 ms at b=512); from pinned memory the copy is just another stream operation."""
+    dev = torch.device(dev)
+    if t.device == dev or dev.type != "cuda":
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
 def _to_act(t, dtype):
     if t.dtype == dtype:
         return t.contiguous()

@@ -267,6 +267,6 @@ def mlm_loss(words, labels, lin, flat):
     lab = labels.reshape(-1)
     sel = (lab != -100).nonzero(as_tuple=False).reshape(-1)        # index arithmetic (host sync only if labels live on the GPU)
     dev = words.device
-    idx = sel.to(dev)
-    labels_sel = lab[sel.to(lab.device)].to(dev)
+    idx = engine.to_device_async(sel, dev)
+    labels_sel = engine.to_device_async(lab[sel.to(lab.device)], dev)
     return MlmHeadFn.apply(words, idx, labels_sel, lin, flat).mean()

@@ -106,7 +106,7 @@ class DECLIP(CLIP):
             ids_aug = et.tokenize(texts_aug, et.context_length)
         dev = flat.flat_p.device
         b = images.shape[0]
-        ids_cat = torch.cat([ids.to(dev), ids_aug.to(dev)], dim=0).long().contiguous()
+        ids_cat = torch.cat([engine.to_device_async(ids, dev), engine.to_device_async(ids_aug, dev)], dim=0).long().contiguous()
         want_words = self.text_mask_type is not None
         side = self._fork(images)                # text tower on the side stream, both image views on the caller's (clip.py)
         with self._on(side):

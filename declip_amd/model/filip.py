@@ -96,7 +96,7 @@ class FILIP(CLIP):
             tok = et.tokenize(self.sample_captions(caps), et.context_length, self.text_mask_type)
             ids = tok[0] if self.text_mask_type is not None else tok
         dev = flat.flat_p.device
-        ids = ids.to(dev).long().contiguous()
+        ids = engine.to_device_async(ids, dev).long().contiguous()
         b = images.shape[0]
         side = self._fork(images)                                               # text tower on the side stream (clip.py)
         with self._on(side):

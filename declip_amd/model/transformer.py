@@ -180,11 +180,11 @@ class TextTransformer(_Tower):
             ids, labels = tok if mask_type is not None else (tok, None)
         flat = self._flat()
         dev = flat.flat_p.device
-        ids = ids.to(dev, non_blocking=True).long().contiguous()
+        ids = engine.to_device_async(ids, dev).long().contiguous()
         want_dense = return_dense or mask_type is not None
         out = engine.TextTowerFn.apply(flat.anchor, ids, self, want_dense)
         if mask_type is not None:
-            return out[0], out[1], labels.to(dev)
+            return out[0], out[1], engine.to_device_async(labels, dev)
         if return_dense:
             return out
         return out

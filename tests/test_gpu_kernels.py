@@ -346,6 +346,26 @@ def test_cos_rows(dtype):
     assert rel_err(dp, pr.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
 
 
+def test_nn_bank_query_ties_and_ragged_sizes():
+    """Duplicate bank rows: the lowest index wins (torch.topk on the reference's sim matrix returns the first maximum); row
+    counts / bank sizes that are not multiples of the 64 x 128 tiles of the matrix-pipe kernel; a D that takes the VALU path."""
+    ops = _ops()
+    for rows, size, D in [(70, 4100, 512), (3, 129, 96), (33, 2049, 100)]:
+        bank = torch.nn.functional.normalize(rnd(size, D, seed=90), dim=1)
+        q = torch.nn.functional.normalize(rnd(rows, D, seed=91), dim=1)
+        lo, hi = 5, size - 2
+        bank[hi] = bank[lo]                                 # duplicates far apart (different tiles / chunks)
+        q[1] = bank[lo]
+        q[2] = bank[size - 1]                               # the very last (ragged) bank row
+        idx, feats = ops.nn_bank_query(q.to(cuda), bank.to(cuda))
+        got = idx.cpu()
+        sim = q.double() @ bank.double().t()
+        assert int(got[1]) == lo and int(got[2]) == size - 1, (rows, size, D, got[:3])
+        chosen = sim[torch.arange(rows), got]
+        assert float((sim.max(1)[0] - chosen).max()) < 2e-6
+        assert torch.equal(feats.cpu(), bank[got])
+
+
 @pytest.mark.parametrize("rows,size,D", [(40, 5000, 512), (7, 300, 64), (512, 65536, 512)])
 def test_nn_bank_query_exact(rows, size, D):
     ops = _ops()
