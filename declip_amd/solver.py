@@ -314,6 +314,10 @@ class ClsSolver(object):
         t_last = time.time()
         for curr_step in range(start, end + 1):
             out = self.train_step(curr_step)
+            if curr_step == start:           # everything long-lived exists now: keep it out of the cyclic collector's scans
+                import gc
+                gc.collect()
+                gc.freeze()
             self.meters["loss"].reduce_update(out["loss"].detach().clone())
             if "top1" in out:
                 self.meters["top1"].reduce_update(out["top1"].detach() / self.world_size)

@@ -9,18 +9,11 @@ OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="${@:---steps 4 --warmup 2 --no-cpu-baseline}"
-# kernel table with the towers on ONE stream (per-kernel durations = the kernel alone on the chip) ...
+# kernel table with the towers on ONE stream: per-kernel durations = the kernel alone on the chip (a trace of the two-stream
+# run is not informative: rocprofv3 serialises the dispatches it times)
 DH_TOWER_STREAMS=0 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 DB=$(find $OUT/trace -name "*.db" | head -1)
 if [ -n "$DB" ]; then python $ROOT/tools/rocpd_stats.py $DB > $OUT/stats.txt 2>&1; fi
-# (a kernel trace of the two-stream run is not informative: rocprofv3 serialises the dispatches it times)
-find $OUT/trace -name "*.db" | head -1)
-if [ -n "$DB" ]; then python $ROOT/tools/rocpd_stats.py $DB > $OUT/stats.txt 2>&1; fi
-# ... and as shipped (image / text tower on two streams: durations include the time a kernel shares the chip)
-rocprofv3 --kernel-trace --stats -d $OUT/trace2 -o trace -- python $ROOT/bench.py $ARGS > $OUT/trace_streams.log 2>&1
-DB2=$(find $OUT/trace2 -name "*.db" | head -1)
-if [ -n "$DB2" ]; then python $ROOT/tools/rocpd_stats.py $DB2 > $OUT/stats_streams.txt 2>&1; fi
-find $OUT/trace -name "*stats*.csv" | head -3
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$tag -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/pmc_$tag.log 2>&1
