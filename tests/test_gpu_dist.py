@@ -73,3 +73,64 @@ def test_two_ranks_on_one_gpu_match_two_reference_ranks(streams, bucket_bytes, p
             pytest.fail("rank timed out")
         assert p.exitcode == 0
     assert q.get() == "ok"
+
+
+def _rccl_worker(port, out):
+    """One rank, backend nccl (= RCCL), DH_DIST_FORCE=1: the packed all-gather / reduce-scatter autograd, the flat parameter
+    broadcast and the bucketed asynchronous all-reduce launched from both tower streams all go through RCCL; with one rank
+    every collective is the identity, so the step must reproduce the non-distributed one."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      DH_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    from declip_amd import dist as dd
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.optim import build_adamw
+    from declip_amd.testing import build_clip
+    dd.initialize("nccl")
+    assert dist.get_backend() == "nccl" and dd.is_dist()
+    cfg, b, seed = synth.VITB32, 256, 4
+    images = synth.synth_images(b, res=cfg["res"], seed=seed).cuda()
+    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"]).cuda()
+    crit = ClipInfoCELoss()
+
+    def run(distributed):
+        os.environ["DH_DIST_FORCE"] = "1" if distributed else "0"
+        model = build_clip(cfg, dtype="bf16", use_allgather=distributed, seed=seed)
+        wrapped = dd.DistModule(model, sync=False, bucket_bytes=8 << 20) if distributed else model
+        opt = build_adamw(model, lr=1e-4, weight_decay=0.1)
+        losses = []
+        for _ in range(3):
+            li, lt = wrapped({"images": images, "captions": ids})
+            loss, _ = crit(li, lt)
+            opt.zero_grad()
+            loss.backward()
+            if distributed:
+                wrapped.sync_gradients()
+            opt.step()
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        return losses
+
+    l_dist, l_ref = run(True), run(False)
+    assert l_dist[0] == l_ref[0], (l_dist, l_ref)
+    for a, c in zip(l_dist, l_ref):
+        assert abs(a - c) <= 3e-3 * abs(c), (l_dist, l_ref)        # run-to-run noise of two bf16 runs (DESIGN.md s2)
+    out.put("ok")
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_collectives_are_the_identity():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_rccl_worker, args=(29721, q))
+    p.start()
+    p.join(300)
+    if p.is_alive():
+        p.terminate()
+        p.join(10)
+        pytest.fail("RCCL worker timed out")
+    assert p.exitcode == 0
+    assert q.get() == "ok"
