@@ -230,7 +230,7 @@ def main():
                                      "fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d" % b),
                            global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world,
                            tower_streams=1 + len(model.__dict__["_flat_store"].side_streams)),
-               loss=round(float(loss) * world, 5))
+               loss=round(float(loss.detach()) * world, 5))
     if roofline is not None:
         out["roofline"] = roofline
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -39,7 +39,8 @@ def get_world_size():
 
 
 def get_local_rank():
-    return int(os.environ.get("LOCAL_RANK", get_rank() % max(1, torch.cuda.device_count() or 1)))
+    ndev = max(1, torch.cuda.device_count() or 1)
+    return int(os.environ.get("LOCAL_RANK", get_rank())) % ndev      # ranks beyond the device count share devices (gloo tests)
 
 
 def initialize(backend="nccl"):
@@ -56,6 +57,7 @@ def initialize(backend="nccl"):
         # RCCL kernels hold some CUs while the gradient all-reduce overlaps the backward pass: let the persistent GEMM hand
         # out its tiles dynamically (a static partition loses a whole tile time per occupied CU; gemm_v4.hip / probe_contention)
         os.environ.setdefault("DH_V4_DYNAMIC", "1")
+    backend = os.environ.get("DH_DIST_BACKEND", backend)     # e.g. gloo: several ranks sharing one GPU (RCCL refuses that)
     if torch.cuda.is_available():
         torch.cuda.set_device(get_local_rank())
     else:

@@ -110,6 +110,9 @@ class FlatParams:
         the ragged last round of one tower's persistent GEMMs, its HBM-bound LayerNorm / attention launches and the other
         tower's MFMA work fill each other's idle CUs (one 256x256 workgroup owns a CU; the hardware queues interleave at
         workgroup granularity)."""
+        if not self.side_streams and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            # the shared anchor leaf is consumed by towers on different streams on purpose; its gradient is never used
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         while len(self.side_streams) <= i:
             self.side_streams.append(torch.cuda.Stream(device=self.flat_p.device))
         return self.side_streams[i]
