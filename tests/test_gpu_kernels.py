@@ -143,7 +143,8 @@ def attn_ref(qkv, heads, causal):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("b,L,heads,causal", [(3, 50, 12, False), (2, 77, 8, True), (2, 5, 2, False), (1, 16, 2, True), (2, 33, 1, True)])
+@pytest.mark.parametrize("b,L,heads,causal", [(3, 50, 12, False), (2, 77, 8, True), (2, 5, 2, False), (1, 16, 2, True), (2, 33, 1, True),
+                                              (1, 128, 2, True), (2, 128, 1, False), (3, 1, 2, True), (700, 50, 12, False)])
 def test_attention(dtype, b, L, heads, causal):
     ops = _ops()
     d = heads * 64
