@@ -522,6 +522,7 @@ extern "C" int dh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, in
 #undef CALL
   } else {
     size_t lds = (size_t)(3 * L * (hd + 1) + L * (L + 1)) * sizeof(float);
+    DH_REQUIRE(lds <= 160 * 1024, "dh_attn_fwd: sequence too long for the fp32 / generic path (L <= 126 at hd = 64; the bf16 MFMA path takes L <= 128)");
     if (dtype == DH_BF16) {
       hipFuncSetAttribute((const void*)attn_fwd_generic_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(attn_fwd_generic_kernel<bf16_t>, dim3(b * heads), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, lse, L, heads, hd, causal, scale);
@@ -547,7 +548,7 @@ extern "C" int dh_attn_bwd(int dtype, const void* qkv, const void* out, const vo
 #undef CALL
   } else {
     size_t lds = (size_t)(4 * L * (hd + 1) + 2 * L * (L + 1) + L) * sizeof(float);
-    DH_REQUIRE(lds <= 160 * 1024, "dh_attn_bwd: sequence too long for the fp32 path");
+    DH_REQUIRE(lds <= 160 * 1024, "dh_attn_bwd: sequence too long for the fp32 / generic path (L <= 91 at hd = 64; the bf16 MFMA path takes L <= 128)");
     if (dtype == DH_BF16) {
       hipFuncSetAttribute((const void*)attn_bwd_generic_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(attn_bwd_generic_kernel<bf16_t>, dim3(b * heads), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, L, heads, hd, causal, scale);

@@ -112,7 +112,8 @@ int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const float* w, c
  *   P = softmax(q k^T / sqrt(hd) [+ causal -inf]);  o = P v.
  * qkv: [b, L, 3*heads*hd] (q | k | v blocks, each heads*hd wide, head-major), out: [b, L, heads*hd],
  * lse: [b, heads, L] fp32 (log-sum-exp of the scaled scores; saved for backward).
- * hd must be 64 for DH_BF16 (MFMA path); L <= 128.
+ * hd must be 64 for DH_BF16 (MFMA path); L <= 128.  The fp32 validation kernels keep the [L, L] matrices in LDS as well:
+ * forward L <= 126, backward L <= 91 at hd = 64 (longer sequences return DH_ERR_ARG, nothing is launched).
  * bwd recomputes P from q,k,lse: dqkv [b, L, 3*heads*hd]. */
 int dh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, int b, int L, int heads, int hd, int causal,
                 dh_stream_t stream);

@@ -144,10 +144,19 @@ def attn_ref(qkv, heads, causal):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("b,L,heads,causal", [(3, 50, 12, False), (2, 77, 8, True), (2, 5, 2, False), (1, 16, 2, True), (2, 33, 1, True),
-                                              (1, 128, 2, True), (2, 128, 1, False), (3, 1, 2, True), (700, 50, 12, False)])
+                                              (1, 128, 2, True), (2, 128, 1, False), (2, 91, 2, True), (3, 1, 2, True), (700, 50, 12, False)])
 def test_attention(dtype, b, L, heads, causal):
     ops = _ops()
     d = heads * 64
+    if dtype == torch.float32 and L > 91:
+        # fp32 validation kernels keep q, k, v (, dO) AND the [L, L] matrices in LDS: forward L <= 126, backward L <= 91 --
+        # beyond that the call must fail with an error, not launch
+        from declip_amd.lib import DeclipHipError
+        qkv = rnd(b, L, 3 * d, seed=17).to(cuda)
+        with pytest.raises(DeclipHipError):
+            out, lse = ops.attn_fwd(qkv.view(b * L, 3 * d), b, L, heads, causal)
+            ops.attn_bwd(qkv.view(b * L, 3 * d), out, out, lse, b, L, heads, causal)
+        return
     qkv = rnd(b, L, 3 * d, seed=17).to(dtype)
     dout = rnd(b, L, d, seed=18).to(dtype)
     qr = qkv.double().requires_grad_(True)
