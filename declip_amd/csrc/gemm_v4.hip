@@ -1113,7 +1113,8 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
     // at most 32 slices (reduction traffic), at least 4 K-tiles per slice
     const int tiles = dh_cdiv(a->N, BN) * dh_cdiv(a->M, BM);
     int sp = num_cus() / tiles;
-    if (sp > 32) sp = 32;
+    if (sp > 32 && tiles > 4) sp = 32;            // reduction traffic grows with the slice count ...
+    if (sp > 64) sp = 64;                         // ... except for the smallest weights (<= 4 tiles: 1 MB of fp32 per slice)
     if (sp > a->K / (4 * BK)) sp = a->K / (4 * BK);
     if (sp < 1) sp = 1;
     if (a->ws) while (sp > 1 && a->ws_bytes < (int64_t)sp * a->M * a->N * 4 + (int64_t)sp * dh_cdiv(a->N, BN) * a->M * 4) --sp;

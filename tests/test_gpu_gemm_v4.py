@@ -87,7 +87,7 @@ def test_v4_dx_plain_and_dgelu(M, N, K):
 
 
 @pytest.mark.parametrize("use_ws", [True, False])
-@pytest.mark.parametrize("rows,out_f,in_f", [(1024, 512, 768), (8192, 768, 768), (25600, 768, 3072)])
+@pytest.mark.parametrize("rows,out_f,in_f", [(1024, 512, 768), (8192, 768, 768), (25600, 768, 3072), (39424, 512, 512)])   # last: 4 tiles -> 64 K-slices
 def test_v4_weight_grad_splitk_and_bias_grad(rows, out_f, in_f, use_ws):
     """dW += dY^T X with the fused bias gradient: split-K partial tiles + reduce pass (workspace) or fp32 atomics."""
     ops = _ops()
