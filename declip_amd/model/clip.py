@@ -107,16 +107,17 @@ class CLIP(nn.Module):
 
     def features(self, images, texts):
         """normalised (image, text) features, fp32 [b,E] (clip.py:123-130)."""
-        # the towers are independent until the loss: text on a side stream, image on the caller's.  autograd replays each
-        # tower's backward on its forward stream, so the two backward passes overlap the same way.
+        # the towers are independent until the loss: one of them goes to a side stream.  autograd replays each tower's
+        # backward on its forward stream, so the two backward passes overlap the same way.  The longer (image) tower is
+        # enqueued first, on the side stream; the text tower follows on the caller's stream (+0.5 % over the other arrangements)
         side = self._fork(images)
         with self._on(side):
-            txt = engine.L2NormFn.apply(self.encode_text(texts), 1e-10)
-        img = engine.L2NormFn.apply(self.visual(images), 0.0)
-        self._join(side, txt)
+            img = engine.L2NormFn.apply(self.visual(images), 0.0)
+        txt = engine.L2NormFn.apply(self.encode_text(texts), 1e-10)
+        self._join(side, img)
         return img, txt
 
-    # ---- two tower streams (FlatParams.side_stream): fork before the text tower, join after the image tower is enqueued
+    # ---- two tower streams (FlatParams.side_stream): fork before the first tower, join after the second one is enqueued
     def _fork(self, images):
         if not self._two_streams(images):
             return None
