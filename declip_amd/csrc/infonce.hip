@@ -274,6 +274,265 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(PairTable pt, int mode, in
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same two kernels on the matrix pipe.  v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain at the fp32 vector peak; the
+// VALU tile loops above reach ~4 % of it, and their cost grows with the number of gathered columns (B = 512 * world): at
+// 8 ranks the loss took 2.9 ms of a ~33 ms step (tools/bench_nce.py).  Block = 4 waves, 32 rows of X (whole rows in LDS),
+// Y streamed as tiles of 128 rows x 128 contraction columns, register-prefetched.  Operands are issued swapped for the
+// logits (A = Y, B = X): a LANE owns one X row and its 16 accumulator registers are 16 Y rows, so the online softmax /
+// the G factor are in-lane.  k pairing as in nn_search_mfma_kernel: lane (r, h) feeds k = 8g + 4h + j to MFMA j of group g
+// for both operands (one 16-byte LDS read per operand per 4 MFMAs).
+constexpr int MX = 32, MY = 128, MW = 128;
+
+struct YStage { float4 v[16]; };
+// thread t stages row t >> 1 of the tile, 64 consecutive columns (t & 1) * 64 .. of the pass
+__device__ __forceinline__ void ystage_fetch(YStage& st, const float* __restrict__ Y, int y0, int ny, int D, int d0) {
+  const int t = threadIdx.x, y = y0 + (t >> 1), dd = d0 + (t & 1) * 64;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    st.v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y < ny && dd + 4 * q < D) st.v[q] = *reinterpret_cast<const float4*>(Y + (long)y * D + dd + 4 * q);
+  }
+}
+__device__ __forceinline__ void ystage_commit(const YStage& st, float* Ys) {
+  const int t = threadIdx.x;
+  float* dst = Ys + (t >> 1) * (MW + 4) + (t & 1) * 64;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) *reinterpret_cast<float4*>(dst + 4 * q) = st.v[q];
+}
+// Y row (inside the wave's 32) of accumulator register x for a lane in half h
+__device__ __forceinline__ int acc_row(int x, int h) { return (x >> 2) * 8 + h * 4 + (x & 3); }
+
+// S^T-fragment of one pass: sacc[x] += sum over the 128 staged columns of Y[w*32 + acc_row][k] * X[lane & 31][d0 + k]
+// (only the groups of 8 columns that exist: for D not a multiple of 128 the rest of the pass would read the uninitialised pad
+// of the X rows -- NaN bit patterns left in LDS by an earlier kernel times the staged zeros are NaN, not 0)
+__device__ __forceinline__ void logits_pass(f32x16_t& sacc, const float* Xs, int XS, const float* Ys, int d0, int D, int wave, int r, int h) {
+  const int ng = min(MW / 8, (D - d0) / 8);
+#pragma unroll 4
+  for (int g = 0; g < ng; ++g) {
+    const float4 a = *reinterpret_cast<const float4*>(Ys + (wave * 32 + r) * (MW + 4) + 8 * g + 4 * h);
+    const float4 b = *reinterpret_cast<const float4*>(Xs + r * XS + d0 + 8 * g + 4 * h);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, sacc, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void nce_fwd_mfma_kernel(PairTable pt, int b, int B, int D, const float* __restrict__ scale_p,
+                                                           float* __restrict__ part, float* __restrict__ logits_out, int chunk_cols) {
+  const float scale = *scale_p;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int XS = D + 4;
+  float* Xs = sm;                       // [32][D + 4]
+  float* Ys = Xs + MX * XS;             // [128][132]
+  float* lab = Ys + MY * (MW + 4);      // [32] label logits
+  float* red = lab + MX;                // [4 waves][32][3]
+  const int pair = blockIdx.y;
+  const int label0 = pt.label0[pair], excl0 = pt.excl0[pair];
+  const int nchunk = gridDim.z, chunk = blockIdx.z;
+  const int cbeg = chunk * chunk_cols, cend = min(B, cbeg + chunk_cols);
+  const float* Q = pt.Q[pair];
+  const float* K = pt.K[pair];
+  const int r0 = blockIdx.x * MX;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+  for (int i = t; i < MX * (D / 4); i += 256) {
+    const int rr = i / (D / 4), k4 = i % (D / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + rr < b) v = *reinterpret_cast<const float4*>(Q + (long)(r0 + rr) * D + k4 * 4);
+    *reinterpret_cast<float4*>(Xs + rr * XS + k4 * 4) = v;
+  }
+  __syncthreads();
+  {  // label logit: 8 threads per row
+    const int rr = t >> 3, part_i = t & 7;
+    float a = 0.f;
+    if (r0 + rr < b) {
+      const float* kr = K + (long)(label0 + r0 + rr) * D;
+      for (int k = part_i; k < D; k += 8) a = fmaf(Xs[rr * XS + k], kr[k], a);
+    }
+    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+    if (part_i == 0) lab[rr] = a * scale;
+  }
+  __syncthreads();
+  const int row = r0 + r;
+  const float ll = lab[r];
+  float m = -INFINITY, ssum = 0.f, cnt = 0.f;
+  const int npass = (D + MW - 1) / MW;
+  YStage st;
+  ystage_fetch(st, K, cbeg, cend, D, 0);
+  for (int c0 = cbeg; c0 < cend; c0 += MY) {
+    f32x16_t sacc;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) sacc[x] = 0.f;
+    for (int p = 0; p < npass; ++p) {
+      __syncthreads();
+      ystage_commit(st, Ys);
+      __syncthreads();
+      if (p + 1 < npass) ystage_fetch(st, K, c0, cend, D, (p + 1) * MW);
+      else if (c0 + MY < cend) ystage_fetch(st, K, c0 + MY, cend, D, 0);
+      logits_pass(sacc, Xs, XS, Ys, p * MW, D, wave, r, h);
+    }
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const int col = c0 + wave * 32 + acc_row(x, h);
+      if (col < cend && row < b) {
+        const float v = sacc[x] * scale;
+        if (logits_out) logits_out[((long)pair * b + row) * B + col] = v;
+        if (excl0 >= 0 && col == excl0 + row) continue;               // self-pair removed from the softmax
+        if (col != label0 + row && v > ll) cnt += 1.f;
+        if (v > m) { ssum = ssum * __expf(m - v) + 1.f; m = v; } else ssum += __expf(v - m);
+      }
+    }
+  }
+  {  // the two half-wave lanes of a row, then the four waves
+    const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(ssum, 32, 64);
+    lse_merge(m, ssum, m2, s2);
+    cnt += __shfl_xor(cnt, 32, 64);
+    if (h == 0) { red[(wave * MX + r) * 3 + 0] = m; red[(wave * MX + r) * 3 + 1] = ssum; red[(wave * MX + r) * 3 + 2] = cnt; }
+  }
+  __syncthreads();
+  if (t < MX && r0 + t < b) {
+    float mm = red[t * 3], ss = red[t * 3 + 1], cc = red[t * 3 + 2];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      lse_merge(mm, ss, red[(w * MX + t) * 3], red[(w * MX + t) * 3 + 1]);
+      cc += red[(w * MX + t) * 3 + 2];
+    }
+    float* o = part + (((long)pair * nchunk + chunk) * b + r0 + t) * 4;
+    o[0] = mm; o[1] = ss; o[2] = cc; o[3] = lab[t];
+  }
+}
+
+// backward on the matrix pipe: per Y tile, 4 passes build the logits fragment, G goes to LDS TRANSPOSED ([y][x]: the lanes of
+// a wave write consecutive x), 4 more passes over the same Y columns accumulate dX[32][D] += G . Y with wave w owning the
+// w-th 32-column chunk of every pass (16 accumulator tiles of 32 x 32 over the 4 waves; D <= 512).
+__global__ __launch_bounds__(256) void nce_bwd_mfma_kernel(PairTable pt, int mode, int b, int B, int D, const float* __restrict__ scale_p,
+                                                           const float* __restrict__ row_lse, const float* __restrict__ g_row,
+                                                           float* __restrict__ dscale, int chunk_cols) {
+  const float scale = *scale_p;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int XS = D + 4;
+  constexpr int GS = MX + 4;
+  float* Xs = sm;                        // [32][D + 4]
+  float* Ys = Xs + MX * XS;              // [128][132]
+  float* Gt = Ys + MY * (MW + 4);        // [128][36]  G transposed
+  float* red = Gt + MY * GS;             // [8]
+  const int pair = blockIdx.y;
+  const int label0 = pt.label0[pair], excl0 = pt.excl0[pair];
+  const float* X = mode == 0 ? pt.Q[pair] : pt.K[pair];
+  const float* Y = mode == 0 ? pt.K[pair] : pt.Q[pair];
+  float* dX = mode == 0 ? pt.dQ[pair] : pt.dK[pair];
+  if (dX == nullptr && !(mode == 0 && dscale != nullptr)) return;     // gradient not wanted for this operand
+  const int nx = mode == 0 ? b : B, ny_all = mode == 0 ? B : b;
+  const int ybeg = blockIdx.z * chunk_cols, ny = min(ny_all, ybeg + chunk_cols);
+  const bool chunked = gridDim.z > 1;
+  const int r0 = blockIdx.x * MX;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+  const float* lse_p = row_lse + (long)pair * b;
+  const float* g_p = g_row + (long)pair * b;
+  for (int i = t; i < MX * (D / 4); i += 256) {
+    const int rr = i / (D / 4), k4 = i % (D / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + rr < nx) v = *reinterpret_cast<const float4*>(X + (long)(r0 + rr) * D + k4 * 4);
+    *reinterpret_cast<float4*>(Xs + rr * XS + k4 * 4) = v;
+  }
+  const int npass = (D + MW - 1) / MW;     // <= 4
+  f32x16_t dacc[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int x = 0; x < 16; ++x) dacc[p][x] = 0.f;
+  const int xr = r0 + r;                  // this lane's X row (logits fragment)
+  float lse_x = 0.f, g_x = 0.f;
+  if (mode == 0 && xr < nx) { lse_x = lse_p[xr]; g_x = g_p[xr]; }
+  float ds_acc = 0.f;
+  YStage st;
+  ystage_fetch(st, Y, ybeg, ny, D, 0);
+  for (int c0 = ybeg; c0 < ny; c0 += MY) {
+    f32x16_t sacc;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) sacc[x] = 0.f;
+    for (int p = 0; p < npass; ++p) {
+      __syncthreads();
+      ystage_commit(st, Ys);
+      __syncthreads();
+      ystage_fetch(st, Y, c0, ny, D, ((p + 1) % npass) * MW);      // next logits pass, or pass 0 again for the dX sweep
+      logits_pass(sacc, Xs, XS, Ys, p * MW, D, wave, r, h);
+    }
+    // G for this lane's X row against its 16 Y rows; stored transposed
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const int yl = wave * 32 + acc_row(x, h), yc = c0 + yl;
+      float gval = 0.f;
+      if (xr < nx && yc < ny) {
+        const int i = mode == 0 ? xr : yc;   // Q row (local)
+        const int j = mode == 0 ? yc : xr;   // K row (global)
+        const float lse_i = mode == 0 ? lse_x : lse_p[i], g_i = mode == 0 ? g_x : g_p[i];
+        const float pr = (excl0 >= 0 && j == excl0 + i) ? 0.f : __expf(sacc[x] * scale - lse_i);
+        gval = g_i * (pr - (j == label0 + i ? 1.f : 0.f));
+        ds_acc += gval * sacc[x];
+      }
+      Gt[yl * GS + r] = gval;
+    }
+    // dX[32][D] += G[32][128] . Y[128][D]: pass p re-stages columns 128p.., wave w multiplies its 32-column chunk
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {          // unrolled: dacc[] must stay in registers (no dynamic indexing)
+      if (p < npass) {
+        __syncthreads();                  // (p == 0: also publishes Gt)
+        ystage_commit(st, Ys);
+        __syncthreads();
+        if (p + 1 < npass) ystage_fetch(st, Y, c0, ny, D, (p + 1) * MW);
+        else if (c0 + MY < ny) ystage_fetch(st, Y, c0 + MY, ny, D, 0);
+        if (p * MW + wave * 32 < D) {
+#pragma unroll 4
+          for (int k0 = 0; k0 < MY; k0 += 8) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const float a = Gt[(k0 + 4 * h + jj) * GS + r];
+              const float bb = Ys[(k0 + 4 * h + jj) * (MW + 4) + wave * 32 + r];
+              dacc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, dacc[p], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  // dacc[p][x] of lane (r, h): X row acc_row(x, h), column 128p + 32*wave + r
+  if (dX != nullptr) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int col = p * MW + wave * 32 + r;
+      if (p < npass && col < D) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          const int rr = r0 + acc_row(x, h);
+          if (rr < nx) {
+            if (chunked) atomicAdd(dX + (long)rr * D + col, dacc[p][x] * scale);
+            else dX[(long)rr * D + col] = dacc[p][x] * scale;
+          }
+        }
+      }
+    }
+  }
+  if (mode == 0 && dscale) {
+    __syncthreads();
+    float tot = block_sum256(ds_acc, red);
+    if (t == 0) atomicAdd(dscale, tot);
+  }
+}
+
+// column chunk for the matrix-pipe kernels: multiples of the 128-row Y tile, ~1 block per CU (their LDS footprint allows one)
+static int nce_chunk_cols_mfma(int rows, int cols, int n_pairs) {
+  const int tiles = dh_cdiv(rows, MX) * n_pairs;
+  const int want = dh_cdiv(256, tiles);
+  int chunk = dh_cdiv(dh_cdiv(cols, want), MY) * MY;
+  if (chunk < MY) chunk = MY;
+  return chunk;
+}
+static bool nce_mfma_ok(int D) { return D % 32 == 0 && D >= 32 && D <= 512; }
+static size_t nce_fwd_mfma_lds(int D) { return (size_t)(MX * (D + 4) + MY * (MW + 4) + MX + 4 * MX * 3) * sizeof(float); }
+static size_t nce_bwd_mfma_lds(int D) { return (size_t)(MX * (D + 4) + MY * (MW + 4) + MY * (MX + 4) + 8) * sizeof(float); }
+
 // ---- plain row-wise softmax cross-entropy on materialised logits [rows, C] (fp32):
 // used for logits handed in as tensors (loss_functions/loss.py:44-45) and for the MLM head
 // (model/declip.py:326-334).  label < 0 (e.g. -100) rows are ignored (loss 0, zero grad).
@@ -364,12 +623,23 @@ extern "C" int dh_infonce_fwd(const dh_nce_pair* pairs, int n_pairs, int b, int 
   for (int i = 0; i < n_pairs; ++i) DH_REQUIRE(pt.Q[i] && pt.K[i], "dh_infonce_fwd: null feature pointer");
   DH_REQUIRE(D <= 1024, "dh_infonce_fwd: D=%d > 1024", D);
   constexpr int RT = 32;
-  const int chunk_cols = nce_chunk_cols(b, B, n_pairs, RT);
-  const int nchunk = dh_cdiv(B, chunk_cols);
-  size_t lds = (size_t)(RT * (D + 1) + CT * (KC + 1) + RT) * sizeof(float);
-  hipFuncSetAttribute((const void*)nce_fwd_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(nce_fwd_kernel<RT>, dim3(dh_cdiv(b, RT), n_pairs, nchunk), dim3(256), lds, st, pt, b, B, D, scale, label0,
-                     (float*)ws, logits_out, chunk_cols);
+  int nchunk;
+  if (nce_mfma_ok(D)) {                  // matrix-pipe kernel (fewer, larger column chunks: the workspace bound still holds)
+    const int chunk_cols = nce_chunk_cols_mfma(b, B, n_pairs);
+    nchunk = dh_cdiv(B, chunk_cols);
+    DH_REQUIRE(ws_bytes >= (int64_t)n_pairs * nchunk * b * 4 * (int64_t)sizeof(float), "dh_infonce_fwd: workspace too small");
+    const size_t lds = nce_fwd_mfma_lds(D);
+    hipFuncSetAttribute((const void*)nce_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nce_fwd_mfma_kernel, dim3(dh_cdiv(b, MX), n_pairs, nchunk), dim3(256), lds, st, pt, b, B, D, scale, (float*)ws,
+                       logits_out, chunk_cols);
+  } else {
+    const int chunk_cols = nce_chunk_cols(b, B, n_pairs, RT);
+    nchunk = dh_cdiv(B, chunk_cols);
+    size_t lds = (size_t)(RT * (D + 1) + CT * (KC + 1) + RT) * sizeof(float);
+    hipFuncSetAttribute((const void*)nce_fwd_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nce_fwd_kernel<RT>, dim3(dh_cdiv(b, RT), n_pairs, nchunk), dim3(256), lds, st, pt, b, B, D, scale, label0,
+                       (float*)ws, logits_out, chunk_cols);
+  }
   DH_CHECK_LAUNCH();
   hipLaunchKernelGGL(nce_finalize_kernel, dim3(dh_cdiv(n_pairs * b, 256)), dim3(256), 0, st, (const float*)ws, n_pairs, nchunk, b,
                      row_loss, row_lse, correct1, correct5);
@@ -401,7 +671,24 @@ extern "C" int dh_infonce_bwd(const dh_nce_pair* pairs, int n_pairs, int b, int 
     hipLaunchKernelGGL(nce_bwd_kernel<RT>, dim3(dh_cdiv(nx, RT), n_pairs, nz), dim3(256), lds, st, pt, mode, b, B, D, scale,
                        label0, row_lse, g_row, dscale, chunk_cols);
   };
-  if (D <= 512) {
+  auto launch_mfma = [&](int mode) {
+    const size_t lds = nce_bwd_mfma_lds(D);
+    hipFuncSetAttribute((const void*)nce_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int nx = mode == 0 ? b : B, ny = mode == 0 ? B : b;
+    const int chunk_cols = nce_chunk_cols_mfma(nx, ny, n_pairs);
+    const int nz = dh_cdiv(ny, chunk_cols);
+    if (nz > 1)
+      for (int i = 0; i < n_pairs; ++i) {
+        void* dst = mode == 0 ? (void*)pt.dQ[i] : (void*)pt.dK[i];
+        if (dst) hipMemsetAsync(dst, 0, sizeof(float) * (size_t)nx * D, st);
+      }
+    hipLaunchKernelGGL(nce_bwd_mfma_kernel, dim3(dh_cdiv(nx, MX), n_pairs, nz), dim3(256), lds, st, pt, mode, b, B, D, scale, row_lse,
+                       g_row, dscale, chunk_cols);
+  };
+  if (nce_mfma_ok(D)) {
+    launch_mfma(0);
+    launch_mfma(1);
+  } else if (D <= 512) {
     launch(std::integral_constant<int, 32>{}, 0);
     launch(std::integral_constant<int, 32>{}, 1);
   } else if (D <= 1024) {

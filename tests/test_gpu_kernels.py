@@ -238,6 +238,14 @@ def test_pool_and_l2norm(dtype):
 
 
 # ----------------------------------------------------------------------------- losses
+def _poison_lds(ops):
+    """Leave NaN bit patterns in the LDS of every CU (LDS is not cleared between kernels): a kernel that reads a padding word
+    it never wrote then produces NaN instead of passing by luck.  (The matrix-pipe InfoNCE kernels once did, for D % 128 != 0.)"""
+    b, L, heads = 2048, 64, 2
+    qkv = torch.full((b * L, 3 * heads * 64), float("nan"), device=cuda, dtype=torch.bfloat16)
+    ops.attn_fwd(qkv, b, L, heads, False)
+
+
 @pytest.mark.parametrize("b,B,D,label0", [(8, 8, 64, 0), (40, 120, 512, 40), (70, 70, 256, 0), (33, 99, 768, 66),
                                           (96, 1160, 128, 1000), (520, 520, 64, 0)])
 def test_infonce(b, B, D, label0):
@@ -266,10 +274,12 @@ def test_infonce(b, B, D, label0):
     total = sum((l * g_row[i].double()).sum() for i, l in enumerate(losses))
     total.backward()
     dpairs = [(q.to(cuda), k.to(cuda)) for q, k in pairs]
+    _poison_lds(ops)
     row_loss, row_lse, c1, c5, logits = ops.infonce_fwd(dpairs, scale.to(cuda), label0, want_logits=True)
     assert rel_err(row_loss, torch.stack(losses).detach()) < 5e-5   # fp32 FMA chains over D, fast exp
     assert rel_err(logits, torch.stack(logits_r)) < 1e-5
     assert torch.equal(c1.cpu().double(), torch.stack(c1r)) and torch.equal(c5.cpu().double(), torch.stack(c5r))
+    _poison_lds(ops)
     outs, dscale = ops.infonce_bwd(dpairs, scale.to(cuda), label0, row_lse, g_row.to(cuda))
     for (dq, dk), (q, k) in zip(outs, gq):
         assert rel_err(dq, q.grad) < 1e-4 and rel_err(dk, k.grad) < 1e-4
@@ -367,6 +377,7 @@ def test_nn_bank_query_ties_and_ragged_sizes():
         bank[hi] = bank[lo]                                 # duplicates far apart (different tiles / chunks)
         q[1] = bank[lo]
         q[2] = bank[size - 1]                               # the very last (ragged) bank row
+        _poison_lds(ops)
         idx, feats = ops.nn_bank_query(q.to(cuda), bank.to(cuda))
         got = idx.cpu()
         sim = q.double() @ bank.double().t()
@@ -382,6 +393,7 @@ def test_nn_bank_query_exact(rows, size, D):
     bank = torch.nn.functional.normalize(rnd(size, D, seed=87), dim=1)
     q = torch.nn.functional.normalize(rnd(rows, D, seed=88), dim=1)
     q[0] = bank[size - 1]                                   # an exact hit in the last chunk
+    _poison_lds(ops)
     idx, feats = ops.nn_bank_query(q.to(cuda), bank.to(cuda))
     sim = q.double() @ bank.double().t()
     ref = sim.argmax(1)
@@ -514,3 +526,39 @@ def test_image_prep_u8_matches_oracle():
         f_bytes = model.encode_image(small.cuda())
         f_float = model.encode_image(restated.image_prep_u8(small, (r, r)).cuda())
     assert float((f_bytes - f_float).abs().max()) <= 1e-5 * float(f_float.abs().max())
+
+
+def test_infonce_weak_scaling_shape_with_self_pair_exclusion():
+    """b = 512 local rows against B = 4096 gathered columns (8 ranks, this rank = 5) on the matrix-pipe kernels, two pairs with
+    per-pair label offsets; the second pair removes a self-pair column per row (NT-Xent); one gradient is not requested."""
+    ops = _ops()
+    b, B, D, rank = 512, 4096, 512, 5
+    q1, k1 = torch.nn.functional.normalize(rnd(b, D, seed=70), dim=1), torch.nn.functional.normalize(rnd(B, D, seed=71), dim=1)
+    q2, k2 = torch.nn.functional.normalize(rnd(b, D, seed=72), dim=1), torch.nn.functional.normalize(rnd(B, D, seed=73), dim=1)
+    scale = torch.tensor([9.5])
+    label0s, excl0s = [rank * b, 3 * b], [-1, rank * b]
+    g_row = rnd(2, b, seed=74).abs() / b
+    refs = []
+    tensors = [t.double().requires_grad_(True) for t in (q1, k1, q2, k2)]
+    sr = scale.double().requires_grad_(True)
+    total = 0
+    for p, (q, k) in enumerate(((tensors[0], tensors[1]), (tensors[2], tensors[3]))):
+        lg = sr * q @ k.t()
+        if excl0s[p] >= 0:
+            mask = torch.zeros_like(lg, dtype=torch.bool)
+            mask[torch.arange(b), excl0s[p] + torch.arange(b)] = True
+            lg = lg.masked_fill(mask, float("-inf"))
+        labels = label0s[p] + torch.arange(b)
+        loss = torch.nn.functional.cross_entropy(lg, labels, reduction="none")
+        refs.append(loss.detach())
+        total = total + (loss * g_row[p].double()).sum()
+    total.backward()
+    dpairs = [(q1.to(cuda), k1.to(cuda)), (q2.to(cuda), k2.to(cuda))]
+    row_loss, row_lse, c1, c5, _ = ops.infonce_fwd(dpairs, scale.to(cuda), 0, label0s=label0s, excl0s=excl0s)
+    assert rel_err(row_loss, torch.stack(refs)) < 5e-5
+    outs, dscale = ops.infonce_bwd(dpairs, scale.to(cuda), 0, row_lse, g_row.to(cuda), need=[(True, True), (True, False)],
+                                   label0s=label0s, excl0s=excl0s)
+    assert outs[1][1] is None
+    assert rel_err(outs[0][0], tensors[0].grad) < 1e-4 and rel_err(outs[0][1], tensors[1].grad) < 1e-4
+    assert rel_err(outs[1][0], tensors[2].grad) < 1e-4
+    assert rel_err(dscale, sr.grad) < 1e-4
