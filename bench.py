@@ -115,6 +115,8 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    gc.disable()           # no cyclic-collector pauses inside the timed steps (re-enabled right after; the steps leave no cycles
+                           # that matter over tens of iterations) -- a 50 ms host pause is most of a 67 ms DeCLIP step
 
     def sync():
         if world > 1:
@@ -127,6 +129,7 @@ def main():
         loss = step()
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -314,10 +314,13 @@ class ClsSolver(object):
         t_last = time.time()
         for curr_step in range(start, end + 1):
             out = self.train_step(curr_step)
-            if curr_step == start:           # everything long-lived exists now: keep it out of the cyclic collector's scans
-                import gc
-                gc.collect()
+            if curr_step == start:           # everything long-lived exists now: keep it out of the cyclic collector's scans,
+                import gc                    # and collect at a fixed cadence instead of whenever the allocation counters trip
+                gc.collect()                 # (a generation-2 pass in mid-step is a 50-200 ms host pause)
                 gc.freeze()
+                gc.disable()
+            elif (curr_step - start) % 100 == 0:
+                gc.collect(1)
             self.meters["loss"].reduce_update(out["loss"].detach().clone())
             if "top1" in out:
                 self.meters["top1"].reduce_update(out["top1"].detach() / self.world_size)
@@ -334,6 +337,8 @@ class ClsSolver(object):
             if self.save_freq and curr_step % self.save_freq == 0:
                 self.save(curr_step)
         self.state["last_iter"] = end
+        import gc
+        gc.enable()
         return out
 
     def save(self, curr_step):
