@@ -378,6 +378,8 @@ class ClsSolver(object):
         was_training = self.model.training
         self.model.eval()
         class_emb = zeroshot.class_embeddings(m, texts, label_num, text_chunk=int(self.config.get("eval_text_chunk", 2048)))
+        if zeroshot._is_identity(ensemble):      # the reference's datasets: scores = softmax(logits) @ I (clip_dataset.py:281)
+            ensemble = None
         meter = zeroshot.ZeroShotMeter(self.device)
         t0, n_img = time.time(), 0
         for batch in loader:

@@ -263,3 +263,25 @@ def test_zero_shot_prompt_templates(tmp_path):
     assert zeroshot.prompts_for("fox", "file:%s" % f) == ["itap of a fox.", "a fox in the wild."]
     with pytest.raises(NotImplementedError):
         zeroshot.prompts_for("x", "prompt7")
+
+
+def test_zero_shot_from_prompt_strings(mocked_engine, tmp_path):
+    """Class prompts as TEXT: templates -> host-thread BPE tokeniser of the C-ABI library -> text tower -> ensemble mean.  The ids
+    the tower sees must be what the Python tokeniser produces, and the class embeddings must match an id-tensor call."""
+    from declip_amd import bpe, zeroshot
+    from declip_amd.testing import build_clip
+    from oracle import ref_harness
+    g = load_golden("zeroshot_tiny")
+    cfg = g["cfg"]
+    model = build_clip(cfg, dtype="fp32", seed=g["seed"], device="cpu").eval()
+    path = ref_harness.synthetic_bpe_path()
+    model.encode_text._bpe_path = path
+    names = {0: "cat", 2: "dog", 1: "red fox"}
+    texts, mat = zeroshot.label_texts(names, "prompt6")
+    assert texts[6] == "a photo of a red fox." and mat.shape == (3, 3)
+    emb = zeroshot.class_embeddings(model, texts, 3, text_chunk=5)           # chunk does not divide 18: ragged last chunk
+    assert isinstance(model.encode_text.tokenizer, bpe.NativeTokenizer)
+    ids = bpe.tokenize(bpe.SimpleTokenizer(path), texts, context_length=cfg["ctx"])
+    emb_ids = zeroshot.class_embeddings(model, ids, 3)
+    assert float((emb - emb_ids).abs().max()) <= 1e-6
+    assert float((emb.norm(dim=-1) - 1).abs().max()) < 1e-5
