@@ -1,0 +1,103 @@
+"""Input prefetcher: the reference's `DataPrefetcher` (solver/clip_solver.py:30-63, switched on by `data.train.prefetch`) with the
+parts it left commented out actually done, so that at > 10^4 pairs/s per GPU the host side of a batch is never on the step's
+critical path:
+
+  * a background thread pulls the next host batch from the loader, tokenises string captions with the host-thread BPE of the
+    C-ABI library (`bpe.NativeTokenizer`; the ctypes call releases the GIL) and pins the tensors;
+  * the host->device copies of batch i+1 are enqueued on a copy stream while step i computes; `next()` makes the caller's
+    stream wait for that copy's event (no host synchronisation) and hands the device batch over;
+  * images may stay uint8 HWC (the vision tower normalises bytes on the GPU, `dh_image_prep_u8`): 4x less PCIe traffic.
+
+`next()` returns None when the loader is exhausted, as the reference's does.  Works without a GPU (device "cpu": same
+ordering / tokenisation logic, plain tensors) so the host logic is covered by the CPU tests.
+"""
+import queue
+import threading
+
+import torch
+
+from . import bpe
+
+__all__ = ["DataPrefetcher"]
+
+_END = object()
+
+
+class DataPrefetcher(object):
+    def __init__(self, loader, device="cuda", tokenizer=None, context_length=77, depth=2):
+        self.device = torch.device(device)
+        self.tokenizer, self.context_length = tokenizer, context_length
+        self._it = iter(loader)
+        self._q = queue.Queue(maxsize=max(1, depth))
+        self._cuda = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=self.device) if self._cuda else None
+        self._staged, self._event = None, None
+        self._thread = threading.Thread(target=self._work, name="declip-prefetch", daemon=True)
+        self._thread.start()
+        self._stage()
+
+    # ---- worker thread: host-side preparation -------------------------------------------------------------------------
+    def _prepare(self, batch):
+        out = dict(batch)
+        caps = out.get("captions")
+        if self.tokenizer is not None and caps is not None and not torch.is_tensor(caps):
+            # the reference's batches carry a list of captions per sample and use the first one (clip.py:110-111)
+            texts = [c if isinstance(c, str) else c[0] for c in caps]
+            out["captions"] = bpe.tokenize(self.tokenizer, texts, self.context_length)
+        if self._cuda:
+            for k, v in out.items():
+                if torch.is_tensor(v) and not v.is_cuda and not v.is_pinned():
+                    out[k] = v.pin_memory()
+        return out
+
+    def _work(self):
+        try:
+            for batch in self._it:
+                self._q.put(self._prepare(batch))
+            self._q.put(_END)
+        except BaseException as e:       # surfaces in the training thread at the next next()
+            self._q.put(e)
+
+    # ---- training thread ---------------------------------------------------------------------------------------------
+    def _stage(self):
+        """Take the next prepared host batch and enqueue its copies on the copy stream."""
+        item = self._q.get()
+        if item is _END:
+            self._staged = None
+            self._q.put(_END)            # stays exhausted
+            return
+        if isinstance(item, BaseException):
+            self._staged = item
+            return
+        if not self._cuda:
+            self._staged = item
+            return
+        with torch.cuda.stream(self.stream):
+            dev = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in item.items()}
+            self._event = torch.cuda.Event()
+            self._event.record(self.stream)
+        self._staged = dev
+
+    def next(self):
+        batch = self._staged
+        if batch is None:
+            return None
+        if isinstance(batch, BaseException):
+            raise batch
+        if self._cuda:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self._event)
+            for v in batch.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(cur)          # allocated under the copy stream, consumed on this one
+        self._stage()                             # batch i+1's copies overlap step i
+        return batch
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        b = self.next()
+        if b is None:
+            raise StopIteration
+        return b

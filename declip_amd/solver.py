@@ -308,7 +308,19 @@ class ClsSolver(object):
 
     def train(self, max_steps=None):
         if not hasattr(self.loader, "get"):
-            self._iter = iter(self.loader)
+            d = self.config.get("data", AttrDict())
+            if d.get("train", AttrDict()).get("prefetch", d.get("prefetch", True)):
+                # clip_solver.py:335-337 (`data.train.prefetch`): host batches are tokenised / pinned on a background thread
+                # and copied on a side stream one step ahead (declip_amd/prefetch.py)
+                from .prefetch import DataPrefetcher
+                m = self.model.module
+                tower = m.text_encoder if hasattr(m, "text_encoder") else m.encode_text
+                tok = None
+                if self.kind in ("clip", "slip") and getattr(tower, "_bpe_path", None) and os.path.exists(tower._bpe_path):
+                    tok = tower._get_tokenizer()          # the other families augment / mask the caption TEXT in forward()
+                self._iter = DataPrefetcher(self.loader, self.device, tokenizer=tok, context_length=int(tower.context_length))
+            else:
+                self._iter = iter(self.loader)
         start = self.state["last_iter"] + 1
         end = self.max_iter if max_steps is None else min(self.max_iter, start + max_steps - 1)
         t_last = time.time()

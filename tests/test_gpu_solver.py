@@ -31,3 +31,52 @@ def test_solver_reduces_loss_on_a_fixed_batch(kind):
     last = float(s.train()["loss"].detach())
     assert last == last and last < first
     assert 3.0 <= float(s.model.module.logit_scale.detach()) <= 6.0
+
+
+def test_solver_prefetcher_bytes_and_strings_match_floats_and_ids(tmp_path):
+    """A user loader that yields what a decoder yields -- uint8 HWC images and caption strings -- through the prefetcher
+    (background tokenisation, pinned staging, copies on a side stream, bytes normalised on the GPU) gives the same first losses as
+    the same data handed over as normalised floats and token ids."""
+    import yaml
+    from declip_amd import bpe
+    from declip_amd.prefetch import DataPrefetcher
+    from declip_amd.solver import ClsSolver
+    from oracle import ref_harness, restated
+    path = ref_harness.synthetic_bpe_path()
+    cfg = _config("clip")
+    cfg["model"]["kwargs"]["text_encode"]["bpe_path"] = path
+    p = tmp_path / "config.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    g = torch.Generator().manual_seed(3)
+    raw = [torch.randint(0, 256, (32, 64, 64, 3), generator=g, dtype=torch.uint8) for _ in range(4)]
+    caps = [[["caption %d of batch %d, it's a photo!" % (j, i), "second caption"] for j in range(32)] for i in range(4)]
+
+    def as_decoder():
+        for im, c in zip(raw, caps):
+            yield {"images": im, "captions": c}
+
+    def as_tensors():
+        tok = bpe.SimpleTokenizer(path)
+        for im, c in zip(raw, caps):
+            yield {"images": restated.image_prep_u8(im, (64, 64)), "captions": bpe.tokenize(tok, [x[0] for x in c], 32)}
+
+    def run(loader):
+        torch.manual_seed(0)                                  # same initial weights for both runs
+        s = ClsSolver(str(p), train_loader=loader)
+        rec, orig = [], s.train_step
+
+        def wrapped(step):
+            out = orig(step)
+            rec.append(out["loss"].detach())
+            return out
+        s.train_step = wrapped
+        s.train(max_steps=4)
+        torch.cuda.synchronize()
+        return s, [float(x) for x in rec]
+
+    s1, l1 = run(as_decoder())
+    s2, l2 = run(as_tensors())
+    assert isinstance(s1._iter, DataPrefetcher) and s1._iter.next() is None
+    assert len(l1) == len(l2) == 4 and l1[0] == l1[0]
+    for a, c in zip(l1, l2):
+        assert abs(a - c) <= 2e-2 * abs(c), (l1, l2)        # bf16 towers; the inputs agree to fp32 rounding

@@ -1,0 +1,70 @@
+"""Host logic of the input prefetcher (declip_amd/prefetch.py; reference: DataPrefetcher, clip_solver.py:30-63) on CPU: order,
+tokenisation of string captions on the worker thread, exhaustion, error propagation, and the solver picking it up for a
+user-supplied loader."""
+import pytest
+import torch
+
+from declip_amd import bpe
+from declip_amd.prefetch import DataPrefetcher
+from oracle import ref_harness
+
+
+def _batches(n, b=3):
+    for i in range(n):
+        yield {"images": torch.full((b, 3, 4, 4), float(i)), "captions": [["photo number %d of a cat" % (i * b + j), "unused"] for j in range(b)],
+               "meta": "batch%d" % i}
+
+
+def test_prefetcher_order_tokenisation_and_exhaustion():
+    tok = bpe.NativeTokenizer(ref_harness.synthetic_bpe_path())
+    pf = DataPrefetcher(_batches(5), device="cpu", tokenizer=tok, context_length=16)
+    seen = []
+    while True:
+        b = pf.next()
+        if b is None:
+            break
+        i = len(seen)
+        assert float(b["images"][0, 0, 0, 0]) == float(i) and b["meta"] == "batch%d" % i
+        ref = bpe.tokenize(bpe.SimpleTokenizer(ref_harness.synthetic_bpe_path()), ["photo number %d of a cat" % (i * 3 + j) for j in range(3)], 16)
+        assert b["captions"].dtype == torch.long and torch.equal(b["captions"], ref)       # first caption of each sample
+        seen.append(i)
+    assert seen == [0, 1, 2, 3, 4]
+    assert pf.next() is None and pf.next() is None                                        # stays exhausted
+    # iterator protocol + pre-tokenised captions pass through untouched
+    ids = torch.arange(12).view(3, 4)
+    got = list(DataPrefetcher(iter([{"images": torch.zeros(3, 1), "captions": ids}]), device="cpu", tokenizer=tok))
+    assert len(got) == 1 and got[0]["captions"] is ids
+
+
+def test_prefetcher_propagates_loader_errors():
+    def bad():
+        yield {"images": torch.zeros(1)}
+        raise RuntimeError("decoder exploded")
+    pf = DataPrefetcher(bad(), device="cpu")
+    assert pf.next() is not None
+    with pytest.raises(RuntimeError, match="decoder exploded"):
+        pf.next()
+
+
+def test_solver_wraps_a_user_loader(monkeypatch, tmp_path):
+    import cpu_ops_mock
+    import yaml
+    from declip_amd import engine, ops, synth
+    from declip_amd.solver import ClsSolver
+    from test_solver_cpu_mock import _config
+    for name in dir(cpu_ops_mock):
+        if not name.startswith("_") and callable(getattr(cpu_ops_mock, name)) and hasattr(ops, name):
+            monkeypatch.setattr(ops, name, getattr(cpu_ops_mock, name))
+    monkeypatch.setattr(engine, "_require_gpu", lambda p, name: None)
+    cfg = _config("clip", max_iter=5)
+    cfg["saver"] = dict(print_freq=1, save_freq=0, pretrain=dict(auto_resume=False))
+    p = tmp_path / "config.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+
+    def loader():
+        for i in range(5):
+            yield {"images": synth.synth_images(4, res=32, seed=i), "captions": synth.synth_tokens(4, ctx=16, seed=i)}
+    s = ClsSolver(str(p), train_loader=loader(), device="cpu")
+    out = s.train()
+    assert isinstance(s._iter, DataPrefetcher) and s.state["last_iter"] == 5 and torch.isfinite(out["loss"]).all()
+    assert s._iter.next() is None
