@@ -11,6 +11,14 @@ import torch.multiprocessing as mp
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _free_port():
+    """A port nobody listens on right now (fixed port numbers collide with lingering sockets of earlier runs)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _init(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, HERE)
@@ -132,8 +140,9 @@ def _w_zero_shot(rank, world, port, out):
         out.put("ok")
 
 
-@pytest.mark.parametrize("fn,port", [(_w_gather, 29611), (_w_reducer, 29612), (_w_clip, 29613), (_w_zero_shot, 29614)])
-def test_world2(fn, port):
+@pytest.mark.parametrize("fn", [_w_gather, _w_reducer, _w_clip, _w_zero_shot])
+def test_world2(fn):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     procs = [ctx.Process(target=fn, args=(r, 2, port, q)) for r in range(2)]

@@ -14,6 +14,14 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _free_port():
+    """A port nobody listens on right now (fixed port numbers collide with lingering sockets of earlier runs)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _worker(rank, world, port, streams, bucket_bytes, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       DH_TOWER_STREAMS=streams, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -58,8 +66,9 @@ def _worker(rank, world, port, streams, bucket_bytes, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("streams,bucket_bytes,port", [("1", 1 << 14, 29711), ("0", 1 << 14, 29712), ("1", 48 << 20, 29713)])
-def test_two_ranks_on_one_gpu_match_two_reference_ranks(streams, bucket_bytes, port):
+@pytest.mark.parametrize("streams,bucket_bytes", [("1", 1 << 14), ("0", 1 << 14), ("1", 48 << 20)])
+def test_two_ranks_on_one_gpu_match_two_reference_ranks(streams, bucket_bytes):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, streams, bucket_bytes, q)) for r in range(2)]
@@ -125,7 +134,7 @@ def _rccl_worker(port, out):
 def test_one_rank_rccl_collectives_are_the_identity():
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    p = ctx.Process(target=_rccl_worker, args=(29721, q))
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
     p.start()
     p.join(300)
     if p.is_alive():
