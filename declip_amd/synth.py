@@ -89,7 +89,7 @@ def synth_state(shapes, seed=0, logit_scale=None):
     for idx, (name, shape) in enumerate(shapes.items()):
         g = torch.Generator().manual_seed(seed * 100003 + idx * 7919 + 17)
         leaf = name.rsplit(".", 1)[-1]
-        is_norm = any(t in name for t in (".ln_", "ln_pre", "ln_post", "ln_final", ".bn"))
+        is_norm = any(t in name for t in (".ln_", "ln_pre", "ln_post", "ln_final", ".bn", "downsample.1."))
         if name.endswith("logit_scale") or name.endswith("logit_scale_dense"):
             v = torch.full(shape, math.log(1 / 0.07) if logit_scale is None else logit_scale)
         elif is_norm and leaf == "weight":
@@ -119,11 +119,48 @@ def synth_state(shapes, seed=0, logit_scale=None):
     return sd
 
 
+def resnet_shapes(width, layers, res, embed_dim, prefix="visual."):
+    """ModifiedResNet state_dict (image_encoder/modified_resnet.py:118-191), registration order of the reference."""
+    s = OrderedDict()
+    s[prefix + "conv1.weight"] = (width // 2, 3, 3, 3)
+    _bn_shapes(s, prefix + "bn1.", width // 2)
+    s[prefix + "conv2.weight"] = (width // 2, width // 2, 3, 3)
+    _bn_shapes(s, prefix + "bn2.", width // 2)
+    s[prefix + "conv3.weight"] = (width, width // 2, 3, 3)
+    _bn_shapes(s, prefix + "bn3.", width)
+    inplanes = width
+    for li, (planes, blocks) in enumerate(zip((width, width * 2, width * 4, width * 8), layers)):
+        for bi in range(blocks):
+            stride = 2 if (li > 0 and bi == 0) else 1
+            p = "%slayer%d.%d." % (prefix, li + 1, bi)
+            s[p + "conv1.weight"] = (planes, inplanes, 1, 1)
+            _bn_shapes(s, p + "bn1.", planes)
+            s[p + "conv2.weight"] = (planes, planes, 3, 3)
+            _bn_shapes(s, p + "bn2.", planes)
+            s[p + "conv3.weight"] = (planes * 4, planes, 1, 1)
+            _bn_shapes(s, p + "bn3.", planes * 4)
+            if stride > 1 or inplanes != planes * 4:
+                s[p + "downsample.0.weight"] = (planes * 4, inplanes, 1, 1)
+                _bn_shapes(s, p + "downsample.1.", planes * 4)
+            inplanes = planes * 4
+    d = width * 32
+    s[prefix + "attnpool.positional_embedding"] = ((res // 32) ** 2 + 1, d)
+    for n in ("k_proj", "q_proj", "v_proj"):
+        s[prefix + "attnpool.%s.weight" % n], s[prefix + "attnpool.%s.bias" % n] = (d, d), (d,)
+    s[prefix + "attnpool.c_proj.weight"], s[prefix + "attnpool.c_proj.bias"] = (embed_dim, d), (embed_dim,)
+    s[prefix + "fc.weight"], s[prefix + "fc.bias"] = (embed_dim, 2048), (embed_dim,)      # modified_resnet.py:167 (2048 hard-coded)
+    return s
+
+
 def clip_shapes(cfg):
-    """cfg keys: v_width v_layers patch res t_width t_layers ctx embed_dim vocab"""
+    """cfg keys: v_width v_layers patch res t_width t_layers ctx embed_dim vocab
+    (vision == "resnet": r_width r_layers instead of v_width v_layers patch)"""
     s = OrderedDict()
     s["logit_scale"] = (1,)
-    s.update(vit_shapes(cfg["v_width"], cfg["v_layers"], cfg["patch"], cfg["res"], cfg["embed_dim"]))
+    if cfg.get("vision") == "resnet":
+        s.update(resnet_shapes(cfg["r_width"], cfg["r_layers"], cfg["res"], cfg["embed_dim"]))
+    else:
+        s.update(vit_shapes(cfg["v_width"], cfg["v_layers"], cfg["patch"], cfg["res"], cfg["embed_dim"]))
     s.update(text_shapes(cfg["t_width"], cfg["t_layers"], cfg["ctx"], cfg["embed_dim"],
                          cfg.get("vocab", VOCAB), prefix=cfg.get("text_prefix", "encode_text.")))
     return s
@@ -206,6 +243,13 @@ VITB32 = dict(v_width=768, v_layers=12, v_heads=12, patch=32, res=224,
               t_width=512, t_layers=12, t_heads=8, ctx=77, embed_dim=512, vocab=VOCAB)
 TINY = dict(v_width=128, v_layers=2, v_heads=2, patch=32, res=96,
             t_width=128, t_layers=2, t_heads=2, ctx=16, embed_dim=64, vocab=VOCAB)
+
+# CLIP-R50 (BASELINE.json configs[0], experiments/clip_experiments/yfcc15m/yfcc15m_r50_clip/config.yaml) and a small
+# ModifiedResNet that still ends on the 7x7 map the attention pool requires (modified_resnet.py:207)
+R50 = dict(vision="resnet", r_width=64, r_layers=(3, 4, 6, 3), r_heads=32, res=224,
+           t_width=512, t_layers=12, t_heads=8, ctx=77, embed_dim=1024, vocab=VOCAB)
+R50_TINY = dict(vision="resnet", r_width=16, r_layers=(1, 2, 1, 1), r_heads=8, res=224,
+                t_width=128, t_layers=2, t_heads=2, ctx=16, embed_dim=64, vocab=VOCAB)
 
 # FILIP needs >= 16 image tokens and >= 16 text tokens: 160 px / 32 = 25 patches, 24-token context
 FILIP_SMALL = dict(v_width=128, v_layers=2, v_heads=2, patch=32, res=160,

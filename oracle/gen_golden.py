@@ -37,9 +37,15 @@ def grad_digest(named_grads):
 def build_ref_clip(ref, cfg, use_allgather):
     vt = ref.modules["prototype.model.image_encoder.visual_transformer"]
     tt = ref.modules["prototype.model.text_encoder.text_transformer"]
-    vis = vt.VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
-                               layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"],
-                               checkpoint=False)
+    if cfg.get("vision") == "resnet":
+        # clip.py:148-155 (clip_res50) with the shipped BatchNorm switch (yfcc15m_r50_clip/config.yaml: use_sync_bn False)
+        mr = ref.modules["prototype.model.image_encoder.modified_resnet"]
+        vis = mr.ModifiedResNet(layers=tuple(cfg["r_layers"]), embed_dim=cfg["embed_dim"], heads=cfg["r_heads"],
+                                input_resolution=cfg["res"], width=cfg["r_width"], use_sync_bn=False)
+    else:
+        vis = vt.VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
+                                   layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"],
+                                   checkpoint=False)
     txt = tt.TextTransformer(embed_dim=cfg["embed_dim"], context_length=cfg["ctx"],
                              transformer_width=cfg["t_width"], transformer_heads=cfg["t_heads"],
                              transformer_layers=cfg["t_layers"], positional_embedding_flag=True,
@@ -100,6 +106,17 @@ def run_clip_rank(rank, world, cfg, b, seed, logit_scale, ret):
         ret.update(loss=float(total), loss_rank0=float(loss.detach() * world),
                    logits_i=logits_i.detach().clone(), logits_t=logits_t.detach().clone(),
                    labels=labels.clone(), grads=grad_digest(grads))
+        if cfg.get("vision") == "resnet":
+            # BatchNorm side effects of the training forward, then the eval-mode tower (running statistics) on the same images
+            bufs = dict(model.named_buffers())
+            ret["bn_buffers"] = {k: bufs[k].detach().clone() for k in
+                                 ("visual.bn1.running_mean", "visual.bn1.running_var", "visual.bn3.running_var",
+                                  "visual.layer2.0.downsample.1.running_mean", "visual.layer4.0.bn3.running_var",
+                                  "visual.bn2.num_batches_tracked")}
+            model.eval()
+            with torch.no_grad():
+                feat, dense = model.visual(images[sl], return_dense=True)
+            ret["eval_features"], ret["eval_dense_sum"] = feat.clone(), float(dense.double().sum())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -417,6 +434,7 @@ FIXTURES = {
     "clip_tiny_scale5": lambda: gen_clip("clip_tiny_scale5", synth.TINY, b=4, seed=3, logit_scale=5.0),
     "clip_tiny_w2": lambda: gen_clip("clip_tiny_w2", synth.TINY, b=3, world=2, seed=5),
     "clip_vitb32_b8": lambda: gen_clip("clip_vitb32_b8", synth.VITB32, b=8, seed=1),
+    "clip_r50_tiny": lambda: gen_clip("clip_r50_tiny", synth.R50_TINY, b=3, seed=9),
     "declip_tiny": lambda: gen_declip("declip_tiny", synth.TINY, b=6, seed=2),
     "slip_tiny": lambda: gen_slip("slip_tiny", synth.TINY, b=5, seed=4),
     "filip_small": lambda: gen_filip("filip_small", synth.FILIP_SMALL, b=5, seed=6),

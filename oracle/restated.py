@@ -102,6 +102,70 @@ def text_tower(ids, sd, cfg, prefix="encode_text.", return_dense=False):
     return (out, x) if return_dense else out
 
 
+def batch_norm2d(x, sd, p, training=True, eps=1e-5, momentum=0.1, new_stats=None):
+    """nn.BatchNorm2d (modified_resnet.py:138 with use_sync_bn False) = F.batch_norm: batch statistics over (N, H, W) with
+    the biased variance in training mode, running statistics in eval mode; in training the running buffers move by `momentum`
+    towards the batch mean / UNBIASED variance (returned through `new_stats`; `sd` itself is never modified).
+    torch's own kernel is called rather than a hand-written mean/var formula: the ResNet's gradients are discontinuous in the
+    ReLU masks (one flipped mask moves a BatchNorm bias gradient -- a sum of cancelling terms -- by ~1 %), and a formula that
+    rounds differently flips a mask somewhere in 2 M activations often enough to matter at the 3e-4 pin of the golden test."""
+    if not training:
+        return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], False, momentum, eps)
+    rm, rv = sd[p + "running_mean"].detach().clone(), sd[p + "running_var"].detach().clone()
+    y = F.batch_norm(x, rm, rv, sd[p + "weight"], sd[p + "bias"], True, momentum, eps)
+    if new_stats is not None:
+        new_stats[p + "running_mean"], new_stats[p + "running_var"] = rm, rv
+    return y
+
+
+def bottleneck(x, sd, p, stride, training=True, new_stats=None):
+    """modified_resnet.py:14-56: 1x1 -> 3x3 -> (avgpool) -> 1x1, every stride taken by an average pool; the shortcut is
+    avgpool + 1x1 conv + BN whenever the shape changes."""
+    out = F.relu(batch_norm2d(F.conv2d(x, sd[p + "conv1.weight"]), sd, p + "bn1.", training, new_stats=new_stats))
+    out = F.relu(batch_norm2d(F.conv2d(out, sd[p + "conv2.weight"], padding=1), sd, p + "bn2.", training, new_stats=new_stats))
+    if stride > 1:
+        out = F.avg_pool2d(out, stride)
+    out = batch_norm2d(F.conv2d(out, sd[p + "conv3.weight"]), sd, p + "bn3.", training, new_stats=new_stats)
+    identity = x
+    if (p + "downsample.0.weight") in sd:
+        identity = F.avg_pool2d(x, stride) if stride > 1 else x
+        identity = batch_norm2d(F.conv2d(identity, sd[p + "downsample.0.weight"]), sd, p + "downsample.1.", training, new_stats=new_stats)
+    return F.relu(out + identity)
+
+
+def attention_pool(x, sd, p, heads):
+    """modified_resnet.py:59-96: tokens = [mean token; HW tokens] + positional embedding, multi-head attention with separate
+    q/k/v projections, c_proj as the output projection; only the mean token's output is returned."""
+    b, c = x.shape[0], x.shape[1]
+    t = x.reshape(b, c, -1).permute(0, 2, 1)                       # [b, HW, C]
+    t = torch.cat([t.mean(dim=1, keepdim=True), t], dim=1) + sd[p + "positional_embedding"]
+    hd = c // heads
+    L = t.shape[1]
+    q = (t @ sd[p + "q_proj.weight"].t() + sd[p + "q_proj.bias"]).reshape(b, L, heads, hd).transpose(1, 2) * (hd ** -0.5)
+    k = (t @ sd[p + "k_proj.weight"].t() + sd[p + "k_proj.bias"]).reshape(b, L, heads, hd).transpose(1, 2)
+    v = (t @ sd[p + "v_proj.weight"].t() + sd[p + "v_proj.bias"]).reshape(b, L, heads, hd).transpose(1, 2)
+    o = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).transpose(1, 2).reshape(b, L, c)
+    return o[:, 0, :] @ sd[p + "c_proj.weight"].t() + sd[p + "c_proj.bias"]
+
+
+def resnet_tower(images, sd, cfg, prefix="visual.", return_dense=False, training=True, new_stats=None):
+    """modified_resnet.py:193-214: 3-conv stem (first one stride 2) + avgpool(2), four bottleneck stages, attention pool on
+    the 7x7 map; `dense` = the last feature map as [b, HW, C]."""
+    x = images
+    for i, (stride, name) in enumerate(((2, "1"), (1, "2"), (1, "3"))):
+        x = F.conv2d(x, sd[prefix + "conv%s.weight" % name], stride=stride, padding=1)
+        x = F.relu(batch_norm2d(x, sd, prefix + "bn%s." % name, training, new_stats=new_stats))
+    x = F.avg_pool2d(x, 2)
+    for li, blocks in enumerate(cfg["r_layers"]):
+        for bi in range(blocks):
+            x = bottleneck(x, sd, "%slayer%d.%d." % (prefix, li + 1, bi), 2 if (li > 0 and bi == 0) else 1, training, new_stats)
+    dense = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+    if x.shape[3] != 7:
+        raise NotImplementedError("the adaptive-pool + fc branch (modified_resnet.py:209-211) is not restated: use a 224 px input")
+    out = attention_pool(x, sd, prefix + "attnpool.", cfg["r_heads"])
+    return (out, dense) if return_dense else out
+
+
 def image_prep_u8(src, out_hw, crop_xy=None, flip=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
     """uint8 HWC -> normalised fp32 CHW: crop window (x0, y0), horizontal flip, ToTensor (x / 255), Normalize ((x - mean) / std)
     -- the tail of the reference's input pipelines (data/transforms.py + torchvision ToTensor / Normalize as composed in
@@ -135,13 +199,17 @@ def normalize_features(img, txt):
             txt / (txt.norm(dim=-1, keepdim=True) + 1e-10))
 
 
-def clip_forward(images, ids, sd, cfg, world=1):
+def clip_forward(images, ids, sd, cfg, world=1, new_stats=None):
     """clip.py:118-146 for `world` emulated ranks on one process.
 
     images [B,3,H,W], ids [B,ctx] hold the GLOBAL batch, rank r owning rows
     [r*b,(r+1)*b).  Returns per-rank (logits_per_image, logits_per_text), each
     [b,B] (local rows x gathered columns, clip.py:136-141)."""
-    img = vision_tower(images, sd, cfg)
+    if cfg.get("vision") == "resnet":
+        assert world == 1, "BatchNorm statistics are per rank (use_sync_bn False): emulate ranks one at a time"
+        img = resnet_tower(images, sd, cfg, new_stats=new_stats)
+    else:
+        img = vision_tower(images, sd, cfg)
     txt = text_tower(ids, sd, cfg, prefix=cfg.get("text_prefix", "encode_text."))
     img, txt = normalize_features(img, txt)
     s = clamp_scale(sd["logit_scale"], cfg.get("scale_clamp", 100.0))
@@ -190,10 +258,10 @@ def accuracy(output, target, topk=(1, 5)):
     return [correct[:min(k, maxk)].reshape(-1).float().sum() * (100.0 / target.shape[0]) for k in topk]
 
 
-def clip_step_loss(images, ids, sd, cfg, world=1):
+def clip_step_loss(images, ids, sd, cfg, world=1, new_stats=None):
     """solver/clip_solver.py:413-430: per-rank loss/world summed over ranks is what
     the SUM-all-reduced gradients correspond to (quirk 14)."""
-    per_rank, feats = clip_forward(images, ids, sd, cfg, world)
+    per_rank, feats = clip_forward(images, ids, sd, cfg, world, new_stats=new_stats)
     total = 0.0
     metrics = []
     for r, (li, lt) in enumerate(per_rank):

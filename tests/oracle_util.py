@@ -25,17 +25,20 @@ def oracle_clip_run(cfg, b, world=1, seed=0, logit_scale=None):
     """Run the restated CLIP step on CPU fp32; returns loss, per-rank logits, grads by name."""
     shapes = synth.clip_shapes(cfg)
     sd = synth.synth_state(shapes, seed=seed, logit_scale=logit_scale)
-    frozen = {"visual.conv1.weight"}                       # visual_transformer.py:45-51
+    resnet = cfg.get("vision") == "resnet"
+    frozen = set() if resnet else {"visual.conv1.weight"}  # visual_transformer.py:45-51 (the ResNet stem trains)
     for k, v in sd.items():
-        v.requires_grad_(k not in frozen)
+        if v.dtype.is_floating_point and "running_" not in k:
+            v.requires_grad_(k not in frozen)
     B = b * world
     images = synth.synth_images(B, res=cfg["res"], seed=seed)
     ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
-    total, per_rank, feats, metrics = restated.clip_step_loss(images, ids, sd, cfg, world)
+    new_stats = {} if resnet else None
+    total, per_rank, feats, metrics = restated.clip_step_loss(images, ids, sd, cfg, world, new_stats=new_stats)
     total.backward()
-    grads = {k: v.grad for k, v in sd.items()}
+    grads = {k: v.grad for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
     return dict(loss=total.detach(), per_rank=per_rank, feats=feats, grads=grads, sd=sd,
-                images=images, ids=ids, metrics=metrics)
+                images=images, ids=ids, metrics=metrics, new_stats=new_stats)
 
 
 def check_grad_digests(golden_grads, grads, rtol, atol_frac=1e-4):
