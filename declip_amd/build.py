@@ -46,7 +46,7 @@ def build(force=False, verbose=True):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % src)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--no-undefined", "-o", LIB] + objs   # a missing symbol fails the build, not the dlopen
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -72,6 +72,14 @@ _PROTOS = {
     "dh_ce_rows_bwd_padded": (c_int, [_P, c_int64, _P, c_int, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
     "dh_bn1d_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, c_int, _P]),
     "dh_bn1d_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "dh_conv_rows": (c_int, [c_int, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dh_bn2d_ws_bytes": (c_int64, [c_int, c_int]),
+    "dh_bn2d_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_int, c_int, _P, c_int64, _P]),
+    "dh_bn2d_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P]),
+    "dh_avgpool_fwd": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dh_avgpool_bwd": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dh_attnpool_tokens_fwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "dh_attnpool_tokens_bwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
     "dh_cos_rows_fwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, _P]),
     "dh_cos_rows_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, _P]),
     "dh_nn_bank_ws_bytes": (c_int64, [c_int, c_int]),

@@ -397,3 +397,111 @@ def maxsim_scatter(dlogits, arg, scale, b, B, J, dtype):
     check(L.load().dh_maxsim_scatter(dt(G), ptr(_contig(dlogits, "dlogits")), ptr(arg), ptr(scale), ptr(G), G.stride(0), b, B, J,
                                      stream()), "dh_maxsim_scatter")
     return G
+
+
+# ---------------------------------------------------------------------------------------------
+# ModifiedResNet tower (csrc/resnet_ops.hip): NHWC activations as [N*H*W, C] pixel rows
+# ---------------------------------------------------------------------------------------------
+def conv_rows(x, N, H, W, C, stride=1, pad=1, out=None):
+    """3x3 patches of an NHWC activation x [N*H*W, C] -> rows [N*Ho*Wo, 9*C], inner order (c, ky, kx)
+    (== conv.weight.view(Cout, Cin*9))."""
+    _contig(x, "x")
+    assert x.shape == (N * H * W, C)
+    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    if out is None:
+        out = torch.empty(N * Ho * Wo, 9 * C, device=x.device, dtype=x.dtype)
+    assert out.shape == (N * Ho * Wo, 9 * C) and out.is_contiguous() and out.dtype == x.dtype
+    check(L.load().dh_conv_rows(dt(x), ptr(x), 0, C, 0, ptr(out), N, H, W, C, 3, stride, pad, 9 * C, stream()), "dh_conv_rows")
+    return out, Ho, Wo
+
+
+def conv_rows_image(images, c0, dtype, stride=2, pad=1, out=None):
+    """3x3 patches of the fp32 NCHW image batch (3 channels from c0) -> rows [N*Ho*Wo, 32] (K = 27 zero-padded)."""
+    _contig(images, "images")
+    assert images.dtype == torch.float32 and images.dim() == 4
+    N, ct, H, W = images.shape
+    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    if out is None:
+        out = torch.empty(N * Ho * Wo, 32, device=images.device, dtype=dtype)
+    assert out.shape == (N * Ho * Wo, 32) and out.is_contiguous()
+    check(L.load().dh_conv_rows(dt(out), ptr(images), 1, ct, c0, ptr(out), N, H, W, 3, 3, stride, pad, 32, stream()), "dh_conv_rows")
+    return out, Ho, Wo
+
+
+_BN_WS = {}
+
+
+def _bn_ws(device, nbytes):
+    key = (device.type, device.index, stream())
+    ws = _BN_WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _BN_WS[key] = ws
+    return ws
+
+
+def bn2d_fwd(x, w, b, running_mean, running_var, relu, training, residual=None, eps=1e-5, momentum=0.1):
+    """y = relu?(BatchNorm(x) (+ residual)) on pixel rows x [R, C]; returns (y, save_mean [C], save_invstd [C])."""
+    _contig(x, "x")
+    R, C = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        assert residual.shape == x.shape and residual.dtype == x.dtype and residual.is_contiguous()
+    lib = L.load()
+    nbytes = lib.dh_bn2d_ws_bytes(R, C)
+    ws = _bn_ws(x.device, nbytes)
+    check(lib.dh_bn2d_fwd(dt(x), ptr(x), ptr(residual), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(invstd), ptr(running_mean),
+                          ptr(running_var), R, C, eps, momentum, int(relu), int(training), ptr(ws), ws.numel() * 4, stream()),
+          "dh_bn2d_fwd")
+    return y, mean, invstd
+
+
+def bn2d_bwd(dy, x, y, w, mean, invstd, dw, db, relu, want_dres=False):
+    """-> dx (, dres = dy masked by the ReLU: the gradient of the residual branch); dw, db accumulate."""
+    _contig(dy, "dy"), _contig(x, "x")
+    R, C = x.shape
+    assert dy.shape == x.shape and dy.dtype == x.dtype and dw.dtype == torch.float32 and db.dtype == torch.float32
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    lib = L.load()
+    nbytes = lib.dh_bn2d_ws_bytes(R, C)
+    ws = _bn_ws(x.device, nbytes)
+    check(lib.dh_bn2d_bwd(dt(x), ptr(dy), ptr(x), ptr(y) if relu else None, ptr(w), ptr(mean), ptr(invstd), ptr(dx), ptr(dres),
+                          ptr(dw), ptr(db), R, C, int(relu), ptr(ws), ws.numel() * 4, stream()), "dh_bn2d_bwd")
+    return (dx, dres) if want_dres else dx
+
+
+def avgpool_fwd(x, N, H, W, C, k):
+    _contig(x, "x")
+    assert x.shape == (N * H * W, C)
+    y = torch.empty(N * (H // k) * (W // k), C, device=x.device, dtype=x.dtype)
+    check(L.load().dh_avgpool_fwd(dt(x), ptr(x), ptr(y), N, H, W, C, k, stream()), "dh_avgpool_fwd")
+    return y
+
+
+def avgpool_bwd(dy, N, H, W, C, k):
+    _contig(dy, "dy")
+    assert dy.shape == (N * (H // k) * (W // k), C)
+    dx = torch.empty(N * H * W, C, device=dy.device, dtype=dy.dtype)
+    check(L.load().dh_avgpool_bwd(dt(dy), ptr(dy), ptr(dx), N, H, W, C, k, stream()), "dh_avgpool_bwd")
+    return dx
+
+
+def attnpool_tokens_fwd(x, pos, b, HW):
+    _contig(x, "x")
+    C = x.shape[1]
+    assert x.shape[0] == b * HW and pos.shape == (HW + 1, C) and pos.dtype == torch.float32 and pos.is_contiguous()
+    tok = torch.empty(b * (HW + 1), C, device=x.device, dtype=x.dtype)
+    check(L.load().dh_attnpool_tokens_fwd(dt(x), ptr(x), ptr(pos), ptr(tok), b, HW, C, stream()), "dh_attnpool_tokens_fwd")
+    return tok
+
+
+def attnpool_tokens_bwd(dtok, dpos, b, HW):
+    _contig(dtok, "dtok")
+    C = dtok.shape[1]
+    assert dtok.shape[0] == b * (HW + 1) and (dpos is None or (dpos.shape == (HW + 1, C) and dpos.dtype == torch.float32))
+    dx = torch.empty(b * HW, C, device=dtok.device, dtype=dtok.dtype)
+    check(L.load().dh_attnpool_tokens_bwd(dt(dtok), ptr(dtok), ptr(dx), ptr(dpos), b, HW, C, stream()), "dh_attnpool_tokens_bwd")
+    return dx

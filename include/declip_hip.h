@@ -252,6 +252,40 @@ int dh_adamw_segmented(float* p, const float* g, float* m, float* v, void* p_bf1
                        float beta1, float beta2, float eps, int step, float grad_scale, dh_stream_t stream);
 int dh_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, dh_stream_t stream);
 
+/* ---------------------------------------------------------------- ModifiedResNet tower ---
+ * prototype/model/image_encoder/modified_resnet.py (BASELINE configs[0]: clip_res50).  Activations are NHWC, i.e.
+ * row-major [N*H*W][C] "pixel rows" (the token-major layout of the transformer towers): a 1x1 convolution is dh_gemm
+ * on the activation as stored, a 3x3 convolution is dh_conv_rows + dh_gemm against conv.weight viewed [Cout][Cin*9]
+ * as stored (nn.Conv2d of modified_resnet.py:20-29,144-149; bias-free).  C must be a multiple of 8 everywhere.
+ *
+ * dh_conv_rows: rows[(n,oy,ox)][c*9 + ky*3 + kx] = src[n, oy*stride-pad+ky, ox*stride-pad+kx, c], 0 outside; k == 3.
+ *   src_layout 0: NHWC activation of `dtype`, Kpad == 9*C.
+ *   src_layout 1: fp32 NCHW image batch [N][c_total][H][W], the 3 channels from c0 (a channel-stacked view,
+ *                 data/transforms.py:38-54), rows of `dtype` with K = 27 zero-padded to Kpad == 32 (stem conv1). */
+int dh_conv_rows(int dtype, const void* src, int src_layout, int c_total, int c0, void* rows, int N, int H, int W, int C, int k,
+                 int stride, int pad, int Kpad, dh_stream_t stream);
+/* nn.BatchNorm2d (modified_resnet.py:138, use_sync_bn False: per-rank statistics) on [rows][C], fused with the ReLU and
+ * the residual add that follow it in Bottleneck.forward (modified_resnet.py:44-56): y = relu?(bn(x) (+ residual)).
+ * training: batch mean / biased variance (saved as save_mean / save_invstd [C]); running_mean / running_var (may both be
+ * NULL) move by `momentum` towards the batch mean / unbiased variance.  training == 0: running statistics.
+ * Deterministic two-level reductions through the caller's workspace (dh_bn2d_ws_bytes). */
+int64_t dh_bn2d_ws_bytes(int rows, int C);
+int dh_bn2d_fwd(int dtype, const void* x, const void* residual_or_null, const float* w, const float* b, void* y, float* save_mean,
+                float* save_invstd, float* running_mean, float* running_var, int rows, int C, float eps, float momentum, int relu,
+                int training, void* ws, int64_t ws_bytes, dh_stream_t stream);
+/* Backward of the same: dyr = dy masked by (y > 0) when relu; dx = w*invstd*(dyr - mean(dyr) - xhat*mean(dyr*xhat));
+ * dres_or_null receives dyr (the gradient of the residual branch); dw += sum dyr*xhat, db += sum dyr (fp32, accumulate). */
+int dh_bn2d_bwd(int dtype, const void* dy, const void* x, const void* y_or_null, const float* w, const float* save_mean,
+                const float* save_invstd, void* dx, void* dres_or_null, float* dw, float* db, int rows, int C, int relu, void* ws,
+                int64_t ws_bytes, dh_stream_t stream);
+/* nn.AvgPool2d(k) on NHWC (modified_resnet.py:26,36,149); H and W multiples of k. */
+int dh_avgpool_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, int k, dh_stream_t stream);
+int dh_avgpool_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int k, dh_stream_t stream);
+/* AttentionPool2d token matrix (modified_resnet.py:70-72): tok [b][HW+1][C], tok[:,0] = mean over the HW pixel rows,
+ * tok[:,1:] = the pixel rows, plus positional_embedding [HW+1][C] (fp32).  bwd: dx [b*HW][C], dpos += sum_b dtok. */
+int dh_attnpool_tokens_fwd(int dtype, const void* x, const float* pos, void* tok, int b, int HW, int C, dh_stream_t stream);
+int dh_attnpool_tokens_bwd(int dtype, const void* dtok, void* dx, float* dpos_or_null, int b, int HW, int C, dh_stream_t stream);
+
 /* ---- host side: caption tokeniser (no device work) ----------------------------------------------
  * Byte-level BPE of model/utils/text_utils/simple_tokenizer.py:62-134 + the [SOT] ids [EOT] / zero-pad /
  * truncate-keeping-EOT layout of text_encoder/text_transformer.py:144-180, batch-parallel on host threads.

@@ -1,0 +1,73 @@
+"""Host emulation of the HBM-bound HIP kernels (TEST INFRASTRUCTURE, see tests/hipemu/hip/hip_runtime.h).
+
+`emu_ops(sources)` compiles the given csrc/*.hip files as plain C++ against the stand-in HIP runtime, loads the result with
+ctypes under the C-ABI prototypes of declip_amd.lib and returns the `declip_amd.ops` module re-pointed at it (CPU tensors,
+no stream), so the SAME Python wrappers, argument orders and C entry points run as on the GPU -- only the kernels' threads
+are fibers on the host.  The GPU parity tests remain the judges of the device build; this catches index arithmetic, bounds,
+reduction and argument-order mistakes without a GPU."""
+import contextlib
+import ctypes
+import hashlib
+import os
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "declip_amd", "csrc")
+EMU = os.path.join(ROOT, "tests", "hipemu")
+_CACHE = {}
+
+
+def _clangxx():
+    for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++")):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def build_emu(sources, grid_cap=8):
+    cxx = _clangxx()
+    if cxx is None:
+        pytest.skip("no clang++ for the host emulation build")
+    files = [os.path.join(EMU, "emu.cpp")] + [os.path.join(CSRC, s) for s in sources]
+    h = hashlib.sha256(str(grid_cap).encode())
+    for f in files + [os.path.join(EMU, "hip", "hip_runtime.h"), os.path.join(CSRC, "dh_common.h"), os.path.join(ROOT, "include", "declip_hip.h")]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    out = os.path.join(tempfile.gettempdir(), "libdh_emu_%s.so" % h.hexdigest()[:16])
+    if not os.path.exists(out):
+        tmp = out + ".%d.tmp" % os.getpid()
+        cmd = [cxx, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-DDH_GRID_CAP=%d" % grid_cap, "-Wno-unknown-pragmas",
+               "-Wno-pass-failed", "-I", EMU] + files + ["-o", tmp]
+        subprocess.check_call(cmd)
+        os.replace(tmp, out)
+    return out
+
+
+@contextlib.contextmanager
+def emu_ops(sources, symbols):
+    """declip_amd.ops bound to the host-emulated library for the duration of the block."""
+    from declip_amd import lib as L
+    from declip_amd import ops
+    key = tuple(sources)
+    lib = _CACHE.get(key)
+    if lib is None:
+        lib = ctypes.CDLL(build_emu(sources))
+        for name in symbols:
+            res, args = L._PROTOS[name]
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        lib.dh_last_error.restype = ctypes.c_char_p
+        _CACHE[key] = lib
+    saved = (L.load, ops.ptr, ops.stream, L._lib)
+    L.load = lambda: lib
+    L._lib = lib
+    ops.ptr = lambda t: None if t is None else t.data_ptr()
+    ops.stream = lambda: None
+    try:
+        yield ops
+    finally:
+        L.load, ops.ptr, ops.stream, L._lib = saved
