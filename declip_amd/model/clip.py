@@ -16,9 +16,10 @@ from torch import nn
 
 from .. import dist as dh_dist
 from .. import engine
+from .resnet import modified_resnet_R50
 from .transformer import text_transformers, visual_transformer_B16, visual_transformer_B32
 
-__all__ = ["clip_vitb32", "clip_vitb16", "CLIP", "LazyLogits"]
+__all__ = ["clip_vitb32", "clip_vitb16", "clip_res50", "CLIP", "LazyLogits"]
 
 
 class LazyLogits:
@@ -170,6 +171,14 @@ def _engine_kwargs(kwargs):
 def clip_vitb32(**kwargs):
     """model/clip.py:158-165; extra optional kwargs block `engine: {dtype: bf16|fp32, fused_loss: bool}`."""
     image_encode = visual_transformer_B32(**kwargs["image_encode"])
+    text_encode = text_transformers(**kwargs["text_encode"])
+    return CLIP(image_encode, text_encode, **kwargs["clip"], **_engine_kwargs(kwargs))
+
+
+def clip_res50(**kwargs):
+    """model/clip.py:148-155 (BASELINE.json configs[0]; image_encode: {embed_dim, use_sync_bn: False, bn_*}, as in
+    experiments/clip_experiments/yfcc15m/yfcc15m_r50_clip/config.yaml:2-19)."""
+    image_encode = modified_resnet_R50(**kwargs["image_encode"])
     text_encode = text_transformers(**kwargs["text_encode"])
     return CLIP(image_encode, text_encode, **kwargs["clip"], **_engine_kwargs(kwargs))
 

@@ -1,5 +1,5 @@
 """Model registry (reference: prototype/model/__init__.py:15-21)."""
-from declip_amd.model.clip import clip_vitb16, clip_vitb32  # noqa: F401
+from declip_amd.model.clip import clip_res50, clip_vitb16, clip_vitb32  # noqa: F401
 from declip_amd.model.declip import declip_vitb32  # noqa: F401
 from declip_amd.model.defilip import defilip_vitb32  # noqa: F401
 from declip_amd.model.filip import filip_vitb32  # noqa: F401

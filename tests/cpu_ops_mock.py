@@ -349,3 +349,34 @@ def image_prep_u8(src, out_hw, crop_xy=None, flip=None, mean=(0.485, 0.456, 0.40
         return res
     out[:, c0:c0 + 3] = res
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# ModifiedResNet ops: no torch stand-ins -- the REAL wrappers and C entry points run on the host-emulated build of
+# csrc/resnet_ops.hip (tests/hipemu_util.py), so the engine-level CPU tests execute the kernels' own code.
+# ---------------------------------------------------------------------------------------------
+from declip_amd import ops as _real_ops  # noqa: E402
+
+_RESNET_SYMS = ["dh_conv_rows", "dh_bn2d_ws_bytes", "dh_bn2d_fwd", "dh_bn2d_bwd", "dh_avgpool_fwd", "dh_avgpool_bwd",
+                "dh_attnpool_tokens_fwd", "dh_attnpool_tokens_bwd"]
+_RESNET_ORIG = {n: getattr(_real_ops, n) for n in ("conv_rows", "conv_rows_image", "bn2d_fwd", "bn2d_bwd", "avgpool_fwd", "avgpool_bwd",
+                                                   "attnpool_tokens_fwd", "attnpool_tokens_bwd")}
+
+
+def _emulated(name):
+    def call(*args, **kwargs):
+        from hipemu_util import emu_ops
+        with emu_ops(["resnet_ops.hip"], _RESNET_SYMS):
+            return _RESNET_ORIG[name](*args, **kwargs)
+    call.__name__ = name
+    return call
+
+
+conv_rows = _emulated("conv_rows")
+conv_rows_image = _emulated("conv_rows_image")
+bn2d_fwd = _emulated("bn2d_fwd")
+bn2d_bwd = _emulated("bn2d_bwd")
+avgpool_fwd = _emulated("avgpool_fwd")
+avgpool_bwd = _emulated("avgpool_bwd")
+attnpool_tokens_fwd = _emulated("attnpool_tokens_fwd")
+attnpool_tokens_bwd = _emulated("attnpool_tokens_bwd")

@@ -41,12 +41,14 @@ def oracle_clip_run(cfg, b, world=1, seed=0, logit_scale=None):
                 images=images, ids=ids, metrics=metrics, new_stats=new_stats)
 
 
-def check_grad_digests(golden_grads, grads, rtol, atol_frac=1e-4):
-    """Compare gradient digests: norm, 8-element head, seeded projection."""
+def check_grad_digests(golden_grads, grads, rtol, atol_frac=1e-4, only=None):
+    """Compare gradient digests: norm, 8-element head, seeded projection (`only`: predicate selecting the names to check)."""
     names = list(golden_grads.keys())
     bad = []
     gmax = max((v["norm"] for v in golden_grads.values() if v is not None), default=1.0)
     for idx, name in enumerate(names):
+        if only is not None and not only(name):
+            continue
         ref = golden_grads[name]
         g = grads.get(name)
         if ref is None:
