@@ -165,7 +165,7 @@ class FlatParams:
         self._zero_event = None
         self.join_streams()                      # gradients written on the side streams are final from here on
         for p in self.params:
-            if not p.requires_grad:
+            if not p.requires_grad or getattr(p, "_dh_grad_none", False):   # parameters off the path keep grad None (torch semantics)
                 continue
             view = self.gview(p)
             if p.grad is None:

@@ -15,7 +15,7 @@ from ..heads import NNMemoryBankModule, mlm_loss, prediction_MLP, projection_MLP
 from .clip import CLIP, LazyLogits, _engine_kwargs
 from .transformer import text_transformers, visual_transformer_B32
 
-__all__ = ["DECLIP", "declip_vitb32"]
+__all__ = ["DECLIP", "declip_vitb32", "declip_res50"]
 
 
 class DECLIP(CLIP):
@@ -165,6 +165,15 @@ class DECLIP(CLIP):
     def _extra_outputs(self, ret, st):
         """hook for DEFILIP (adds the token-wise 'filip' logits)."""
         return None
+
+
+def declip_res50(**kwargs):
+    """model/declip.py:339-346 (the two image views go through the ModifiedResNet one after the other: per-view BatchNorm
+    statistics, as in the reference)."""
+    from .resnet import modified_resnet_R50
+    image_encode = modified_resnet_R50(**kwargs["image_encode"])
+    text_encode = text_transformers(**kwargs["text_encode"])
+    return DECLIP(image_encode, text_encode, **kwargs["clip"], **_engine_kwargs(kwargs))
 
 
 def declip_vitb32(**kwargs):

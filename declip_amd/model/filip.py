@@ -15,7 +15,7 @@ from ..heads import LinearFn
 from .clip import CLIP, LazyLogits, _engine_kwargs
 from .transformer import text_transformers, visual_transformer_B32
 
-__all__ = ["FILIP", "filip_vitb32"]
+__all__ = ["FILIP", "filip_vitb32", "filip_res50"]
 
 
 class FILIP(CLIP):
@@ -116,6 +116,14 @@ class FILIP(CLIP):
             ttok = LinearFn.apply(words.reshape(b * T, -1), self.text_mapping, flat)
             ret["dense_logits"] = self.get_weighted_dense_logits(itok, ttok, b, J, T, label0)
         return ret
+
+
+def filip_res50(**kwargs):
+    """model/filip.py:146-153 (dense tokens = the 7x7 feature map, 2048 wide)."""
+    from .resnet import modified_resnet_R50
+    image_encode = modified_resnet_R50(**kwargs["image_encode"])
+    text_encode = text_transformers(**kwargs["text_encode"])
+    return FILIP(image_encode, text_encode, **kwargs["clip"], dense_mapping_image=2048, **_engine_kwargs(kwargs))
 
 
 def filip_vitb32(**kwargs):

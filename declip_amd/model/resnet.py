@@ -88,6 +88,8 @@ class ModifiedResNet(_Tower):
         self.attnpool = AttentionPool2d(input_resolution // 32, feat_dim, heads, embed_dim)
         self.adaptivepool = nn.AdaptiveAvgPool2d((1, 1))
         self.fc = nn.Linear(2048, embed_dim)                    # modified_resnet.py:167 (only reached off the 7x7 path)
+        for p in self.fc.parameters():
+            p._dh_grad_none = True      # never on the 224 px path: grad stays None and the optimizer leaves it alone, as in torch
         std = self.attnpool.c_proj.in_features ** -0.5
         for lin in (self.attnpool.q_proj, self.attnpool.k_proj, self.attnpool.v_proj, self.attnpool.c_proj):
             nn.init.normal_(lin.weight, std=std)

@@ -39,7 +39,7 @@ class FlatAdamW(torch.optim.Optimizer):
         for pid in self._seg_pid:
             gi = self._param_group.get(pid)
             p = self._by_id[pid]
-            if gi is None or not p.requires_grad:
+            if gi is None or not p.requires_grad or getattr(p, "_dh_grad_none", False):   # torch.optim.AdamW skips grad-None parameters
                 lrs.append(0.0), wds.append(0.0)
             else:
                 g = self.param_groups[gi]

@@ -1,8 +1,8 @@
 """Model registry (reference: prototype/model/__init__.py:15-21)."""
 from declip_amd.model.clip import clip_res50, clip_vitb16, clip_vitb32  # noqa: F401
-from declip_amd.model.declip import declip_vitb32  # noqa: F401
+from declip_amd.model.declip import declip_res50, declip_vitb32  # noqa: F401
 from declip_amd.model.defilip import defilip_vitb32  # noqa: F401
-from declip_amd.model.filip import filip_vitb32  # noqa: F401
+from declip_amd.model.filip import filip_res50, filip_vitb32  # noqa: F401
 from declip_amd.model.slip import slip_vitb32  # noqa: F401
 
 

@@ -176,6 +176,56 @@ def test_flat_adamw_tables_match_torch_adamw(mocked_engine):
     assert torch.equal(got["visual.conv1.weight"].detach(), synth.synth_state(synth.clip_shapes(cfg), seed=seed)["visual.conv1.weight"])
 
 
+def test_resnet_flat_adamw_steps_match_torch_adamw(mocked_engine):
+    """CLIP-R50 (tiny): 2 optimiser steps, engine + FlatAdamW vs the restatement + torch.optim.AdamW.  BatchNorm affine
+    parameters sit in the no-decay group, the unused fc (modified_resnet.py:167,209-211) keeps grad None and is never touched."""
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.optim import build_adamw
+    from declip_amd.testing import build_clip
+    from oracle import restated
+    cfg, b, seed = synth.R50_TINY, 3, 21
+    model = build_clip(cfg, dtype="fp32", seed=seed, device="cpu")
+    opt = build_adamw(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
+    crit = ClipInfoCELoss()
+    sd = synth.synth_state(synth.clip_shapes(cfg), seed=seed)
+    train = [k for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k and not k.startswith("visual.fc.")]
+    for k in train:
+        sd[k].requires_grad_(True)
+    decay = {n for n, p in model.named_parameters() if p.dim() > 1 and "logit_scale" not in n and not n.endswith("bias")}
+    ref_opt = torch.optim.AdamW([dict(params=[sd[k] for k in train if k in decay], weight_decay=0.1),
+                                 dict(params=[sd[k] for k in train if k not in decay], weight_decay=0.0)],
+                                lr=1e-3, betas=(0.9, 0.98), eps=1e-8)
+    for step in range(2):
+        images = synth.synth_images(b, res=cfg["res"], seed=seed + step)
+        ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed + step, vocab=cfg["vocab"])
+        opt.zero_grad()
+        li, lt = model({"images": images, "captions": ids})
+        loss, _ = crit(li, lt)
+        loss.backward()
+        assert model.visual.fc.weight.grad is None
+        opt.step()
+        ref_opt.zero_grad()
+        total, _, _, _ = restated.clip_step_loss(images, ids, sd, cfg, 1)
+        total.backward()
+        ref_opt.step()
+        # step 0 is the same function on both sides; from step 1 on the parameters differ where Adam's first update
+        # (lr * sign(g)) saw a near-zero gradient whose sign is rounding noise (BatchNorm biases: sums of cancelling terms)
+        tol = 2e-4 if step == 0 else 3e-3
+        assert abs(float(loss.detach()) - float(total.detach())) <= tol * abs(float(total.detach())), (step, float(loss.detach()), float(total.detach()))
+    got = dict(model.named_parameters())
+    fresh = synth.synth_state(synth.clip_shapes(cfg), seed=seed)
+    assert torch.equal(got["visual.fc.weight"].detach(), fresh["visual.fc.weight"])
+    assert torch.equal(got["visual.fc.bias"].detach(), fresh["visual.fc.bias"])
+    for k in ("visual.bn1.weight", "visual.layer2.1.bn3.bias", "visual.layer3.0.conv2.weight", "visual.attnpool.q_proj.weight", "visual.conv1.weight"):
+        a, r = got[k].detach(), sd[k].detach()
+        diff = (a - r).abs()
+        assert float(diff.max()) <= 2 * 1e-3 * 2 + 1e-4 * float(r.abs().max()), k          # Adam's step bound
+        # the bulk within a third of one Adam step (gradient noise of a few % on cancelling sums moves the 2nd update a little)
+        assert int((diff > 0.3 * 1e-3 + 1e-4 * float(r.abs().max())).sum()) <= max(1, int(0.05 * diff.numel())), k
+        assert float((a - fresh[k]).abs().max()) > 0, k                                      # and it did move
+
+
 def test_declip_engine_composition_matches_golden(mocked_engine):
     """DECLIP model + solver loss composition on the engine (mock kernels) vs the reference golden."""
     from declip_amd.heads import SimsiamLoss

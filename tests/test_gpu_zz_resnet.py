@@ -1,0 +1,244 @@
+"""ModifiedResNet tower (BASELINE.json configs[0] family) on the GPU: the tower's kernels against torch CPU references
+through the C-ABI, the CLIP-R50 training step against the golden generated from the unmodified reference (fp32 at the
+north_star tolerance on the forward; bf16 at the documented looser bounds), BatchNorm buffers, eval mode, and the full-size
+ResNet-50 at the configs[0] batch against the oracle.
+
+STATUS: these kernels and the tower engine were written after round 1's GPU budget had been spent.  They are verified on
+the CPU by running the same C entry points through the host emulation (tests/test_hipemu_resnet.py,
+tests/test_engine_cpu_mock.py::test_resnet_engine_composition_matches_golden); their FIRST hardware run is this file, hence
+the non-strict xfail marker (an XPASS line = verified on hardware; remove the marker then).  Sorted last on purpose."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle_util import check_grad_digests, load_golden, oracle_clip_run
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.xfail(strict=False, reason="first hardware run of the ModifiedResNet path (round 1 GPU budget was spent "
+                                                     "before it was written); verified through the host emulation on CPU")]
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 2e-2
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def nchw(rows, N, H, W):
+    return rows.reshape(N, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, dtype, scale=None):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    s = float(b.abs().max()) if scale is None else scale
+    assert float((a - b).abs().max()) <= _tol(dtype) * max(s, 1e-6), (float((a - b).abs().max()), s)
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,H,W,C,stride", [(2, 9, 7, 16, 1), (1, 12, 12, 8, 2), (4, 56, 56, 64, 1), (2, 7, 7, 512, 1)])
+def test_conv_rows_nhwc(dtype, N, H, W, C, stride):
+    from declip_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(N, C, H, W).to(dtype)
+    rows, Ho, Wo = ops.conv_rows(nhwc(x).cuda(), N, H, W, C, stride=stride, pad=1)
+    ref = F.unfold(x.float(), 3, padding=1, stride=stride).transpose(1, 2).reshape(N * Ho * Wo, C * 9)
+    assert torch.equal(rows.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_rows_image_view(dtype):
+    from declip_amd import ops
+    torch.manual_seed(1)
+    N, H, W = 3, 224, 224
+    img = torch.randn(N, 6, H, W)
+    for c0 in (0, 3):
+        rows, Ho, Wo = ops.conv_rows_image(img.cuda(), c0, dtype, stride=2, pad=1)
+        ref = F.unfold(img[:, c0:c0 + 3], 3, padding=1, stride=2).transpose(1, 2).reshape(N * Ho * Wo, 27)
+        assert (Ho, Wo) == (112, 112)
+        assert torch.equal(rows[:, :27].float().cpu(), ref.to(dtype).float())
+        assert float(rows[:, 27:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("R,C,relu,res", [(37, 8, True, False), (3000, 16, True, True), (100352, 64, True, False), (1568, 2048, True, True),
+                                          (64, 2056, False, False)])
+def test_bn2d_fwd_bwd(dtype, R, C, relu, res):
+    from declip_amd import ops
+    torch.manual_seed(2)
+    x = (torch.randn(R, C) * 1.5 + 0.3).to(dtype)
+    r = torch.randn(R, C).to(dtype) if res else None
+    w, b = 1 + 0.1 * torch.randn(C), 0.1 * torch.randn(C)
+    rm, rv = torch.randn(C) * 0.1, torch.rand(C) + 0.5
+    dy = torch.randn(R, C).to(dtype)
+    xr, wr, br = x.float().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    yr = F.batch_norm(xr, rm_ref, rv_ref, wr, br, True, 0.1, 1e-5)
+    if res:
+        yr = yr + r.float()
+    if relu:
+        yr = F.relu(yr)
+    rm2, rv2 = rm.cuda(), rv.cuda()
+    xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
+    y, mean, invstd = ops.bn2d_fwd(xc, wc, bc, rm2, rv2, relu, True, residual=r.cuda() if res else None)
+    close(y, yr, dtype)
+    close(rm2, rm_ref, torch.float32), close(rv2, rv_ref, torch.float32)
+    mask = (y.float().cpu() > 0).float() if relu else torch.ones(R, C)
+    g_x, g_w, g_b = torch.autograd.grad(F.batch_norm(xr, None, None, wr, br, True, 0.1, 1e-5), (xr, wr, br), dy.float() * mask)
+    dw, db = torch.full((C,), 0.5).cuda(), torch.full((C,), -0.25).cuda()
+    out = ops.bn2d_bwd(dy.cuda(), xc, y, wc, mean, invstd, dw, db, relu, want_dres=res)
+    dx, dres = out if res else (out, None)
+    close(dx, g_x, dtype)
+    close(dw - 0.5, g_w, dtype, float(g_w.abs().max()) * (10 if dtype == torch.float32 else 1))
+    close(db + 0.25, g_b, dtype, float(g_b.abs().max()) * (10 if dtype == torch.float32 else 1))
+    if res:
+        assert torch.equal(dres.float().cpu(), (dy.float() * mask).to(dtype).float())
+    # run-to-run determinism of the two-level reductions (no atomics)
+    dw2, db2 = torch.full((C,), 0.5).cuda(), torch.full((C,), -0.25).cuda()
+    out2 = ops.bn2d_bwd(dy.cuda(), xc, y, wc, mean, invstd, dw2, db2, relu, want_dres=res)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dx, out2[0] if res else out2)
+    y_eval, _, _ = ops.bn2d_fwd(xc, wc, bc, rm2, rv2, False, False)
+    close(y_eval, F.batch_norm(x.float(), rm2.cpu(), rv2.cpu(), w, b, False, 0.1, 1e-5), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,H,W,C,k", [(2, 8, 12, 16, 2), (1, 6, 6, 8, 3), (4, 112, 112, 64, 2)])
+def test_avgpool(dtype, N, H, W, C, k):
+    from declip_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(N, C, H, W).to(dtype)
+    xr = x.float().requires_grad_()
+    yr = F.avg_pool2d(xr, k)
+    dy = torch.randn_like(yr).to(dtype)
+    yr.backward(dy.float())
+    y = ops.avgpool_fwd(nhwc(x).cuda(), N, H, W, C, k)
+    dx = ops.avgpool_bwd(nhwc(dy).cuda(), N, H, W, C, k)
+    close(nchw(y.cpu(), N, H // k, W // k), yr, dtype)
+    close(nchw(dx.cpu(), N, H, W), xr.grad, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attnpool_tokens(dtype):
+    from declip_amd import ops
+    torch.manual_seed(4)
+    b, HW, C = 5, 49, 2048
+    x = torch.randn(b, HW, C).to(dtype)
+    pos = torch.randn(HW + 1, C)
+    xr, pr = x.float().requires_grad_(), pos.clone().requires_grad_()
+    tr = torch.cat([xr.mean(dim=1, keepdim=True), xr], dim=1) + pr
+    dtok = torch.randn(b, HW + 1, C).to(dtype)
+    tr.backward(dtok.float())
+    tok = ops.attnpool_tokens_fwd(x.reshape(b * HW, C).cuda(), pos.cuda(), b, HW)
+    dpos = torch.full((HW + 1, C), 2.0).cuda()
+    dx = ops.attnpool_tokens_bwd(dtok.reshape(b * (HW + 1), C).cuda(), dpos, b, HW)
+    close(tok.reshape(b, HW + 1, C), tr, dtype)
+    close(dx.reshape(b, HW, C), xr.grad, dtype)
+    close(dpos - 2.0, pr.grad, torch.float32 if dtype == torch.float32 else dtype)
+
+
+# ------------------------------------------------------------------------------------------------ the CLIP-R50 step
+def run_engine(cfg, b, seed, dtype):
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.testing import build_clip
+    model = build_clip(cfg, dtype=dtype, seed=seed)
+    images = synth.synth_images(b, res=cfg["res"], seed=seed).cuda()
+    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"]).cuda()
+    li, lt = model({"images": images, "captions": ids})
+    loss, _ = ClipInfoCELoss()(li, lt)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
+    return model, dict(loss=float(loss), logits_i=li.materialize().detach().float().cpu(), logits_t=lt.materialize().detach().float().cpu(),
+                       grads=grads, images=images)
+
+
+def _is_bn(n):
+    return ".bn" in n or "downsample.1." in n
+
+
+def test_clip_r50_fp32_matches_reference_golden():
+    """forward at the north_star tolerance (1e-3).  Gradients: the ResNet's gradient is discontinuous in its ReLU masks and a
+    single flipped mask (a different fp32 summation order is enough) moves BatchNorm affine gradients -- sums of cancelling
+    terms -- by ~1 % (measured on the CPU, oracle/restated.py batch_norm2d): convolution / linear weights at 5e-3,
+    BatchNorm affine parameters at 5e-2 on the norm."""
+    g = load_golden("clip_r50_tiny")
+    model, out = run_engine(g["cfg"], g["b"], g["seed"], "fp32")
+    assert abs(out["loss"] - g["loss"]) <= 1e-3 * abs(g["loss"])
+    scale = float(g["logits_i"].abs().max())
+    assert float((out["logits_i"] - g["logits_i"]).abs().max()) <= 1e-3 * scale
+    assert float((out["logits_t"] - g["logits_t"]).abs().max()) <= 1e-3 * scale
+    check_grad_digests(g["grads"], out["grads"], rtol=5e-3, only=lambda n: not _is_bn(n))
+    for n, ref in g["grads"].items():
+        if _is_bn(n):
+            assert abs(float(out["grads"][n].double().norm()) - ref["norm"]) <= 5e-2 * ref["norm"], n
+    bufs = dict(model.named_buffers())
+    for k, v in g["bn_buffers"].items():
+        if k.endswith("num_batches_tracked"):
+            assert int(bufs[k]) == int(v)
+        else:
+            assert float((bufs[k].cpu() - v).abs().max()) <= 1e-3 * max(1.0, float(v.abs().max())), k
+    model.eval()
+    with torch.no_grad():
+        feat, dense = model.visual(out["images"], return_dense=True)
+    assert float((feat.cpu() - g["eval_features"]).abs().max()) <= 1e-3 * float(g["eval_features"].abs().max())
+    assert abs(float(dense.double().sum()) - g["eval_dense_sum"]) <= 1e-3 * max(1.0, abs(g["eval_dense_sum"]))
+
+
+def test_clip_r50_bf16_close_to_reference():
+    g = load_golden("clip_r50_tiny")
+    _, out = run_engine(g["cfg"], g["b"], g["seed"], "bf16")
+    assert abs(out["loss"] - g["loss"]) <= 3e-2 * abs(g["loss"])
+    scale = float(g["logits_i"].abs().max())
+    assert float((out["logits_i"] - g["logits_i"]).abs().max()) <= 6e-2 * scale
+    bad = []
+    gmax = max(v["norm"] for v in g["grads"].values() if v is not None)
+    for n, ref in g["grads"].items():
+        if ref is None or ref["norm"] < 1e-3 * gmax:
+            continue
+        got = float(out["grads"][n].double().norm())
+        if abs(got - ref["norm"]) > 0.15 * ref["norm"]:
+            bad.append((n, got, ref["norm"]))
+    assert len(bad) <= max(2, len(g["grads"]) // 25), bad[:8]
+
+
+def test_clip_r50_full_size_fp32_against_oracle():
+    """BASELINE.json configs[0]: CLIP ResNet-50 + 12-layer text transformer, fp32 (batch 8 here so that the CPU oracle
+    finishes in seconds; the batch-32 step itself is exercised below)."""
+    from declip_amd import synth
+    cfg, b, seed = synth.R50, 8, 3
+    ref = oracle_clip_run(cfg, b, 1, seed, None)
+    _, out = run_engine(cfg, b, seed, "fp32")
+    assert abs(out["loss"] - float(ref["loss"])) <= 1e-3 * abs(float(ref["loss"]))
+    li = ref["per_rank"][0][0].detach()
+    assert float((out["logits_i"] - li).abs().max()) <= 1e-3 * float(li.abs().max())
+    for n in ("visual.attnpool.c_proj.weight", "visual.layer4.2.conv3.weight", "visual.layer1.0.conv1.weight", "visual.conv1.weight",
+              "encode_text.text_projection.weight"):
+        r = ref["grads"][n]
+        assert float((out["grads"][n] - r).norm()) <= 2e-2 * float(r.norm()), n
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_clip_r50_batch32_step_trains(dtype):
+    """configs[0] batch: three optimiser steps on one seeded batch must lower the loss (fp32 and bf16)."""
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.optim import build_adamw
+    from declip_amd.testing import build_clip
+    cfg, b = synth.R50, 32
+    model = build_clip(cfg, dtype=dtype, seed=0)
+    opt = build_adamw(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
+    crit = ClipInfoCELoss()
+    batch = {"images": synth.synth_images(b, seed=0).cuda(), "captions": synth.synth_tokens(b, seed=0).cuda()}
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        li, lt = model(batch)
+        loss, _ = crit(li, lt)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
