@@ -157,8 +157,13 @@ def gen_declip(name, cfg, b, seed=0, nn_size=256):
     vt = ref.modules["prototype.model.image_encoder.visual_transformer"]
     tt = ref.modules["prototype.model.text_encoder.text_transformer"]
     with contextlib.redirect_stdout(io.StringIO()):
-        vis = vt.VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
-                                   layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"], checkpoint=False)
+        if cfg.get("vision") == "resnet":      # declip.py:339-346 (declip_res50) with the shipped BatchNorm switch
+            mr = ref.modules["prototype.model.image_encoder.modified_resnet"]
+            vis = mr.ModifiedResNet(layers=tuple(cfg["r_layers"]), embed_dim=cfg["embed_dim"], heads=cfg["r_heads"],
+                                    input_resolution=cfg["res"], width=cfg["r_width"], use_sync_bn=False)
+        else:
+            vis = vt.VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
+                                       layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"], checkpoint=False)
         txt = tt.TextTransformer(embed_dim=cfg["embed_dim"], context_length=cfg["ctx"], transformer_width=cfg["t_width"],
                                  transformer_heads=cfg["t_heads"], transformer_layers=cfg["t_layers"],
                                  positional_embedding_flag=True, checkpoint=False, bpe_path=ref_harness.synthetic_bpe_path(),
@@ -206,6 +211,10 @@ def gen_declip(name, cfg, b, seed=0, nn_size=256):
                bank_ptr=int(model.nn_replacer_text.bank_ptr), bank_sum=float(model.nn_replacer_text.bank.double().sum()),
                bn1_running_mean=model.projector.bn1.running_mean.clone(), bn1_running_var=model.projector.bn1.running_var.clone(),
                torch_version=torch.__version__)
+    if cfg.get("vision") == "resnet":          # the tower saw two views: its BatchNorm buffers moved twice
+        bufs = dict(model.named_buffers())
+        ret["bn_buffers"] = {k: bufs[k].detach().clone() for k in ("visual.bn1.running_mean", "visual.layer4.0.bn3.running_var",
+                                                                   "visual.bn2.num_batches_tracked")}
     path = os.path.join(GOLDEN_DIR, name + ".pt")
     torch.save(ret, path)
     print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
@@ -436,6 +445,7 @@ FIXTURES = {
     "clip_vitb32_b8": lambda: gen_clip("clip_vitb32_b8", synth.VITB32, b=8, seed=1),
     "clip_r50_tiny": lambda: gen_clip("clip_r50_tiny", synth.R50_TINY, b=3, seed=9),
     "declip_tiny": lambda: gen_declip("declip_tiny", synth.TINY, b=6, seed=2),
+    "declip_r50_tiny": lambda: gen_declip("declip_r50_tiny", synth.R50_TINY, b=4, seed=12),
     "slip_tiny": lambda: gen_slip("slip_tiny", synth.TINY, b=5, seed=4),
     "filip_small": lambda: gen_filip("filip_small", synth.FILIP_SMALL, b=5, seed=6),
     "defilip_small": lambda: gen_defilip("defilip_small", synth.FILIP_SMALL, b=4, seed=7),

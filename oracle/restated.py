@@ -166,6 +166,13 @@ def resnet_tower(images, sd, cfg, prefix="visual.", return_dense=False, training
     return (out, dense) if return_dense else out
 
 
+def image_tower(images, sd, cfg, **kw):
+    """the image encoder the config names: visual_transformer.py (default) or modified_resnet.py (cfg["vision"] == "resnet")."""
+    if cfg.get("vision") == "resnet":
+        return resnet_tower(images, sd, cfg, **kw)
+    return vision_tower(images, sd, cfg, **kw)
+
+
 def image_prep_u8(src, out_hw, crop_xy=None, flip=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
     """uint8 HWC -> normalised fp32 CHW: crop window (x0, y0), horizontal flip, ToTensor (x / 255), Normalize ((x - mean) / std)
     -- the tail of the reference's input pipelines (data/transforms.py + torchvision ToTensor / Normalize as composed in
@@ -338,8 +345,8 @@ def declip_step_loss(images, ids_masked, labels, ids_aug, sd, cfg, bank, bank_pt
     images [b,6,H,W]; returns total loss, parts dict, updated (bank, ptr)."""
     b = images.shape[0]
     tp = cfg.get("text_prefix", "encode_text.")
-    img1 = vision_tower(images[:, 0:3], sd, cfg)
-    img2 = vision_tower(images[:, 3:6], sd, cfg)
+    img1 = image_tower(images[:, 0:3], sd, cfg)
+    img2 = image_tower(images[:, 3:6], sd, cfg)
     txt, words = text_tower(ids_masked, sd, cfg, prefix=tp, return_dense=True)
     txt_aug = text_tower(ids_aug, sd, cfg, prefix=tp)
     z1, z2 = projection_mlp(img1, sd, "projector."), projection_mlp(img2, sd, "projector.")

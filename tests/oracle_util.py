@@ -72,9 +72,10 @@ def check_grad_digests(golden_grads, grads, rtol, atol_frac=1e-4, only=None):
 
 def oracle_declip_run(cfg, b, seed=0, nn_size=256):
     sd = synth.synth_state(synth.declip_shapes(cfg), seed=seed)
+    frozen = set() if cfg.get("vision") == "resnet" else {"visual.conv1.weight"}
     for k, v in sd.items():
         if v.dtype.is_floating_point and "running_" not in k:
-            v.requires_grad_(k != "visual.conv1.weight")
+            v.requires_grad_(k not in frozen)
     images = synth.synth_images(b, views=2, res=cfg["res"], seed=seed)
     ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
     ids_aug = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"])

@@ -226,6 +226,55 @@ def test_resnet_flat_adamw_steps_match_torch_adamw(mocked_engine):
         assert float((a - fresh[k]).abs().max()) > 0, k                                      # and it did move
 
 
+def test_resnet_views_and_dense_paths(mocked_engine):
+    """ModifiedResNet.forward(n_views=2, return_dense=True) on channel-stacked views == the two views encoded one after the
+    other (per-view BatchNorm statistics, running buffers updated twice, gradients accumulated over both passes), and the
+    dense output [b, 49, C] carries gradient (FILIP-R50 / DeFILIP surface, modified_resnet.py:206)."""
+    from declip_amd import synth
+    from declip_amd.testing import build_clip
+    cfg, b, seed = synth.R50_TINY, 2, 5
+    images = synth.synth_images(b, views=2, res=cfg["res"], seed=seed)
+    g = torch.Generator().manual_seed(0)
+
+    def weights_like(t):
+        return torch.randn(t.shape, generator=g)
+
+    def run(two_calls):
+        model = build_clip(cfg, dtype="fp32", seed=seed, device="cpu")
+        vis = model.visual
+        model._flat_store.begin_step()
+        if two_calls:
+            o1, d1 = vis(images, return_dense=True, channel_offset=0)
+            o2, d2 = vis(images, return_dense=True, channel_offset=3)
+            out, dense = torch.cat([o1, o2]), torch.cat([d1, d2])
+        else:
+            out, dense = vis(images, return_dense=True, n_views=2)
+        return model, out, dense
+
+    ma, oa, da = run(False)
+    mb, ob, db = run(True)
+    assert oa.shape == (2 * b, cfg["embed_dim"]) and da.shape == (2 * b, 49, cfg["r_width"] * 32)
+    assert torch.equal(oa, ob) and torch.equal(da, db)
+    w_o, w_d = weights_like(oa), weights_like(da)
+    for m, o, d in ((ma, oa, da), (mb, ob, db)):
+        ((o * w_o).sum() + (d.float() * w_d).sum()).backward()
+    ga = {n: p.grad for n, p in ma.named_parameters() if n.startswith("visual.") and p.grad is not None}
+    gb = {n: p.grad for n, p in mb.named_parameters() if n.startswith("visual.") and p.grad is not None}
+    assert set(ga) == set(gb) and "visual.conv1.weight" in ga and "visual.attnpool.positional_embedding" in ga
+    for n in ga:
+        assert float((ga[n] - gb[n]).abs().max()) <= 1e-5 * float(gb[n].abs().max() + 1e-12), n
+    ba, bb = dict(ma.named_buffers()), dict(mb.named_buffers())
+    assert int(ba["visual.bn1.num_batches_tracked"]) == 2
+    for n in ba:
+        assert torch.equal(ba[n], bb[n]), n
+    # the dense gradient alone reaches the trunk but not the attention pool
+    mc, oc, dc = run(False)
+    (dc.float() * w_d).sum().backward()
+    gc_ = {n: p.grad for n, p in mc.named_parameters()}
+    assert float(gc_["visual.layer4.0.conv3.weight"].abs().max()) > 0
+    assert float(gc_["visual.attnpool.q_proj.weight"].abs().max()) == 0.0
+
+
 def test_declip_engine_composition_matches_golden(mocked_engine):
     """DECLIP model + solver loss composition on the engine (mock kernels) vs the reference golden."""
     from declip_amd.heads import SimsiamLoss
@@ -251,6 +300,40 @@ def test_declip_engine_composition_matches_golden(mocked_engine):
     assert abs(float(model.nn_replacer_text.bank.double().sum()) - g["bank_sum"]) <= 1e-3
     assert torch.allclose(model.projector.bn1.running_mean, g["bn1_running_mean"], rtol=1e-4, atol=1e-6)
     assert torch.allclose(model.projector.bn1.running_var, g["bn1_running_var"], rtol=1e-4, atol=1e-6)
+
+
+def test_declip_r50_engine_composition_matches_golden(mocked_engine):
+    """declip_res50 surface: DECLIP on the ModifiedResNet tower (two views, per-view BatchNorm statistics, tower kernels on
+    the host emulation) + the solver's loss composition vs the reference golden."""
+    from declip_amd.heads import SimsiamLoss
+    from declip_amd.loss import ClipInfoCELoss, NTXentLoss
+    from declip_amd.steps import declip_loss
+    from declip_amd.testing import build_declip, declip_batch
+    g = load_golden("declip_r50_tiny")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    model = build_declip(cfg, dtype="fp32", seed=seed, nn_size=g["nn_size"], device="cpu")
+    batch = declip_batch(cfg, b, seed=seed, device="cpu")
+    out = declip_loss(model, batch, ClipInfoCELoss(), SimsiamLoss(), NTXentLoss(b))
+    out["loss"].backward()
+    assert abs(float(out["loss"].detach()) - g["loss"]) <= 1e-4 * abs(g["loss"])
+    for k in ("clip", "nn", "simsiam", "mlm", "convirt"):
+        assert abs(float(out["parts"][k]) - g["parts"][k]) <= 2e-4 * max(1.0, abs(g["parts"][k])), k
+    li1 = out["outputs"]["logits"][0].materialize().detach()
+    assert float((li1 - g["logits_i1"]).abs().max()) <= 1e-4 * float(g["logits_i1"].abs().max())
+    grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+    is_bn = lambda n: ".bn" in n or "downsample.1." in n       # noqa: E731
+    check_grad_digests(g["grads"], grads, rtol=3e-3, only=lambda n: not is_bn(n))
+    for n, ref in g["grads"].items():
+        if is_bn(n) and ref is not None and ref["norm"] > 1e-6:
+            assert abs(float(grads[n].double().norm()) - ref["norm"]) <= 5e-2 * ref["norm"], n
+    bufs = dict(model.named_buffers())
+    for k, v in g["bn_buffers"].items():
+        if k.endswith("num_batches_tracked"):
+            assert int(bufs[k]) == int(v) == 2
+        else:
+            assert float((bufs[k] - v).abs().max()) <= 1e-4 * max(1.0, float(v.abs().max())), k
 
 
 def test_slip_engine_composition_matches_golden(mocked_engine):

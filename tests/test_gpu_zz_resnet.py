@@ -242,3 +242,25 @@ def test_clip_r50_batch32_step_trains(dtype):
         opt.step()
         losses.append(float(loss))
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+
+
+def test_declip_r50_fp32_matches_reference_golden():
+    """declip_res50 (model/declip.py:339-346): both views through the ModifiedResNet, full DeCLIP loss composition."""
+    from declip_amd.heads import SimsiamLoss
+    from declip_amd.loss import ClipInfoCELoss, NTXentLoss
+    from declip_amd.steps import declip_loss
+    from declip_amd.testing import build_declip, declip_batch
+    g = load_golden("declip_r50_tiny")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_declip(cfg, dtype="fp32", seed=seed, nn_size=g["nn_size"])
+    batch = declip_batch(cfg, b, seed=seed)
+    out = declip_loss(model, batch, ClipInfoCELoss(), SimsiamLoss(), NTXentLoss(b))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"].detach()) - g["loss"]) <= 1e-3 * abs(g["loss"])
+    for k in ("clip", "nn", "simsiam", "mlm", "convirt"):
+        assert abs(float(out["parts"][k]) - g["parts"][k]) <= 1e-3 * max(1.0, abs(g["parts"][k])), k
+    grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
+    check_grad_digests(g["grads"], grads, rtol=5e-3, only=lambda n: not _is_bn(n))
+    bufs = dict(model.named_buffers())
+    assert int(bufs["visual.bn2.num_batches_tracked"]) == 2
