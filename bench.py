@@ -20,19 +20,22 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 GFLOP_PER_PAIR = 43.87          # CLIP ViT-B/32 fwd+bwd, SURVEY.md s8(d) / BASELINE.md s3
+GFLOP_PER_PAIR_R50 = 53.9       # CLIP ResNet-50 (configs[0]): trunk 10.73 + attention pool 1.28 + text 5.96 fwd, x3 minus the stem's dX
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(batch=16, steps=2):
+def cpu_baseline(batch=16, steps=2, cfg=None, label="CLIP ViT-B/32"):
     """The oracle restatement (kind "port") of the same step on the host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from declip_amd import synth
     from oracle import restated
-    cfg = synth.VITB32
+    cfg = cfg or synth.VITB32
     threads = torch.get_num_threads()
     sd = synth.synth_state(synth.clip_shapes(cfg), seed=0)
+    frozen = set() if cfg.get("vision") == "resnet" else {"visual.conv1.weight"}
     for k, v in sd.items():
-        v.requires_grad_(k != "visual.conv1.weight")
+        if v.dtype.is_floating_point and "running_" not in k:
+            v.requires_grad_(k not in frozen)
     opt = torch.optim.AdamW([v for v in sd.values() if v.requires_grad], lr=1e-4, betas=(0.9, 0.98), weight_decay=0.1)
     images = synth.synth_images(batch, seed=0)
     ids = synth.synth_tokens(batch, seed=0)
@@ -46,7 +49,7 @@ def cpu_baseline(batch=16, steps=2):
         times.append(time.time() - t0)
     dt = sorted(times[1:])[len(times[1:]) // 2]
     return dict(value=round(batch / dt, 3), unit="pairs/s", cores=threads, kind="port",
-                sample="CLIP ViT-B/32 fp32 fwd+bwd+AdamW, batch %d, 1 warm-up + %d timed steps (median), torch CPU oracle restatement" % (batch, steps))
+                sample="%s fp32 fwd+bwd+AdamW, batch %d, 1 warm-up + %d timed steps (median), torch CPU oracle restatement" % (label, batch, steps))
 
 
 def main():
@@ -54,9 +57,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 512; clip_r50: 32, the configs[0] batch)")
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--model", default="clip", choices=["clip", "declip"], help="clip = BASELINE.json metric; declip = configs[2] variant")
+    ap.add_argument("--model", default="clip", choices=["clip", "declip", "clip_r50"],
+                    help="clip = BASELINE.json metric; declip = configs[2] variant; clip_r50 = configs[0] (CLIP ResNet-50, batch 32; add --dtype fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -76,10 +80,10 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    cfg = synth.VITB32
-    b = args.batch
+    cfg = synth.R50 if args.model == "clip_r50" else synth.VITB32
+    b = args.batch if args.batch is not None else (32 if args.model == "clip_r50" else 512)
     crit = ClipInfoCELoss()
-    if args.model == "clip":
+    if args.model in ("clip", "clip_r50"):
         model = build_clip(cfg, dtype=args.dtype, use_allgather=(world > 1), seed=0, load_synth=False)
         images = synth.synth_images(b, seed=rank).to(dev)
         ids = synth.synth_tokens(b, seed=rank).to(dev)
@@ -95,7 +99,7 @@ def main():
 
     def step():
         opt.zero_grad()
-        if args.model == "clip":
+        if args.model in ("clip", "clip_r50"):
             li, lt = wrapped(batch)
             loss, _ = crit(li, lt)
             loss = loss / world                  # clip_solver.py:418
@@ -220,24 +224,28 @@ def main():
                         launches_per_step=len(records) // nprof, gemm_ms_per_step=round(ms / nprof, 3),
                         note="kernel durations measured with both towers on one stream (no co-running launches)",
                         gemm_gflop_per_step=round(flops / nprof / 1e9, 1),
-                        step_mfma_frac=round(pairs_per_s * (GFLOP_PER_PAIR if args.model == "clip" else 89.9) / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
+                        step_mfma_frac=round(pairs_per_s * {"clip": GFLOP_PER_PAIR, "clip_r50": GFLOP_PER_PAIR_R50}.get(args.model, 89.9) / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
 
-    gflop_pair = GFLOP_PER_PAIR if args.model == "clip" else 89.9
-    name = "CLIP" if args.model == "clip" else "DeCLIP"
-    out = dict(metric="image-text pairs/sec %s ViT-B/32" % name, value=round(pairs_per_s, 2), unit="pairs/s", n_gpus=world,
+    name = {"clip": "CLIP ViT-B/32", "declip": "DeCLIP ViT-B/32", "clip_r50": "CLIP ResNet-50"}[args.model]
+    workloads = {
+        "clip": "CLIP ViT-B/32 + 12-layer text transformer, InfoNCE, fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d, 224x224 images, "
+                "77-token captions, random-init weights" % b,
+        "declip": "DeCLIP ViT-B/32 (2 image views + masked/augmented text, 8+4 InfoNCE pairs, SimSiam, NN bank 65536, MLM), "
+                  "fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d" % b,
+        "clip_r50": "CLIP ModifiedResNet-50 (per-rank BatchNorm, attention pool) + 12-layer text transformer, InfoNCE, "
+                    "fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d (BASELINE.json configs[0]), 224x224 images, 77-token captions" % b,
+    }
+    out = dict(metric="image-text pairs/sec %s" % name, value=round(pairs_per_s, 2), unit="pairs/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
-               config=dict(workload=("CLIP ViT-B/32 + 12-layer text transformer, InfoNCE, fwd+bwd+grad-allreduce+AdamW; "
-                                     "per-GPU batch %d, 224x224 images, 77-token captions, random-init weights" % b) if args.model == "clip" else
-                                    ("DeCLIP ViT-B/32 (2 image views + masked/augmented text, 8+4 InfoNCE pairs, SimSiam, NN bank 65536, MLM), "
-                                     "fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d" % b),
+               config=dict(workload=workloads[args.model],
                            global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world,
                            tower_streams=1 + len(model.__dict__["_flat_store"].side_streams)),
                loss=round(float(loss.detach()) * world, 5))
     if roofline is not None:
         out["roofline"] = roofline
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(batch=8, cfg=synth.R50, label="CLIP ResNet-50") if args.model == "clip_r50" else cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
