@@ -90,6 +90,38 @@ def test_solver_trains_saves_and_resumes(mocked, tmp_path, kind):
     assert s2.state["last_iter"] == 6
 
 
+def test_solver_clip_res50_trains_saves_and_evaluates(mocked, tmp_path):
+    """`type: clip_res50` through model_entry and the solver loop (yfcc15m_r50_clip/config.yaml keys; a narrow 4-block
+    ModifiedResNet so that the host-emulated kernels stay fast): BatchNorm parameters land in bn_w / bn_b, the BatchNorm buffers
+    travel through the checkpoint, zero-shot evaluate runs the tower in eval mode and restores training mode."""
+    import yaml
+    from declip_amd.solver import AttrDict, ClsSolver, param_groups
+    cfg = _config("clip", max_iter=4)
+    cfg["model"]["type"] = "clip_res50"
+    cfg["model"]["kwargs"]["image_encode"] = dict(embed_dim=32, layers=[1, 1, 1, 1], width=16, heads=8, bn_group_size=32,
+                                                  bn_sync_stats=True, use_sync_bn=False)
+    cfg["data"].update(batch_size=2, input_size=224)
+    cfg["data"]["test"] = dict(type="synthetic", label_num=4, prompts_num=2, batch_size=2, batches=1)
+    cfg["saver"].update(save_freq=2)
+    cfgp = tmp_path / "config.yaml"
+    cfgp.write_text(yaml.safe_dump(cfg))
+    s = ClsSolver(str(cfgp), device="cpu")
+    model = s.model.module
+    groups = param_groups(model, AttrDict(cfg).optimizer)
+    names = {id(p): n for n, p in model.named_parameters()}
+    normal = {names[id(p)] for p in groups[0]["params"]}
+    assert "visual.layer1.0.conv2.weight" in normal and "visual.attnpool.positional_embedding" in normal
+    assert "visual.bn1.weight" not in normal and "visual.layer3.0.downsample.1.bias" not in normal
+    out = s.train(max_steps=2)
+    assert torch.isfinite(out["loss"]).all()
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoints", "ckpt.pth.tar"))
+    assert int(ck["model"]["module.visual.bn1.num_batches_tracked"]) == 2
+    assert float(ck["model"]["module.visual.layer4.0.bn3.running_mean"].abs().max()) > 0
+    m = s.evaluate()
+    assert m["count"] == 2 and 0.0 <= m["top1"] <= 100.0
+    assert s.model.training and int(model.visual.bn1.num_batches_tracked) == 2      # eval left the buffers alone
+
+
 def test_solver_zero_shot_evaluate_synthetic(mocked, tmp_path):
     """--evaluate on the built-in synthetic set: forward only, metrics are chance-level but well formed, mode restored."""
     import yaml
