@@ -213,8 +213,11 @@ def clip_forward(images, ids, sd, cfg, world=1, new_stats=None):
     [r*b,(r+1)*b).  Returns per-rank (logits_per_image, logits_per_text), each
     [b,B] (local rows x gathered columns, clip.py:136-141)."""
     if cfg.get("vision") == "resnet":
-        assert world == 1, "BatchNorm statistics are per rank (use_sync_bn False): emulate ranks one at a time"
-        img = resnet_tower(images, sd, cfg, new_stats=new_stats)
+        # BatchNorm statistics are per rank (use_sync_bn False): every emulated rank runs the tower on its own rows
+        # (new_stats receives rank 0's buffer updates)
+        bl = images.shape[0] // world
+        img = torch.cat([resnet_tower(images[r * bl:(r + 1) * bl], sd, cfg, new_stats=new_stats if r == 0 else None)
+                         for r in range(world)], dim=0)
     else:
         img = vision_tower(images, sd, cfg)
     txt = text_tower(ids, sd, cfg, prefix=cfg.get("text_prefix", "encode_text."))

@@ -106,6 +106,60 @@ def _w_clip(rank, world, port, out):
         out.put("ok")
 
 
+def _w_clip_r50(rank, world, port, out):
+    """Data-parallel CLIP-R50 step (ModifiedResNet tower on the host-emulated kernels, per-rank BatchNorm statistics, flat
+    bucket reducer fed by resnet_engine's grads_ready calls) against the golden of TWO reference ranks; the BatchNorm
+    buffers stay per rank (rank 0's are compared)."""
+    _init(rank, world, port)
+    import cpu_ops_mock
+    from declip_amd import dist as dd
+    from declip_amd import engine, ops, synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.testing import build_clip
+    from oracle_util import check_grad_digests, load_golden
+    for name in dir(cpu_ops_mock):
+        if not name.startswith("_") and callable(getattr(cpu_ops_mock, name)) and hasattr(ops, name):
+            setattr(ops, name, getattr(cpu_ops_mock, name))
+    engine._require_gpu = lambda p, name: None
+    g = load_golden("clip_r50_tiny_w2")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_clip(cfg, dtype="fp32", use_allgather=True, seed=seed, device="cpu")
+    wrapped = dd.DistModule(model, sync=False, bucket_bytes=1 << 18)      # several buckets inside the tower's backward
+    B = b * world
+    images = synth.synth_images(B, res=cfg["res"], seed=seed)[rank * b:(rank + 1) * b]
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])[rank * b:(rank + 1) * b]
+    launched = []
+    red = model._flat_store.reducer
+    orig_launch = red._launch
+    red._launch = lambda lo, hi: (launched.append((lo, hi)), orig_launch(lo, hi))[1]
+    li, lt = wrapped({"images": images, "captions": ids})
+    loss, labels = ClipInfoCELoss()(li, lt)
+    loss = loss / world
+    loss.backward()
+    wrapped.sync_gradients()
+    total = loss.detach().clone()
+    torch.distributed.all_reduce(total)
+    # every element of the flat gradient buffer was reduced exactly once
+    spans = sorted(x for x in launched if x[1] > x[0])
+    assert spans[0][0] == 0 and spans[-1][1] == model._flat_store.total and len(spans) >= 3
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 == b0, (spans,)
+    if rank == 0:
+        assert abs(float(total) - g["loss"]) <= 1e-4 * abs(g["loss"])
+        assert float((li.materialize().detach() - g["logits_i"]).abs().max()) <= 1e-4 * float(g["logits_i"].abs().max())
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+        is_bn = lambda n: ".bn" in n or "downsample.1." in n       # noqa: E731
+        check_grad_digests(g["grads"], grads, rtol=3e-3, only=lambda n: not is_bn(n))
+        for n, ref in g["grads"].items():
+            if is_bn(n) and ref is not None and ref["norm"] > 1e-6:
+                assert abs(float(grads[n].double().norm()) - ref["norm"]) <= 5e-2 * ref["norm"], n
+        bufs = dict(model.named_buffers())
+        for k, v in g["bn_buffers"].items():
+            if not k.endswith("num_batches_tracked"):
+                assert float((bufs[k] - v).abs().max()) <= 1e-4 * max(1.0, float(v.abs().max())), k
+        out.put("ok")
+
+
 def _w_zero_shot(rank, world, port, out):
     """Zero-shot evaluate sharded over two ranks: each rank classifies its own batches, the hit counters are summed, and
     every rank reports the metrics of the whole set (== a one-rank run over all batches)."""
@@ -140,7 +194,7 @@ def _w_zero_shot(rank, world, port, out):
         out.put("ok")
 
 
-@pytest.mark.parametrize("fn", [_w_gather, _w_reducer, _w_clip, _w_zero_shot])
+@pytest.mark.parametrize("fn", [_w_gather, _w_reducer, _w_clip, _w_clip_r50, _w_zero_shot])
 def test_world2(fn):
     port = _free_port()
     ctx = mp.get_context("spawn")
