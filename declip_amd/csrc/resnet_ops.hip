@@ -383,6 +383,133 @@ extern "C" int dh_bn2d_bwd(int dtype, const void* dy, const void* x, const void*
   return DH_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ BatchNorm2d across ranks
+// Synchronised BatchNorm (the `use_sync_bn: True` branch of modified_resnet.py:118-140; semantics of
+// torch.nn.SyncBatchNorm): the statistics of a layer are per-channel SUMS, so the exchange between ranks is one SUM
+// all-reduce of [2C + 1] doubles (sums, sums of squares / of dy*xhat, row count) between the reduction and the apply pass.
+// The three stages of dh_bn2d_fwd / dh_bn2d_bwd as separate entry points; the row count travels in DEVICE memory (no host
+// round trip between the collective and the apply pass).
+__global__ __launch_bounds__(256) void bn2d_sums_finalize_kernel(const float* __restrict__ partial, int slabs, long R, int C,
+                                                                 double* __restrict__ sums) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0) sums[2 * C] = (double)R;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < slabs; ++b) { s += (double)partial[(long)b * 2 * C + c]; q += (double)partial[(long)b * 2 * C + C + c]; }
+  sums[c] = s;
+  sums[C + c] = q;
+}
+
+__global__ __launch_bounds__(256) void bn2d_stats_from_sums_kernel(const double* __restrict__ sums, int C, float eps, float momentum,
+                                                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                                   float* __restrict__ run_mean, float* __restrict__ run_var) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double n = sums[2 * C];
+  const double m = sums[c] / n;
+  double var = sums[C + c] / n - m * m;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)m;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (run_mean) {
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    run_mean[c] = (float)((1.0 - (double)momentum) * (double)run_mean[c] + (double)momentum * m);
+    run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * unbiased);
+  }
+}
+
+// dw / db take the LOCAL sums (the parameter gradients are summed over ranks by the gradient all-reduce); the two means of
+// the dx formula are GLOBAL sums over the global row count
+__global__ __launch_bounds__(256) void bn2d_bwd_from_sums_kernel(const double* __restrict__ local, const double* __restrict__ global,
+                                                                 int C, float* __restrict__ dw, float* __restrict__ db,
+                                                                 float* __restrict__ m12) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  db[c] += (float)local[c];
+  dw[c] += (float)local[C + c];
+  const double n = global[2 * C];
+  m12[c] = (float)(global[c] / n);
+  m12[C + c] = (float)(global[C + c] / n);
+}
+
+extern "C" int dh_bn2d_sums(int dtype, int mode, const void* x, const void* dy, const void* y, const float* mean, const float* invstd,
+                            int relu, int rows, int C, double* sums, void* ws, int64_t ws_bytes, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(x && sums && rows > 0 && C > 0 && (mode == 0 || mode == 1), "dh_bn2d_sums: bad args");
+  DH_REQUIRE(mode == 0 || (dy && mean && invstd && (!relu || y)), "dh_bn2d_sums: mode 1 needs dy, mean, invstd (and y with relu)");
+  DH_REQUIRE(C % 8 == 0, "dh_bn2d_sums: C must be a multiple of 8 (C=%d)", C);
+  DH_REQUIRE(dtype == DH_F32 || dtype == DH_BF16, "dh_bn2d_sums: bad dtype");
+  DH_REQUIRE(ws && ws_bytes >= dh_bn2d_ws_bytes(rows, C), "dh_bn2d_sums: workspace too small");
+  const long R = rows;
+  int cgb, gx, slabs, rps;
+  bn_geometry(R, C, &cgb, &gx, &slabs, &rps);
+  float* partial = (float*)ws;
+  if (mode == 0) {
+    if (dtype == DH_BF16)
+      hipLaunchKernelGGL((bn2d_reduce_kernel<bf16_t, 0>), dim3(gx, slabs), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr,
+                         (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, R, C, cgb, rps, 0);
+    else
+      hipLaunchKernelGGL((bn2d_reduce_kernel<float, 0>), dim3(gx, slabs), dim3(256), 0, st, (const float*)x, (const float*)nullptr,
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, R, C, cgb, rps, 0);
+  } else {
+    if (dtype == DH_BF16)
+      hipLaunchKernelGGL((bn2d_reduce_kernel<bf16_t, 1>), dim3(gx, slabs), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y,
+                         mean, invstd, partial, R, C, cgb, rps, relu);
+    else
+      hipLaunchKernelGGL((bn2d_reduce_kernel<float, 1>), dim3(gx, slabs), dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y,
+                         mean, invstd, partial, R, C, cgb, rps, relu);
+  }
+  DH_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn2d_sums_finalize_kernel, dim3(dh_cdiv(C + 1, 256)), dim3(256), 0, st, (const float*)partial, slabs, R, C, sums);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_bn2d_fwd_apply(int dtype, const void* x, const void* residual, const float* w, const float* b, const double* sums,
+                                 void* y, float* save_mean, float* save_invstd, float* running_mean, float* running_var, int rows, int C,
+                                 float eps, float momentum, int relu, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(x && w && b && sums && y && save_mean && save_invstd && rows > 0 && C > 0, "dh_bn2d_fwd_apply: bad args");
+  DH_REQUIRE(C % 8 == 0, "dh_bn2d_fwd_apply: C must be a multiple of 8 (C=%d)", C);
+  DH_REQUIRE(dtype == DH_F32 || dtype == DH_BF16, "dh_bn2d_fwd_apply: bad dtype");
+  DH_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "dh_bn2d_fwd_apply: running_mean / running_var go together");
+  hipLaunchKernelGGL(bn2d_stats_from_sums_kernel, dim3(dh_cdiv(C, 256)), dim3(256), 0, st, sums, C, eps, momentum, save_mean, save_invstd,
+                     running_mean, running_var);
+  DH_CHECK_LAUNCH();
+  const long R = rows, ntask = R * (C / 8);
+  if (dtype == DH_BF16)
+    hipLaunchKernelGGL(bn2d_apply_kernel<bf16_t>, dim3(grid_for(ntask)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, w, b,
+                       (const float*)save_mean, (const float*)save_invstd, (bf16_t*)y, R, C, relu);
+  else
+    hipLaunchKernelGGL(bn2d_apply_kernel<float>, dim3(grid_for(ntask)), dim3(256), 0, st, (const float*)x, (const float*)residual, w, b,
+                       (const float*)save_mean, (const float*)save_invstd, (float*)y, R, C, relu);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_bn2d_bwd_apply(int dtype, const void* dy, const void* x, const void* y, const float* w, const float* save_mean,
+                                 const float* save_invstd, const double* sums_local, const double* sums_global, void* dx, void* dres,
+                                 float* dw, float* db, int rows, int C, int relu, void* ws, int64_t ws_bytes, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(dy && x && w && save_mean && save_invstd && sums_local && sums_global && dx && dw && db && (!relu || y) && rows > 0 && C > 0,
+             "dh_bn2d_bwd_apply: bad args");
+  DH_REQUIRE(C % 8 == 0, "dh_bn2d_bwd_apply: C must be a multiple of 8 (C=%d)", C);
+  DH_REQUIRE(dtype == DH_F32 || dtype == DH_BF16, "dh_bn2d_bwd_apply: bad dtype");
+  DH_REQUIRE(ws && ws_bytes >= (int64_t)sizeof(float) * 2 * C, "dh_bn2d_bwd_apply: workspace too small (2*C floats)");
+  float* m12 = (float*)ws;
+  hipLaunchKernelGGL(bn2d_bwd_from_sums_kernel, dim3(dh_cdiv(C, 256)), dim3(256), 0, st, sums_local, sums_global, C, dw, db, m12);
+  DH_CHECK_LAUNCH();
+  const long R = rows, ntask = R * (C / 8);
+  if (dtype == DH_BF16)
+    hipLaunchKernelGGL(bn2d_bwd_apply_kernel<bf16_t>, dim3(grid_for(ntask)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y,
+                       w, save_mean, save_invstd, (const float*)m12, (bf16_t*)dx, (bf16_t*)dres, R, C, relu);
+  else
+    hipLaunchKernelGGL(bn2d_bwd_apply_kernel<float>, dim3(grid_for(ntask)), dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y,
+                       w, save_mean, save_invstd, (const float*)m12, (float*)dx, (float*)dres, R, C, relu);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ average pool
 // nn.AvgPool2d(k) on NHWC (modified_resnet.py:26,36,149): y[n, oy, ox, :] = mean of the k x k window.
 template <typename T>

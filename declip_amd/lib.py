@@ -76,6 +76,9 @@ _PROTOS = {
     "dh_bn2d_ws_bytes": (c_int64, [c_int, c_int]),
     "dh_bn2d_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_int, c_int, _P, c_int64, _P]),
     "dh_bn2d_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P]),
+    "dh_bn2d_sums": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_int64, _P]),
+    "dh_bn2d_fwd_apply": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_int, _P]),
+    "dh_bn2d_bwd_apply": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P]),
     "dh_avgpool_fwd": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_avgpool_bwd": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_attnpool_tokens_fwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -4,9 +4,9 @@ Same constructor arguments, module tree and state_dict names as the reference (c
 layer{1..4}.{i}.{conv1,bn1,conv2,bn2,conv3,bn3,downsample.{0,1}}, attnpool.{positional_embedding,k_proj,q_proj,v_proj,c_proj},
 fc), so model-zoo R50 checkpoints load and the solver's isinstance-based parameter groups (bn_w / bn_b, utils/misc.py:267-412)
 keep working.  None of the containers' own forward() is used: the arithmetic runs in declip_amd.resnet_engine on the HIP
-kernels.  BatchNorm is per-rank nn.BatchNorm2d (`use_sync_bn: False`, what the shipped R50 config selects,
-experiments/clip_experiments/yfcc15m/yfcc15m_r50_clip/config.yaml:9); the reference's SyncBN branch cannot be constructed
-(UnboundLocalError + missing link.new_group, modified_resnet.py:127-140) and is refused here.
+kernels.  BatchNorm is per-rank (`use_sync_bn: False`, what the shipped R50 config selects,
+experiments/clip_experiments/yfcc15m/yfcc15m_r50_clip/config.yaml:9) or synchronised over rank groups (`use_sync_bn: True` +
+`bn_group_size`, modified_resnet.py:118-140).
 """
 from collections import OrderedDict
 
@@ -66,9 +66,11 @@ class ModifiedResNet(_Tower):
     def __init__(self, layers, embed_dim, heads, input_resolution=224, width=64, bn_group_size=1, bn_var_mode=None,
                  bn_sync_stats=False, use_sync_bn=True):
         super().__init__()
-        if use_sync_bn:
-            raise DeclipHipError("use_sync_bn: True is not supported (the reference's own SyncBN branch cannot be constructed, "
-                                 "modified_resnet.py:127-140); the shipped R50 configs set use_sync_bn: False")
+        # use_sync_bn: True synchronises the batch statistics over groups of `bn_group_size` consecutive ranks
+        # (resnet_engine.bn_group; torch.nn.SyncBatchNorm semantics -- the reference's own branch, linklink's SyncBatchNorm2d with
+        # `bn_var_mode` / `bn_sync_stats`, cannot be constructed in the released tree, SURVEY.md s9 quirk 19, so those two
+        # arguments are accepted and ignored).  The parameter containers stay nn.BatchNorm2d: same state_dict keys.
+        self.use_sync_bn, self.bn_group_size = bool(use_sync_bn), int(bn_group_size)
         self.output_dim = embed_dim
         self.input_resolution = input_resolution
         self.conv1 = nn.Conv2d(3, width // 2, kernel_size=3, stride=2, padding=1, bias=False)

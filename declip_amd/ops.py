@@ -473,6 +473,43 @@ def bn2d_bwd(dy, x, y, w, mean, invstd, dw, db, relu, want_dres=False):
     return (dx, dres) if want_dres else dx
 
 
+def bn2d_sums(x, dy=None, y=None, mean=None, invstd=None, relu=False):
+    """[2C + 1] float64: per-channel (sum x, sum x^2) -- or, with dy, (sum dyr, sum dyr*xhat) -- and the row count."""
+    _contig(x, "x")
+    R, C = x.shape
+    sums = torch.empty(2 * C + 1, device=x.device, dtype=torch.float64)
+    lib = L.load()
+    ws = _bn_ws(x.device, lib.dh_bn2d_ws_bytes(R, C))
+    mode = 0 if dy is None else 1
+    check(lib.dh_bn2d_sums(dt(x), mode, ptr(x), ptr(dy), ptr(y) if relu else None, ptr(mean), ptr(invstd), int(relu), R, C, ptr(sums),
+                           ptr(ws), ws.numel() * 4, stream()), "dh_bn2d_sums")
+    return sums
+
+
+def bn2d_fwd_apply(x, w, b, sums, running_mean, running_var, relu, residual=None, eps=1e-5, momentum=0.1):
+    _contig(x, "x")
+    R, C = x.shape
+    assert sums.dtype == torch.float64 and sums.numel() == 2 * C + 1
+    y = torch.empty_like(x)
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+    check(L.load().dh_bn2d_fwd_apply(dt(x), ptr(x), ptr(residual), ptr(w), ptr(b), ptr(sums), ptr(y), ptr(mean), ptr(invstd),
+                                     ptr(running_mean), ptr(running_var), R, C, eps, momentum, int(relu), stream()), "dh_bn2d_fwd_apply")
+    return y, mean, invstd
+
+
+def bn2d_bwd_apply(dy, x, y, w, mean, invstd, sums_local, sums_global, dw, db, relu, want_dres=False):
+    _contig(dy, "dy"), _contig(x, "x")
+    R, C = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    ws = _bn_ws(x.device, 8 * C)
+    check(L.load().dh_bn2d_bwd_apply(dt(x), ptr(dy), ptr(x), ptr(y) if relu else None, ptr(w), ptr(mean), ptr(invstd), ptr(sums_local),
+                                     ptr(sums_global), ptr(dx), ptr(dres), ptr(dw), ptr(db), R, C, int(relu), ptr(ws), ws.numel() * 4,
+                                     stream()), "dh_bn2d_bwd_apply")
+    return (dx, dres) if want_dres else dx
+
+
 def avgpool_fwd(x, N, H, W, C, k):
     _contig(x, "x")
     assert x.shape == (N * H * W, C)

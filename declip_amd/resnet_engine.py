@@ -38,23 +38,68 @@ def _w_flipped(flat, conv):
     return w.flip(2, 3).permute(1, 0, 2, 3).reshape(w.shape[1], -1).contiguous()
 
 
+def bn_group(tower):
+    """Process group the tower's BatchNorm layers synchronise their statistics over, or None for per-rank statistics.
+    `use_sync_bn: True` with `bn_group_size: g` (modified_resnet.py:118-140, simple_group_split :98-105): consecutive ranks in
+    groups of g; g <= 1 is per-rank BatchNorm, g >= world the whole job.  Created once, collectively, at the first forward."""
+    from . import dist as dh_dist
+    import torch.distributed as tdist
+    if not getattr(tower, "use_sync_bn", False) or not dh_dist.is_dist():
+        return None
+    cached = tower.__dict__.get("_bn_group")
+    if cached is not None:
+        return cached[0]
+    world, rank, g = tdist.get_world_size(), tdist.get_rank(), int(tower.bn_group_size)
+    grp = None
+    if g >= world:
+        grp = tdist.group.WORLD
+    elif g > 1:
+        if world % g:
+            raise DeclipHipError("bn_group_size %d does not divide the world size %d" % (g, world))
+        for first in range(0, world, g):                          # every rank creates every group (collective call)
+            h = tdist.new_group(list(range(first, first + g)))
+            if first <= rank < first + g:
+                grp = h
+    tower.__dict__["_bn_group"] = (grp,)
+    return grp
+
+
 class _BN:
-    """forward + saved state of one BatchNorm2d (+ReLU (+residual)) application."""
+    """forward + saved state of one BatchNorm2d (+ReLU (+residual)) application; `group` != None synchronises the batch
+    statistics over that process group (one all-reduce of [2C+1] doubles per direction)."""
 
-    __slots__ = ("bn", "x", "y", "mean", "invstd", "relu", "has_res")
+    __slots__ = ("bn", "x", "y", "mean", "invstd", "relu", "has_res", "group")
 
-    def __init__(self, bn, x, relu, training, residual=None, update_stats=True):
+    def __init__(self, bn, x, relu, training, residual=None, group=None):
         self.bn, self.x, self.relu, self.has_res = bn, x, relu, residual is not None
-        rm = bn.running_mean if (not training or (update_stats and bn.track_running_stats)) else None
+        self.group = group if training else None
+        track = bn.track_running_stats and bn.running_mean is not None
+        rm = bn.running_mean if (not training or track) else None
         rv = bn.running_var if rm is not None else None
-        self.y, self.mean, self.invstd = ops.bn2d_fwd(x, bn.weight.data, bn.bias.data, rm, rv, relu, training, residual=residual,
-                                                      eps=bn.eps, momentum=0.1 if bn.momentum is None else bn.momentum)
-        if training and update_stats and bn.track_running_stats and bn.num_batches_tracked is not None:
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        if self.group is not None:
+            import torch.distributed as tdist
+            sums = ops.bn2d_sums(x)
+            tdist.all_reduce(sums, group=self.group)
+            self.y, self.mean, self.invstd = ops.bn2d_fwd_apply(x, bn.weight.data, bn.bias.data, sums, rm, rv, relu, residual=residual,
+                                                                eps=bn.eps, momentum=momentum)
+        else:
+            self.y, self.mean, self.invstd = ops.bn2d_fwd(x, bn.weight.data, bn.bias.data, rm, rv, relu, training, residual=residual,
+                                                          eps=bn.eps, momentum=momentum)
+        if training and track and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)                       # buffer bookkeeping (nn.BatchNorm2d.forward)
 
     def backward(self, flat, dy):
         g = flat.gview
-        return ops.bn2d_bwd(dy, self.x, self.y, self.bn.weight.data, self.mean, self.invstd, g(self.bn.weight), g(self.bn.bias),
+        bn = self.bn
+        if self.group is not None:
+            import torch.distributed as tdist
+            local = ops.bn2d_sums(self.x, dy=dy, y=self.y, mean=self.mean, invstd=self.invstd, relu=self.relu)
+            glob = local.clone()
+            tdist.all_reduce(glob, group=self.group)
+            return ops.bn2d_bwd_apply(dy, self.x, self.y, bn.weight.data, self.mean, self.invstd, local, glob, g(bn.weight), g(bn.bias),
+                                      self.relu, want_dres=self.has_res)
+        return ops.bn2d_bwd(dy, self.x, self.y, bn.weight.data, self.mean, self.invstd, g(bn.weight), g(bn.bias),
                             self.relu, want_dres=self.has_res)
 
 
@@ -91,13 +136,13 @@ def _conv1x1_bwd(flat, conv, dy, x, residual=None):
 class _Block:
     """One Bottleneck (modified_resnet.py:14-56): forward at construction, backward() returns the input gradient."""
 
-    def __init__(self, flat, blk, x, N, H, W, training):
+    def __init__(self, flat, blk, x, N, H, W, training, group=None):
         self.blk, self.x, self.geom = blk, x, (N, H, W)
         s = blk.stride
         self.c1 = ops.gemm(x, _w2d(flat, blk.conv1), ws=_ws(x))
-        self.b1 = _BN(blk.bn1, self.c1, True, training)
+        self.b1 = _BN(blk.bn1, self.c1, True, training, group=group)
         self.k2 = _Conv3(blk.conv2, self.b1.y, N, H, W)
-        self.b2 = _BN(blk.bn2, self.k2.forward(flat), True, training)
+        self.b2 = _BN(blk.bn2, self.k2.forward(flat), True, training, group=group)
         P = self.b2.y.shape[1]
         self.p2 = ops.avgpool_fwd(self.b2.y, N, H, W, P, s) if s > 1 else self.b2.y
         c3 = ops.gemm(self.p2, _w2d(flat, blk.conv3), ws=_ws(x))
@@ -106,9 +151,9 @@ class _Block:
         if blk.downsample is not None:
             self.px = ops.avgpool_fwd(x, N, H, W, x.shape[1], s) if s > 1 else x
             cd = ops.gemm(self.px, _w2d(flat, blk.downsample[1]), ws=_ws(x))
-            self.bd = _BN(blk.downsample[2], cd, False, training)
+            self.bd = _BN(blk.downsample[2], cd, False, training, group=group)
             identity = self.bd.y
-        self.b3 = _BN(blk.bn3, c3, True, training, residual=identity)
+        self.b3 = _BN(blk.bn3, c3, True, training, residual=identity, group=group)
         self.out = self.b3.y
         self.out_hw = (H // s, W // s)
 
@@ -184,15 +229,16 @@ def _forward_pass(flat, tower, images, c0, training):
     dtype = flat.act_dtype
     b, _, Hi, Wi = images.shape
     st = {"b": b}
+    grp = bn_group(tower) if training else None
     # ---- stem (modified_resnet.py:144-150,194-199): conv1 stride 2 on the image, conv2, conv3, avgpool(2)
     rows0, H, W = ops.conv_rows_image(images, c0, dtype, stride=2, pad=1)
     st["rows0"] = rows0
     c = ops.gemm(rows0, _stem_conv1_weight(flat, tower, dtype, images.device), ws=_ws(rows0))
-    s1 = _BN(tower.bn1, c, True, training)
+    s1 = _BN(tower.bn1, c, True, training, group=grp)
     k2 = _Conv3(tower.conv2, s1.y, b, H, W)
-    s2 = _BN(tower.bn2, k2.forward(flat), True, training)
+    s2 = _BN(tower.bn2, k2.forward(flat), True, training, group=grp)
     k3 = _Conv3(tower.conv3, s2.y, b, H, W)
-    s3 = _BN(tower.bn3, k3.forward(flat), True, training)
+    s3 = _BN(tower.bn3, k3.forward(flat), True, training, group=grp)
     x = ops.avgpool_fwd(s3.y, b, H, W, s3.y.shape[1], 2)
     st["stem"] = (s1, k2, s2, k3, s3, H, W)
     H, W = H // 2, W // 2
@@ -200,7 +246,7 @@ def _forward_pass(flat, tower, images, c0, training):
     blocks = []
     for layer in (tower.layer1, tower.layer2, tower.layer3, tower.layer4):
         for blk in layer:
-            bk = _Block(flat, blk, x, b, H, W, training)
+            bk = _Block(flat, blk, x, b, H, W, training, group=grp)
             x, (H, W) = bk.out, bk.out_hw
             blocks.append(bk)
     st["blocks"] = blocks

@@ -12,7 +12,8 @@ def build_clip(cfg, dtype="bf16", use_allgather=False, seed=0, logit_scale=None,
     if cfg.get("vision") == "resnet":
         from .model.resnet import ModifiedResNet
         vis = ModifiedResNet(layers=tuple(cfg["r_layers"]), embed_dim=cfg["embed_dim"], heads=cfg["r_heads"],
-                             input_resolution=cfg["res"], width=cfg["r_width"], use_sync_bn=False)
+                             input_resolution=cfg["res"], width=cfg["r_width"], use_sync_bn=cfg.get("r_sync_bn", False),
+                             bn_group_size=cfg.get("r_bn_group", 1))
     else:
         vis = VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
                                 layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"])
@@ -36,7 +37,8 @@ def build_declip(cfg, dtype="bf16", seed=0, nn_size=256, fused_loss=True, device
     if cfg.get("vision") == "resnet":
         from .model.resnet import ModifiedResNet
         vis = ModifiedResNet(layers=tuple(cfg["r_layers"]), embed_dim=cfg["embed_dim"], heads=cfg["r_heads"],
-                             input_resolution=cfg["res"], width=cfg["r_width"], use_sync_bn=False)
+                             input_resolution=cfg["res"], width=cfg["r_width"], use_sync_bn=cfg.get("r_sync_bn", False),
+                             bn_group_size=cfg.get("r_bn_group", 1))
     else:
         vis = VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
                                 layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"])

@@ -278,6 +278,22 @@ int dh_bn2d_fwd(int dtype, const void* x, const void* residual_or_null, const fl
 int dh_bn2d_bwd(int dtype, const void* dy, const void* x, const void* y_or_null, const float* w, const float* save_mean,
                 const float* save_invstd, void* dx, void* dres_or_null, float* dw, float* db, int rows, int C, int relu, void* ws,
                 int64_t ws_bytes, dh_stream_t stream);
+/* The same in three stages for BatchNorm synchronised across ranks (`use_sync_bn: True`, modified_resnet.py:118-140;
+ * torch.nn.SyncBatchNorm semantics): per-channel SUMS are what ranks exchange -- ONE SUM all-reduce of `sums`
+ * ([2*C + 1] doubles: mode 0 (sum x, sum x^2), mode 1 (sum dyr, sum dyr*xhat); last element = row count, kept in device
+ * memory so that nothing returns to the host between the collective and the apply pass).
+ *   forward : dh_bn2d_sums(mode 0) -> all-reduce(sums) -> dh_bn2d_fwd_apply (mean / invstd / running stats from the global
+ *             sums, then y = relu?(bn(x) (+ residual)));
+ *   backward: dh_bn2d_sums(mode 1) -> copy, all-reduce -> dh_bn2d_bwd_apply (dw, db += LOCAL sums -- the gradient all-reduce
+ *             sums them over ranks --, the two means of the dx formula from the GLOBAL sums). */
+int dh_bn2d_sums(int dtype, int mode, const void* x, const void* dy_or_null, const void* y_or_null, const float* save_mean_or_null,
+                 const float* save_invstd_or_null, int relu, int rows, int C, double* sums, void* ws, int64_t ws_bytes, dh_stream_t stream);
+int dh_bn2d_fwd_apply(int dtype, const void* x, const void* residual_or_null, const float* w, const float* b, const double* sums, void* y,
+                      float* save_mean, float* save_invstd, float* running_mean, float* running_var, int rows, int C, float eps,
+                      float momentum, int relu, dh_stream_t stream);
+int dh_bn2d_bwd_apply(int dtype, const void* dy, const void* x, const void* y_or_null, const float* w, const float* save_mean,
+                      const float* save_invstd, const double* sums_local, const double* sums_global, void* dx, void* dres_or_null,
+                      float* dw, float* db, int rows, int C, int relu, void* ws /* >= 2*C floats */, int64_t ws_bytes, dh_stream_t stream);
 /* nn.AvgPool2d(k) on NHWC (modified_resnet.py:26,36,149); H and W multiples of k. */
 int dh_avgpool_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, int k, dh_stream_t stream);
 int dh_avgpool_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int k, dh_stream_t stream);

@@ -357,10 +357,11 @@ def image_prep_u8(src, out_hw, crop_xy=None, flip=None, mean=(0.485, 0.456, 0.40
 # ---------------------------------------------------------------------------------------------
 from declip_amd import ops as _real_ops  # noqa: E402
 
-_RESNET_SYMS = ["dh_conv_rows", "dh_bn2d_ws_bytes", "dh_bn2d_fwd", "dh_bn2d_bwd", "dh_avgpool_fwd", "dh_avgpool_bwd",
-                "dh_attnpool_tokens_fwd", "dh_attnpool_tokens_bwd"]
-_RESNET_ORIG = {n: getattr(_real_ops, n) for n in ("conv_rows", "conv_rows_image", "bn2d_fwd", "bn2d_bwd", "avgpool_fwd", "avgpool_bwd",
-                                                   "attnpool_tokens_fwd", "attnpool_tokens_bwd")}
+_RESNET_SYMS = ["dh_conv_rows", "dh_bn2d_ws_bytes", "dh_bn2d_fwd", "dh_bn2d_bwd", "dh_bn2d_sums", "dh_bn2d_fwd_apply", "dh_bn2d_bwd_apply",
+                "dh_avgpool_fwd", "dh_avgpool_bwd", "dh_attnpool_tokens_fwd", "dh_attnpool_tokens_bwd"]
+_RESNET_ORIG = {n: getattr(_real_ops, n) for n in ("conv_rows", "conv_rows_image", "bn2d_fwd", "bn2d_bwd", "bn2d_sums", "bn2d_fwd_apply",
+                                                   "bn2d_bwd_apply", "avgpool_fwd", "avgpool_bwd", "attnpool_tokens_fwd",
+                                                   "attnpool_tokens_bwd")}
 
 
 def _emulated(name):
@@ -376,6 +377,9 @@ conv_rows = _emulated("conv_rows")
 conv_rows_image = _emulated("conv_rows_image")
 bn2d_fwd = _emulated("bn2d_fwd")
 bn2d_bwd = _emulated("bn2d_bwd")
+bn2d_sums = _emulated("bn2d_sums")
+bn2d_fwd_apply = _emulated("bn2d_fwd_apply")
+bn2d_bwd_apply = _emulated("bn2d_bwd_apply")
 avgpool_fwd = _emulated("avgpool_fwd")
 avgpool_bwd = _emulated("avgpool_bwd")
 attnpool_tokens_fwd = _emulated("attnpool_tokens_fwd")

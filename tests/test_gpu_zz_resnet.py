@@ -105,6 +105,45 @@ def test_bn2d_fwd_bwd(dtype, R, C, relu, res):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_bn2d_staged_across_two_shards(dtype):
+    """synchronised BatchNorm stages (dh_bn2d_sums / _fwd_apply / _bwd_apply): two shards of a batch with added sums ==
+    BatchNorm over the whole batch."""
+    from declip_amd import ops
+    torch.manual_seed(5)
+    R, C, cut = 5000, 256, 1777
+    x = (torch.randn(R, C) * 1.3 - 0.2).to(dtype)
+    res, dy = torch.randn(R, C).to(dtype), torch.randn(R, C).to(dtype)
+    w, b = 1 + 0.1 * torch.randn(C), 0.1 * torch.randn(C)
+    xr, wr, br = x.float().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    rm_ref, rv_ref = torch.zeros(C), torch.ones(C)
+    yr = F.relu(F.batch_norm(xr, rm_ref, rv_ref, wr, br, True, 0.1, 1e-5) + res.float())
+    wc, bc = w.cuda(), b.cuda()
+    shards = [tuple(t[a:z].contiguous().cuda() for t in (x, res, dy)) for a, z in ((0, cut), (cut, R))]
+    sums = [ops.bn2d_sums(xs) for xs, _, _ in shards]
+    total = sums[0] + sums[1]
+    assert float(total[-1]) == R
+    outs = []
+    for xs, rs, _ in shards:
+        rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+        outs.append(ops.bn2d_fwd_apply(xs, wc, bc, total, rm, rv, True, residual=rs))
+        close(rm, rm_ref, torch.float32), close(rv, rv_ref, torch.float32)
+    y = torch.cat([o[0] for o in outs])
+    close(y, yr, dtype)
+    mask = (y.float().cpu() > 0).float()
+    g_x, g_w, g_b = torch.autograd.grad(F.batch_norm(xr, None, None, wr, br, True, 0.1, 1e-5), (xr, wr, br), dy.float() * mask)
+    loc = [ops.bn2d_sums(xs, dy=ds, y=o[0], mean=o[1], invstd=o[2], relu=True) for (xs, _, ds), o in zip(shards, outs)]
+    glob = loc[0] + loc[1]
+    dxs, dws, dbs = [], [], []
+    for (xs, _, ds), o, lc in zip(shards, outs, loc):
+        dw, db = torch.zeros(C).cuda(), torch.zeros(C).cuda()
+        dx, _ = ops.bn2d_bwd_apply(ds, xs, o[0], wc, o[1], o[2], lc, glob, dw, db, True, want_dres=True)
+        dxs.append(dx), dws.append(dw), dbs.append(db)
+    close(torch.cat(dxs), g_x, dtype)
+    close(dws[0] + dws[1], g_w, dtype, float(g_w.abs().max()) * (10 if dtype == torch.float32 else 1))
+    close(dbs[0] + dbs[1], g_b, dtype, float(g_b.abs().max()) * (10 if dtype == torch.float32 else 1))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,H,W,C,k", [(2, 8, 12, 16, 2), (1, 6, 6, 8, 3), (4, 112, 112, 64, 2)])
 def test_avgpool(dtype, N, H, W, C, k):
     from declip_amd import ops

@@ -6,8 +6,8 @@ import torch.nn.functional as F
 
 from hipemu_util import emu_ops
 
-SYMS = ["dh_conv_rows", "dh_bn2d_ws_bytes", "dh_bn2d_fwd", "dh_bn2d_bwd", "dh_avgpool_fwd", "dh_avgpool_bwd",
-        "dh_attnpool_tokens_fwd", "dh_attnpool_tokens_bwd"]
+SYMS = ["dh_conv_rows", "dh_bn2d_ws_bytes", "dh_bn2d_fwd", "dh_bn2d_bwd", "dh_bn2d_sums", "dh_bn2d_fwd_apply", "dh_bn2d_bwd_apply",
+        "dh_avgpool_fwd", "dh_avgpool_bwd", "dh_attnpool_tokens_fwd", "dh_attnpool_tokens_bwd"]
 DTYPES = [torch.float32, torch.bfloat16]
 
 
@@ -97,6 +97,48 @@ def test_bn2d_fwd_bwd(dtype, R, C, relu, res):
         # eval mode: running statistics
         y_eval, _, _ = ops.bn2d_fwd(x, w, b, rm2, rv2, False, False)
         close(y_eval, F.batch_norm(x.float(), rm2, rv2, w, b, False, 0.1, 1e-5), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bn2d_staged_across_two_shards(dtype):
+    """the three-stage entry points of synchronised BatchNorm: two "ranks" hold the halves of a batch, their sums are added
+    (what the all-reduce does) -> identical to BatchNorm over the whole batch; dw / db are per-rank partial sums."""
+    torch.manual_seed(5)
+    R, C = 90, 24
+    x = (torch.randn(R, C) * 1.3 - 0.2).to(dtype)
+    res = torch.randn(R, C).to(dtype)
+    dy = torch.randn(R, C).to(dtype)
+    w, b = 1 + 0.1 * torch.randn(C), 0.1 * torch.randn(C)
+    cut = 37                                                       # uneven shards
+    xr, wr, br = x.float().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    rm_ref, rv_ref = torch.zeros(C), torch.ones(C)
+    yr = F.relu(F.batch_norm(xr, rm_ref, rv_ref, wr, br, True, 0.1, 1e-5) + res.float())
+    with emu_ops(["resnet_ops.hip"], SYMS) as ops:
+        shards = [(x[:cut].contiguous(), res[:cut].contiguous(), dy[:cut].contiguous()), (x[cut:].contiguous(), res[cut:].contiguous(), dy[cut:].contiguous())]
+        sums = [ops.bn2d_sums(xs) for xs, _, _ in shards]
+        assert float(sums[0][-1]) == cut and float(sums[1][-1]) == R - cut
+        total = sums[0] + sums[1]
+        outs, rms = [], []
+        for xs, rs, _ in shards:
+            rm, rv = torch.zeros(C), torch.ones(C)
+            outs.append(ops.bn2d_fwd_apply(xs, w, b, total, rm, rv, True, residual=rs))
+            rms.append((rm, rv))
+        y = torch.cat([o[0] for o in outs])
+        close(y, yr.detach(), dtype)
+        for rm, rv in rms:                                         # every rank ends with the global running statistics
+            close(rm, rm_ref, torch.float32), close(rv, rv_ref, torch.float32)
+        mask = (y.float() > 0).float()
+        g_x, g_w, g_b = torch.autograd.grad(F.batch_norm(xr, None, None, wr, br, True, 0.1, 1e-5), (xr, wr, br), dy.float() * mask)
+        ys = [o[0] for o in outs]
+        loc = [ops.bn2d_sums(xs, dy=ds, y=yy, mean=o[1], invstd=o[2], relu=True) for (xs, _, ds), yy, o in zip(shards, ys, outs)]
+        glob = loc[0] + loc[1]
+        dxs, dws, dbs = [], [], []
+        for (xs, _, ds), yy, o, lc in zip(shards, ys, outs, loc):
+            dw, db = torch.zeros(C), torch.zeros(C)
+            dx, dres = ops.bn2d_bwd_apply(ds, xs, yy, w, o[1], o[2], lc, glob, dw, db, True, want_dres=True)
+            dxs.append(dx), dws.append(dw), dbs.append(db)
+        close(torch.cat(dxs), g_x, dtype)
+        close(dws[0] + dws[1], g_w, dtype, float(g_w.abs().max())), close(dbs[0] + dbs[1], g_b, dtype, float(g_b.abs().max()))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
