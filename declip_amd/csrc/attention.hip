@@ -98,7 +98,7 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
   constexpr int NKS = (L16 + 31) / 32;          // 32-wide k-steps over the keys
   constexpr bool KTAIL = (L16 % 32) != 0;
   constexpr int TS = L16 + 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  DH_DYN_LDS_A16(unsigned char, smem_raw);
   bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);  // [L16][RS]
   bf16_t* Ks = Qs + L16 * RS;                        // [L16][RS]
   bf16_t* Vs = Ks + L16 * RS;                        // [L16][RS]
@@ -209,7 +209,7 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
   constexpr int NKS = (L16 + 31) / 32;
   constexpr bool KTAIL = (L16 % 32) != 0;
   constexpr int TS = L16 + 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  DH_DYN_LDS_A16(unsigned char, smem_raw);
   bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);  // [L16][RS] row-major tiles
   bf16_t* Ks = Qs + L16 * RS;
   bf16_t* Vs = Ks + L16 * RS;
@@ -367,7 +367,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                                float* __restrict__ lse, int L, int heads, int hd,
                                                                int causal, float scale) {
-  extern __shared__ float smf[];
+  DH_DYN_LDS(float, smf);
   const int hs = hd + 1;
   float* Q = smf; float* K = Q + L * hs; float* V = K + L * hs; float* S = V + L * hs;  // S [L][L+1]
   const int bh = blockIdx.x, bi = bh / heads, h = bh % heads;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const T* __restri
                                                                const T* __restrict__ dout, const float* __restrict__ lse,
                                                                T* __restrict__ dqkv, int L, int heads, int hd,
                                                                int causal, float scale) {
-  extern __shared__ float smf[];
+  DH_DYN_LDS(float, smf);
   const int hs = hd + 1, ls = L + 1;
   float* Q = smf; float* K = Q + L * hs; float* V = K + L * hs; float* G = V + L * hs;
   float* P = G + L * hs; float* dS = P + L * ls; float* Dq = dS + L * ls;

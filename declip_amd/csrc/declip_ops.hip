@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void cos_rows_bwd_kernel(const T* __restrict__
 constexpr int NN_RT = 32, NN_CT = 64, NN_KC = 32;
 __global__ __launch_bounds__(256) void nn_search_kernel(const float* __restrict__ Q, const float* __restrict__ bank, int rows,
                                                         int size, int D, int chunk, float* __restrict__ pval, int* __restrict__ pidx) {
-  extern __shared__ float sm[];
+  DH_DYN_LDS(float, sm);
   float* Xs = sm;                          // [32][D+1]
   float* Ys = Xs + NN_RT * (D + 1);        // [64][33]
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float* __restrict_
 constexpr int NM_QT = 64, NM_BT = 128, NM_KC = 32;
 __global__ __launch_bounds__(256) void nn_search_mfma_kernel(const float* __restrict__ Q, const float* __restrict__ bank, int rows,
                                                              int size, int D, int chunk, float* __restrict__ pval, int* __restrict__ pidx) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+  DH_DYN_LDS_A16(float, sm);
   const int QS = D + 4, BS = NM_KC + 4;                      // row strides: = 4 (mod 32) words -> conflict-free 16-byte reads
   float* Xs = sm;                                            // [64][QS]
   float* Ys = Xs + NM_QT * QS;                               // [128][BS]

@@ -14,6 +14,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 #define DH_WAVE 64
 
+// dynamic LDS of a kernel.  The host emulation build of the HBM-/LDS-level kernels (tests/hipemu, -DDH_HOST_EMU: HIP threads as
+// fibers, test infrastructure only) hands out one buffer per running block instead.
+#ifndef DH_HOST_EMU
+#define DH_DYN_LDS(T, name) extern __shared__ T name[]
+#define DH_DYN_LDS_A16(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+#else
+#define DH_DYN_LDS(T, name) T* name = (T*)emu_dyn_lds()
+#define DH_DYN_LDS_A16(T, name) T* name = (T*)emu_dyn_lds()
+#endif
+
 // ----------------------------------------------------------------------------- errors
 void dh_set_error(const char* fmt, ...);
 #define DH_FAIL(code, ...)        \

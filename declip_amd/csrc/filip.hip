@@ -13,7 +13,7 @@ constexpr int TOPK = 16;
 // block per sample; a [J][D], b [T][D] fp32 (already L2-normalised); J,T <= 128, D <= 1024
 __global__ __launch_bounds__(256) void filip_select_kernel(const float* __restrict__ A, const float* __restrict__ Bt, int J, int T, int D,
                                                            int64_t* __restrict__ idx_a, int64_t* __restrict__ idx_b) {
-  extern __shared__ float sm[];
+  DH_DYN_LDS(float, sm);
   float* sA = sm;            // [D] sum over image tokens
   float* sB = sA + D;        // [D] sum over text tokens
   float* sc = sB + D;        // [256] scores (image then text)

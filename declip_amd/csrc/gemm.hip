@@ -120,7 +120,7 @@ template <bool TA, bool TB, typename TO>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(const bf16_t* __restrict__ A, long lda,
                                                         const bf16_t* __restrict__ B, long ldb, int M, int N, int K,
                                                         int k_per_split, EpiParams e) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  DH_DYN_LDS_A16(unsigned char, smem_raw);
   bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);  // [2 stages][A tile | B tile]
 
   const int t = threadIdx.x;

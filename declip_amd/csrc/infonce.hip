@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(PairTable pt, int b, int B
                                                       float* __restrict__ part, float* __restrict__ logits_out, int chunk_cols) {
   constexpr int RPT = RT / 16;
   const float scale = *scale_p;
-  extern __shared__ float sm[];
+  DH_DYN_LDS(float, sm);
   float* Xs = sm;                      // [RT][D+1]
   float* Ys = Xs + RT * (D + 1);       // [64][KC+1]
   float* lab = Ys + CT * (KC + 1);     // [RT] label logits
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(PairTable pt, int mode, in
                                                       const float* __restrict__ g_row, float* __restrict__ dscale, int chunk_cols) {
   constexpr int RPT = RT / 16;
   const float scale = *scale_p;
-  extern __shared__ float sm[];
+  DH_DYN_LDS(float, sm);
   float* Xs = sm;                        // [RT][D+1]
   float* dXs = Xs + RT * (D + 1);        // [RT][D+1]
   float* Ys = dXs + RT * (D + 1);        // [64][KC+1]
@@ -322,7 +322,7 @@ __device__ __forceinline__ void logits_pass(f32x16_t& sacc, const float* Xs, int
 __global__ __launch_bounds__(256) void nce_fwd_mfma_kernel(PairTable pt, int b, int B, int D, const float* __restrict__ scale_p,
                                                            float* __restrict__ part, float* __restrict__ logits_out, int chunk_cols) {
   const float scale = *scale_p;
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+  DH_DYN_LDS_A16(float, sm);
   const int XS = D + 4;
   float* Xs = sm;                       // [32][D + 4]
   float* Ys = Xs + MX * XS;             // [128][132]
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void nce_bwd_mfma_kernel(PairTable pt, int mod
                                                            const float* __restrict__ row_lse, const float* __restrict__ g_row,
                                                            float* __restrict__ dscale, int chunk_cols) {
   const float scale = *scale_p;
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+  DH_DYN_LDS_A16(float, sm);
   const int XS = D + 4;
   constexpr int GS = MX + 4;
   float* Xs = sm;                        // [32][D + 4]

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ part, int rows, int d) {
-  extern __shared__ float sm[];  // [4 waves][2][d]
+  DH_DYN_LDS(float, sm);  // [4 waves][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwaves = gridDim.x * 4;
   const int nchunk = d >> 3;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, NCH <= 2 ? 4 : 2) void ln_bwd_bf16_kernel(cons
                                                              const float* __restrict__ w, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
                                                              bf16_t* __restrict__ dx, float* __restrict__ part, int rows, int d) {
-  extern __shared__ float sm[];  // [4 waves][2][d]
+  DH_DYN_LDS(float, sm);  // [4 waves][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwaves = gridDim.x * 4;
   const int nchunk = d >> 3;
@@ -270,7 +270,9 @@ __global__ __launch_bounds__(256, NCH <= 2 ? 4 : 2) void ln_bwd_bf16_kernel(cons
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       // opaque to the optimiser: the unpacked floats of the statistics pass must die there, not be carried to this pass
+#ifndef DH_HOST_EMU   // (a VGPR constraint: meaningless on the host build of tests/hipemu)
       asm volatile("" : "+v"(xr[c].x), "+v"(xr[c].y), "+v"(xr[c].z), "+v"(xr[c].w), "+v"(dr[c].x), "+v"(dr[c].y), "+v"(dr[c].z), "+v"(dr[c].w));
+#endif
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {

@@ -1,0 +1,10 @@
+// TEST INFRASTRUCTURE ONLY -- the GEMM families written with inline ISA (gemm_v4 / gemm_v3 / gemm_glds) cannot be emulated:
+// on the host build the dispatcher of gemm.hip sees them decline every problem and falls through to the plain HIP C++ kernels
+// (MFMA-builtin tiles and the generic VALU kernel), which are what the emulation covers.
+#include <hip/hip_runtime.h>
+
+#include "../../include/declip_hip.h"
+
+bool dh_gemm_try_glds(const dh_gemm_args*, int, hipStream_t) { return false; }
+bool dh_gemm_try_v3(const dh_gemm_args*, int, hipStream_t) { return false; }
+bool dh_gemm_try_v4(const dh_gemm_args*, int, hipStream_t) { return false; }

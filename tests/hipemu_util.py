@@ -32,7 +32,7 @@ def build_emu(sources, grid_cap=8):
     cxx = _clangxx()
     if cxx is None:
         pytest.skip("no clang++ for the host emulation build")
-    files = [os.path.join(EMU, "emu.cpp")] + [os.path.join(CSRC, s) for s in sources]
+    files = [os.path.join(EMU, "emu.cpp")] + [os.path.join(EMU, s) if s.startswith("emu_") else os.path.join(CSRC, s) for s in sources]
     h = hashlib.sha256(str(grid_cap).encode())
     for f in files + [os.path.join(EMU, "hip", "hip_runtime.h"), os.path.join(CSRC, "dh_common.h"), os.path.join(ROOT, "include", "declip_hip.h")]:
         with open(f, "rb") as fh:
@@ -40,7 +40,7 @@ def build_emu(sources, grid_cap=8):
     out = os.path.join(tempfile.gettempdir(), "libdh_emu_%s.so" % h.hexdigest()[:16])
     if not os.path.exists(out):
         tmp = out + ".%d.tmp" % os.getpid()
-        cmd = [cxx, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-DDH_GRID_CAP=%d" % grid_cap, "-Wno-unknown-pragmas",
+        cmd = [cxx, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-DDH_HOST_EMU", "-DDH_GRID_CAP=%d" % grid_cap, "-Wno-unknown-pragmas",
                "-Wno-pass-failed", "-I", EMU] + files + ["-o", tmp]
         subprocess.check_call(cmd)
         os.replace(tmp, out)
@@ -71,3 +71,44 @@ def emu_ops(sources, symbols):
         yield ops
     finally:
         L.load, ops.ptr, ops.stream, L._lib = saved
+
+
+# Everything of declip_amd/csrc that is plain HIP C++ (MFMA builtins, shuffles, LDS): all kernels except the three GEMM families
+# written with inline ISA, whose place in the dispatcher is taken by stubs that decline (tests/hipemu/emu_stubs.cpp).
+ALL_SOURCES = ["embed.hip", "layernorm.hip", "declip_ops.hip", "filip.hip", "infonce.hip", "attention.hip", "gemm.hip", "resnet_ops.hip",
+               "emu_stubs.cpp"]
+_NOT_EMULATED = {"dh_bpe_create", "dh_bpe_destroy", "dh_bpe_vocab_size", "dh_bpe_encode", "dh_version", "dh_device_info", "dh_gemm_v4_enable",
+                 "dh_last_error"}
+
+
+def all_symbols():
+    from declip_amd import lib as L
+    return [n for n in L._PROTOS if n not in _NOT_EMULATED]
+
+
+@contextlib.contextmanager
+def emulated_gpu():
+    """Run GPU-side test code on the host: declip_amd.ops bound to the emulated library, `.cuda()` / `.to("cuda")` are identities,
+    the model builders of declip_amd.testing place models on the CPU.  Inside the block the `-m gpu` test functions of
+    tests/test_gpu_*.py can be called as they are (those that do not name the device literally)."""
+    import functools
+
+    import torch
+
+    from declip_amd import engine, testing
+    saved = dict(t_cuda=torch.Tensor.cuda, m_cuda=torch.nn.Module.cuda, sync=torch.cuda.synchronize, req=engine._require_gpu)
+    builders = {n: getattr(testing, n) for n in dir(testing) if n.startswith("build_") or n.endswith("_batch")}
+    with emu_ops(ALL_SOURCES, all_symbols()) as ops:
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.nn.Module.cuda = lambda self, *a, **k: self
+        torch.cuda.synchronize = lambda *a, **k: None
+        engine._require_gpu = lambda p, name: None
+        for n, f in builders.items():
+            setattr(testing, n, functools.partial(f, device="cpu"))
+        try:
+            yield ops
+        finally:
+            torch.Tensor.cuda, torch.nn.Module.cuda = saved["t_cuda"], saved["m_cuda"]
+            torch.cuda.synchronize, engine._require_gpu = saved["sync"], saved["req"]
+            for n, f in builders.items():
+                setattr(testing, n, f)
