@@ -228,18 +228,21 @@ def test_clip_r50_fp32_matches_reference_golden():
 
 
 def test_clip_r50_bf16_close_to_reference():
+    """bf16 activations through 17 BatchNorm layers at batch 3 (bounds from the run of this test on the host emulation, where the
+    bf16 arithmetic is the kernels' own: loss 1.2e-3, cosine error 6e-3, median gradient-norm error 1 %, BatchNorm affine
+    gradients -- sums of cancelling terms -- up to 24 %)."""
     g = load_golden("clip_r50_tiny")
     _, out = run_engine(g["cfg"], g["b"], g["seed"], "bf16")
-    assert abs(out["loss"] - g["loss"]) <= 3e-2 * abs(g["loss"])
-    scale = float(g["logits_i"].abs().max())
-    assert float((out["logits_i"] - g["logits_i"]).abs().max()) <= 6e-2 * scale
+    assert abs(out["loss"] - g["loss"]) <= 1e-2 * abs(g["loss"])
+    logit_scale = 1 / 0.07
+    assert float((out["logits_i"] - g["logits_i"]).abs().max()) <= 1.5e-2 * logit_scale          # cosine similarities within 1.5e-2
     bad = []
     gmax = max(v["norm"] for v in g["grads"].values() if v is not None)
     for n, ref in g["grads"].items():
         if ref is None or ref["norm"] < 1e-3 * gmax:
             continue
         got = float(out["grads"][n].double().norm())
-        if abs(got - ref["norm"]) > 0.15 * ref["norm"]:
+        if abs(got - ref["norm"]) > (0.5 if _is_bn(n) else 0.15) * ref["norm"]:
             bad.append((n, got, ref["norm"]))
     assert len(bad) <= max(2, len(g["grads"]) // 25), bad[:8]
 
