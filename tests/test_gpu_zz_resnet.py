@@ -4,9 +4,9 @@ north_star tolerance on the forward; bf16 at the documented looser bounds), Batc
 ResNet-50 at the configs[0] batch against the oracle.
 
 STATUS: these kernels and the tower engine were written after round 1's GPU budget had been spent.  They are verified on
-the CPU by running the same C entry points through the host emulation (tests/test_hipemu_resnet.py,
-tests/test_engine_cpu_mock.py::test_resnet_engine_composition_matches_golden); their FIRST hardware run is this file, hence
-the non-strict xfail marker (an XPASS line = verified on hardware; remove the marker then).  Sorted last on purpose."""
+the CPU by running the same C entry points through the host emulation (tests/test_hipemu_resnet.py, tests/test_engine_cpu_mock.py,
+and THIS file's tests on the emulation: tests/test_hipemu_step.py); their FIRST hardware run is this file, hence the non-strict
+xfail marker (an XPASS line = verified on hardware; remove the marker then).  Sorted last on purpose."""
 import pytest
 import torch
 import torch.nn.functional as F
