@@ -251,6 +251,9 @@ R50 = dict(vision="resnet", r_width=64, r_layers=(3, 4, 6, 3), r_heads=32, res=2
 R50_TINY = dict(vision="resnet", r_width=16, r_layers=(1, 2, 1, 1), r_heads=8, res=224,
                 t_width=128, t_layers=2, t_heads=2, ctx=16, embed_dim=64, vocab=VOCAB)
 
+# filip_res50: 49 dense tokens of width*32 channels; >= 16 text tokens (v_width = the dense image width the FILIP heads see)
+R50_TINY_FILIP = dict(R50_TINY, ctx=24, v_width=16 * 32)
+
 # FILIP needs >= 16 image tokens and >= 16 text tokens: 160 px / 32 = 25 patches, 24-token context
 FILIP_SMALL = dict(v_width=128, v_layers=2, v_heads=2, patch=32, res=160,
                    t_width=128, t_layers=2, t_heads=2, ctx=24, embed_dim=64, vocab=VOCAB)

@@ -96,8 +96,13 @@ def slip_batch(cfg, b, seed=0, device="cuda"):
 
 def build_filip(cfg, dtype="bf16", seed=0, fused_loss=True, device="cuda", load_synth=True):
     from .model.filip import FILIP
-    vis = VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
-                            layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"])
+    if cfg.get("vision") == "resnet":
+        from .model.resnet import ModifiedResNet
+        vis = ModifiedResNet(layers=tuple(cfg["r_layers"]), embed_dim=cfg["embed_dim"], heads=cfg["r_heads"],
+                             input_resolution=cfg["res"], width=cfg["r_width"], use_sync_bn=False)
+    else:
+        vis = VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
+                                layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"])
     txt = TextTransformer(embed_dim=cfg["embed_dim"], context_length=cfg["ctx"], transformer_width=cfg["t_width"],
                           transformer_heads=cfg["t_heads"], transformer_layers=cfg["t_layers"],
                           positional_embedding_flag=True, checkpoint=False, bpe_path=None,

@@ -276,8 +276,13 @@ def gen_filip(name, cfg, b, seed=0):
     vt = ref.modules["prototype.model.image_encoder.visual_transformer"]
     tt = ref.modules["prototype.model.text_encoder.text_transformer"]
     with contextlib.redirect_stdout(io.StringIO()):
-        vis = vt.VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
-                                   layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"], checkpoint=False)
+        if cfg.get("vision") == "resnet":      # filip.py:146-153 (filip_res50: dense tokens = the 7x7 map, width*32 channels)
+            mr = ref.modules["prototype.model.image_encoder.modified_resnet"]
+            vis = mr.ModifiedResNet(layers=tuple(cfg["r_layers"]), embed_dim=cfg["embed_dim"], heads=cfg["r_heads"],
+                                    input_resolution=cfg["res"], width=cfg["r_width"], use_sync_bn=False)
+        else:
+            vis = vt.VisualTransformer(input_resolution=cfg["res"], patch_size=cfg["patch"], width=cfg["v_width"],
+                                       layers=cfg["v_layers"], heads=cfg["v_heads"], embed_dim=cfg["embed_dim"], checkpoint=False)
         txt = tt.TextTransformer(embed_dim=cfg["embed_dim"], context_length=cfg["ctx"], transformer_width=cfg["t_width"],
                                  transformer_heads=cfg["t_heads"], transformer_layers=cfg["t_layers"],
                                  positional_embedding_flag=True, checkpoint=False, bpe_path=ref_harness.synthetic_bpe_path(),
@@ -449,6 +454,7 @@ FIXTURES = {
     "declip_r50_tiny": lambda: gen_declip("declip_r50_tiny", synth.R50_TINY, b=4, seed=12),
     "slip_tiny": lambda: gen_slip("slip_tiny", synth.TINY, b=5, seed=4),
     "filip_small": lambda: gen_filip("filip_small", synth.FILIP_SMALL, b=5, seed=6),
+    "filip_r50_tiny": lambda: gen_filip("filip_r50_tiny", synth.R50_TINY_FILIP, b=4, seed=13),
     "defilip_small": lambda: gen_defilip("defilip_small", synth.FILIP_SMALL, b=4, seed=7),
     "zeroshot_tiny": lambda: gen_zeroshot("zeroshot_tiny", synth.TINY, label_num=7, prompts_num=3, b=5, batches=2, seed=8),
 }

@@ -441,7 +441,7 @@ def filip_dense_logits(d1, d2, log_scale_dense, top_k=16):
 def filip_step_loss(images, ids_masked, sd, cfg, weights=(0.0, 1.0)):
     """FILIP.forward (model/filip.py:109-142) + filip_solver.py:435-532, one rank; view 1 only."""
     b = images.shape[0]
-    img, dense = vision_tower(images[:, 0:3], sd, cfg, return_dense=True)
+    img, dense = image_tower(images[:, 0:3], sd, cfg, return_dense=True)
     txt, words = text_tower(ids_masked, sd, cfg, return_dense=True)
     img_n, txt_n = normalize_features(img, txt)
     s = sd["logit_scale"].exp()

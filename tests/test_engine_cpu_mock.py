@@ -373,6 +373,26 @@ def test_filip_engine_composition_matches_golden(mocked_engine):
     check_grad_digests(g["grads"], grads, rtol=1e-3)
 
 
+def test_filip_r50_engine_composition_matches_golden(mocked_engine):
+    """filip_res50 surface: the dense output [b, 49, C] of the ModifiedResNet feeds FILIP's token selection / max-sim loss, its
+    gradient returns into the trunk through ResNetTowerFn's dense input (the attention pool sees a zero-weighted CLIP loss)."""
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.steps import filip_loss
+    from declip_amd.testing import build_filip, filip_batch
+    g = load_golden("filip_r50_tiny")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_filip(cfg, dtype="fp32", seed=seed, device="cpu")
+    out = filip_loss(model, filip_batch(cfg, b, seed=seed, device="cpu"), ClipInfoCELoss())
+    out["loss"].backward()
+    assert abs(float(out["loss"].detach()) - g["loss"]) <= 1e-4 * abs(g["loss"])
+    dli, dlt = out["outputs"]["dense_logits"]
+    assert float((dli.detach() - g["dense_logits_i"]).abs().max()) <= 1e-4 * float(g["dense_logits_i"].abs().max())
+    assert float((dlt.detach() - g["dense_logits_t"]).abs().max()) <= 1e-4 * float(g["dense_logits_t"].abs().max())
+    grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+    is_bn = lambda n: ".bn" in n or "downsample.1." in n       # noqa: E731
+    check_grad_digests(g["grads"], grads, rtol=3e-3, only=lambda n: not is_bn(n))
+
+
 def test_defilip_engine_composition_matches_golden(mocked_engine):
     from declip_amd.heads import SimsiamLoss
     from declip_amd.loss import ClipInfoCELoss

@@ -306,3 +306,21 @@ def test_declip_r50_fp32_matches_reference_golden():
     check_grad_digests(g["grads"], grads, rtol=5e-3, only=lambda n: not _is_bn(n))
     bufs = dict(model.named_buffers())
     assert int(bufs["visual.bn2.num_batches_tracked"]) == 2
+
+
+def test_filip_r50_fp32_matches_reference_golden():
+    """filip_res50 (model/filip.py:146-153): token-wise max-sim loss on the 7x7 feature map of the ModifiedResNet."""
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.steps import filip_loss
+    from declip_amd.testing import build_filip, filip_batch
+    g = load_golden("filip_r50_tiny")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_filip(cfg, dtype="fp32", seed=seed)
+    out = filip_loss(model, filip_batch(cfg, b, seed=seed), ClipInfoCELoss())
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"].detach()) - g["loss"]) <= 1e-3 * abs(g["loss"])
+    dli = out["outputs"]["dense_logits"][0].detach().cpu()
+    assert float((dli - g["dense_logits_i"]).abs().max()) <= 1e-3 * float(g["dense_logits_i"].abs().max())
+    grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
+    check_grad_digests(g["grads"], grads, rtol=5e-3, only=lambda n: not _is_bn(n))
