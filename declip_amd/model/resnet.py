@@ -89,9 +89,10 @@ class ModifiedResNet(_Tower):
         feat_dim = width * 32
         self.attnpool = AttentionPool2d(input_resolution // 32, feat_dim, heads, embed_dim)
         self.adaptivepool = nn.AdaptiveAvgPool2d((1, 1))
-        self.fc = nn.Linear(2048, embed_dim)                    # modified_resnet.py:167 (only reached off the 7x7 path)
+        self.fc = nn.Linear(2048, embed_dim)                    # modified_resnet.py:167 (the head when the final map is not 7 wide)
         for p in self.fc.parameters():
-            p._dh_grad_none = True      # never on the 224 px path: grad stays None and the optimizer leaves it alone, as in torch
+            p._dh_grad_none = True      # the head off the path keeps grad None and is left alone by the optimizer, as in torch
+                                        # (resnet_engine sets this per forward: attention pool at 224 px, adaptive pool + fc otherwise)
         std = self.attnpool.c_proj.in_features ** -0.5
         for lin in (self.attnpool.q_proj, self.attnpool.k_proj, self.attnpool.v_proj, self.attnpool.c_proj):
             nn.init.normal_(lin.weight, std=std)

@@ -250,11 +250,26 @@ def _forward_pass(flat, tower, images, c0, training):
             x, (H, W) = bk.out, bk.out_hw
             blocks.append(bk)
     st["blocks"] = blocks
-    if (H, W) != (7, 7) or W * H + 1 != tower.attnpool.positional_embedding.shape[0]:
-        raise NotImplementedError("the adaptive-pool + fc branch of ModifiedResNet.forward (modified_resnet.py:209-211) is not "
-                                  "built: the attention pool needs a 7x7 final map (224 px input), got %dx%d" % (H, W))
-    # ---- attention pool (modified_resnet.py:59-96): tokens, q/k/v projections, attention, c_proj of the mean token
     ap = tower.attnpool
+    on_attnpool = W == 7                                          # modified_resnet.py:207: `if x.size(3) == 7`
+    for p_ in ap.parameters():
+        p_._dh_grad_none = not on_attnpool                        # the head that is off the path keeps grad None (torch semantics)
+    for p_ in tower.fc.parameters():
+        p_._dh_grad_none = on_attnpool
+    if not on_attnpool:
+        # ---- adaptive average pool + fc (modified_resnet.py:209-211), any input size whose final map is square
+        C = x.shape[1]
+        if H != W or tower.fc.weight.shape[1] != C:
+            raise DeclipHipError("ModifiedResNet: the adaptive-pool + fc head needs a square final map and fc.in_features == %d "
+                                 "(got %dx%d, fc.in_features %d)" % (C, H, W, tower.fc.weight.shape[1]))
+        pooled = ops.avgpool_fwd(x, b, H, W, C, H)                # [b, C]: mean over the whole map
+        out = ops.gemm(pooled, flat.wview(tower.fc.weight), bias=tower.fc.bias.data, out_dtype=torch.float32)
+        st.update(x_last=x, pooled=pooled, out=out, dense=x.view(b, H * W, C), geom=(H * W, C, 0, 0), head="fc", hw=(H, W))
+        return st
+    if H != 7 or H * W + 1 != ap.positional_embedding.shape[0]:
+        raise DeclipHipError("ModifiedResNet: attention pool built for %d tokens, final map is %dx%d"
+                             % (ap.positional_embedding.shape[0] - 1, H, W))
+    # ---- attention pool (modified_resnet.py:59-96): tokens, q/k/v projections, attention, c_proj of the mean token
     HW, C, heads = H * W, x.shape[1], ap.num_heads
     L = HW + 1
     tok = ops.attnpool_tokens_fwd(x, ap.positional_embedding.data, b, HW)
@@ -267,7 +282,8 @@ def _forward_pass(flat, tower, images, c0, training):
     a, lse = ops.attn_fwd(qkv, b, L, heads, False)
     pooled = ops.pool_rows_fwd(a, None, b, L)                     # token 0 = the mean token's output (x[0], :96)
     out = ops.gemm(pooled, w(ap.c_proj.weight), bias=ap.c_proj.bias.data, out_dtype=torch.float32)
-    st.update(x_last=x, tok=tok, qkv=qkv, a=a, lse=lse, pooled=pooled, out=out, dense=x.view(b, HW, C), geom=(HW, C, heads, L))
+    st.update(x_last=x, tok=tok, qkv=qkv, a=a, lse=lse, pooled=pooled, out=out, dense=x.view(b, HW, C), geom=(HW, C, heads, L),
+              head="attnpool")
     return st
 
 
@@ -279,7 +295,16 @@ def _backward_pass(flat, tower, st, dout, ddense, last):
     ap = tower.attnpool
     w = flat.wview
     x_last = st["x_last"]
-    if dout is not None:
+    if st["head"] == "fc":
+        if dout is not None:
+            do = _to_act(dout, dtype)
+            weight_grad(do, st["pooled"], g(tower.fc.weight), g(tower.fc.bias))
+            dpooled = ops.gemm(do, w(tower.fc.weight), b_kmajor=True)
+            H, W = st["hw"]
+            dx = ops.avgpool_bwd(dpooled, b, H, W, C, H)
+        else:
+            dx = torch.zeros_like(x_last)
+    elif dout is not None:
         do = _to_act(dout, dtype)
         weight_grad(do, st["pooled"], g(ap.c_proj.weight), g(ap.c_proj.bias))
         dpooled = ops.gemm(do, w(ap.c_proj.weight), b_kmajor=True)
@@ -300,7 +325,7 @@ def _backward_pass(flat, tower, st, dout, ddense, last):
     if ddense is not None:
         dx.add_(ddense.reshape(b * HW, C).to(dtype))
     if last:
-        flat.grads_ready(list(ap.parameters()))
+        flat.grads_ready(list(ap.parameters()) if st["head"] == "attnpool" else list(tower.fc.parameters()))
     for bk in reversed(st["blocks"]):
         dx = bk.backward(flat, dx)
         if last:

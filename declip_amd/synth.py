@@ -251,6 +251,11 @@ R50 = dict(vision="resnet", r_width=64, r_layers=(3, 4, 6, 3), r_heads=32, res=2
 R50_TINY = dict(vision="resnet", r_width=16, r_layers=(1, 2, 1, 1), r_heads=8, res=224,
                 t_width=128, t_layers=2, t_heads=2, ctx=16, embed_dim=64, vocab=VOCAB)
 
+# the other head of ModifiedResNet.forward (adaptive pool + fc, modified_resnet.py:209-211): any input whose final map is not 7 wide;
+# fc is hard-wired to 2048 inputs, so the width must be 64
+R50_FC = dict(vision="resnet", r_width=64, r_layers=(1, 1, 1, 1), r_heads=32, res=64,
+              t_width=128, t_layers=2, t_heads=2, ctx=16, embed_dim=64, vocab=VOCAB)
+
 # filip_res50: 49 dense tokens of width*32 channels; >= 16 text tokens (v_width = the dense image width the FILIP heads see)
 R50_TINY_FILIP = dict(R50_TINY, ctx=24, v_width=16 * 32)
 

@@ -449,6 +449,7 @@ FIXTURES = {
     "clip_tiny_w2": lambda: gen_clip("clip_tiny_w2", synth.TINY, b=3, world=2, seed=5),
     "clip_vitb32_b8": lambda: gen_clip("clip_vitb32_b8", synth.VITB32, b=8, seed=1),
     "clip_r50_tiny": lambda: gen_clip("clip_r50_tiny", synth.R50_TINY, b=3, seed=9),
+    "clip_r50_fc": lambda: gen_clip("clip_r50_fc", synth.R50_FC, b=3, seed=15),
     "clip_r50_tiny_w2": lambda: gen_clip("clip_r50_tiny_w2", synth.R50_TINY, b=2, world=2, seed=10),
     "declip_tiny": lambda: gen_declip("declip_tiny", synth.TINY, b=6, seed=2),
     "declip_r50_tiny": lambda: gen_declip("declip_r50_tiny", synth.R50_TINY, b=4, seed=12),

@@ -160,9 +160,10 @@ def resnet_tower(images, sd, cfg, prefix="visual.", return_dense=False, training
         for bi in range(blocks):
             x = bottleneck(x, sd, "%slayer%d.%d." % (prefix, li + 1, bi), 2 if (li > 0 and bi == 0) else 1, training, new_stats)
     dense = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
-    if x.shape[3] != 7:
-        raise NotImplementedError("the adaptive-pool + fc branch (modified_resnet.py:209-211) is not restated: use a 224 px input")
-    out = attention_pool(x, sd, prefix + "attnpool.", cfg["r_heads"])
+    if x.shape[3] == 7:                                           # modified_resnet.py:207
+        out = attention_pool(x, sd, prefix + "attnpool.", cfg["r_heads"])
+    else:                                                         # :209-211 (`.squeeze()` drops the batch axis at b == 1)
+        out = F.adaptive_avg_pool2d(x, (1, 1)).squeeze() @ sd[prefix + "fc.weight"].t() + sd[prefix + "fc.bias"]
     return (out, dense) if return_dense else out
 
 

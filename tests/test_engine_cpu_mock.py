@@ -176,6 +176,24 @@ def test_flat_adamw_tables_match_torch_adamw(mocked_engine):
     assert torch.equal(got["visual.conv1.weight"].detach(), synth.synth_state(synth.clip_shapes(cfg), seed=seed)["visual.conv1.weight"])
 
 
+def test_resnet_fc_head_matches_golden(mocked_engine):
+    """64 px input: the final map is 2x2, ModifiedResNet.forward takes the adaptive-pool + fc head (modified_resnet.py:209-211);
+    the attention pool is off the path (grad None, untouched by the optimiser), fc trains."""
+    from declip_amd.optim import build_adamw
+    g = load_golden("clip_r50_fc")
+    model, loss, li, lt, grads, _, _ = _run(g["cfg"], g["b"], g["seed"], g["logit_scale"], "fp32")
+    assert abs(loss - g["loss"]) <= 1e-4 * abs(g["loss"])
+    assert float((li.materialize().detach() - g["logits_i"]).abs().max()) <= 1e-4 * float(g["logits_i"].abs().max())
+    is_bn = lambda n: ".bn" in n or "downsample.1." in n       # noqa: E731
+    check_grad_digests(g["grads"], grads, rtol=3e-3, only=lambda n: not is_bn(n))
+    assert grads["visual.attnpool.q_proj.weight"] is None and float(grads["visual.fc.weight"].abs().max()) > 0
+    before = model.visual.attnpool.c_proj.weight.detach().clone()
+    fc_before = model.visual.fc.weight.detach().clone()
+    build_adamw(model, lr=1e-3).step()
+    assert torch.equal(model.visual.attnpool.c_proj.weight.detach(), before)
+    assert float((model.visual.fc.weight.detach() - fc_before).abs().max()) > 0
+
+
 def test_resnet_flat_adamw_steps_match_torch_adamw(mocked_engine):
     """CLIP-R50 (tiny): 2 optimiser steps, engine + FlatAdamW vs the restatement + torch.optim.AdamW.  BatchNorm affine
     parameters sit in the no-decay group, the unused fc (modified_resnet.py:167,209-211) keeps grad None and is never touched."""

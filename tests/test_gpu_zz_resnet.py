@@ -324,3 +324,13 @@ def test_filip_r50_fp32_matches_reference_golden():
     assert float((dli - g["dense_logits_i"]).abs().max()) <= 1e-3 * float(g["dense_logits_i"].abs().max())
     grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
     check_grad_digests(g["grads"], grads, rtol=5e-3, only=lambda n: not _is_bn(n))
+
+
+def test_clip_r50_fc_head_fp32_matches_reference_golden():
+    """64 px input -> 2x2 final map -> adaptive average pool + fc (modified_resnet.py:209-211) instead of the attention pool."""
+    g = load_golden("clip_r50_fc")
+    model, out = run_engine(g["cfg"], g["b"], g["seed"], "fp32")
+    assert abs(out["loss"] - g["loss"]) <= 1e-3 * abs(g["loss"])
+    assert float((out["logits_i"] - g["logits_i"]).abs().max()) <= 1e-3 * float(g["logits_i"].abs().max())
+    check_grad_digests(g["grads"], out["grads"], rtol=5e-3, only=lambda n: not _is_bn(n))
+    assert out["grads"]["visual.attnpool.q_proj.weight"] is None
