@@ -369,6 +369,79 @@ __global__ __launch_bounds__(256) void image_prep_u8_kernel(const uint8_t* __res
   }
 }
 
+// RandomResizedCrop / Resize + CenterCrop of decoded uint8 HWC images on the GPU (the resize the reference's pipelines run on CPU
+// workers or in DALI: data/imagenet_dataloader.py:36-47,105-111 -> torchvision TF.resized_crop / Resize on PIL images = PIL
+// Image.crop + Image.resize(BILINEAR): an ANTIALIASED triangle filter -- support max(scale, 1) source pixels, taps clamped to the
+// crop box, weights normalised per axis), fused with the optional mirror, ToTensor (/255) and Normalize.
+// One thread = one output pixel, all 3 channels; x- and y-weights are recomputed on the fly (ALU is free next to the gather).
+__device__ __forceinline__ float tri_w(int j, float center, float invscale) {
+  const float t = ((float)j - center + 0.5f) * invscale;
+  return fmaxf(0.f, 1.f - fabsf(t));
+}
+
+__global__ __launch_bounds__(256) void image_resized_crop_u8_kernel(const uint8_t* __restrict__ src, int src_h, int src_w,
+                                                                    const int* __restrict__ params, const uint8_t* __restrict__ flip,
+                                                                    float m0, float m1, float m2, float s0, float s1, float s2,
+                                                                    float* __restrict__ dst, int c_total, int c0, int b, int H, int W,
+                                                                    int round_u8) {
+  const long n = (long)b * H * W;
+  const float mean[3] = {m0, m1, m2}, inv[3] = {1.f / s0, 1.f / s1, 1.f / s2};
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(t % W);
+    const int y = (int)((t / W) % H);
+    const int bi = (int)(t / ((long)W * H));
+    const int* p = params + 8 * bi;
+    const int bx = p[0], by = p[1], bw = p[2], bh = p[3], Wf = p[4], Hf = p[5], ox = p[6], oy = p[7];
+    const bool mir = flip && flip[bi];
+    // position of this output pixel inside the Wf x Hf image the crop box is resized to
+    const int fx = ox + (mir ? W - 1 - x : x), fy = oy + y;
+    const float sx = (float)bw / (float)Wf, sy = (float)bh / (float)Hf;
+    const float supx = sx >= 1.f ? sx : 1.f, supy = sy >= 1.f ? sy : 1.f;
+    const float isx = sx >= 1.f ? 1.f / sx : 1.f, isy = sy >= 1.f ? 1.f / sy : 1.f;
+    const float cx = ((float)fx + 0.5f) * sx, cy = ((float)fy + 0.5f) * sy;
+    int x_lo = (int)(cx - supx + 0.5f), x_hi = (int)(cx + supx + 0.5f);
+    int y_lo = (int)(cy - supy + 0.5f), y_hi = (int)(cy + supy + 0.5f);
+    if (x_lo < 0) x_lo = 0;
+    if (y_lo < 0) y_lo = 0;
+    if (x_hi > bw) x_hi = bw;
+    if (y_hi > bh) y_hi = bh;
+    float wsx = 0.f, wsy = 0.f;
+    for (int j = x_lo; j < x_hi; ++j) wsx += tri_w(j, cx, isx);
+    for (int i = y_lo; i < y_hi; ++i) wsy += tri_w(i, cy, isy);
+    float acc[3] = {0.f, 0.f, 0.f};
+    const uint8_t* img = src + (long)bi * src_h * src_w * 3;
+    for (int i = y_lo; i < y_hi; ++i) {
+      const float wy = tri_w(i, cy, isy);
+      const uint8_t* row = img + ((long)(by + i) * src_w + bx) * 3;
+      float r[3] = {0.f, 0.f, 0.f};
+      for (int j = x_lo; j < x_hi; ++j) {
+        const float wx = tri_w(j, cx, isx);
+        r[0] += wx * (float)row[3 * j]; r[1] += wx * (float)row[3 * j + 1]; r[2] += wx * (float)row[3 * j + 2];
+      }
+      acc[0] += wy * r[0]; acc[1] += wy * r[1]; acc[2] += wy * r[2];
+    }
+    const float norm = 1.f / (wsx * wsy);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = acc[c] * norm;
+      if (round_u8) v = fminf(fmaxf(floorf(v + 0.5f), 0.f), 255.f);   // the PIL image between resize and ToTensor is uint8
+      dst[(((long)bi * c_total + c0 + c) * H + y) * W + x] = (v / 255.f - mean[c]) * inv[c];
+    }
+  }
+}
+
+extern "C" int dh_image_resized_crop_u8(const uint8_t* src, int b, int src_h, int src_w, const int* params_dev, const uint8_t* flip_dev,
+                                        const float* mean3, const float* std3, float* dst, int c_total, int c0, int H, int W,
+                                        int round_u8, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(src && params_dev && dst && mean3 && std3 && b > 0 && H > 0 && W > 0 && src_h > 0 && src_w > 0 && c0 >= 0 && c0 + 3 <= c_total,
+             "dh_image_resized_crop_u8: bad args");
+  hipLaunchKernelGGL(image_resized_crop_u8_kernel, dim3(grid_for((long)b * H * W)), dim3(256), 0, st, src, src_h, src_w, params_dev, flip_dev,
+                     mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], dst, c_total, c0, b, H, W, round_u8);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
 extern "C" int dh_image_prep_u8(const uint8_t* src, int b, int src_h, int src_w, const int* crop_xy_dev, const uint8_t* flip_dev,
                                 const float* mean3, const float* std3, float* dst, int c_total, int c0, int H, int W,
                                 dh_stream_t stream) {

@@ -57,6 +57,7 @@ _PROTOS = {
     "dh_text_embed_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "dh_text_embed_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, POINTER(c_int64), c_int, _P]),
     "dh_image_prep_u8": (c_int, [_P, c_int, c_int, c_int, _P, _P, POINTER(c_float), POINTER(c_float), _P, c_int, c_int, c_int, c_int, _P]),
+    "dh_image_resized_crop_u8": (c_int, [_P, c_int, c_int, c_int, _P, _P, POINTER(c_float), POINTER(c_float), _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_im2row": (c_int, [c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "dh_vit_assemble_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "dh_vit_assemble_bwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P]),

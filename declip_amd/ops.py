@@ -153,6 +153,26 @@ def image_prep_u8(src, out_hw, crop_xy=None, flip=None, mean=IMAGENET_MEAN, std=
     return out
 
 
+def image_resized_crop_u8(src, params, out_hw, flip=None, mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None, c0=0, round_u8=True):
+    """uint8 canvas [b, Hs, Ws, 3] on the GPU -> fp32 [b, C, H, W] channels c0..c0+2: crop box -> antialiased bilinear resize -> window
+    -> optional mirror -> ToTensor -> Normalize.  params: int32 [b, 8] device tensor (x0, y0, w, h, Wf, Hf, ox, oy), see
+    include/declip_hip.h; flip: uint8/bool [b] device tensor or None."""
+    assert src.dtype == torch.uint8 and src.dim() == 4 and src.shape[3] == 3 and src.is_contiguous()
+    b, Hs, Ws, _ = src.shape
+    H, W = out_hw
+    assert params.dtype == torch.int32 and params.shape == (b, 8) and params.is_contiguous()
+    if out is None:
+        out = torch.empty(b, 3, H, W, device=src.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == b and tuple(out.shape[2:]) == (H, W)
+    if flip is not None:
+        flip = flip.to(torch.uint8).contiguous()
+        assert flip.shape == (b,)
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    check(L.load().dh_image_resized_crop_u8(ptr(src), b, Hs, Ws, ptr(params), ptr(flip), m3, s3, ptr(out), out.shape[1], c0, H, W,
+                                            int(round_u8), stream()), "dh_image_resized_crop_u8")
+    return out
+
+
 def im2row(images, c0, patch, dtype, out=None):
     _contig(images, "images")
     assert images.dtype == torch.float32

@@ -6,7 +6,11 @@ critical path:
     C-ABI library (`bpe.NativeTokenizer`; the ctypes call releases the GIL) and pins the tensors;
   * the host->device copies of batch i+1 are enqueued on a copy stream while step i computes; `next()` makes the caller's
     stream wait for that copy's event (no host synchronisation) and hands the device batch over;
-  * images may stay uint8 HWC (the vision tower normalises bytes on the GPU, `dh_image_prep_u8`): 4x less PCIe traffic.
+  * images may stay uint8 HWC (the vision tower normalises bytes on the GPU, `dh_image_prep_u8`): 4x less PCIe traffic;
+  * a batch may also carry decoded images at their SOURCE size on one uint8 canvas plus crop boxes (`image_boxes`, int32 [b, 8] or
+    [b, views, 8] from declip_amd.augment; optional `image_flip`): RandomResizedCrop / Resize + CenterCrop, mirror, ToTensor and
+    Normalize then run on the GPU right behind the copy, on the copy stream (`dh_image_resized_crop_u8`) -- the multi-view models
+    get all their views from ONE upload of the decoded image, and no CPU core resizes pixels.
 
 `next()` returns None when the loader is exhausted, as the reference's does.  Works without a GPU (device "cpu": same
 ordering / tokenisation logic, plain tensors) so the host logic is covered by the CPU tests.
@@ -16,16 +20,40 @@ import threading
 
 import torch
 
-from . import bpe
+from . import bpe, ops
 
-__all__ = ["DataPrefetcher"]
+__all__ = ["DataPrefetcher", "crops_on_device"]
+
+
+def crops_on_device(batch, out_hw):
+    """`images` uint8 [b, Hs, Ws, 3] + `image_boxes` int32 [b, 8] | [b, V, 8] (+ `image_flip` [b] | [b, V]) on the device ->
+    `images` fp32 [b, 3 * V, H, W] (channel-stacked views, data/transforms.py:38-54); the box / flip entries are consumed."""
+    boxes = batch.get("image_boxes")
+    if boxes is None:
+        return batch
+    out = dict(batch)
+    src = out["images"]
+    boxes = out.pop("image_boxes")
+    flip = out.pop("image_flip", None)
+    if boxes.dim() == 2:
+        boxes = boxes[:, None, :]
+        flip = None if flip is None else flip[:, None]
+    b, V = boxes.shape[0], boxes.shape[1]
+    H, W = out_hw
+    images = torch.empty(b, 3 * V, H, W, device=src.device, dtype=torch.float32)
+    for v in range(V):
+        ops.image_resized_crop_u8(src, boxes[:, v].contiguous(), (H, W), flip=None if flip is None else flip[:, v].contiguous(),
+                                  out=images, c0=3 * v)
+    out["images"] = images
+    return out
 
 _END = object()
 
 
 class DataPrefetcher(object):
-    def __init__(self, loader, device="cuda", tokenizer=None, context_length=77, depth=2):
+    def __init__(self, loader, device="cuda", tokenizer=None, context_length=77, depth=2, image_size=224):
         self.device = torch.device(device)
+        self.image_hw = (image_size, image_size) if isinstance(image_size, int) else tuple(image_size)
         self.tokenizer, self.context_length = tokenizer, context_length
         self._it = iter(loader)
         self._q = queue.Queue(maxsize=max(1, depth))
@@ -74,6 +102,7 @@ class DataPrefetcher(object):
             return
         with torch.cuda.stream(self.stream):
             dev = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in item.items()}
+            dev = crops_on_device(dev, self.image_hw)      # resize / mirror / normalise behind the copy, on the copy stream
             self._event = torch.cuda.Event()
             self._event.record(self.stream)
         self._staged = dev

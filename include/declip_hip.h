@@ -142,6 +142,19 @@ int dh_im2row(int dtype, const float* images, int c_total, int c0, void* rows, i
 int dh_image_prep_u8(const uint8_t* src, int b, int src_h, int src_w, const int* crop_xy_dev, const uint8_t* flip_dev,
                      const float* mean3, const float* std3, float* dst, int c_total, int c0, int H, int W,
                      dh_stream_t stream);
+/* RandomResizedCrop / Resize + CenterCrop on the GPU for decoded uint8 HWC images (what the reference's CPU workers / DALI do:
+ * data/imagenet_dataloader.py:36-47 `STANDARD_SLIP` RandomResizedCrop(224, scale=(0.5, 1)), :105-111 `ONECROP` Resize(256) +
+ * CenterCrop(224); torchvision on PIL images = Image.crop + Image.resize(BILINEAR): antialiased triangle filter with support
+ * max(scale, 1), taps clamped to the crop box), fused with mirror, ToTensor and Normalize.  The images of a batch share one
+ * [b][src_h][src_w][3] canvas (each in its top-left corner).  params_dev int32 [b][8] in DEVICE memory:
+ *   x0, y0, w, h : the crop box in the source;   Wf, Hf : the size the box is resized to;
+ *   ox, oy       : where the H x W output window sits inside that Wf x Hf image
+ * (RandomResizedCrop: Wf = W, Hf = H, ox = oy = 0; Resize(s) + CenterCrop: box = whole image, Wf x Hf = the resized image,
+ * ox, oy = the centre window).  round_u8 != 0 rounds the resized value to an integer grey level first, as the uint8 PIL image
+ * between resize and ToTensor does.  dst as in dh_image_prep_u8. */
+int dh_image_resized_crop_u8(const uint8_t* src, int b, int src_h, int src_w, const int* params_dev, const uint8_t* flip_dev,
+                             const float* mean3, const float* std3, float* dst, int c_total, int c0, int H, int W, int round_u8,
+                             dh_stream_t stream);
 /* x[b,0,:] = cls + pos[0]; x[b,1+p,:] = patches[b,p,:] + pos[1+p]  (visual_transformer.py:60-62) */
 int dh_vit_assemble_fwd(int dtype, const void* patches, const float* cls, const float* pos, void* x, int b, int np,
                         int d, dh_stream_t stream);

@@ -167,6 +167,28 @@ def resnet_tower(images, sd, cfg, prefix="visual.", return_dense=False, training
     return (out, dense) if return_dense else out
 
 
+def image_resized_crop_u8(src, params, out_hw, flip=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), round_u8=True):
+    """crop box -> antialiased bilinear resize -> output window -> mirror -> ToTensor -> Normalize, one image at a time: what
+    torchvision's RandomResizedCrop / RandomCropMinSize / Resize + CenterCrop do on PIL images in the reference's workers
+    (data/imagenet_dataloader.py:36-47,105-111; data/transforms.py:133-157), with PIL's triangle filter restated by torch's
+    antialiased bilinear (same filter in float; PIL itself is compared in tests/test_hipemu_kernels.py).
+    params [b, 8]: x0, y0, w, h, Wf, Hf, ox, oy."""
+    H, W = out_hw
+    b = src.shape[0]
+    out = torch.empty(b, 3, H, W, dtype=torch.float32)
+    m, s = torch.tensor(mean).view(3, 1, 1), torch.tensor(std).view(3, 1, 1)
+    for i in range(b):
+        x0, y0, w, h, Wf, Hf, ox, oy = [int(v) for v in params[i]]
+        crop = src[i, y0:y0 + h, x0:x0 + w].permute(2, 0, 1).float()[None]
+        r = F.interpolate(crop, size=(Hf, Wf), mode="bilinear", antialias=True, align_corners=False)[0, :, oy:oy + H, ox:ox + W]
+        if flip is not None and bool(flip[i]):
+            r = r.flip(2)
+        if round_u8:
+            r = (r + 0.5).floor().clamp(0, 255)
+        out[i] = (r / 255.0 - m) / s
+    return out
+
+
 def image_tower(images, sd, cfg, **kw):
     """the image encoder the config names: visual_transformer.py (default) or modified_resnet.py (cfg["vision"] == "resnet")."""
     if cfg.get("vision") == "resnet":

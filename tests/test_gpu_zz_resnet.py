@@ -334,3 +334,26 @@ def test_clip_r50_fc_head_fp32_matches_reference_golden():
     assert float((out["logits_i"] - g["logits_i"]).abs().max()) <= 1e-3 * float(g["logits_i"].abs().max())
     check_grad_digests(g["grads"], out["grads"], rtol=5e-3, only=lambda n: not _is_bn(n))
     assert out["grads"]["visual.attnpool.q_proj.weight"] is None
+
+
+def test_image_resized_crop_u8_matches_oracle():
+    """on-GPU RandomResizedCrop / Resize + CenterCrop of decoded uint8 images (dh_image_resized_crop_u8) against the oracle
+    restatement (torch antialiased bilinear), full-size 224 px outputs from mixed source sizes."""
+    import numpy as np
+    from declip_amd import augment, ops
+    from oracle import restated
+    g = torch.Generator().manual_seed(0)
+    sizes = [(480, 640), (333, 500), (600, 400), (224, 224), (1080, 720), (256, 341)]
+    canvas = torch.randint(0, 256, (len(sizes), 1080, 720, 3), generator=g, dtype=torch.uint8)
+    rng = np.random.default_rng(1)
+    flip = torch.tensor([0, 1, 0, 1, 1, 0], dtype=torch.uint8)
+    for params in (augment.random_resized_crop_params(sizes, (224, 224), generator=rng), augment.resize_center_crop_params(sizes, 256, 224)):
+        # unrounded: the filter itself, tight
+        out = ops.image_resized_crop_u8(canvas.cuda(), torch.from_numpy(params).cuda(), (224, 224), flip=flip.cuda(), round_u8=False)
+        ref = restated.image_resized_crop_u8(canvas, params, (224, 224), flip=flip, round_u8=False)
+        assert float((out.cpu() - ref).abs().max()) <= 1e-4
+        # rounded to grey levels like the PIL pipeline: identical except where the value sits on a rounding boundary
+        out = ops.image_resized_crop_u8(canvas.cuda(), torch.from_numpy(params).cuda(), (224, 224), flip=flip.cuda())
+        ref = restated.image_resized_crop_u8(canvas, params, (224, 224), flip=flip)
+        diff = (out.cpu() - ref).abs()
+        assert float(diff.max()) <= 1.01 / 255 / 0.224 and float((diff > 1e-6).float().mean()) <= 1e-3

@@ -55,3 +55,103 @@ def test_gpu_kernel_test_on_host_emulation(monkeypatch, name, args):
     monkeypatch.setattr(T, "_poison_lds", lambda ops: None)      # the emulation NaN-poisons a block's dynamic LDS itself
     with emulated_gpu():
         getattr(T, name)(*args)
+
+
+def _pil_resized_crop(img_u8, box, Wf, Hf, ox, oy, W, H, flip):
+    """what the reference's workers do per image: PIL crop + resize(BILINEAR) (+ centre window, mirror), still uint8"""
+    from PIL import Image
+    x0, y0, w, h = box
+    im = Image.fromarray(img_u8.numpy()).crop((x0, y0, x0 + w, y0 + h)).resize((Wf, Hf), Image.BILINEAR)
+    im = im.crop((ox, oy, ox + W, oy + H))
+    if flip:
+        im = im.transpose(Image.FLIP_LEFT_RIGHT)
+    import numpy as np
+    return torch.from_numpy(np.asarray(im).copy())
+
+
+def test_image_resized_crop_matches_pil_and_torch_antialias():
+    """dh_image_resized_crop_u8 on the host emulation against (a) PIL itself -- the library the reference's torchvision transforms
+    call -- within one grey level (PIL resamples in two uint8 passes with fixed-point weights), unbiased;
+    (b) torch's antialiased bilinear on the crop box, which is the same filter in float, to 1e-4."""
+    import numpy as np
+    import torch.nn.functional as F
+    from declip_amd import augment
+    g = torch.Generator().manual_seed(0)
+    sizes = [(300, 400), (250, 230), (512, 340), (224, 224), (97, 130)]
+    Hs, Ws = 512, 400
+    canvas = torch.zeros(len(sizes), Hs, Ws, 3, dtype=torch.uint8)
+    for n, (h, w) in enumerate(sizes):
+        # smooth structure + noise: pure noise would hide filter-phase errors behind +-1 rounding
+        yy, xx = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+        base = torch.stack([127 + 100 * torch.sin(xx / 9 + n), 127 + 100 * torch.cos(yy / 7), 127 + 60 * torch.sin((xx + yy) / 13)], dim=-1)
+        canvas[n, :h, :w] = (base + 20 * torch.randn(h, w, 3, generator=g)).clamp(0, 255).to(torch.uint8)
+    rng = np.random.default_rng(1)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    cases = [("rrc", augment.random_resized_crop_params(sizes, (224, 224), generator=rng), (224, 224)),
+             ("minsize", augment.random_crop_min_size_params(sizes, 224, generator=rng), (224, 224)),
+             ("onecrop", augment.resize_center_crop_params(sizes[:4], 256, 224), (224, 224)),
+             ("upscale", np.array([[10, 20, 50, 40, 96, 64, 0, 0]] * 2, dtype=np.int32), (64, 96))]
+    for name, params, (H, W) in cases:
+        b = params.shape[0]
+        flip = torch.tensor([i % 2 for i in range(b)], dtype=torch.uint8)
+        with emulated_gpu() as ops:
+            out = ops.image_resized_crop_u8(canvas[:b].contiguous(), torch.from_numpy(params), (H, W), flip=flip, mean=mean, std=std)
+            raw = ops.image_resized_crop_u8(canvas[:b].contiguous(), torch.from_numpy(params), (H, W), flip=flip, mean=(0, 0, 0), std=(1, 1, 1),
+                                            round_u8=False)
+        m, s = torch.tensor(mean).view(3, 1, 1), torch.tensor(std).view(3, 1, 1)
+        for i in range(b):
+            x0, y0, w, h, Wf, Hf, ox, oy = [int(v) for v in params[i]]
+            levels = ((out[i] * s + m) * 255.0).round()                                    # back to grey levels
+            pil = _pil_resized_crop(canvas[i], (x0, y0, w, h), Wf, Hf, ox, oy, W, H, bool(flip[i])).permute(2, 0, 1).float()
+            # PIL rounds to uint8 after its horizontal pass and again after the vertical one: a quarter of the pixels land one level
+            # away from the single-pass result, never two, and (but for exact .5 ties, which its fixed-point weights break downwards) without a sign
+            d = levels - pil
+            assert float(d.abs().max()) <= 1.0 and float(d.abs().mean()) <= 0.3 and abs(float(d.mean())) <= 0.1, \
+                (name, i, float(d.abs().max()), float(d.abs().mean()), float(d.mean()))
+            crop = canvas[i, y0:y0 + h, x0:x0 + w].permute(2, 0, 1).float()[None]
+            ref = F.interpolate(crop, size=(Hf, Wf), mode="bilinear", antialias=True, align_corners=False)[0, :, oy:oy + H, ox:ox + W]
+            if flip[i]:
+                ref = ref.flip(2)
+            assert float((raw[i] * 255.0 - ref).abs().max()) <= 2e-3, (name, i)
+
+
+def test_crop_box_generators():
+    import numpy as np
+    from declip_amd import augment
+    rng = np.random.default_rng(3)
+    sizes = [(480, 640)] * 400 + [(50, 600)] * 10
+    p = augment.random_resized_crop_params(sizes, (224, 224), scale=(0.5, 1.0), generator=rng)
+    x0, y0, w, h = p[:, 0], p[:, 1], p[:, 2], p[:, 3]
+    hs, ws = np.array([s[0] for s in sizes]), np.array([s[1] for s in sizes])
+    assert (x0 >= 0).all() and (y0 >= 0).all() and (x0 + w <= ws).all() and (y0 + h <= hs).all()
+    frac = (w[:400] * h[:400]) / (480.0 * 640.0)
+    assert 0.49 <= frac.min() and frac.max() <= 1.0 and 0.60 <= frac.mean() <= 0.80            # area ~ U(0.5, 1), large non-square boxes are redrawn
+    asp = w[:400] / h[:400]
+    assert 0.74 <= asp.min() and asp.max() <= 1.34
+    assert (p[400:, 2] == 67).all() and (p[400:, 3] == 50).all()          # 12:1 images: fallback box, aspect clamped to 4/3
+    q = augment.random_crop_min_size_params([(300, 500), (500, 300), (64, 64)], 224, generator=rng)
+    assert q[0, 2] == q[0, 3] == 300 and q[0, 1] == 0 and 0 <= q[0, 0] <= 200
+    assert q[1, 2] == q[1, 3] == 300 and q[1, 0] == 0 and 0 <= q[1, 1] <= 200 and tuple(q[2, :4]) == (0, 0, 64, 64)
+    r = augment.resize_center_crop_params([(480, 640), (640, 480)], 256, 224)
+    assert tuple(r[0]) == (0, 0, 640, 480, 341, 256, 58, 16) and tuple(r[1]) == (0, 0, 480, 640, 256, 341, 16, 58)
+
+
+def test_prefetcher_crops_views_from_one_upload():
+    """prefetch.crops_on_device: two views (DeCLIP) cut from ONE uint8 canvas -> channel-stacked fp32 [b, 6, H, W]; view v equals a
+    single-view call with that view's boxes / flips."""
+    import numpy as np
+    from declip_amd import augment
+    from declip_amd.prefetch import crops_on_device
+    g = torch.Generator().manual_seed(2)
+    sizes = [(120, 160), (200, 140), (96, 96)]
+    canvas = torch.randint(0, 256, (3, 200, 160, 3), generator=g, dtype=torch.uint8)
+    rng = np.random.default_rng(5)
+    boxes = np.stack([augment.random_resized_crop_params(sizes, (64, 64), generator=rng) for _ in range(2)], axis=1)     # [b, 2, 8]
+    flips = torch.tensor([[0, 1], [1, 1], [0, 0]], dtype=torch.uint8)
+    with emulated_gpu() as ops:
+        out = crops_on_device({"images": canvas, "image_boxes": torch.from_numpy(boxes), "image_flip": flips, "captions": "kept"}, (64, 64))
+        assert out["captions"] == "kept" and "image_boxes" not in out and out["images"].shape == (3, 6, 64, 64)
+        for v in range(2):
+            one = ops.image_resized_crop_u8(canvas, torch.from_numpy(np.ascontiguousarray(boxes[:, v])), (64, 64), flip=flips[:, v].contiguous())
+            assert torch.equal(out["images"][:, 3 * v:3 * v + 3], one)
+        assert crops_on_device({"images": canvas}, (64, 64))["images"] is canvas                  # nothing to do without boxes
