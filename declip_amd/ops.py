@@ -30,7 +30,7 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, 
         M, N, K = dims
     else:
         assert K == Kb, "contraction mismatch %d vs %d" % (K, Kb)
-    assert A.stride(1) == 1 and B.stride(1) == 1
+    assert (A.shape[1] == 1 or A.stride(1) == 1) and (B.shape[1] == 1 or B.stride(1) == 1)      # (a 1-wide dim may report any stride)
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=out_dtype or A.dtype)
     assert (dims is not None or out.shape == (M, N)) and out.stride(1) == 1
@@ -38,7 +38,7 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, 
     a.dtype, a.c_dtype = dt(A), dt(out)
     a.a_kmajor, a.b_kmajor = int(a_kmajor), int(b_kmajor)
     a.M, a.N, a.K = M, N, K
-    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(out), out.stride(0)
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = ptr(A), max(A.stride(0), A.shape[1]), ptr(B), max(B.stride(0), B.shape[1]), ptr(out), out.stride(0)
     if bias is not None:
         assert bias.dtype == torch.float32 and (dims is not None or bias.numel() == N)
     a.bias = ptr(bias)
