@@ -318,7 +318,9 @@ class ClsSolver(object):
                 tok = None
                 if self.kind in ("clip", "slip") and getattr(tower, "_bpe_path", None) and os.path.exists(tower._bpe_path):
                     tok = tower._get_tokenizer()          # the other families augment / mask the caption TEXT in forward()
-                self._iter = DataPrefetcher(self.loader, self.device, tokenizer=tok, context_length=int(tower.context_length))
+                # user loaders may hand decoded uint8 canvases + crop boxes (declip_amd.augment): cropped / resized on the GPU
+                self._iter = DataPrefetcher(self.loader, self.device, tokenizer=tok, context_length=int(tower.context_length),
+                                            image_size=int(d.get("input_size", 224)))
             else:
                 self._iter = iter(self.loader)
         start = self.state["last_iter"] + 1
