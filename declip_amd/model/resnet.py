@@ -18,50 +18,56 @@ from ..lib import DeclipHipError
 from .transformer import _Tower
 
 
+def _conv(cin, cout, k, stride=1):
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False)
+
+
+def _conv_bn_chain(module, specs):
+    """registers conv<i> / bn<i> pairs (i = 1, 2, ...) on `module` from (cin, cout, kernel, stride) tuples"""
+    for i, (cin, cout, k, stride) in enumerate(specs, 1):
+        setattr(module, "conv%d" % i, _conv(cin, cout, k, stride))
+        setattr(module, "bn%d" % i, nn.BatchNorm2d(cout))
+
+
 class Bottleneck(nn.Module):
-    """modified_resnet.py:14-56 (parameters + geometry only)."""
+    """modified_resnet.py:14-56 -- parameters and geometry only: 1x1 -> 3x3 -> 1x1 (x4 channels), every convolution stride 1,
+    the block's stride taken by an average pool after the 3x3; `downsample` (avgpool + 1x1 conv + BN under the reference's
+    Sequential keys "-1", "0", "1") whenever the shape changes."""
     expansion = 4
 
     def __init__(self, inplanes, planes, stride=1):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        wide = planes * self.expansion
+        _conv_bn_chain(self, [(inplanes, planes, 1, 1), (planes, planes, 3, 1), (planes, wide, 1, 1)])
+        self.stride = stride
         self.avgpool = nn.AvgPool2d(stride) if stride > 1 else nn.Identity()
-        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = None
-        self.stride = stride
-        if stride > 1 or inplanes != planes * Bottleneck.expansion:
-            self.downsample = nn.Sequential(OrderedDict([
-                ("-1", nn.AvgPool2d(stride)),
-                ("0", nn.Conv2d(inplanes, planes * self.expansion, 1, stride=1, bias=False)),
-                ("1", nn.BatchNorm2d(planes * self.expansion))]))
+        if stride > 1 or inplanes != wide:
+            self.downsample = nn.Sequential(OrderedDict((("-1", nn.AvgPool2d(stride)), ("0", _conv(inplanes, wide, 1)),
+                                                         ("1", nn.BatchNorm2d(wide)))))
 
     def forward(self, x):
         raise DeclipHipError("Bottleneck runs inside the HIP engine (resnet_engine); the container is never called")
 
 
 class AttentionPool2d(nn.Module):
-    """modified_resnet.py:59-96."""
+    """modified_resnet.py:59-96 (parameters: positional embedding for HW + 1 tokens, separate k / q / v projections, c_proj)."""
 
     def __init__(self, spacial_dim, embed_dim, num_heads, output_dim=None):
         super().__init__()
-        self.positional_embedding = nn.Parameter(torch.randn(spacial_dim ** 2 + 1, embed_dim) / embed_dim ** 0.5)
-        self.k_proj = nn.Linear(embed_dim, embed_dim)
-        self.q_proj = nn.Linear(embed_dim, embed_dim)
-        self.v_proj = nn.Linear(embed_dim, embed_dim)
-        self.c_proj = nn.Linear(embed_dim, output_dim or embed_dim)
         self.num_heads = num_heads
+        self.positional_embedding = nn.Parameter(torch.randn(spacial_dim ** 2 + 1, embed_dim) / embed_dim ** 0.5)
+        for name, out_features in (("k_proj", embed_dim), ("q_proj", embed_dim), ("v_proj", embed_dim), ("c_proj", output_dim or embed_dim)):
+            setattr(self, name, nn.Linear(embed_dim, out_features))
 
     def forward(self, x):
         raise DeclipHipError("AttentionPool2d runs inside the HIP engine (resnet_engine); the container is never called")
 
 
 class ModifiedResNet(_Tower):
-    """modified_resnet.py:106-214."""
+    """modified_resnet.py:106-214: 3-convolution stem (the first with stride 2) + avgpool, four bottleneck stages of widths
+    width * (1, 2, 4, 8), attention pool on the final map (adaptive pool + fc when it is not 7 wide)."""
 
     def __init__(self, layers, embed_dim, heads, input_resolution=224, width=64, bn_group_size=1, bn_var_mode=None,
                  bn_sync_stats=False, use_sync_bn=True):
@@ -71,43 +77,34 @@ class ModifiedResNet(_Tower):
         # `bn_var_mode` / `bn_sync_stats`, cannot be constructed in the released tree, SURVEY.md s9 quirk 19, so those two
         # arguments are accepted and ignored).  The parameter containers stay nn.BatchNorm2d: same state_dict keys.
         self.use_sync_bn, self.bn_group_size = bool(use_sync_bn), int(bn_group_size)
-        self.output_dim = embed_dim
-        self.input_resolution = input_resolution
-        self.conv1 = nn.Conv2d(3, width // 2, kernel_size=3, stride=2, padding=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(width // 2)
-        self.conv2 = nn.Conv2d(width // 2, width // 2, kernel_size=3, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(width // 2)
-        self.conv3 = nn.Conv2d(width // 2, width, kernel_size=3, padding=1, bias=False)
-        self.bn3 = nn.BatchNorm2d(width)
-        self.avgpool = nn.AvgPool2d(2)
-        self.relu = nn.ReLU(inplace=True)
+        self.output_dim, self.input_resolution = embed_dim, input_resolution
+        half = width // 2
+        _conv_bn_chain(self, [(3, half, 3, 2), (half, half, 3, 1), (half, width, 3, 1)])
+        self.avgpool, self.relu = nn.AvgPool2d(2), nn.ReLU(inplace=True)
         self._inplanes = width
-        self.layer1 = self._make_layer(width, layers[0])
-        self.layer2 = self._make_layer(width * 2, layers[1], stride=2)
-        self.layer3 = self._make_layer(width * 4, layers[2], stride=2)
-        self.layer4 = self._make_layer(width * 8, layers[3], stride=2)
-        feat_dim = width * 32
-        self.attnpool = AttentionPool2d(input_resolution // 32, feat_dim, heads, embed_dim)
+        for i, blocks in enumerate(layers):
+            setattr(self, "layer%d" % (i + 1), self._make_layer(width << i, blocks, stride=1 if i == 0 else 2))
+        self.attnpool = AttentionPool2d(input_resolution // 32, width * 32, heads, embed_dim)
         self.adaptivepool = nn.AdaptiveAvgPool2d((1, 1))
         self.fc = nn.Linear(2048, embed_dim)                    # modified_resnet.py:167 (the head when the final map is not 7 wide)
         for p in self.fc.parameters():
             p._dh_grad_none = True      # the head off the path keeps grad None and is left alone by the optimizer, as in torch
                                         # (resnet_engine sets this per forward: attention pool at 224 px, adaptive pool + fc otherwise)
-        std = self.attnpool.c_proj.in_features ** -0.5
-        for lin in (self.attnpool.q_proj, self.attnpool.k_proj, self.attnpool.v_proj, self.attnpool.c_proj):
-            nn.init.normal_(lin.weight, std=std)
+        # initial distributions of the reference (modified_resnet.py:169-178)
+        ap = self.attnpool
+        for lin in (ap.q_proj, ap.k_proj, ap.v_proj, ap.c_proj):
+            nn.init.normal_(lin.weight, std=ap.c_proj.in_features ** -0.5)
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
-            for name, param in stage.named_parameters():
-                if name.endswith("bn3.weight"):
-                    nn.init.zeros_(param)
+            for blk in stage:
+                nn.init.zeros_(blk.bn3.weight)
         resnet_engine.check_supported(self)
 
     def _make_layer(self, planes, blocks, stride=1):
-        layers = [Bottleneck(self._inplanes, planes, stride)]
-        self._inplanes = planes * Bottleneck.expansion
-        for _ in range(1, blocks):
-            layers.append(Bottleneck(self._inplanes, planes))
-        return nn.Sequential(*layers)
+        chain = []
+        for i in range(blocks):                                  # only the first block of a stage strides / widens
+            chain.append(Bottleneck(self._inplanes, planes, stride if i == 0 else 1))
+            self._inplanes = planes * Bottleneck.expansion
+        return nn.Sequential(*chain)
 
     def forward(self, x, return_dense=False, channel_offset=0, n_views=1):
         """x: [b, 3*views, 224, 224] fp32 (or uint8 [b, H, W, 3]) on the GPU -> [b, embed_dim] fp32
