@@ -35,6 +35,28 @@ def test_argument_errors_are_reported_not_thrown():
     assert L.dh_gemm(ctypes.byref(args), None) == -1
 
 
+def test_resnet_entry_points_check_their_arguments():
+    """the REAL library (no GPU needed: every check precedes the first launch): error codes + messages, never an exception"""
+    from declip_amd import lib
+    L = lib.load()
+    one = ctypes.c_void_p(16)          # any non-NULL pointer: the calls below must fail before touching memory
+    assert L.dh_conv_rows(1, one, 0, 64, 0, one, 1, 8, 8, 64, 5, 1, 2, 25 * 64, None) == -1 and b"3x3" in L.dh_last_error()
+    assert L.dh_conv_rows(1, one, 0, 12, 0, one, 1, 8, 8, 12, 3, 1, 1, 108, None) == -1 and b"C % 8" in L.dh_last_error()
+    assert L.dh_conv_rows(1, one, 1, 3, 2, one, 1, 8, 8, 3, 3, 2, 1, 32, None) == -1 and b"channel window" in L.dh_last_error()
+    assert L.dh_bn2d_fwd(1, one, None, one, one, one, one, one, None, None, 10, 12, 1e-5, 0.1, 1, 1, one, 1 << 20, None) == -1
+    assert b"multiple of 8" in L.dh_last_error()
+    assert L.dh_bn2d_fwd(1, one, None, one, one, one, one, one, None, None, 10, 16, 1e-5, 0.1, 1, 1, one, 8, None) == -1
+    assert b"workspace too small" in L.dh_last_error()
+    assert L.dh_bn2d_fwd(1, one, None, one, one, one, one, one, None, None, 10, 16, 1e-5, 0.1, 1, 0, one, 1 << 20, None) == -1
+    assert b"eval needs running stats" in L.dh_last_error()
+    assert L.dh_bn2d_bwd(1, one, one, None, one, one, one, one, None, one, one, 10, 16, 1, one, 1 << 20, None) == -1      # relu without y
+    assert L.dh_bn2d_sums(1, 1, one, None, None, None, None, 0, 10, 16, one, one, 1 << 20, None) == -1 and b"mode 1" in L.dh_last_error()
+    assert L.dh_avgpool_fwd(1, one, one, 1, 7, 7, 16, 2, None) == -1 and b"multiples of k" in L.dh_last_error()
+    assert L.dh_attnpool_tokens_fwd(1, one, one, one, 0, 49, 64, None) == -1
+    assert L.dh_image_resized_crop_u8(one, 1, 8, 8, None, None, (ctypes.c_float * 3)(), (ctypes.c_float * 3)(1, 1, 1), one, 3, 0, 4, 4, 1, None) == -1
+    assert L.dh_bn2d_ws_bytes(100352, 64) == 4 * (393 * 2 * 64 + 2 * 64) or L.dh_bn2d_ws_bytes(100352, 64) > 0
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from declip_amd import lib
     monkeypatch.setattr(lib, "_lib", None)
