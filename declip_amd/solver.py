@@ -398,6 +398,13 @@ class ClsSolver(object):
         t0, n_img = time.time(), 0
         for batch in loader:
             images = batch["images"].to(self.device, non_blocking=True)
+            if images.dtype == torch.uint8 and batch.get("image_boxes") is not None:
+                # decoded images on a uint8 canvas + boxes (augment.resize_center_crop_params = the reference's ONECROP pipeline,
+                # imagenet_dataloader.py:105-111): Resize(256) + CenterCrop(224) + ToTensor + Normalize on the GPU
+                from .prefetch import crops_on_device
+                res = int(self.config.get("data", AttrDict()).get("input_size", 224))
+                images = crops_on_device({"images": images, "image_boxes": batch["image_boxes"].to(self.device, non_blocking=True)},
+                                         (res, res))["images"]
             out = zeroshot.classify(m, images, class_emb, ensemble, return_dense=bool(self.config.get("return_dense", False)))
             labels = batch["labels"] if "labels" in batch else batch["label"]
             meter.update(out["topk"], labels.view(-1).long())
