@@ -79,3 +79,19 @@ def resize_center_crop_params(sizes, resize=256, crop=224):
             raise ValueError("image %dx%d is smaller than the crop after Resize(%d)" % (w, h, resize))
         out[n] = (0, 0, w, h, Wf, Hf, int(round((Wf - crop) / 2.0)), int(round((Hf - crop) / 2.0)))
     return out
+
+
+def make_canvas(images, pinned=False):
+    """Stack decoded HWC uint8 images of different sizes on one [b, Hmax, Wmax, 3] canvas (each in its top-left corner) -- the
+    `src` of dh_image_resized_crop_u8 -- and return (canvas tensor, [(h, w), ...]).  The padding is never read: every crop box
+    lies inside its image.  `pinned` allocates page-locked memory so that the upload is an asynchronous copy."""
+    import torch
+    sizes = [(int(im.shape[0]), int(im.shape[1])) for im in images]
+    H, W = max(h for h, _ in sizes), max(w for _, w in sizes)
+    canvas = torch.zeros(len(images), H, W, 3, dtype=torch.uint8, pin_memory=bool(pinned))
+    for n, im in enumerate(images):
+        t = im if torch.is_tensor(im) else torch.from_numpy(np.ascontiguousarray(im))
+        if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+            raise ValueError("image %d: expected uint8 [h, w, 3], got %s %s" % (n, t.dtype, tuple(t.shape)))
+        canvas[n, :t.shape[0], :t.shape[1]] = t
+    return canvas, sizes

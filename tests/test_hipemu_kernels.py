@@ -115,6 +115,27 @@ def test_image_resized_crop_matches_pil_and_torch_antialias():
             assert float((raw[i] * 255.0 - ref).abs().max()) <= 2e-3, (name, i)
 
 
+def test_make_canvas_and_full_intake_path():
+    """decoded images of different sizes -> canvas -> boxes -> on-device crops == the oracle's per-image pipeline"""
+    import numpy as np
+    from declip_amd import augment
+    from declip_amd.prefetch import crops_on_device
+    from oracle import restated
+    g = torch.Generator().manual_seed(9)
+    imgs = [torch.randint(0, 256, (h, w, 3), generator=g, dtype=torch.uint8) for h, w in ((90, 120), (150, 80), (64, 64))]
+    canvas, sizes = augment.make_canvas([imgs[0].numpy(), imgs[1], imgs[2]])
+    assert canvas.shape == (3, 150, 120, 3) and sizes == [(90, 120), (150, 80), (64, 64)]
+    assert torch.equal(canvas[1, :150, :80], imgs[1]) and int(canvas[0, 90:].max()) == 0
+    params = augment.resize_center_crop_params(sizes, 72, 64)
+    with emulated_gpu():
+        out = crops_on_device({"images": canvas, "image_boxes": torch.from_numpy(params)}, (64, 64))["images"]
+    ref = restated.image_resized_crop_u8(canvas, params, (64, 64))
+    d = (out - ref).abs()
+    assert float(d.max()) <= 1.01 / 255 / 0.224 and float((d > 1e-6).float().mean()) <= 2e-3
+    with pytest.raises(ValueError):
+        augment.make_canvas([torch.zeros(4, 4, dtype=torch.uint8)])
+
+
 def test_crop_box_generators():
     import numpy as np
     from declip_amd import augment
