@@ -48,3 +48,14 @@ def test_gpu_model_test_on_host_emulation_slow(module, name, args):
     mod = importlib.import_module(module)
     with emulated_gpu():
         getattr(mod, name)(*args)
+
+
+def test_smoke_entry_on_host_emulation(monkeypatch):
+    """__graft_entry__.smoke() -- the driver's first GPU call of a round -- end to end on the emulated kernels."""
+    import torch
+
+    import __graft_entry__ as entry
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    with emulated_gpu():
+        entry.smoke()
