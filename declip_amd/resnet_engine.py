@@ -64,6 +64,15 @@ def bn_group(tower):
     return grp
 
 
+_TRACKED = []      # num_batches_tracked buffers touched by the pass in flight: bumped together (53 tiny launches -> 1)
+
+
+def _bump_tracked():
+    if _TRACKED:
+        torch._foreach_add_(list(_TRACKED), 1)
+        _TRACKED.clear()
+
+
 class _BN:
     """forward + saved state of one BatchNorm2d (+ReLU (+residual)) application; `group` != None synchronises the batch
     statistics over that process group (one all-reduce of [2C+1] doubles per direction)."""
@@ -87,7 +96,7 @@ class _BN:
             self.y, self.mean, self.invstd = ops.bn2d_fwd(x, bn.weight.data, bn.bias.data, rm, rv, relu, training, residual=residual,
                                                           eps=bn.eps, momentum=momentum)
         if training and track and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)                       # buffer bookkeeping (nn.BatchNorm2d.forward)
+            _TRACKED.append(bn.num_batches_tracked)              # buffer bookkeeping (nn.BatchNorm2d.forward), one launch per pass
 
     def backward(self, flat, dy):
         g = flat.gview
@@ -229,6 +238,7 @@ def _forward_pass(flat, tower, images, c0, training):
     dtype = flat.act_dtype
     b, _, Hi, Wi = images.shape
     st = {"b": b}
+    _TRACKED.clear()
     grp = bn_group(tower) if training else None
     # ---- stem (modified_resnet.py:144-150,194-199): conv1 stride 2 on the image, conv2, conv3, avgpool(2)
     rows0, H, W = ops.conv_rows_image(images, c0, dtype, stride=2, pad=1)
@@ -265,6 +275,7 @@ def _forward_pass(flat, tower, images, c0, training):
         pooled = ops.avgpool_fwd(x, b, H, W, C, H)                # [b, C]: mean over the whole map
         out = ops.gemm(pooled, flat.wview(tower.fc.weight), bias=tower.fc.bias.data, out_dtype=torch.float32)
         st.update(x_last=x, pooled=pooled, out=out, dense=x.view(b, H * W, C), geom=(H * W, C, 0, 0), head="fc", hw=(H, W))
+        _bump_tracked()
         return st
     if H != 7 or H * W + 1 != ap.positional_embedding.shape[0]:
         raise DeclipHipError("ModifiedResNet: attention pool built for %d tokens, final map is %dx%d"
@@ -284,6 +295,7 @@ def _forward_pass(flat, tower, images, c0, training):
     out = ops.gemm(pooled, w(ap.c_proj.weight), bias=ap.c_proj.bias.data, out_dtype=torch.float32)
     st.update(x_last=x, tok=tok, qkv=qkv, a=a, lse=lse, pooled=pooled, out=out, dense=x.view(b, HW, C), geom=(HW, C, heads, L),
               head="attnpool")
+    _bump_tracked()
     return st
 
 
