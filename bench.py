@@ -240,7 +240,8 @@ def main():
                scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                config=dict(workload=workloads[args.model],
                            global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world,
-                           tower_streams=1 + len(model.__dict__["_flat_store"].side_streams)),
+                           tower_streams=1 + len(model.__dict__["_flat_store"].side_streams),
+                           text_packed=os.environ.get("DH_TEXT_PACKED", "0") == "1"),   # captions computed up to <|endoftext|> only (opt-in)
                loss=round(float(loss.detach()) * world, 5))
     if roofline is not None:
         out["roofline"] = roofline

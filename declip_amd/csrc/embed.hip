@@ -291,6 +291,70 @@ extern "C" int dh_text_embed_fwd(int dtype, const int64_t* ids, const float* tab
   return DH_OK;
 }
 
+// ---- packed (variable-length) captions: only the tokens up to and including <|endoftext|> of every caption are rows.
+// Under the causal mask a token never sees a later one and only the EOT row is pooled (text_transformer.py:136-142,203), so
+// the padding rows of the reference's [b, 77] layout are dead work: ~45 % of the text tower on the synthetic captions of
+// SURVEY.md s8(d) (lengths U{6..75}), more on real ones.  x[r] = table[ids_p[r]] + pos[pos_idx[r]] for r < rows, 0 up to rows_pad.
+template <typename T>
+__global__ __launch_bounds__(256) void text_embed_packed_fwd_kernel(const int64_t* __restrict__ ids_p, const int* __restrict__ pos_idx,
+                                                                    const float* __restrict__ table, const float* __restrict__ pos,
+                                                                    T* __restrict__ x, int rows, int rows_pad, int d) {
+  const int nchunk = d >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)rows_pad * nchunk; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / nchunk), ch = (int)(i % nchunk);
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (row < rows) {
+      float p[8];
+      ld8(table + ids_p[row] * d + ch * 8, a);
+      ld8(pos + (long)pos_idx[row] * d + ch * 8, p);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += p[k];
+    }
+    st8(x + (long)row * d + ch * 8, a);
+  }
+}
+
+// dpos[p, :] += sum over the captions i longer than p of dx[cu[i] + p, :]   (no atomics: one block owns (p, 64 columns))
+template <typename T>
+__global__ __launch_bounds__(256) void packed_pos_grad_kernel(const T* __restrict__ dx, const int* __restrict__ cu, int b, int d,
+                                                              float* __restrict__ dpos) {
+  __shared__ float red[4][64];
+  const int p = blockIdx.y;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < d)
+    for (int i = rl; i < b; i += 4) {
+      const int r0 = cu[i], len = cu[i + 1] - r0;
+      if (p < len) s += ld<T>(dx + (long)(r0 + p) * d + c);
+    }
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < d) dpos[(long)p * d + c] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+extern "C" int dh_text_embed_packed_fwd(int dtype, const int64_t* ids_p, const int* pos_idx, const float* table, const float* pos,
+                                        void* x, int rows, int rows_pad, int d, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(ids_p && pos_idx && table && pos && x && rows > 0 && rows_pad >= rows && d % 8 == 0, "dh_text_embed_packed_fwd: bad args");
+  if (dtype == DH_BF16) hipLaunchKernelGGL(text_embed_packed_fwd_kernel<bf16_t>, dim3(grid_for((long)rows_pad * d / 8)), dim3(256), 0, st, ids_p, pos_idx, table, pos, (bf16_t*)x, rows, rows_pad, d);
+  else if (dtype == DH_F32) hipLaunchKernelGGL(text_embed_packed_fwd_kernel<float>, dim3(grid_for((long)rows_pad * d / 8)), dim3(256), 0, st, ids_p, pos_idx, table, pos, (float*)x, rows, rows_pad, d);
+  else DH_FAIL(DH_ERR_ARG, "dh_text_embed_packed_fwd: bad dtype");
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_packed_pos_grad(int dtype, const void* dx, const int* cu_seqlens, int b, int Lmax, int d, float* dpos, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(dx && cu_seqlens && dpos && b > 0 && Lmax > 0 && d > 0, "dh_packed_pos_grad: bad args");
+  dim3 grid(dh_cdiv(d, 64), Lmax);
+  if (dtype == DH_BF16) hipLaunchKernelGGL(packed_pos_grad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dx, cu_seqlens, b, d, dpos);
+  else if (dtype == DH_F32) hipLaunchKernelGGL(packed_pos_grad_kernel<float>, grid, dim3(256), 0, st, (const float*)dx, cu_seqlens, b, d, dpos);
+  else DH_FAIL(DH_ERR_ARG, "dh_packed_pos_grad: bad dtype");
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
 static int launch_batch_reduce(int dtype, const void* dx, float* out, int b, int Lx, int d, hipStream_t st) {
   int bsplit = b >= 64 ? 8 : 1;
   int bpb = dh_cdiv(b, bsplit);

@@ -56,6 +56,8 @@ _PROTOS = {
     "dh_attn_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_text_embed_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "dh_text_embed_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, POINTER(c_int64), c_int, _P]),
+    "dh_text_embed_packed_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "dh_packed_pos_grad": (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P, _P]),
     "dh_image_prep_u8": (c_int, [_P, c_int, c_int, c_int, _P, _P, POINTER(c_float), POINTER(c_float), _P, c_int, c_int, c_int, c_int, _P]),
     "dh_image_resized_crop_u8": (c_int, [_P, c_int, c_int, c_int, _P, _P, POINTER(c_float), POINTER(c_float), _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_im2row": (c_int, [c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),

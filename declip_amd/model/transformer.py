@@ -180,8 +180,17 @@ class TextTransformer(_Tower):
             ids, labels = tok if mask_type is not None else (tok, None)
         flat = self._flat()
         dev = flat.flat_p.device
-        ids = engine.to_device_async(ids, dev).long().contiguous()
         want_dense = return_dense or mask_type is not None
+        packed = not want_dense and os.environ.get("DH_TEXT_PACKED", "0") == "1"
+        host_rows = None
+        if packed and not ids.is_cuda and getattr(ids, "_dh_rows", None) is None:
+            host_rows = int((ids.argmax(dim=-1) + 1).sum())         # counted on the host copy: no device read in the step
+        ids = engine.to_device_async(ids, dev).long().contiguous()
+        if packed:
+            # variable-length captions: only the rows up to <|endoftext|> are computed (engine.PackedCaptions; same outputs)
+            if host_rows is not None:
+                ids._dh_rows = (ids._version, host_rows)
+            return engine.TextTowerPackedFn.apply(flat.anchor, ids, self)
         out = engine.TextTowerFn.apply(flat.anchor, ids, self, want_dense)
         if mask_type is not None:
             return out[0], out[1], engine.to_device_async(labels, dev)

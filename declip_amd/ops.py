@@ -130,6 +130,29 @@ def text_embed_bwd(ids, dx, dtable, dpos, hot_ids=(0,)):
           "dh_text_embed_bwd")
 
 
+def text_embed_packed_fwd(ids_p, pos_idx, table, pos, dtype, rows, rows_pad):
+    """packed captions: x [rows_pad, d], x[r] = table[ids_p[r]] + pos[pos_idx[r]] for r < rows, zero rows after."""
+    assert ids_p.dtype == torch.int64 and pos_idx.dtype == torch.int32 and ids_p.numel() >= rows and pos_idx.numel() >= rows
+    d = table.shape[1]
+    x = torch.empty(rows_pad, d, device=table.device, dtype=dtype)
+    check(L.load().dh_text_embed_packed_fwd(dt(x), ptr(_contig(ids_p, "ids")), ptr(_contig(pos_idx, "pos_idx")), ptr(table), ptr(pos), ptr(x),
+                                            rows, rows_pad, d, stream()), "dh_text_embed_packed_fwd")
+    return x
+
+
+def text_embed_packed_bwd(ids_p, cu, dx, dtable, dpos, rows, Lmax, hot_ids=()):
+    """gradients of the packed embedding: token table by scatter-add over the packed ids, positions by a per-position reduction."""
+    d = dx.shape[1]
+    if dtable is not None:
+        hot = (ctypes.c_int64 * max(1, len(hot_ids)))(*hot_ids)
+        check(L.load().dh_text_embed_bwd(dt(dx), ptr(_contig(ids_p, "ids")), ptr(_contig(dx, "dx")), ptr(dtable), None, rows, 1, d, hot,
+                                         len(hot_ids), stream()), "dh_text_embed_bwd")
+    if dpos is not None:
+        assert cu.dtype == torch.int32
+        check(L.load().dh_packed_pos_grad(dt(dx), ptr(dx), ptr(_contig(cu, "cu")), cu.numel() - 1, Lmax, d, ptr(dpos), stream()),
+              "dh_packed_pos_grad")
+
+
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)     # transforms.Normalize of the reference pipelines
 
 

@@ -129,6 +129,15 @@ int dh_text_embed_fwd(int dtype, const int64_t* ids, const float* table, const f
                       dh_stream_t stream);
 int dh_text_embed_bwd(int dtype, const int64_t* ids, const void* dx, float* dtable, float* dpos, int b, int L, int d,
                       const int64_t* hot_ids_host, int n_hot, dh_stream_t stream);
+/* Packed (variable-length) captions.  Under the causal mask a token never attends to a later one and only the <|endoftext|>
+ * row is pooled (text_encoder/text_transformer.py:136-142,203), so the rows after EOT of the reference's [b][77] layout are dead
+ * work; the packed text tower keeps only the rows up to and including EOT: [rows = sum len_i][d], zero rows up to rows_pad
+ * (whole GEMM tiles).  x[r] = table[ids_p[r]] + pos[pos_idx[r]].  Token-table gradient: dh_text_embed_bwd on the packed ids
+ * (b = rows, L = 1, dpos NULL); positional gradient: dh_packed_pos_grad, dpos[p] += sum_{i: len_i > p} dx[cu[i] + p]
+ * (cu_seqlens int32 [b + 1], device). */
+int dh_text_embed_packed_fwd(int dtype, const int64_t* ids_p, const int* pos_idx, const float* table, const float* pos, void* x,
+                             int rows, int rows_pad, int d, dh_stream_t stream);
+int dh_packed_pos_grad(int dtype, const void* dx, const int* cu_seqlens, int b, int Lmax, int d, float* dpos, dh_stream_t stream);
 /* Vision: im2row of the stride-P patch conv (visual_transformer.py:14-15,56-59):
  * images [b,3,H,W] fp32 (channel offset c0 of C_total channels, for channel-stacked views,
  * data/transforms.py:38-41) -> rows [b*gh*gw, 3*P*P] (dtype), inner order (c,ph,pw). */

@@ -357,3 +357,36 @@ def test_image_resized_crop_u8_matches_oracle():
         ref = restated.image_resized_crop_u8(canvas, params, (224, 224), flip=flip)
         diff = (out.cpu() - ref).abs()
         assert float(diff.max()) <= 1.01 / 255 / 0.224 and float((diff > 1e-6).float().mean()) <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ packed captions (DH_TEXT_PACKED=1)
+@pytest.mark.parametrize("name", ["clip_tiny", "clip_vitb32_b8"])
+def test_packed_text_tower_fp32_matches_reference_golden(monkeypatch, name):
+    """the text tower on the rows up to <|endoftext|> only (engine.PackedCaptions) passes the same reference goldens."""
+    import test_gpu_clip as G
+    monkeypatch.setenv("DH_TEXT_PACKED", "1")
+    G.test_clip_fp32_matches_reference_golden(name)
+
+
+def test_packed_text_tower_bf16_full_size_equals_padded(monkeypatch):
+    """ViT-B/32 + 12-layer text tower, batch 256, bf16: packed vs padded step on the same weights and batch (the GEMMs of the
+    packed tower see M = sum of caption lengths rounded up to whole 256-row tiles)."""
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.testing import build_clip
+    cfg, b = synth.VITB32, 256
+    images, ids = synth.synth_images(b, seed=4).cuda(), synth.synth_tokens(b, seed=4).cuda()
+    res = {}
+    for packed in ("0", "1"):
+        monkeypatch.setenv("DH_TEXT_PACKED", packed)
+        model = build_clip(cfg, dtype="bf16", seed=2)
+        li, lt = model({"images": images, "captions": ids})
+        loss, _ = ClipInfoCELoss()(li, lt)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[packed] = (float(loss), {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None})
+    (l0, g0), (l1, g1) = res["0"], res["1"]
+    assert abs(l0 - l1) <= 2e-3 * abs(l0)
+    for n in g0:
+        if n.startswith("encode_text.") and float(g0[n].norm()) > 1e-6:
+            assert abs(float(g1[n].norm()) - float(g0[n].norm())) <= 3e-2 * float(g0[n].norm()), n

@@ -59,3 +59,66 @@ def test_smoke_entry_on_host_emulation(monkeypatch):
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
     with emulated_gpu():
         entry.smoke()
+
+
+PACKED = [
+    ("test_gpu_clip", "test_clip_fp32_matches_reference_golden", ("clip_tiny",)),
+    ("test_gpu_clip", "test_clip_fp32_matches_reference_golden", ("clip_tiny_scale5",)),
+    ("test_gpu_clip", "test_clip_bf16_close_to_reference", ("clip_tiny", 1e-2, 5e-2)),
+    ("test_gpu_clip", "test_train_steps_flat_adamw_matches_torch_adamw_on_oracle", ()),
+    ("test_gpu_clip", "test_slip_step_matches_reference_golden", ("fp32", 1e-3)),
+]
+
+
+@pytest.mark.parametrize("module,name,args", PACKED, ids=["packed-%s-%d" % (c[1], i) for i, c in enumerate(PACKED)])
+def test_packed_text_tower_passes_the_same_goldens(monkeypatch, module, name, args):
+    """DH_TEXT_PACKED=1: the text tower computes only the rows up to <|endoftext|> of every caption (engine.PackedCaptions) -- and
+    has to pass the very same reference goldens / oracle comparisons as the padded layout, at the same tolerances."""
+    monkeypatch.setenv("DH_TEXT_PACKED", "1")
+    mod = importlib.import_module(module)
+    with emulated_gpu():
+        getattr(mod, name)(*args)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_packed_text_tower_equals_padded_on_edge_lengths(monkeypatch, dtype):
+    """captions of minimal length (SOT, EOT), of the full context and in between, batch of one: features, parameter gradients and
+    the row bookkeeping of the packed tower against the padded one (same kernels, same weights)."""
+    import torch
+
+    from declip_amd import engine, synth
+    from declip_amd.testing import build_clip
+    cfg = synth.TINY
+    ctx, V = cfg["ctx"], cfg["vocab"]
+
+    def caption(n_words, seed):
+        g = torch.Generator().manual_seed(seed)
+        row = torch.zeros(ctx, dtype=torch.long)
+        row[0] = V - 2
+        row[1:1 + n_words] = torch.randint(0, V - 3, (n_words,), generator=g)
+        row[1 + n_words] = V - 1
+        return row
+
+    for lens in ([0, ctx - 2, 5, 1, 9], [ctx - 2], [0]):
+        ids = torch.stack([caption(n, i) for i, n in enumerate(lens)])
+        res = {}
+        for packed in ("0", "1"):
+            monkeypatch.setenv("DH_TEXT_PACKED", packed)
+            with emulated_gpu():
+                model = build_clip(cfg, dtype=dtype, seed=3, device="cpu")
+                out = model.encode_text(ids.clone())
+                w = torch.linspace(-1, 1, out.numel()).view_as(out)
+                (out * w).sum().backward()
+                res[packed] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()
+                                                      if n.startswith("encode_text.") and p.grad is not None})
+        pk = engine.PackedCaptions(ids, 8)
+        assert pk.rows == sum(n + 2 for n in lens) and pk.rows_pad % 8 == 0 and pk.cu.tolist()[-1] == pk.rows
+        tol = 1e-5 if dtype == "fp32" else 3e-2
+        (o0, g0), (o1, g1) = res["0"], res["1"]
+        assert float((o0 - o1).abs().max()) <= tol * float(o0.abs().max())
+        assert set(g0) == set(g1)
+        for n in g0:
+            assert float((g0[n] - g1[n]).abs().max()) <= tol * float(g0[n].abs().max() + 1e-12), (lens, n)
+        # the positional embedding beyond the longest caption receives exactly no gradient, as in the padded layout
+        longest = max(lens) + 2
+        assert float(g1["encode_text.positional_embedding"][longest:].abs().max() if longest < ctx else 0.0) == 0.0
