@@ -91,9 +91,11 @@ __device__ __forceinline__ bf16x8_t kmask(bf16x8_t f, bool dead) {
 // ------------------------------------------------------------------------------------------
 // forward, bf16 / MFMA.  blockDim = 64 * NKB; wave w owns queries [16w, 16w+16)
 // ------------------------------------------------------------------------------------------
-template <int NKB>  // number of 16-key blocks (L16/16), compile-time so scores stay in registers
+// VL: variable-length (packed) sequences -- pair (bi, h) owns rows cu[bi] .. cu[bi+1] of qkv / out instead of bi*L .. bi*L + L
+// (lse stays [b][heads][L]); the dense instantiation is the code it was before the template parameter existed.
+template <int NKB, bool VL>  // NKB: number of 16-key blocks (L16/16), compile-time so scores stay in registers
 __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
-                                     int L, int heads, int causal, float scale, int nbh) {
+                                     int L, int heads, int causal, float scale, int nbh, const int* __restrict__ cu) {
   constexpr int L16 = NKB * 16;
   constexpr int NKS = (L16 + 31) / 32;          // 32-wide k-steps over the keys
   constexpr bool KTAIL = (L16 % 32) != 0;
@@ -111,17 +113,20 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
   TileRegs rq, rk, rv;
   {
     const int bh0 = blockIdx.x;
-    const bf16_t* qg0 = qkv + (long)(bh0 / heads) * L * gs + (bh0 % heads) * HD;
-    rq = tile_load(qg0, gs, L, tid, nthr); rk = tile_load(qg0 + d_model, gs, L, tid, nthr); rv = tile_load(qg0 + 2 * d_model, gs, L, tid, nthr);
+    const int L0 = VL ? cu[bh0 / heads + 1] - cu[bh0 / heads] : L;
+    const bf16_t* qg0 = qkv + (VL ? (long)cu[bh0 / heads] * gs : (long)(bh0 / heads) * L * gs) + (bh0 % heads) * HD;
+    rq = tile_load(qg0, gs, L0, tid, nthr); rk = tile_load(qg0 + d_model, gs, L0, tid, nthr); rv = tile_load(qg0 + 2 * d_model, gs, L0, tid, nthr);
   }
   for (int bh = blockIdx.x; bh < nbh; bh += gridDim.x) {
   const int bi = bh / heads, h = bh % heads;
+  const int Lp = VL ? cu[bi + 1] - cu[bi] : L;              // length of this sequence (rows cu[bi] .. of qkv / out when packed)
   tile_store(rq, Qs, tid, nthr); tile_store(rk, Ks, tid, nthr); tile_store(rv, Vs, tid, nthr);
   __syncthreads();
   if (bh + (int)gridDim.x < nbh) {         // next pair's tiles: in flight during this pair's arithmetic
     const int bn = bh + gridDim.x;
-    const bf16_t* qn = qkv + (long)(bn / heads) * L * gs + (bn % heads) * HD;
-    rq = tile_load(qn, gs, L, tid, nthr); rk = tile_load(qn + d_model, gs, L, tid, nthr); rv = tile_load(qn + 2 * d_model, gs, L, tid, nthr);
+    const int L1 = VL ? cu[bn / heads + 1] - cu[bn / heads] : L;
+    const bf16_t* qn = qkv + (VL ? (long)cu[bn / heads] * gs : (long)(bn / heads) * L * gs) + (bn % heads) * HD;
+    rq = tile_load(qn, gs, L1, tid, nthr); rk = tile_load(qn + d_model, gs, L1, tid, nthr); rv = tile_load(qn + 2 * d_model, gs, L1, tid, nthr);
   }
 
   const int qb = wave;
@@ -149,7 +154,7 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
     for (int r = 0; r < 4; ++r) {
       const int key = kb * 16 + 4 * (lane >> 4) + r;
       float v = s[kb][r] * scale;
-      if (key >= L || (causal && key > q)) v = -INFINITY;
+      if (key >= Lp || (causal && key > q)) v = -INFINITY;
       s[kb][r] = v;
       mx = fmaxf(mx, v);
     }
@@ -165,7 +170,7 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
     }
   sum = quad_sum(sum);
   const float inv = 1.f / sum;
-  if (q < L && (lane >> 4) == 0) lse[((long)bi * heads + h) * L + q] = mx + __logf(sum);
+  if (q < Lp && (lane >> 4) == 0) lse[((long)bi * heads + h) * L + q] = mx + __logf(sum);
   // P[q][key..key+3] <- transpose of the C fragment: one 8-byte store per fragment
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
@@ -188,10 +193,10 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
     }
     // C^T layout: lane&15 = query row, registers = 4 consecutive head-dim columns 4*(lane>>4)+r -> one 8-byte store
     const int qq = qb * 16 + (lane & 15);
-    if (qq < L) {
+    if (qq < Lp) {
       uint2 w;
       w.x = pack2bf_hw(acc[0], acc[1]); w.y = pack2bf_hw(acc[2], acc[3]);
-      *reinterpret_cast<uint2*>(out + ((long)bi * L + qq) * d_model + h * HD + db * 16 + 4 * (lane >> 4)) = w;
+      *reinterpret_cast<uint2*>(out + ((VL ? (long)cu[bi] : (long)bi * L) + qq) * d_model + h * HD + db * 16 + 4 * (lane >> 4)) = w;
     }
   }
   __syncthreads();                         // every wave is done with the tiles before the next pair overwrites them
@@ -201,10 +206,11 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
 // ------------------------------------------------------------------------------------------
 // backward, bf16 / MFMA
 // ------------------------------------------------------------------------------------------
-template <int NKB>
+template <int NKB, bool VL>
 __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                      const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                     bf16_t* __restrict__ dqkv, int L, int heads, int causal, float scale, int nbh) {
+                                     bf16_t* __restrict__ dqkv, int L, int heads, int causal, float scale, int nbh,
+                                     const int* __restrict__ cu) {
   constexpr int L16 = NKB * 16;
   constexpr int NKS = (L16 + 31) / 32;
   constexpr bool KTAIL = (L16 % 32) != 0;
@@ -224,13 +230,13 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
   const int lane = tid & 63, wave = tid >> 6;
   // D[q] = sum_d dO[q][d] * O[q][d]: thread -> row tid >> 2, 16 columns (tid & 3) * 16 .. +15 (two 16-byte pieces each of O, dO)
   struct DRegs { uint4 o[2], g[2]; };
-  auto d_load = [&](const bf16_t* og, const bf16_t* gg) {
+  auto d_load = [&](const bf16_t* og, const bf16_t* gg, int Lc) {
     DRegs r;
     const int row = tid >> 2, part = tid & 3;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       r.o[c] = make_uint4(0, 0, 0, 0); r.g[c] = make_uint4(0, 0, 0, 0);
-      if (row < L) {
+      if (row < Lc) {
         r.o[c] = *reinterpret_cast<const uint4*>(og + (long)row * d_model + part * 16 + c * 8);
         r.g[c] = *reinterpret_cast<const uint4*>(gg + (long)row * d_model + part * 16 + c * 8);
       }
@@ -241,14 +247,18 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
   DRegs rd;
   {
     const int bh0 = blockIdx.x, b0 = bh0 / heads, h0 = bh0 % heads;
-    const bf16_t* qg0 = qkv + (long)b0 * L * gs + h0 * HD;
-    const bf16_t* gg0 = dout + (long)b0 * L * d_model + h0 * HD;
-    rq = tile_load(qg0, gs, L, tid, nthr); rk = tile_load(qg0 + d_model, gs, L, tid, nthr); rv = tile_load(qg0 + 2 * d_model, gs, L, tid, nthr);
-    rg = tile_load(gg0, d_model, L, tid, nthr);
-    rd = d_load(out + (long)b0 * L * d_model + h0 * HD, gg0);
+    const long r0 = VL ? (long)cu[b0] : (long)b0 * L;
+    const int L0 = VL ? cu[b0 + 1] - cu[b0] : L;
+    const bf16_t* qg0 = qkv + r0 * gs + h0 * HD;
+    const bf16_t* gg0 = dout + r0 * d_model + h0 * HD;
+    rq = tile_load(qg0, gs, L0, tid, nthr); rk = tile_load(qg0 + d_model, gs, L0, tid, nthr); rv = tile_load(qg0 + 2 * d_model, gs, L0, tid, nthr);
+    rg = tile_load(gg0, d_model, L0, tid, nthr);
+    rd = d_load(out + r0 * d_model + h0 * HD, gg0, L0);
   }
   for (int bh = blockIdx.x; bh < nbh; bh += gridDim.x) {
   const int bi = bh / heads, h = bh % heads;
+  const long row0 = VL ? (long)cu[bi] : (long)bi * L;
+  const int Lp = VL ? cu[bi + 1] - cu[bi] : L;
   tile_store(rq, Qs, tid, nthr); tile_store(rk, Ks, tid, nthr); tile_store(rv, Vs, tid, nthr); tile_store(rg, Gs, tid, nthr);
   {
     const uint32_t* ow = reinterpret_cast<const uint32_t*>(rd.o);
@@ -268,15 +278,17 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int qq = wave * 16 + 4 * (lane >> 4) + r;
-    lse_r[r] = qq < L ? lse[((long)bi * heads + h) * L + qq] : 0.f;
+    lse_r[r] = qq < Lp ? lse[((long)bi * heads + h) * L + qq] : 0.f;
   }
   if (bh + (int)gridDim.x < nbh) {         // next pair's tiles: in flight during this pair's arithmetic
     const int bn = bh + gridDim.x, b1 = bn / heads, h1 = bn % heads;
-    const bf16_t* qn = qkv + (long)b1 * L * gs + h1 * HD;
-    const bf16_t* gn = dout + (long)b1 * L * d_model + h1 * HD;
-    rq = tile_load(qn, gs, L, tid, nthr); rk = tile_load(qn + d_model, gs, L, tid, nthr); rv = tile_load(qn + 2 * d_model, gs, L, tid, nthr);
-    rg = tile_load(gn, d_model, L, tid, nthr);
-    rd = d_load(out + (long)b1 * L * d_model + h1 * HD, gn);
+    const long r1 = VL ? (long)cu[b1] : (long)b1 * L;
+    const int L1 = VL ? cu[b1 + 1] - cu[b1] : L;
+    const bf16_t* qn = qkv + r1 * gs + h1 * HD;
+    const bf16_t* gn = dout + r1 * d_model + h1 * HD;
+    rq = tile_load(qn, gs, L1, tid, nthr); rk = tile_load(qn + d_model, gs, L1, tid, nthr); rv = tile_load(qn + 2 * d_model, gs, L1, tid, nthr);
+    rg = tile_load(gn, d_model, L1, tid, nthr);
+    rd = d_load(out + r1 * d_model + h1 * HD, gn, L1);
   }
 
   // ---- phase 1: wave owns query block qb: S[q][key] (rows q), dP[q][key]
@@ -306,7 +318,7 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qq = qb * 16 + 4 * (lane >> 4) + r;
-        const bool masked = key >= L || qq >= L || (causal && key > qq);
+        const bool masked = key >= Lp || qq >= Lp || (causal && key > qq);
         p[r] = masked ? 0.f : __expf(sacc[r] * scale - lse_r[r]);
         ds[r] = p[r] * (pacc[r] - d_r[r]) * scale;
       }
@@ -323,7 +335,7 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
   // ---- phase 2: wave owns row block rb (keys for dV/dK, queries for dQ); contraction length L16
   {
     const int rb = wave;
-    bf16_t* dq_g = dqkv + (long)bi * L * gs + h * HD;
+    bf16_t* dq_g = dqkv + row0 * gs + h * HD;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       f32x4_t av = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
@@ -344,7 +356,7 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
       }
       // transposed fragments: lane&15 = row (query / key), registers = 4 consecutive head-dim columns -> 8-byte stores
       const int row = rb * 16 + (lane & 15);
-      if (row < L) {
+      if (row < Lp) {
         const long o = (long)row * gs + db * 16 + 4 * (lane >> 4);
         uint2 w;
         w.x = pack2bf_hw(aq[0], aq[1]); w.y = pack2bf_hw(aq[2], aq[3]);
@@ -365,15 +377,17 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                               float* __restrict__ lse, int L, int heads, int hd,
-                                                               int causal, float scale) {
+                                                               float* __restrict__ lse, int Lmax, int heads, int hd,
+                                                               int causal, float scale, const int* __restrict__ cu) {
   DH_DYN_LDS(float, smf);
   const int hs = hd + 1;
-  float* Q = smf; float* K = Q + L * hs; float* V = K + L * hs; float* S = V + L * hs;  // S [L][L+1]
   const int bh = blockIdx.x, bi = bh / heads, h = bh % heads;
+  const long row0 = cu ? (long)cu[bi] : (long)bi * Lmax;     // packed sequences: rows cu[bi] .. cu[bi+1]; lse stays [b][heads][Lmax]
+  const int L = cu ? cu[bi + 1] - cu[bi] : Lmax;
+  float* Q = smf; float* K = Q + L * hs; float* V = K + L * hs; float* S = V + L * hs;  // S [L][L+1]
   const int dm = heads * hd;
   const long gs = 3L * dm;
-  const T* base = qkv + (long)bi * L * gs + h * hd;
+  const T* base = qkv + row0 * gs + h * hd;
   for (int i = threadIdx.x; i < L * hd; i += 256) {
     int r = i / hd, c = i % hd;
     Q[r * hs + c] = ld<T>(base + (long)r * gs + c);
@@ -400,32 +414,34 @@ __global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const T* __restri
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
     for (int k = lane; k < L; k += 64) S[q * (L + 1) + k] *= inv;
-    if (lane == 0) lse[((long)bi * heads + h) * L + q] = mx + __logf(sum);
+    if (lane == 0) lse[((long)bi * heads + h) * Lmax + q] = mx + __logf(sum);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < L * hd; i += 256) {
     int q = i / hd, c = i % hd;
     float a = 0.f;
     for (int k = 0; k < L; ++k) a = fmaf(S[q * (L + 1) + k], V[k * hs + c], a);
-    st<T>(out + ((long)bi * L + q) * dm + h * hd + c, a);
+    st<T>(out + (row0 + q) * dm + h * hd + c, a);
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                                const T* __restrict__ dout, const float* __restrict__ lse,
-                                                               T* __restrict__ dqkv, int L, int heads, int hd,
-                                                               int causal, float scale) {
+                                                               T* __restrict__ dqkv, int Lmax, int heads, int hd,
+                                                               int causal, float scale, const int* __restrict__ cu) {
   DH_DYN_LDS(float, smf);
+  const int bh = blockIdx.x, bi = bh / heads, h = bh % heads;
+  const long row0 = cu ? (long)cu[bi] : (long)bi * Lmax;
+  const int L = cu ? cu[bi + 1] - cu[bi] : Lmax;
   const int hs = hd + 1, ls = L + 1;
   float* Q = smf; float* K = Q + L * hs; float* V = K + L * hs; float* G = V + L * hs;
   float* P = G + L * hs; float* dS = P + L * ls; float* Dq = dS + L * ls;
-  const int bh = blockIdx.x, bi = bh / heads, h = bh % heads;
   const int dm = heads * hd;
   const long gs = 3L * dm;
-  const T* base = qkv + (long)bi * L * gs + h * hd;
-  const T* ob = out + (long)bi * L * dm + h * hd;
-  const T* gb = dout + (long)bi * L * dm + h * hd;
+  const T* base = qkv + row0 * gs + h * hd;
+  const T* ob = out + row0 * dm + h * hd;
+  const T* gb = dout + row0 * dm + h * hd;
   for (int i = threadIdx.x; i < L * hd; i += 256) {
     int r = i / hd, c = i % hd;
     Q[r * hs + c] = ld<T>(base + (long)r * gs + c);
@@ -444,12 +460,12 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const T* __restri
     int q = i / L, k = i % L;
     float s = 0.f, dp = 0.f;
     for (int c = 0; c < hd; ++c) { s = fmaf(Q[q * hs + c], K[k * hs + c], s); dp = fmaf(G[q * hs + c], V[k * hs + c], dp); }
-    float p = (causal && k > q) ? 0.f : __expf(s * scale - lse[((long)bi * heads + h) * L + q]);
+    float p = (causal && k > q) ? 0.f : __expf(s * scale - lse[((long)bi * heads + h) * Lmax + q]);
     P[q * ls + k] = p;
     dS[q * ls + k] = p * (dp - Dq[q]) * scale;
   }
   __syncthreads();
-  T* dbase = dqkv + (long)bi * L * gs + h * hd;
+  T* dbase = dqkv + row0 * gs + h * hd;
   for (int i = threadIdx.x; i < L * hd; i += 256) {
     int r = i / hd, c = i % hd;
     float dq = 0.f, dk = 0.f, dv = 0.f;
@@ -477,26 +493,30 @@ static int attn_cus() {
 
 template <int NKB>
 int launch_fwd_mfma(const bf16_t* qkv, bf16_t* out, float* lse, int b, int L, int heads, int causal, float scale,
-                    hipStream_t st) {
+                    hipStream_t st, const int* cu = nullptr) {
   constexpr int L16 = NKB * 16, TS = L16 + 8;
   size_t lds = (size_t)(3 * L16 * RS + L16 * TS + 64) * sizeof(bf16_t);
-  hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
   int grid = attn_cus() * (per_cu < 1 ? 1 : per_cu);
   if (grid > b * heads) grid = b * heads;
-  hipLaunchKernelGGL(attn_fwd_mfma_kernel<NKB>, dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads);
+  if (cu) hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKB, true>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads, cu);
+  else hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKB, false>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads, cu);
   return 0;
 }
 template <int NKB>
 int launch_bwd_mfma(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int b,
-                    int L, int heads, int causal, float scale, hipStream_t st) {
+                    int L, int heads, int causal, float scale, hipStream_t st, const int* cu = nullptr) {
   constexpr int L16 = NKB * 16, TS = L16 + 8;
   size_t lds = (size_t)(4 * L16 * RS + 2 * L16 * TS + 64) * sizeof(bf16_t) + L16 * sizeof(float);
-  hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NKB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
   int grid = attn_cus() * (per_cu < 1 ? 1 : per_cu);
   if (grid > b * heads) grid = b * heads;
-  hipLaunchKernelGGL(attn_bwd_mfma_kernel<NKB>, dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads);
+  if (cu) hipLaunchKernelGGL((attn_bwd_mfma_kernel<NKB, true>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads, cu);
+  else hipLaunchKernelGGL((attn_bwd_mfma_kernel<NKB, false>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads, cu);
   return 0;
 }
 
@@ -509,15 +529,15 @@ int launch_bwd_mfma(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
     default: DH_FAIL(DH_ERR_UNSUPPORTED, "attention: L=%d unsupported", L); \
   }
 
-extern "C" int dh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, int b, int L, int heads, int hd,
-                           int causal, dh_stream_t stream) {
+static int attn_fwd_impl(int dtype, const void* qkv, void* out, float* lse, int b, int L, int heads, int hd, int causal,
+                         const int* cu, dh_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   DH_REQUIRE(qkv && out && lse && b > 0 && L > 0 && heads > 0, "dh_attn_fwd: bad args");
   DH_REQUIRE(L <= 128 && hd <= 64, "dh_attn_fwd: L<=128 and hd<=64 required (got %d, %d)", L, hd);
   const float scale = 1.0f / sqrtf((float)hd);
   if (dtype == DH_BF16 && hd == 64) {
     const int nkb = (L + 15) / 16;
-#define CALL(N) launch_fwd_mfma<N>((const bf16_t*)qkv, (bf16_t*)out, lse, b, L, heads, causal, scale, st)
+#define CALL(N) launch_fwd_mfma<N>((const bf16_t*)qkv, (bf16_t*)out, lse, b, L, heads, causal, scale, st, cu)
     DISPATCH_NKB(nkb, CALL)
 #undef CALL
   } else {
@@ -525,10 +545,46 @@ extern "C" int dh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, in
     DH_REQUIRE(lds <= 160 * 1024, "dh_attn_fwd: sequence too long for the fp32 / generic path (L <= 126 at hd = 64; the bf16 MFMA path takes L <= 128)");
     if (dtype == DH_BF16) {
       hipFuncSetAttribute((const void*)attn_fwd_generic_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(attn_fwd_generic_kernel<bf16_t>, dim3(b * heads), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, lse, L, heads, hd, causal, scale);
+      hipLaunchKernelGGL(attn_fwd_generic_kernel<bf16_t>, dim3(b * heads), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)out, lse, L, heads, hd, causal, scale, cu);
     } else {
       hipFuncSetAttribute((const void*)attn_fwd_generic_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(attn_fwd_generic_kernel<float>, dim3(b * heads), dim3(256), lds, st, (const float*)qkv, (float*)out, lse, L, heads, hd, causal, scale);
+      hipLaunchKernelGGL(attn_fwd_generic_kernel<float>, dim3(b * heads), dim3(256), lds, st, (const float*)qkv, (float*)out, lse, L, heads, hd, causal, scale, cu);
+    }
+  }
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, int b, int L, int heads, int hd,
+                           int causal, dh_stream_t stream) {
+  return attn_fwd_impl(dtype, qkv, out, lse, b, L, heads, hd, causal, nullptr, stream);
+}
+extern "C" int dh_attn_varlen_fwd(int dtype, const void* qkv, void* out, float* lse, const int* cu_seqlens, int b, int Lmax, int heads,
+                                  int hd, int causal, dh_stream_t stream) {
+  DH_REQUIRE(cu_seqlens, "dh_attn_varlen_fwd: cu_seqlens is NULL");
+  return attn_fwd_impl(dtype, qkv, out, lse, b, Lmax, heads, hd, causal, cu_seqlens, stream);
+}
+
+static int attn_bwd_impl(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int b, int L,
+                         int heads, int hd, int causal, const int* cu, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(qkv && out && dout && lse && dqkv && b > 0 && L > 0 && heads > 0, "dh_attn_bwd: bad args");
+  DH_REQUIRE(L <= 128 && hd <= 64, "dh_attn_bwd: L<=128 and hd<=64 required (got %d, %d)", L, hd);
+  const float scale = 1.0f / sqrtf((float)hd);
+  if (dtype == DH_BF16 && hd == 64) {
+    const int nkb = (L + 15) / 16;
+#define CALL(N) launch_bwd_mfma<N>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, b, L, heads, causal, scale, st, cu)
+    DISPATCH_NKB(nkb, CALL)
+#undef CALL
+  } else {
+    size_t lds = (size_t)(4 * L * (hd + 1) + 2 * L * (L + 1) + L) * sizeof(float);
+    DH_REQUIRE(lds <= 160 * 1024, "dh_attn_bwd: sequence too long for the fp32 / generic path (L <= 91 at hd = 64; the bf16 MFMA path takes L <= 128)");
+    if (dtype == DH_BF16) {
+      hipFuncSetAttribute((const void*)attn_bwd_generic_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_bwd_generic_kernel<bf16_t>, dim3(b * heads), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, L, heads, hd, causal, scale, cu);
+    } else {
+      hipFuncSetAttribute((const void*)attn_bwd_generic_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_bwd_generic_kernel<float>, dim3(b * heads), dim3(256), lds, st, (const float*)qkv, (const float*)out, (const float*)dout, lse, (float*)dqkv, L, heads, hd, causal, scale, cu);
     }
   }
   DH_CHECK_LAUNCH();
@@ -537,26 +593,10 @@ extern "C" int dh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, in
 
 extern "C" int dh_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                            int b, int L, int heads, int hd, int causal, dh_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
-  DH_REQUIRE(qkv && out && dout && lse && dqkv && b > 0 && L > 0 && heads > 0, "dh_attn_bwd: bad args");
-  DH_REQUIRE(L <= 128 && hd <= 64, "dh_attn_bwd: L<=128 and hd<=64 required (got %d, %d)", L, hd);
-  const float scale = 1.0f / sqrtf((float)hd);
-  if (dtype == DH_BF16 && hd == 64) {
-    const int nkb = (L + 15) / 16;
-#define CALL(N) launch_bwd_mfma<N>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, b, L, heads, causal, scale, st)
-    DISPATCH_NKB(nkb, CALL)
-#undef CALL
-  } else {
-    size_t lds = (size_t)(4 * L * (hd + 1) + 2 * L * (L + 1) + L) * sizeof(float);
-    DH_REQUIRE(lds <= 160 * 1024, "dh_attn_bwd: sequence too long for the fp32 / generic path (L <= 91 at hd = 64; the bf16 MFMA path takes L <= 128)");
-    if (dtype == DH_BF16) {
-      hipFuncSetAttribute((const void*)attn_bwd_generic_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(attn_bwd_generic_kernel<bf16_t>, dim3(b * heads), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, L, heads, hd, causal, scale);
-    } else {
-      hipFuncSetAttribute((const void*)attn_bwd_generic_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(attn_bwd_generic_kernel<float>, dim3(b * heads), dim3(256), lds, st, (const float*)qkv, (const float*)out, (const float*)dout, lse, (float*)dqkv, L, heads, hd, causal, scale);
-    }
-  }
-  DH_CHECK_LAUNCH();
-  return DH_OK;
+  return attn_bwd_impl(dtype, qkv, out, dout, lse, dqkv, b, L, heads, hd, causal, nullptr, stream);
+}
+extern "C" int dh_attn_varlen_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                  const int* cu_seqlens, int b, int Lmax, int heads, int hd, int causal, dh_stream_t stream) {
+  DH_REQUIRE(cu_seqlens, "dh_attn_varlen_bwd: cu_seqlens is NULL");
+  return attn_bwd_impl(dtype, qkv, out, dout, lse, dqkv, b, Lmax, heads, hd, causal, cu_seqlens, stream);
 }

@@ -463,7 +463,8 @@ class PackedCaptions:
     removes ~45 % of the text tower's GEMM / LayerNorm work on the synthetic captions of SURVEY.md s8(d), more on real ones.
     Index arithmetic only (torch, on the device)."""
 
-    def __init__(self, ids, tile):
+    def __init__(self, ids, tile, varlen=True):
+        self.varlen = varlen                                             # attention on the packed rows (else: via the dense layout)
         b, L = ids.shape
         lens = ids.argmax(dim=-1) + 1                                    # EOT is the largest id (quirk 5)
         # the row count sizes the buffers, so the host has to know it.  It travels WITH the tensor object: set from the host copy
@@ -493,25 +494,30 @@ class PackedCaptions:
 
 
 def block_fwd_packed(x, r, pk, heads, save):
-    """block_fwd on packed rows [rows_pad, d]; attention runs on the dense [b, L] layout (gather in, gather out) with the
-    verified kernels -- a variable-length attention kernel removes those two copies."""
+    """block_fwd on packed rows [rows_pad, d].  Attention: the variable-length kernels on the packed rows (pk.varlen), or -- the
+    fallback that touches only long-verified kernels, DH_TEXT_PACKED=2 -- gather to the dense [b, L] layout and back."""
     h1, mean1, rstd1 = ops.layernorm_fwd(x, r.ln1_w, r.ln1_b, r.eps1)
     qkv = ops.gemm(h1, r.w_in, bias=r.b_in)
-    qkv_d = ops.gather_rows(qkv, pk.unpack_idx)
-    a_d, lse = ops.attn_fwd(qkv_d, pk.b, pk.L, heads, True)
-    a = ops.gather_rows(a_d, pk.pack_idx, pk.rows_pad)
+    if pk.varlen:
+        a, lse = ops.attn_varlen_fwd(qkv, pk.cu, pk.rows, pk.b, pk.L, heads, True)
+        att_saved = (qkv, a)
+    else:
+        qkv_d = ops.gather_rows(qkv, pk.unpack_idx)
+        a_d, lse = ops.attn_fwd(qkv_d, pk.b, pk.L, heads, True)
+        a = ops.gather_rows(a_d, pk.pack_idx, pk.rows_pad)
+        att_saved = (qkv_d, a_d)
     ws = gemm_workspace(x.device) if x.is_cuda and x.dtype == torch.bfloat16 else None
     x_mid = ops.gemm(a, r.w_out, bias=r.b_out, residual=x, ws=ws)
     h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, r.ln2_w, r.ln2_b, r.eps2)
     u = torch.empty(x.shape[0], r.w_fc.shape[0], device=x.device, dtype=x.dtype) if save else None
     g = ops.gemm(h2, r.w_fc, bias=r.b_fc, epilogue=EPI_GELU, aux=u)
     x_out = ops.gemm(g, r.w_proj, bias=r.b_proj, residual=x_mid, ws=ws)
-    saved = (x, mean1, rstd1, h1, qkv_d, a_d, a, lse, x_mid, mean2, rstd2, h2, u, g) if save else None
+    saved = (x, mean1, rstd1, h1, att_saved, a, lse, x_mid, mean2, rstd2, h2, u, g) if save else None
     return x_out, saved
 
 
 def block_bwd_packed(dx_out, r, saved, pk, heads):
-    x, mean1, rstd1, h1, qkv_d, a_d, a, lse, x_mid, mean2, rstd2, h2, u, g = saved
+    x, mean1, rstd1, h1, att_saved, a, lse, x_mid, mean2, rstd2, h2, u, g = saved
     weight_grad(dx_out, g, r.g_w_proj, r.g_b_proj)
     du = ops.gemm(dx_out, r.w_proj, b_kmajor=True, epilogue=EPI_DGELU, aux=u)
     weight_grad(du, h2, r.g_w_fc, r.g_b_fc)
@@ -520,11 +526,16 @@ def block_bwd_packed(dx_out, r, saved, pk, heads):
     dx_mid = ops.layernorm_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)
     weight_grad(dx_mid, a, r.g_w_out, r.g_b_out)
     da = ops.gemm(dx_mid, r.w_out, b_kmajor=True, ws=ws)
-    # padded queries must carry a ZERO output gradient: a later (padded) query does attend to the valid keys before it
-    da_d = torch.zeros(pk.b * pk.L, da.shape[1], device=da.device, dtype=da.dtype)
-    ops.scatter_rows_add(da[:pk.rows], pk.pack_idx, da_d)
-    dqkv_d = ops.attn_bwd(qkv_d, a_d, da_d, lse, pk.b, pk.L, heads, True)
-    dqkv = ops.gather_rows(dqkv_d, pk.pack_idx, pk.rows_pad)
+    if pk.varlen:
+        qkv, a_p = att_saved
+        dqkv = ops.attn_varlen_bwd(qkv, a_p, da, lse, pk.cu, pk.rows, pk.b, pk.L, heads, True)
+    else:
+        qkv_d, a_d = att_saved
+        # padded queries must carry a ZERO output gradient: a later (padded) query does attend to the valid keys before it
+        da_d = torch.zeros(pk.b * pk.L, da.shape[1], device=da.device, dtype=da.dtype)
+        ops.scatter_rows_add(da[:pk.rows], pk.pack_idx, da_d)
+        dqkv_d = ops.attn_bwd(qkv_d, a_d, da_d, lse, pk.b, pk.L, heads, True)
+        dqkv = ops.gather_rows(dqkv_d, pk.pack_idx, pk.rows_pad)
     weight_grad(dqkv, h1, r.g_w_in, r.g_b_in)
     dh1 = ops.gemm(dqkv, r.w_in, b_kmajor=True, ws=ws)
     return ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
@@ -539,12 +550,14 @@ class TextTowerPackedFn(torch.autograd.Function):
         dtype = flat.act_dtype
         b, L = ids.shape
         tile = 256 if dtype == torch.bfloat16 else 8                    # whole tiles of the persistent GEMM in bf16
+        import os
+        varlen = os.environ.get("DH_TEXT_PACKED", "1") != "2"           # 2: attention through the dense layout (gathers)
         cached = getattr(ids, "_dh_packed", None)                       # a batch tensor that is used again keeps its bookkeeping
-        if cached is not None and cached[0] == (ids._version, tile):
+        if cached is not None and cached[0] == (ids._version, tile, varlen):
             pk = cached[1]
         else:
-            pk = PackedCaptions(ids, tile)
-            ids._dh_packed = ((ids._version, tile), pk)
+            pk = PackedCaptions(ids, tile, varlen)
+            ids._dh_packed = ((ids._version, tile, varlen), pk)
         x = ops.text_embed_packed_fwd(pk.ids_p, pk.pos_idx, tower.token_embedding.weight.data, tower.positional_embedding.data, dtype,
                                       pk.rows, pk.rows_pad)
         refs = [BlockRefs(flat, blk) for blk in tower.transformer.resblocks]

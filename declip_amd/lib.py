@@ -54,6 +54,8 @@ _PROTOS = {
     "dh_layernorm_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int64, _P]),
     "dh_attn_fwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dh_attn_varlen_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dh_attn_varlen_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_text_embed_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "dh_text_embed_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, POINTER(c_int64), c_int, _P]),
     "dh_text_embed_packed_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -113,6 +113,31 @@ def attn_bwd(qkv, out, dout, lse, b, Lq, heads, causal):
     return dqkv
 
 
+def attn_varlen_fwd(qkv, cu, rows, b, Lmax, heads, causal):
+    """attention on packed sequences: qkv [rows_pad, 3d], sequence i = rows cu[i] .. cu[i+1]; out [rows_pad, d] (tail rows zero)."""
+    _contig(qkv, "qkv")
+    assert cu.dtype == torch.int32 and cu.numel() == b + 1
+    d = qkv.shape[-1] // 3
+    out = torch.empty(qkv.shape[0], d, device=qkv.device, dtype=qkv.dtype)
+    if qkv.shape[0] > rows:
+        out[rows:].zero_()
+    lse = torch.empty(b, heads, Lmax, device=qkv.device, dtype=torch.float32)
+    check(L.load().dh_attn_varlen_fwd(dt(qkv), ptr(qkv), ptr(out), ptr(lse), ptr(_contig(cu, "cu")), b, Lmax, heads, d // heads, int(causal),
+                                      stream()), "dh_attn_varlen_fwd")
+    return out, lse
+
+
+def attn_varlen_bwd(qkv, out, dout, lse, cu, rows, b, Lmax, heads, causal):
+    _contig(qkv, "qkv"), _contig(out, "out"), _contig(dout, "dout")
+    d = qkv.shape[-1] // 3
+    dqkv = torch.empty_like(qkv)
+    if qkv.shape[0] > rows:
+        dqkv[rows:].zero_()
+    check(L.load().dh_attn_varlen_bwd(dt(qkv), ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(_contig(cu, "cu")), b, Lmax, heads,
+                                      d // heads, int(causal), stream()), "dh_attn_varlen_bwd")
+    return dqkv
+
+
 def text_embed_fwd(ids, table, pos, dtype):
     b, Lq = ids.shape
     d = table.shape[1]

@@ -119,6 +119,14 @@ int dh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, int b, int L,
                 dh_stream_t stream);
 int dh_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int b,
                 int L, int heads, int hd, int causal, dh_stream_t stream);
+/* The same on PACKED (variable-length) sequences: pair (bi, h) owns rows cu_seqlens[bi] .. cu_seqlens[bi+1] of qkv / out / dout /
+ * dqkv ([rows][3*d] / [rows][d]; cu_seqlens int32 [b + 1] in device memory, every length <= Lmax); lse stays [b][heads][Lmax].
+ * Rows outside the sequences are neither read nor written.  Used by the packed text tower (captions computed up to
+ * <|endoftext|> only). */
+int dh_attn_varlen_fwd(int dtype, const void* qkv, void* out, float* lse, const int* cu_seqlens, int b, int Lmax, int heads, int hd,
+                       int causal, dh_stream_t stream);
+int dh_attn_varlen_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                       const int* cu_seqlens, int b, int Lmax, int heads, int hd, int causal, dh_stream_t stream);
 
 /* ---------------------------------------------------------------- embeddings ------------
  * Text: x[b,l,:] = table[ids[b,l],:] + pos[l,:]   (text_transformer.py:188-190); table/pos fp32.

@@ -176,3 +176,37 @@ def test_prefetcher_crops_views_from_one_upload():
             one = ops.image_resized_crop_u8(canvas, torch.from_numpy(np.ascontiguousarray(boxes[:, v])), (64, 64), flip=flips[:, v].contiguous())
             assert torch.equal(out["images"][:, 3 * v:3 * v + 3], one)
         assert crops_on_device({"images": canvas}, (64, 64))["images"] is canvas                  # nothing to do without boxes
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("causal", [True, False])
+def test_attention_varlen_matches_per_sequence_reference(dtype, causal):
+    """dh_attn_varlen_fwd / _bwd on packed rows (sequence i = rows cu[i] .. cu[i+1]) against dense attention computed sequence by
+    sequence in fp32; lengths 1 .. Lmax incl. one at the maximum, one of a single token; rows outside the sequences untouched."""
+    torch.manual_seed(0)
+    heads, hd, Lmax = 3, 64, 77
+    lens = [5, 77, 1, 33, 16, 64]
+    b, d = len(lens), heads * hd
+    rows = sum(lens)
+    rows_pad = rows + 11
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    qkv = (torch.randn(rows_pad, 3 * d) * 0.7).to(dtype)
+    dout = torch.randn(rows_pad, d).to(dtype)
+    with emulated_gpu() as ops:
+        out, lse = ops.attn_varlen_fwd(qkv, cu, rows, b, Lmax, heads, causal)
+        dqkv = ops.attn_varlen_bwd(qkv, out, dout, lse, cu, rows, b, Lmax, heads, causal)
+    assert float(out[rows:].float().abs().max()) == 0.0 and float(dqkv[rows:].float().abs().max()) == 0.0
+    tol = 2e-5 if dtype == F32 else 2e-2
+    for i, n in enumerate(lens):
+        r0 = int(cu[i])
+        x = qkv[r0:r0 + n].float().requires_grad_()
+        q, k, v = [t.reshape(n, heads, hd).transpose(0, 1) for t in x.split(d, dim=1)]
+        s = (q @ k.transpose(1, 2)) * hd ** -0.5
+        if causal:
+            s = s + torch.full((n, n), float("-inf")).triu_(1)
+        ref = (torch.softmax(s, dim=-1) @ v).transpose(0, 1).reshape(n, d)
+        ref.backward(dout[r0:r0 + n].float())
+        assert float((out[r0:r0 + n].float() - ref.detach()).abs().max()) <= tol * max(1.0, float(ref.abs().max())), (i, n)
+        assert float((dqkv[r0:r0 + n].float() - x.grad).abs().max()) <= tol * max(1.0, float(x.grad.abs().max())) * (1 if dtype == F32 else 3), (i, n)
+        ref_lse = torch.logsumexp(s.detach(), dim=-1)
+        assert float((lse[i, :, :n] - ref_lse).abs().max()) <= (1e-4 if dtype == F32 else 3e-2)

@@ -70,18 +70,22 @@ PACKED = [
 ]
 
 
-@pytest.mark.parametrize("module,name,args", PACKED, ids=["packed-%s-%d" % (c[1], i) for i, c in enumerate(PACKED)])
-def test_packed_text_tower_passes_the_same_goldens(monkeypatch, module, name, args):
-    """DH_TEXT_PACKED=1: the text tower computes only the rows up to <|endoftext|> of every caption (engine.PackedCaptions) -- and
+PACKED_MODES = [("1", c) for c in PACKED] + [("2", c) for c in (PACKED[0], PACKED[2])]       # 1: variable-length attention, 2: via the dense layout
+
+
+@pytest.mark.parametrize("mode,case", PACKED_MODES, ids=["packed%s-%s-%d" % (m, c[1], i) for i, (m, c) in enumerate(PACKED_MODES)])
+def test_packed_text_tower_passes_the_same_goldens(monkeypatch, mode, case):
+    """DH_TEXT_PACKED=1|2: the text tower computes only the rows up to <|endoftext|> of every caption (engine.PackedCaptions) -- and
     has to pass the very same reference goldens / oracle comparisons as the padded layout, at the same tolerances."""
-    monkeypatch.setenv("DH_TEXT_PACKED", "1")
+    module, name, args = case
+    monkeypatch.setenv("DH_TEXT_PACKED", mode)
     mod = importlib.import_module(module)
     with emulated_gpu():
         getattr(mod, name)(*args)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_packed_text_tower_equals_padded_on_edge_lengths(monkeypatch, dtype):
+@pytest.mark.parametrize("dtype,mode", [("fp32", "1"), ("bf16", "1"), ("fp32", "2")])
+def test_packed_text_tower_equals_padded_on_edge_lengths(monkeypatch, dtype, mode):
     """captions of minimal length (SOT, EOT), of the full context and in between, batch of one: features, parameter gradients and
     the row bookkeeping of the packed tower against the padded one (same kernels, same weights)."""
     import torch
@@ -99,10 +103,10 @@ def test_packed_text_tower_equals_padded_on_edge_lengths(monkeypatch, dtype):
         row[1 + n_words] = V - 1
         return row
 
-    for lens in ([0, ctx - 2, 5, 1, 9], [ctx - 2], [0]):
+    for lens in ([0, ctx - 2, 5, 1, 9], [ctx - 2], [0]) if (dtype, mode) == ("fp32", "1") else ([0, ctx - 2, 5, 1, 9],):
         ids = torch.stack([caption(n, i) for i, n in enumerate(lens)])
         res = {}
-        for packed in ("0", "1"):
+        for packed in ("0", mode):
             monkeypatch.setenv("DH_TEXT_PACKED", packed)
             with emulated_gpu():
                 model = build_clip(cfg, dtype=dtype, seed=3, device="cpu")
@@ -114,7 +118,7 @@ def test_packed_text_tower_equals_padded_on_edge_lengths(monkeypatch, dtype):
         pk = engine.PackedCaptions(ids, 8)
         assert pk.rows == sum(n + 2 for n in lens) and pk.rows_pad % 8 == 0 and pk.cu.tolist()[-1] == pk.rows
         tol = 1e-5 if dtype == "fp32" else 3e-2
-        (o0, g0), (o1, g1) = res["0"], res["1"]
+        (o0, g0), (o1, g1) = res["0"], res[mode]
         assert float((o0 - o1).abs().max()) <= tol * float(o0.abs().max())
         assert set(g0) == set(g1)
         for n in g0:
