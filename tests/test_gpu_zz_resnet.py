@@ -390,3 +390,41 @@ def test_packed_text_tower_bf16_full_size_equals_padded(monkeypatch):
     for n in g0:
         if n.startswith("encode_text.") and float(g0[n].norm()) > 1e-6:
             assert abs(float(g1[n].norm()) - float(g0[n].norm())) <= 3e-2 * float(g0[n].norm()), n
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("causal", [True, False])
+def test_attention_varlen_matches_per_sequence_reference(dtype, causal):
+    """dh_attn_varlen_fwd / _bwd: packed rows, sequence i = rows cu[i] .. cu[i+1], against attention computed sequence by sequence."""
+    from declip_amd import ops
+    torch.manual_seed(0)
+    heads, hd, Lmax = 8, 64, 77
+    lens = [5, 77, 1, 33, 16, 64] * 40                 # 240 sequences: several pairs per persistent workgroup
+    b, d = len(lens), heads * hd
+    rows = sum(lens)
+    rows_pad = (rows + 255) // 256 * 256
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    qkv = (torch.randn(rows_pad, 3 * d) * 0.7).to(dtype)
+    dout = torch.randn(rows_pad, d).to(dtype)
+    out, lse = ops.attn_varlen_fwd(qkv.cuda(), cu.cuda(), rows, b, Lmax, heads, causal)
+    dqkv = ops.attn_varlen_bwd(qkv.cuda(), out, dout.cuda(), lse, cu.cuda(), rows, b, Lmax, heads, causal)
+    out, dqkv, lse = out.float().cpu(), dqkv.float().cpu(), lse.cpu()
+    assert float(out[rows:].abs().max()) == 0.0 and float(dqkv[rows:].abs().max()) == 0.0
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for i in list(range(8)) + [b - 1]:
+        n, r0 = lens[i], int(cu[i])
+        x = qkv[r0:r0 + n].float().requires_grad_()
+        q, k, v = [t.reshape(n, heads, hd).transpose(0, 1) for t in x.split(d, dim=1)]
+        s = (q @ k.transpose(1, 2)) * hd ** -0.5
+        if causal:
+            s = s + torch.full((n, n), float("-inf")).triu_(1)
+        ref = (torch.softmax(s, dim=-1) @ v).transpose(0, 1).reshape(n, d)
+        ref.backward(dout[r0:r0 + n].float())
+        assert float((out[r0:r0 + n] - ref.detach()).abs().max()) <= tol * max(1.0, float(ref.abs().max())), (i, n)
+        assert float((dqkv[r0:r0 + n] - x.grad).abs().max()) <= tol * max(1.0, float(x.grad.abs().max())) * (1 if dtype == torch.float32 else 3), (i, n)
+
+
+def test_packed_text_tower_gather_mode_fp32_matches_reference_golden(monkeypatch):
+    import test_gpu_clip as G
+    monkeypatch.setenv("DH_TEXT_PACKED", "2")
+    G.test_clip_fp32_matches_reference_golden("clip_tiny")
