@@ -541,23 +541,28 @@ def block_bwd_packed(dx_out, r, saved, pk, heads):
     return ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
 
 
+def packed_captions(ids, dtype):
+    """PackedCaptions of a device id tensor (kept on the tensor object: a batch that is used again keeps its bookkeeping)."""
+    import os
+    tile = 256 if dtype == torch.bfloat16 else 8                        # whole tiles of the persistent GEMM in bf16
+    varlen = os.environ.get("DH_TEXT_PACKED", "1") != "2"               # 2: attention through the dense layout (gathers)
+    cached = getattr(ids, "_dh_packed", None)
+    if cached is not None and cached[0] == (ids._version, tile, varlen):
+        return cached[1]
+    pk = PackedCaptions(ids, tile, varlen)
+    ids._dh_packed = ((ids._version, tile, varlen), pk)
+    return pk
+
+
 class TextTowerPackedFn(torch.autograd.Function):
-    """forward(anchor, ids, tower) -> proj [b, E] fp32: TextTowerFn (pooled output only) on packed captions."""
+    """forward(anchor, ids, tower, want_words=False) -> proj [b, E] fp32 (, words [rows_pad, width] act dtype: ln_final of every
+    PACKED row, for the masked-LM head): TextTowerFn on packed captions."""
 
     @staticmethod
-    def forward(ctx, anchor, ids, tower):
+    def forward(ctx, anchor, ids, tower, want_words=False):
         flat = tower._flat()
         dtype = flat.act_dtype
-        b, L = ids.shape
-        tile = 256 if dtype == torch.bfloat16 else 8                    # whole tiles of the persistent GEMM in bf16
-        import os
-        varlen = os.environ.get("DH_TEXT_PACKED", "1") != "2"           # 2: attention through the dense layout (gathers)
-        cached = getattr(ids, "_dh_packed", None)                       # a batch tensor that is used again keeps its bookkeeping
-        if cached is not None and cached[0] == (ids._version, tile, varlen):
-            pk = cached[1]
-        else:
-            pk = PackedCaptions(ids, tile, varlen)
-            ids._dh_packed = ((ids._version, tile, varlen), pk)
+        pk = packed_captions(ids, dtype)
         x = ops.text_embed_packed_fwd(pk.ids_p, pk.pos_idx, tower.token_embedding.weight.data, tower.positional_embedding.data, dtype,
                                       pk.rows, pk.rows_pad)
         refs = [BlockRefs(flat, blk) for blk in tower.transformer.resblocks]
@@ -566,29 +571,49 @@ class TextTowerPackedFn(torch.autograd.Function):
         for r in refs:
             x, s = block_fwd_packed(x, r, pk, tower.heads, save)
             saved_blocks.append(s)
-        pooled = ops.gather_rows(x, pk.eot_rows)                        # the EOT row of every caption (text_transformer.py:203)
-        feat, mean_f, rstd_f = ops.layernorm_fwd(pooled, tower.ln_final.weight.data, tower.ln_final.bias.data, tower.ln_final.eps)
+        lnw, lnb = tower.ln_final.weight.data, tower.ln_final.bias.data
+        if want_words:                                                  # ln_final on every row, then the EOT rows (TextTowerFn's dense branch)
+            words, mean_f, rstd_f = ops.layernorm_fwd(x, lnw, lnb, tower.ln_final.eps)
+            feat = ops.gather_rows(words, pk.eot_rows)
+            pooled = None
+        else:
+            pooled = ops.gather_rows(x, pk.eot_rows)                    # the EOT row of every caption (text_transformer.py:203)
+            feat, mean_f, rstd_f = ops.layernorm_fwd(pooled, lnw, lnb, tower.ln_final.eps)
+            words = None
         tp = tower.text_projection
         out = ops.gemm(feat, flat.wview(tp.weight), bias=tp.bias.data, out_dtype=torch.float32)
         ctx.tower, ctx.refs, ctx.saved_blocks, ctx.pk = tower, refs, saved_blocks, pk
-        ctx.misc = (x.shape, pooled, mean_f, rstd_f, feat)
-        return out
+        ctx.misc = (x, pooled, mean_f, rstd_f, feat, want_words)
+        return (out, words) if want_words else out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *grads):
         tower, pk = ctx.tower, ctx.pk
         flat = tower._flat()
         flat.begin_backward()
         dtype = flat.act_dtype
-        xshape, pooled, mean_f, rstd_f, feat = ctx.misc
+        x_final, pooled, mean_f, rstd_f, feat, want_words = ctx.misc
+        dout = grads[0]
+        dwords = grads[1] if want_words else None
         g = flat.gview
         tp = tower.text_projection
-        dout_a = _to_act(dout, dtype)
-        weight_grad(dout_a, feat, g(tp.weight), g(tp.bias))
-        dfeat = ops.gemm(dout_a, flat.wview(tp.weight), b_kmajor=True)
-        dpooled = ops.layernorm_bwd(dfeat, pooled, tower.ln_final.weight.data, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
-        dx = torch.zeros(xshape, device=dpooled.device, dtype=dtype)
-        ops.scatter_rows_add(dpooled, pk.eot_rows, dx)
+        dfeat = None
+        if dout is not None:
+            dout_a = _to_act(dout, dtype)
+            weight_grad(dout_a, feat, g(tp.weight), g(tp.bias))
+            dfeat = ops.gemm(dout_a, flat.wview(tp.weight), b_kmajor=True)
+        lnw = tower.ln_final.weight.data
+        if want_words:
+            dw_total = torch.zeros(x_final.shape, device=x_final.device, dtype=dtype)
+            if dfeat is not None:
+                ops.scatter_rows_add(dfeat, pk.eot_rows, dw_total)
+            if dwords is not None:
+                dw_total.add_(dwords.reshape(dw_total.shape).to(dtype))
+            dx = ops.layernorm_bwd(dw_total, x_final, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
+        else:
+            dpooled = ops.layernorm_bwd(dfeat, pooled, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
+            dx = torch.zeros(x_final.shape, device=dpooled.device, dtype=dtype)
+            ops.scatter_rows_add(dpooled, pk.eot_rows, dx)
         flat.grads_ready([tp.weight, tp.bias, tower.ln_final.weight, tower.ln_final.bias])
         for r, s in zip(reversed(ctx.refs), reversed(ctx.saved_blocks)):
             dx = block_bwd_packed(dx, r, s, pk, tower.heads)
@@ -598,7 +623,7 @@ class TextTowerPackedFn(torch.autograd.Function):
         ops.text_embed_packed_bwd(pk.ids_p, pk.cu, dx, g(te) if te.requires_grad else None, g(pe) if pe.requires_grad else None,
                                   pk.rows, pk.L, hot_ids=(V - 2, V - 1))        # <|startoftext|>, <|endoftext|> (no pad rows here)
         ctx.saved_blocks = ctx.misc = ctx.pk = None
-        return (torch.zeros_like(flat.anchor), None, None)
+        return (torch.zeros_like(flat.anchor), None, None, None)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -270,3 +270,16 @@ def mlm_loss(words, labels, lin, flat):
     idx = engine.to_device_async(sel, dev)
     labels_sel = engine.to_device_async(lab[sel.to(lab.device)], dev)
     return MlmHeadFn.apply(words, idx, labels_sel, lin, flat).mean()
+
+
+def mlm_loss_packed(words_p, pk, n_captions, labels, lin, flat):
+    """mlm_loss on the PACKED word features [rows_pad, width] of engine.TextTowerPackedFn: the masked positions (bi, l) of the first
+    `n_captions` captions are rows cu[bi] + l (a masked token lies inside its caption)."""
+    L = labels.shape[-1]
+    lab = labels.reshape(-1)
+    sel = (lab != -100).nonzero(as_tuple=False).reshape(-1)        # index arithmetic on the labels' own device (the host, normally)
+    dev = words_p.device
+    sel_d = engine.to_device_async(sel, dev)
+    idx = pk.cu[:n_captions].long()[sel_d // L] + sel_d % L
+    labels_sel = engine.to_device_async(lab[sel.to(lab.device)], dev)
+    return MlmHeadFn.apply(words_p.unsqueeze(0), idx, labels_sel, lin, flat).mean()

@@ -6,12 +6,14 @@ reference's forward_type='image_concat'), both text variants in one pass, all fe
 collective, the NN bank lives in HBM, the 12 logits matrices are LazyLogits handles (never materialised)."""
 from random import choice
 
+import os
+
 import torch
 from torch import nn
 
 from .. import dist as dh_dist
 from .. import engine
-from ..heads import NNMemoryBankModule, mlm_loss, prediction_MLP, projection_MLP
+from ..heads import NNMemoryBankModule, mlm_loss, mlm_loss_packed, prediction_MLP, projection_MLP
 from .clip import CLIP, LazyLogits, _engine_kwargs
 from .transformer import text_transformers, visual_transformer_B32
 
@@ -109,8 +111,14 @@ class DECLIP(CLIP):
         ids_cat = torch.cat([engine.to_device_async(ids, dev), engine.to_device_async(ids_aug, dev)], dim=0).long().contiguous()
         want_words = self.text_mask_type is not None
         side = self._fork(images)                # text tower on the side stream, both image views on the caller's (clip.py)
+        # DH_TEXT_PACKED: only the caption rows up to <|endoftext|> are computed (engine.PackedCaptions); not when a subclass needs
+        # the per-token features of the padded layout (DeFILIP's token selection ranks the padding too)
+        packed = os.environ.get("DH_TEXT_PACKED", "0") in ("1", "2") and not getattr(self, "return_filip", False)
         with self._on(side):
-            tout = engine.TextTowerFn.apply(flat.anchor, ids_cat, et, want_words)
+            if packed:
+                tout = engine.TextTowerPackedFn.apply(flat.anchor, ids_cat, et, want_words)
+            else:
+                tout = engine.TextTowerFn.apply(flat.anchor, ids_cat, et, want_words)
         txt_cat, words = (tout[0], tout[1]) if want_words else (tout, None)
         # ---- both image views in one pass
         want_dense = bool(getattr(self, "return_filip", False))
@@ -153,7 +161,11 @@ class DECLIP(CLIP):
             g_nn, g_nn_aug = gathered[4], gathered[5]
             ret["nn_text_logits"] = L(i1, g_nn), L(i2, g_nn), L(i1, g_nn_aug), L(i2, g_nn_aug)
         if self.text_mask_type is not None:
-            ret["text_self_supervised"] = mlm_loss(words[:b], labels, self.text_label_predictor, flat)
+            if packed:
+                ret["text_self_supervised"] = mlm_loss_packed(words, engine.packed_captions(ids_cat, flat.act_dtype), b, labels,
+                                                              self.text_label_predictor, flat)
+            else:
+                ret["text_self_supervised"] = mlm_loss(words[:b], labels, self.text_label_predictor, flat)
         self._extra_outputs(ret, dict(b=b, dense=dense_cat, words=words, label0=label0))
         if not self.fused_loss:
             for k in ("logits", "logits_aug", "nn_text_logits"):
