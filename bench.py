@@ -61,10 +61,15 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--model", default="clip", choices=["clip", "declip", "clip_r50"],
                     help="clip = BASELINE.json metric; declip = configs[2] variant; clip_r50 = configs[0] (CLIP ResNet-50, batch 32; add --dtype fp32)")
+    ap.add_argument("--text-packed", choices=["0", "1", "2"], default=None,
+                    help="text tower on the caption rows up to <|endoftext|> only (DESIGN.md s11; 1 = variable-length attention, "
+                         "2 = attention via the dense layout); default: the DH_TEXT_PACKED environment variable, else 0 (padded, as the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.text_packed is not None:
+        os.environ["DH_TEXT_PACKED"] = args.text_packed
     from declip_amd import dist as dh_dist
     from declip_amd import ops, synth
     from declip_amd.loss import ClipInfoCELoss
@@ -241,7 +246,7 @@ def main():
                config=dict(workload=workloads[args.model],
                            global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world,
                            tower_streams=1 + len(model.__dict__["_flat_store"].side_streams),
-                           text_packed=os.environ.get("DH_TEXT_PACKED", "0") == "1"),   # captions computed up to <|endoftext|> only (opt-in)
+                           text_packed=int(os.environ.get("DH_TEXT_PACKED", "0"))),   # 1 / 2: captions computed up to <|endoftext|> only (opt-in)
                loss=round(float(loss.detach()) * world, 5))
     if roofline is not None:
         out["roofline"] = roofline
