@@ -68,6 +68,7 @@ PACKED = [
     ("test_gpu_clip", "test_train_steps_flat_adamw_matches_torch_adamw_on_oracle", ()),
     ("test_gpu_clip", "test_slip_step_matches_reference_golden", ("fp32", 1e-3)),
     ("test_gpu_clip", "test_declip_step_matches_reference_golden", ("fp32", 1e-3)),      # packed word features feed the MLM head
+    ("test_gpu_zeroshot", "test_zero_shot_fp32_matches_reference_evaluate", (8,)),          # prompt ensembles: short captions, eval mode
 ]
 
 
