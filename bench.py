@@ -64,12 +64,16 @@ def main():
     ap.add_argument("--text-packed", choices=["0", "1", "2"], default=None,
                     help="text tower on the caption rows up to <|endoftext|> only (DESIGN.md s11; 1 = variable-length attention, "
                          "2 = attention via the dense layout); default: the DH_TEXT_PACKED environment variable, else 0 (padded, as the reference)")
+    ap.add_argument("--pooled-last", choices=["0", "1"], default=None,
+                    help="last block of each tower for the pooled row only (DESIGN.md s12); default: DH_POOLED_LAST, else 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
     if args.text_packed is not None:
         os.environ["DH_TEXT_PACKED"] = args.text_packed
+    if args.pooled_last is not None:
+        os.environ["DH_POOLED_LAST"] = args.pooled_last
     from declip_amd import dist as dh_dist
     from declip_amd import ops, synth
     from declip_amd.loss import ClipInfoCELoss
@@ -246,7 +250,7 @@ def main():
                config=dict(workload=workloads[args.model],
                            global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world,
                            tower_streams=1 + len(model.__dict__["_flat_store"].side_streams),
-                           text_packed=int(os.environ.get("DH_TEXT_PACKED", "0"))),   # 1 / 2: captions computed up to <|endoftext|> only (opt-in)
+                           text_packed=int(os.environ.get("DH_TEXT_PACKED", "0")), pooled_last=int(os.environ.get("DH_POOLED_LAST", "0"))),   # 1 / 2: captions computed up to <|endoftext|> only (opt-in)
                loss=round(float(loss.detach()) * world, 5))
     if roofline is not None:
         out["roofline"] = roofline

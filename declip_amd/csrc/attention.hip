@@ -600,3 +600,134 @@ extern "C" int dh_attn_varlen_bwd(int dtype, const void* qkv, const void* out, c
   DH_REQUIRE(cu_seqlens, "dh_attn_varlen_bwd: cu_seqlens is NULL");
   return attn_bwd_impl(dtype, qkv, out, dout, lse, dqkv, b, Lmax, heads, hd, causal, cu_seqlens, stream);
 }
+
+// ------------------------------------------------------------------------------------------
+// Pooled-query attention: ONE query per sequence (the row that is pooled: CLS of the vision tower, <|endoftext|> of the text
+// tower).  In the LAST transformer block only that row's output is ever used (visual_transformer.py:70-72, text_transformer.py:203),
+// so its query projection, attention, out_proj and MLP are needed for b rows instead of b*L -- K and V still come from every row.
+// One wave per (sequence, head), hd == 64 == the wave: lane l owns key l (and l + 64) for the scores and output dim l for the
+// weighted sums.  Keys of sequence i are kv rows row0[i] .. row0[i] + nkeys[i] - 1 (nkeys = position + 1 encodes the causal mask).
+// ------------------------------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void attn_pooled_fwd_kernel(const T* __restrict__ q, const T* __restrict__ kv, T* __restrict__ out,
+                                                              float* __restrict__ lse, const int* __restrict__ row0,
+                                                              const int* __restrict__ nkeys, int npairs, int heads, float scale) {
+  __shared__ float ps[4][128];
+  __shared__ float qs[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int d = heads * 64;
+  for (int pair = blockIdx.x * 4 + wv; pair < npairs; pair += gridDim.x * 4) {
+    const int bi = pair / heads, h = pair % heads;
+    const long r0 = row0[bi];
+    const int n = nkeys[bi];
+    qs[wv][lane] = ld<T>(q + (long)bi * d + h * 64 + lane);
+    __builtin_amdgcn_wave_barrier();
+    float s[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int key = lane + 64 * j;
+      float acc = -INFINITY;
+      if (key < n) {
+        acc = 0.f;
+        const T* kr = kv + (r0 + key) * (2L * d) + h * 64;
+        for (int c = 0; c < 64; ++c) acc += qs[wv][c] * ld<T>(kr + c);
+        acc *= scale;
+      }
+      s[j] = acc;
+    }
+    const float mx = wave_max(fmaxf(s[0], s[1]));
+    const float p0 = s[0] == -INFINITY ? 0.f : __expf(s[0] - mx), p1 = s[1] == -INFINITY ? 0.f : __expf(s[1] - mx);
+    const float sum = wave_sum(p0 + p1);
+    ps[wv][lane] = p0 / sum;
+    ps[wv][lane + 64] = p1 / sum;
+    __builtin_amdgcn_wave_barrier();
+    float o = 0.f;
+    for (int key = 0; key < n; ++key) o += ps[wv][key] * ld<T>(kv + (r0 + key) * (2L * d) + d + h * 64 + lane);
+    st<T>(out + (long)bi * d + h * 64 + lane, o);
+    if (lane == 0) lse[pair] = mx + __logf(sum);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// dq [b][d]; dkv rows of the sequence's keys are WRITTEN (every (row, head) pair has exactly one owner); rows outside stay as the
+// caller initialised them (zero)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_pooled_bwd_kernel(const T* __restrict__ q, const T* __restrict__ kv, const T* __restrict__ dout,
+                                                              const float* __restrict__ lse, T* __restrict__ dq, T* __restrict__ dkv,
+                                                              const int* __restrict__ row0, const int* __restrict__ nkeys, int npairs,
+                                                              int heads, float scale) {
+  __shared__ float ps[4][128], ds[4][128];
+  __shared__ float qs[4][64], gs[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int d = heads * 64;
+  for (int pair = blockIdx.x * 4 + wv; pair < npairs; pair += gridDim.x * 4) {
+    const int bi = pair / heads, h = pair % heads;
+    const long r0 = row0[bi];
+    const int n = nkeys[bi];
+    qs[wv][lane] = ld<T>(q + (long)bi * d + h * 64 + lane);
+    gs[wv][lane] = ld<T>(dout + (long)bi * d + h * 64 + lane);
+    __builtin_amdgcn_wave_barrier();
+    const float l = lse[pair];
+    float p[2], dp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int key = lane + 64 * j;
+      p[j] = 0.f; dp[j] = 0.f;
+      if (key < n) {
+        const T* kr = kv + (r0 + key) * (2L * d) + h * 64;
+        float sc = 0.f, g = 0.f;
+        for (int c = 0; c < 64; ++c) { sc += qs[wv][c] * ld<T>(kr + c); g += gs[wv][c] * ld<T>(kr + d + c); }
+        p[j] = __expf(sc * scale - l);
+        dp[j] = g;
+      }
+    }
+    const float D = wave_sum(p[0] * dp[0] + p[1] * dp[1]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { ps[wv][lane + 64 * j] = p[j]; ds[wv][lane + 64 * j] = p[j] * (dp[j] - D) * scale; }
+    __builtin_amdgcn_wave_barrier();
+    float aq = 0.f;
+    const float qd = qs[wv][lane], gd = gs[wv][lane];
+    for (int key = 0; key < n; ++key) {
+      const long ro = (r0 + key) * (2L * d) + h * 64 + lane;
+      aq += ds[wv][key] * ld<T>(kv + ro);
+      st<T>(dkv + ro, ds[wv][key] * qd);             // dK[key][lane]
+      st<T>(dkv + ro + d, ps[wv][key] * gd);         // dV[key][lane]
+    }
+    st<T>(dq + (long)bi * d + h * 64 + lane, aq);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+}  // namespace
+
+extern "C" int dh_attn_pooled_fwd(int dtype, const void* q, const void* kv, void* out, float* lse, const int* row0, const int* nkeys, int b,
+                                  int heads, int hd, int Lmax, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(q && kv && out && lse && row0 && nkeys && b > 0 && heads > 0, "dh_attn_pooled_fwd: bad args");
+  DH_REQUIRE(hd == 64 && Lmax >= 1 && Lmax <= 128, "dh_attn_pooled_fwd: head dim 64 and at most 128 keys per sequence (got %d, %d)", hd, Lmax);
+  const int npairs = b * heads;
+  int grid = dh_cdiv(npairs, 4);
+  if (grid > 4096) grid = 4096;
+  const float scale = 1.0f / sqrtf((float)hd);
+  if (dtype == DH_BF16) hipLaunchKernelGGL(attn_pooled_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)out, lse, row0, nkeys, npairs, heads, scale);
+  else if (dtype == DH_F32) hipLaunchKernelGGL(attn_pooled_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)q, (const float*)kv, (float*)out, lse, row0, nkeys, npairs, heads, scale);
+  else DH_FAIL(DH_ERR_ARG, "dh_attn_pooled_fwd: bad dtype");
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_attn_pooled_bwd(int dtype, const void* q, const void* kv, const void* dout, const float* lse, void* dq, void* dkv,
+                                  const int* row0, const int* nkeys, int b, int heads, int hd, int Lmax, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(q && kv && dout && lse && dq && dkv && row0 && nkeys && b > 0 && heads > 0, "dh_attn_pooled_bwd: bad args");
+  DH_REQUIRE(hd == 64 && Lmax >= 1 && Lmax <= 128, "dh_attn_pooled_bwd: head dim 64 and at most 128 keys per sequence (got %d, %d)", hd, Lmax);
+  const int npairs = b * heads;
+  int grid = dh_cdiv(npairs, 4);
+  if (grid > 4096) grid = 4096;
+  const float scale = 1.0f / sqrtf((float)hd);
+  if (dtype == DH_BF16) hipLaunchKernelGGL(attn_pooled_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)kv, (const bf16_t*)dout, lse, (bf16_t*)dq, (bf16_t*)dkv, row0, nkeys, npairs, heads, scale);
+  else if (dtype == DH_F32) hipLaunchKernelGGL(attn_pooled_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)q, (const float*)kv, (const float*)dout, lse, (float*)dq, (float*)dkv, row0, nkeys, npairs, heads, scale);
+  else DH_FAIL(DH_ERR_ARG, "dh_attn_pooled_bwd: bad dtype");
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}

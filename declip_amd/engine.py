@@ -267,6 +267,57 @@ def block_bwd(dx_out, r, saved, b, L, heads, causal):
     return ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
 
 
+def pooled_last_block():
+    """DH_POOLED_LAST=1: the last block of a tower runs its query / attention / out_proj / MLP for the POOLED rows only."""
+    import os
+    return os.environ.get("DH_POOLED_LAST", "0") == "1"
+
+
+def block_fwd_pooled(x, r, sel, row0, nkeys, Lmax, heads, save):
+    """The LAST ResidualAttentionBlock when only one row per sequence is used afterwards (CLS: visual_transformer.py:70-72; EOT:
+    text_transformer.py:203): K and V are projected for every row, everything else -- the query projection, the attention of that
+    one query, out_proj, both residuals, ln_2 and the MLP -- runs on the b pooled rows instead of all rows (82 % of the block's
+    flops at L = 50, 81 % at L = 77).  Exactly the same values for the pooled rows as block_fwd.
+    x [R, d]; sel int64 [b] = the pooled rows; row0 / nkeys int32 [b] = each sequence's key rows.  Returns x_out [b, d]."""
+    d = x.shape[1]
+    h1, mean1, rstd1 = ops.layernorm_fwd(x, r.ln1_w, r.ln1_b, r.eps1)
+    ws = gemm_workspace(x.device) if x.is_cuda and x.dtype == torch.bfloat16 else None
+    kv = ops.gemm(h1, r.w_in[d:], bias=r.b_in[d:], ws=ws)                 # k | v of every row
+    h1s = ops.gather_rows(h1, sel)
+    q = ops.gemm(h1s, r.w_in[:d], bias=r.b_in[:d])                        # the pooled rows' queries
+    a, lse = ops.attn_pooled_fwd(q, kv, row0, nkeys, heads, Lmax)
+    xs = ops.gather_rows(x, sel)
+    x_mid = ops.gemm(a, r.w_out, bias=r.b_out, residual=xs)
+    h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, r.ln2_w, r.ln2_b, r.eps2)
+    u = torch.empty(x_mid.shape[0], r.w_fc.shape[0], device=x.device, dtype=x.dtype) if save else None
+    g = ops.gemm(h2, r.w_fc, bias=r.b_fc, epilogue=EPI_GELU, aux=u)
+    x_out = ops.gemm(g, r.w_proj, bias=r.b_proj, residual=x_mid)
+    saved = (x, mean1, rstd1, h1, kv, h1s, q, a, lse, x_mid, mean2, rstd2, h2, u, g) if save else None
+    return x_out, saved
+
+
+def block_bwd_pooled(dx_out, r, saved, sel, row0, nkeys, Lmax, heads):
+    """dx_out [b, d] (gradient of the pooled rows' block output) -> gradient of the block input x [R, d]."""
+    x, mean1, rstd1, h1, kv, h1s, q, a, lse, x_mid, mean2, rstd2, h2, u, g = saved
+    d = x.shape[1]
+    weight_grad(dx_out, g, r.g_w_proj, r.g_b_proj)
+    du = ops.gemm(dx_out, r.w_proj, b_kmajor=True, epilogue=EPI_DGELU, aux=u)
+    weight_grad(du, h2, r.g_w_fc, r.g_b_fc)
+    dh2 = ops.gemm(du, r.w_fc, b_kmajor=True)
+    dx_mid = ops.layernorm_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)       # [b, d]
+    weight_grad(dx_mid, a, r.g_w_out, r.g_b_out)
+    da = ops.gemm(dx_mid, r.w_out, b_kmajor=True)
+    dq, dkv = ops.attn_pooled_bwd(q, kv, da, lse, row0, nkeys, heads, Lmax)
+    weight_grad(dq, h1s, r.g_w_in[:d], r.g_b_in[:d])
+    weight_grad(dkv, h1, r.g_w_in[d:], r.g_b_in[d:])
+    ws = gemm_workspace(x.device) if x.is_cuda and x.dtype == torch.bfloat16 else None
+    dh1 = ops.gemm(dkv, r.w_in[d:], b_kmajor=True, ws=ws)                 # [R, d]
+    ops.scatter_rows_add(ops.gemm(dq, r.w_in[:d], b_kmajor=True), sel, dh1)
+    dx = ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b)
+    ops.scatter_rows_add(dx_mid, sel, dx)                                 # the residual path of the pooled rows (x_mid = x[sel] + ...)
+    return dx
+
+
 def to_device_async(t, dev):
     """Host -> device without stalling the host: a pageable `.to(device)` waits for everything already enqueued on the stream
     (in the DeCLIP step: the whole text tower, ~35 ms at b=512); from pinned memory the copy is just another stream operation."""
@@ -314,15 +365,25 @@ class VisionTowerFn(torch.autograd.Function):
         x, mean0, rstd0 = ops.layernorm_fwd(x0, tower.ln_pre.weight.data, tower.ln_pre.bias.data, tower.ln_pre.eps)
         refs = [BlockRefs(flat, blk) for blk in tower.transformer.resblocks]
         saved_blocks = []
-        for r in refs:
+        pool = None
+        if pooled_last_block() and not want_dense and refs:
+            # the last block only for the CLS rows (their keys: the L rows of the image)
+            seq = torch.arange(b, device=images.device)
+            pool = ((seq * L).contiguous(), (seq * L).to(torch.int32).contiguous(), torch.full((b,), L, device=images.device, dtype=torch.int32))
+        for r in (refs[:-1] if pool is not None else refs):
             x, s = block_fwd(x, r, b, L, heads, False, save=save)
             saved_blocks.append(s)
-        pooled = ops.pool_rows_fwd(x, None, b, L)
+        if pool is not None:
+            pooled, s = block_fwd_pooled(x, refs[-1], pool[0], pool[1], pool[2], L, heads, save)
+            saved_blocks.append(s)
+        else:
+            pooled = ops.pool_rows_fwd(x, None, b, L)
         feat, mean_p, rstd_p = ops.layernorm_fwd(pooled, tower.ln_post.weight.data, tower.ln_post.bias.data, tower.ln_post.eps)
         out = ops.gemm(feat, flat.wview(tower.proj), b_kmajor=True, out_dtype=torch.float32)
         ctx.tower, ctx.refs, ctx.saved_blocks = tower, refs, saved_blocks
         ctx.misc = (b, L, npatch, rows if tower.conv1.weight.requires_grad else None, x0, mean0, rstd0, pooled, mean_p, rstd_p, feat, x)
         ctx.want = (want_dense, want_feature)
+        ctx.pool = pool
         outs = [out]
         if want_dense:
             outs.append(x.view(b, L, width)[:, 1:, :])
@@ -356,15 +417,24 @@ class VisionTowerFn(torch.autograd.Function):
         if dfeat_extra is not None:
             de = _to_act(dfeat_extra, dtype)
             dfeat = de if dfeat is None else dfeat.add_(de)
+        pool = ctx.pool
+        blocks = list(zip(ctx.refs, ctx.saved_blocks))
         if dfeat is not None:
             dpooled = ops.layernorm_bwd(dfeat, pooled, tower.ln_post.weight.data, mean_p, rstd_p, g(tower.ln_post.weight), g(tower.ln_post.bias))
-            dx = ops.pool_rows_bwd(dpooled, None, b, L)
+            dx = ops.pool_rows_bwd(dpooled, None, b, L) if pool is None else None
         else:
+            dpooled = None
             dx = torch.zeros(b * L, width, device=x_final.device, dtype=dtype)
         if ddense is not None:
             dx.view(b, L, width)[:, 1:, :].add_(ddense.to(dtype))
         flat.grads_ready([tower.proj, tower.ln_post.weight, tower.ln_post.bias])
-        for r, s in zip(reversed(ctx.refs), reversed(ctx.saved_blocks)):
+        if pool is not None:
+            r, s = blocks.pop()
+            if dpooled is None:
+                dpooled = torch.zeros(b, width, device=x_final.device, dtype=dtype)
+            dx = block_bwd_pooled(dpooled, r, s, pool[0], pool[1], pool[2], L, heads)
+            flat.grads_ready(r.params)
+        for r, s in reversed(blocks):
             dx = block_bwd(dx, r, s, b, L, heads, False)
             flat.grads_ready(r.params)
         dx0 = ops.layernorm_bwd(dx, x0, tower.ln_pre.weight.data, mean0, rstd0, g(tower.ln_pre.weight), g(tower.ln_pre.bias))
@@ -392,23 +462,33 @@ class TextTowerFn(torch.autograd.Function):
         refs = [BlockRefs(flat, blk) for blk in tower.transformer.resblocks]
         saved_blocks = []
         save = bool(ctx.needs_input_grad[0])
-        for r in refs:
+        eot = ids.argmax(dim=-1)                                    # text_transformer.py:203 (index arithmetic)
+        pool = None
+        if pooled_last_block() and not want_dense and refs:
+            # the last block only for the <|endoftext|> rows (their keys: the rows up to and including EOT: the causal mask)
+            seq = torch.arange(b, device=ids.device)
+            pool = ((seq * L + eot).contiguous(), (seq * L).to(torch.int32).contiguous(), (eot + 1).to(torch.int32).contiguous())
+        for r in (refs[:-1] if pool is not None else refs):
             x, s = block_fwd(x, r, b, L, heads, True, save=save)
             saved_blocks.append(s)
-        eot = ids.argmax(dim=-1)                                    # text_transformer.py:203 (index arithmetic)
         lnw, lnb = tower.ln_final.weight.data, tower.ln_final.bias.data
         if want_dense:
             words, mean_f, rstd_f = ops.layernorm_fwd(x, lnw, lnb, tower.ln_final.eps)
             feat = ops.pool_rows_fwd(words, eot, b, L)
             pooled = None
         else:
-            pooled = ops.pool_rows_fwd(x, eot, b, L)
+            if pool is not None:
+                pooled, s = block_fwd_pooled(x, refs[-1], pool[0], pool[1], pool[2], L, heads, save)
+                saved_blocks.append(s)
+            else:
+                pooled = ops.pool_rows_fwd(x, eot, b, L)
             feat, mean_f, rstd_f = ops.layernorm_fwd(pooled, lnw, lnb, tower.ln_final.eps)
             words = None
         tp = tower.text_projection
         out = ops.gemm(feat, flat.wview(tp.weight), bias=tp.bias.data, out_dtype=torch.float32)
         ctx.tower, ctx.refs, ctx.saved_blocks = tower, refs, saved_blocks
         ctx.misc = (b, L, ids, eot, x, pooled, mean_f, rstd_f, feat, want_dense)
+        ctx.pool = pool
         if want_dense:
             return out, words.view(b, L, width)
         return out
@@ -438,9 +518,14 @@ class TextTowerFn(torch.autograd.Function):
             dx = ops.layernorm_bwd(dw_total, x_final, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
         else:
             dpooled = ops.layernorm_bwd(dfeat, pooled, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
-            dx = ops.pool_rows_bwd(dpooled, eot, b, L)
+            dx = ops.pool_rows_bwd(dpooled, eot, b, L) if ctx.pool is None else None
         flat.grads_ready([tp.weight, tp.bias, tower.ln_final.weight, tower.ln_final.bias])
-        for r, s in zip(reversed(ctx.refs), reversed(ctx.saved_blocks)):
+        blocks = list(zip(ctx.refs, ctx.saved_blocks))
+        if ctx.pool is not None:
+            r, s = blocks.pop()
+            dx = block_bwd_pooled(dpooled, r, s, ctx.pool[0], ctx.pool[1], ctx.pool[2], L, heads)
+            flat.grads_ready(r.params)
+        for r, s in reversed(blocks):
             dx = block_bwd(dx, r, s, b, L, heads, True)
             flat.grads_ready(r.params)
         te, pe = tower.token_embedding.weight, tower.positional_embedding
@@ -568,7 +653,10 @@ class TextTowerPackedFn(torch.autograd.Function):
         refs = [BlockRefs(flat, blk) for blk in tower.transformer.resblocks]
         save = bool(ctx.needs_input_grad[0])
         saved_blocks = []
-        for r in refs:
+        pool = None
+        if pooled_last_block() and not want_words and refs:
+            pool = (pk.eot_rows, pk.cu[:-1].contiguous(), (pk.cu[1:] - pk.cu[:-1]).contiguous())     # EOT rows; keys = the caption's rows
+        for r in (refs[:-1] if pool is not None else refs):
             x, s = block_fwd_packed(x, r, pk, tower.heads, save)
             saved_blocks.append(s)
         lnw, lnb = tower.ln_final.weight.data, tower.ln_final.bias.data
@@ -577,9 +665,14 @@ class TextTowerPackedFn(torch.autograd.Function):
             feat = ops.gather_rows(words, pk.eot_rows)
             pooled = None
         else:
-            pooled = ops.gather_rows(x, pk.eot_rows)                    # the EOT row of every caption (text_transformer.py:203)
+            if pool is not None:
+                pooled, s = block_fwd_pooled(x, refs[-1], pool[0], pool[1], pool[2], pk.L, tower.heads, save)
+                saved_blocks.append(s)
+            else:
+                pooled = ops.gather_rows(x, pk.eot_rows)                # the EOT row of every caption (text_transformer.py:203)
             feat, mean_f, rstd_f = ops.layernorm_fwd(pooled, lnw, lnb, tower.ln_final.eps)
             words = None
+        ctx.pool = pool
         tp = tower.text_projection
         out = ops.gemm(feat, flat.wview(tp.weight), bias=tp.bias.data, out_dtype=torch.float32)
         ctx.tower, ctx.refs, ctx.saved_blocks, ctx.pk = tower, refs, saved_blocks, pk
@@ -612,10 +705,17 @@ class TextTowerPackedFn(torch.autograd.Function):
             dx = ops.layernorm_bwd(dw_total, x_final, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
         else:
             dpooled = ops.layernorm_bwd(dfeat, pooled, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
-            dx = torch.zeros(x_final.shape, device=dpooled.device, dtype=dtype)
-            ops.scatter_rows_add(dpooled, pk.eot_rows, dx)
+            dx = None
+            if ctx.pool is None:
+                dx = torch.zeros(x_final.shape, device=dpooled.device, dtype=dtype)
+                ops.scatter_rows_add(dpooled, pk.eot_rows, dx)
         flat.grads_ready([tp.weight, tp.bias, tower.ln_final.weight, tower.ln_final.bias])
-        for r, s in zip(reversed(ctx.refs), reversed(ctx.saved_blocks)):
+        blocks = list(zip(ctx.refs, ctx.saved_blocks))
+        if ctx.pool is not None:
+            r, s = blocks.pop()
+            dx = block_bwd_pooled(dpooled, r, s, ctx.pool[0], ctx.pool[1], ctx.pool[2], pk.L, tower.heads)
+            flat.grads_ready(r.params)
+        for r, s in reversed(blocks):
             dx = block_bwd_packed(dx, r, s, pk, tower.heads)
             flat.grads_ready(r.params)
         te, pe = tower.token_embedding.weight, tower.positional_embedding

@@ -56,6 +56,8 @@ _PROTOS = {
     "dh_attn_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_varlen_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_varlen_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dh_attn_pooled_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "dh_attn_pooled_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "dh_text_embed_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "dh_text_embed_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, POINTER(c_int64), c_int, _P]),
     "dh_text_embed_packed_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -138,6 +138,28 @@ def attn_varlen_bwd(qkv, out, dout, lse, cu, rows, b, Lmax, heads, causal):
     return dqkv
 
 
+def attn_pooled_fwd(q, kv, row0, nkeys, heads, Lmax):
+    """one query per sequence: q [b, d], kv [rows, 2d]; keys of sequence i = kv rows row0[i] .. row0[i] + nkeys[i] - 1."""
+    _contig(q, "q"), _contig(kv, "kv")
+    b, d = q.shape
+    assert kv.shape[1] == 2 * d and row0.dtype == torch.int32 and nkeys.dtype == torch.int32 and row0.numel() == b == nkeys.numel()
+    out = torch.empty_like(q)
+    lse = torch.empty(b, heads, device=q.device, dtype=torch.float32)
+    check(L.load().dh_attn_pooled_fwd(dt(q), ptr(q), ptr(kv), ptr(out), ptr(lse), ptr(_contig(row0, "row0")), ptr(_contig(nkeys, "nkeys")), b,
+                                      heads, d // heads, Lmax, stream()), "dh_attn_pooled_fwd")
+    return out, lse
+
+
+def attn_pooled_bwd(q, kv, dout, lse, row0, nkeys, heads, Lmax):
+    _contig(q, "q"), _contig(kv, "kv"), _contig(dout, "dout")
+    b, d = q.shape
+    dq = torch.empty_like(q)
+    dkv = torch.zeros_like(kv)
+    check(L.load().dh_attn_pooled_bwd(dt(q), ptr(q), ptr(kv), ptr(dout), ptr(lse), ptr(dq), ptr(dkv), ptr(row0), ptr(nkeys), b, heads,
+                                      d // heads, Lmax, stream()), "dh_attn_pooled_bwd")
+    return dq, dkv
+
+
 def text_embed_fwd(ids, table, pos, dtype):
     b, Lq = ids.shape
     d = table.shape[1]

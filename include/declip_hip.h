@@ -127,6 +127,17 @@ int dh_attn_varlen_fwd(int dtype, const void* qkv, void* out, float* lse, const 
                        int causal, dh_stream_t stream);
 int dh_attn_varlen_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                        const int* cu_seqlens, int b, int Lmax, int heads, int hd, int causal, dh_stream_t stream);
+/* Pooled-query attention for the LAST block of a tower: only the pooled row's output is used downstream (CLS,
+ * image_encoder/visual_transformer.py:70-72; <|endoftext|>, text_encoder/text_transformer.py:203), so that block's query projection,
+ * attention, out_proj and MLP are needed for b rows, not b*L (K, V still come from every row).  q [b][d] (the pooled rows'
+ * queries), kv [rows][2*d] (k | v, head-major, of every row); sequence i's keys are kv rows row0[i] .. row0[i] + nkeys[i] - 1
+ * (row0, nkeys int32 [b] in device memory; nkeys = position + 1 is the causal mask of the text tower, nkeys <= Lmax <= 128);
+ * hd == 64.  out [b][d], lse [b][heads].  bwd writes dq [b][d] and the dkv rows of every sequence's keys (the caller
+ * zero-fills dkv: rows no sequence owns stay zero). */
+int dh_attn_pooled_fwd(int dtype, const void* q, const void* kv, void* out, float* lse, const int* row0, const int* nkeys, int b,
+                       int heads, int hd, int Lmax, dh_stream_t stream);
+int dh_attn_pooled_bwd(int dtype, const void* q, const void* kv, const void* dout, const float* lse, void* dq, void* dkv,
+                       const int* row0, const int* nkeys, int b, int heads, int hd, int Lmax, dh_stream_t stream);
 
 /* ---------------------------------------------------------------- embeddings ------------
  * Text: x[b,l,:] = table[ids[b,l],:] + pos[l,:]   (text_transformer.py:188-190); table/pos fp32.

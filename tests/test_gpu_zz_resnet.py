@@ -428,3 +428,41 @@ def test_packed_text_tower_gather_mode_fp32_matches_reference_golden(monkeypatch
     import test_gpu_clip as G
     monkeypatch.setenv("DH_TEXT_PACKED", "2")
     G.test_clip_fp32_matches_reference_golden("clip_tiny")
+
+
+# ------------------------------------------------------------------------------------------------ last block for the pooled rows (DH_POOLED_LAST=1)
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_pooled_query_matches_reference(dtype):
+    from declip_amd import ops
+    torch.manual_seed(1)
+    heads, hd, L, b = 12, 64, 50, 300
+    d = heads * hd
+    q = (torch.randn(b, d) * 0.8).to(dtype)
+    kv = (torch.randn(b * L, 2 * d) * 0.8).to(dtype)
+    dout = torch.randn(b, d).to(dtype)
+    row0 = (torch.arange(b) * L).to(torch.int32)
+    nkeys = torch.randint(1, L + 1, (b,), generator=torch.Generator().manual_seed(2)).to(torch.int32)
+    out, lse = ops.attn_pooled_fwd(q.cuda(), kv.cuda(), row0.cuda(), nkeys.cuda(), heads, L)
+    dq, dkv = ops.attn_pooled_bwd(q.cuda(), kv.cuda(), dout.cuda(), lse, row0.cuda(), nkeys.cuda(), heads, L)
+    out, dq, dkv = out.float().cpu(), dq.float().cpu(), dkv.float().cpu()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for i in (0, 1, 17, b - 1):
+        r0, n = int(row0[i]), int(nkeys[i])
+        qi, kvi = q[i].float().requires_grad_(), kv[r0:r0 + n].float().requires_grad_()
+        k, v = kvi[:, :d].reshape(n, heads, hd), kvi[:, d:].reshape(n, heads, hd)
+        s = torch.einsum("hc,nhc->hn", qi.reshape(heads, hd), k) * hd ** -0.5
+        ref = torch.einsum("hn,nhc->hc", torch.softmax(s, dim=-1), v).reshape(d)
+        ref.backward(dout[i].float())
+        assert float((out[i] - ref.detach()).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+        assert float((dq[i] - qi.grad).abs().max()) <= 3 * tol * max(1.0, float(qi.grad.abs().max()))
+        assert float((dkv[r0:r0 + n] - kvi.grad).abs().max()) <= 3 * tol * max(1.0, float(kvi.grad.abs().max()))
+        assert float(dkv[r0 + n:r0 + L].abs().max() if n < L else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("env", [{"DH_POOLED_LAST": "1"}, {"DH_POOLED_LAST": "1", "DH_TEXT_PACKED": "1"}])
+@pytest.mark.parametrize("name", ["clip_tiny", "clip_vitb32_b8"])
+def test_pooled_last_block_fp32_matches_reference_golden(monkeypatch, env, name):
+    import test_gpu_clip as G
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    G.test_clip_fp32_matches_reference_golden(name)

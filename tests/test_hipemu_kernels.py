@@ -210,3 +210,41 @@ def test_attention_varlen_matches_per_sequence_reference(dtype, causal):
         assert float((dqkv[r0:r0 + n].float() - x.grad).abs().max()) <= tol * max(1.0, float(x.grad.abs().max())) * (1 if dtype == F32 else 3), (i, n)
         ref_lse = torch.logsumexp(s.detach(), dim=-1)
         assert float((lse[i, :, :n] - ref_lse).abs().max()) <= (1e-4 if dtype == F32 else 3e-2)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_attention_pooled_query_matches_reference(dtype):
+    """dh_attn_pooled_fwd / _bwd: one query per sequence against its keys (kv rows row0 .. row0 + nkeys - 1): outputs, lse, dq and
+    the dkv rows; rows that belong to no sequence (padding between sequences) stay zero."""
+    torch.manual_seed(1)
+    heads, hd = 3, 64
+    d = heads * hd
+    nkeys = [1, 77, 50, 128, 9]
+    gaps = [0, 3, 0, 27, 5]                                 # dense layouts leave unused rows between the sequences
+    row0, r = [], 0
+    for n, g in zip(nkeys, gaps):
+        row0.append(r)
+        r += n + g
+    rows, b = r, len(nkeys)
+    q = (torch.randn(b, d) * 0.8).to(dtype)
+    kv = (torch.randn(rows, 2 * d) * 0.8).to(dtype)
+    dout = torch.randn(b, d).to(dtype)
+    r0_t, n_t = torch.tensor(row0, dtype=torch.int32), torch.tensor(nkeys, dtype=torch.int32)
+    with emulated_gpu() as ops:
+        out, lse = ops.attn_pooled_fwd(q, kv, r0_t, n_t, heads, 128)
+        dq, dkv = ops.attn_pooled_bwd(q, kv, dout, lse, r0_t, n_t, heads, 128)
+    tol = 2e-5 if dtype == F32 else 2e-2
+    owned = torch.zeros(rows, dtype=torch.bool)
+    for i, (r0, n) in enumerate(zip(row0, nkeys)):
+        owned[r0:r0 + n] = True
+        qi = q[i].float().requires_grad_()
+        kvi = kv[r0:r0 + n].float().requires_grad_()
+        k, v = kvi[:, :d].reshape(n, heads, hd), kvi[:, d:].reshape(n, heads, hd)
+        s = torch.einsum("hc,nhc->hn", qi.reshape(heads, hd), k) * hd ** -0.5
+        ref = torch.einsum("hn,nhc->hc", torch.softmax(s, dim=-1), v).reshape(d)
+        ref.backward(dout[i].float())
+        assert float((out[i].float() - ref.detach()).abs().max()) <= tol * max(1.0, float(ref.abs().max())), i
+        assert float((lse[i] - torch.logsumexp(s.detach(), dim=-1)).abs().max()) <= (1e-4 if dtype == F32 else 3e-2)
+        assert float((dq[i].float() - qi.grad).abs().max()) <= tol * 3 * max(1.0, float(qi.grad.abs().max())), i
+        assert float((dkv[r0:r0 + n].float() - kvi.grad).abs().max()) <= tol * 3 * max(1.0, float(kvi.grad.abs().max())), i
+    assert float(dkv[~owned].float().abs().max()) == 0.0

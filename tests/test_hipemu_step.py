@@ -128,3 +128,33 @@ def test_packed_text_tower_equals_padded_on_edge_lengths(monkeypatch, dtype, mod
         # the positional embedding beyond the longest caption receives exactly no gradient, as in the padded layout
         longest = max(lens) + 2
         assert float(g1["encode_text.positional_embedding"][longest:].abs().max() if longest < ctx else 0.0) == 0.0
+
+
+POOLED = [
+    ({"DH_POOLED_LAST": "1"}, ("test_gpu_clip", "test_clip_fp32_matches_reference_golden", ("clip_tiny",))),
+    ({"DH_POOLED_LAST": "1"}, ("test_gpu_clip", "test_clip_bf16_close_to_reference", ("clip_tiny", 1e-2, 5e-2))),
+    ({"DH_POOLED_LAST": "1"}, ("test_gpu_clip", "test_train_steps_flat_adamw_matches_torch_adamw_on_oracle", ())),
+    ({"DH_POOLED_LAST": "1"}, ("test_gpu_clip", "test_slip_step_matches_reference_golden", ("fp32", 1e-3))),
+    ({"DH_POOLED_LAST": "1", "DH_TEXT_PACKED": "1"}, ("test_gpu_clip", "test_clip_fp32_matches_reference_golden", ("clip_tiny_scale5",))),
+    ({"DH_POOLED_LAST": "1", "DH_TEXT_PACKED": "1"}, ("test_gpu_clip", "test_clip_bf16_close_to_reference", ("clip_tiny", 1e-2, 5e-2))),
+    ({"DH_POOLED_LAST": "1", "DH_TEXT_PACKED": "1"}, ("test_gpu_zeroshot", "test_zero_shot_fp32_matches_reference_evaluate", (8,))),
+]
+
+
+@pytest.mark.parametrize("env,case", POOLED, ids=["pooled-%s-%d" % (c[1], i) for i, (e, c) in enumerate(POOLED)])
+def test_pooled_last_block_passes_the_same_goldens(monkeypatch, env, case):
+    """DH_POOLED_LAST=1: the last block of each tower runs its query / attention / out_proj / MLP for the pooled rows only (CLS,
+    <|endoftext|>; engine.block_fwd_pooled) -- alone and together with packed captions -- against the same goldens."""
+    module, name, args = case
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    mod = importlib.import_module(module)
+    calls = []
+    with emulated_gpu() as ops:
+        orig = ops.attn_pooled_fwd
+        ops.attn_pooled_fwd = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            getattr(mod, name)(*args)
+        finally:
+            ops.attn_pooled_fwd = orig
+    assert len(calls) >= 2          # both towers took the pooled path
