@@ -66,7 +66,6 @@ PACKED = [
     ("test_gpu_clip", "test_clip_fp32_matches_reference_golden", ("clip_tiny_scale5",)),
     ("test_gpu_clip", "test_clip_bf16_close_to_reference", ("clip_tiny", 1e-2, 5e-2)),
     ("test_gpu_clip", "test_train_steps_flat_adamw_matches_torch_adamw_on_oracle", ()),
-    ("test_gpu_clip", "test_slip_step_matches_reference_golden", ("fp32", 1e-3)),
     ("test_gpu_clip", "test_declip_step_matches_reference_golden", ("fp32", 1e-3)),      # packed word features feed the MLM head
     ("test_gpu_zeroshot", "test_zero_shot_fp32_matches_reference_evaluate", (8,)),          # prompt ensembles: short captions, eval mode
 ]
@@ -86,7 +85,7 @@ def test_packed_text_tower_passes_the_same_goldens(monkeypatch, mode, case):
         getattr(mod, name)(*args)
 
 
-@pytest.mark.parametrize("dtype,mode", [("fp32", "1"), ("bf16", "1"), ("fp32", "2")])
+@pytest.mark.parametrize("dtype,mode", [("fp32", "1"), ("bf16", "1")])
 def test_packed_text_tower_equals_padded_on_edge_lengths(monkeypatch, dtype, mode):
     """captions of minimal length (SOT, EOT), of the full context and in between, batch of one: features, parameter gradients and
     the row bookkeeping of the packed tower against the padded one (same kernels, same weights)."""
@@ -134,7 +133,7 @@ POOLED = [
     ({"DH_POOLED_LAST": "1"}, ("test_gpu_clip", "test_clip_fp32_matches_reference_golden", ("clip_tiny",))),
     ({"DH_POOLED_LAST": "1"}, ("test_gpu_clip", "test_clip_bf16_close_to_reference", ("clip_tiny", 1e-2, 5e-2))),
     ({"DH_POOLED_LAST": "1"}, ("test_gpu_clip", "test_train_steps_flat_adamw_matches_torch_adamw_on_oracle", ())),
-    ({"DH_POOLED_LAST": "1"}, ("test_gpu_clip", "test_slip_step_matches_reference_golden", ("fp32", 1e-3))),
+    ({"DH_POOLED_LAST": "1", "DH_TEXT_PACKED": "1"}, ("test_gpu_clip", "test_slip_step_matches_reference_golden", ("fp32", 1e-3))),
     ({"DH_POOLED_LAST": "1", "DH_TEXT_PACKED": "1"}, ("test_gpu_clip", "test_clip_fp32_matches_reference_golden", ("clip_tiny_scale5",))),
     ({"DH_POOLED_LAST": "1", "DH_TEXT_PACKED": "1"}, ("test_gpu_clip", "test_clip_bf16_close_to_reference", ("clip_tiny", 1e-2, 5e-2))),
     ({"DH_POOLED_LAST": "1", "DH_TEXT_PACKED": "1"}, ("test_gpu_zeroshot", "test_zero_shot_fp32_matches_reference_evaluate", (8,))),
