@@ -622,6 +622,7 @@ __global__ __launch_bounds__(256) void attn_pooled_fwd_kernel(const T* __restric
     const long r0 = row0[bi];
     const int n = nkeys[bi];
     qs[wv][lane] = ld<T>(q + (long)bi * d + h * 64 + lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS written by some lanes is read by others of the same wave
     __builtin_amdgcn_wave_barrier();
     float s[2];
 #pragma unroll
@@ -641,11 +642,13 @@ __global__ __launch_bounds__(256) void attn_pooled_fwd_kernel(const T* __restric
     const float sum = wave_sum(p0 + p1);
     ps[wv][lane] = p0 / sum;
     ps[wv][lane + 64] = p1 / sum;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS written by some lanes is read by others of the same wave
     __builtin_amdgcn_wave_barrier();
     float o = 0.f;
     for (int key = 0; key < n; ++key) o += ps[wv][key] * ld<T>(kv + (r0 + key) * (2L * d) + d + h * 64 + lane);
     st<T>(out + (long)bi * d + h * 64 + lane, o);
     if (lane == 0) lse[pair] = mx + __logf(sum);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS written by some lanes is read by others of the same wave
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -667,6 +670,7 @@ __global__ __launch_bounds__(256) void attn_pooled_bwd_kernel(const T* __restric
     const int n = nkeys[bi];
     qs[wv][lane] = ld<T>(q + (long)bi * d + h * 64 + lane);
     gs[wv][lane] = ld<T>(dout + (long)bi * d + h * 64 + lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS written by some lanes is read by others of the same wave
     __builtin_amdgcn_wave_barrier();
     const float l = lse[pair];
     float p[2], dp[2];
@@ -685,6 +689,7 @@ __global__ __launch_bounds__(256) void attn_pooled_bwd_kernel(const T* __restric
     const float D = wave_sum(p[0] * dp[0] + p[1] * dp[1]);
 #pragma unroll
     for (int j = 0; j < 2; ++j) { ps[wv][lane + 64 * j] = p[j]; ds[wv][lane + 64 * j] = p[j] * (dp[j] - D) * scale; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS written by some lanes is read by others of the same wave
     __builtin_amdgcn_wave_barrier();
     float aq = 0.f;
     const float qd = qs[wv][lane], gd = gs[wv][lane];
@@ -695,6 +700,7 @@ __global__ __launch_bounds__(256) void attn_pooled_bwd_kernel(const T* __restric
       st<T>(dkv + ro + d, ps[wv][key] * gd);         // dV[key][lane]
     }
     st<T>(dq + (long)bi * d + h * 64 + lane, aq);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS written by some lanes is read by others of the same wave
     __builtin_amdgcn_wave_barrier();
   }
 }
