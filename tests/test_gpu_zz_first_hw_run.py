@@ -3,10 +3,15 @@ through the C-ABI, the CLIP-R50 training step against the golden generated from 
 north_star tolerance on the forward; bf16 at the documented looser bounds), BatchNorm buffers, eval mode, and the full-size
 ResNet-50 at the configs[0] batch against the oracle.
 
-STATUS: these kernels and the tower engine were written after round 1's GPU budget had been spent.  They are verified on
-the CPU by running the same C entry points through the host emulation (tests/test_hipemu_resnet.py, tests/test_engine_cpu_mock.py,
-and THIS file's tests on the emulation: tests/test_hipemu_step.py); their FIRST hardware run is this file, hence the non-strict
-xfail marker (an XPASS line = verified on hardware; remove the marker then).  Sorted last on purpose."""
+Also here, for the same reason (written after the GPU budget was gone): the on-GPU RandomResizedCrop image intake, the
+variable-length attention kernels and the packed-caption text tower (DH_TEXT_PACKED), the pooled-query attention and the
+last-block-for-the-pooled-rows path (DH_POOLED_LAST).
+
+STATUS: everything in this file was written after round 1's GPU budget had been spent.  It is verified on the CPU by running the
+same C entry points through the host emulation of the kernels (tests/test_hipemu_resnet.py, tests/test_hipemu_kernels.py,
+tests/test_engine_cpu_mock.py, and THIS file's own tests on the emulation: tests/test_hipemu_step.py, tools/run_gpu_test_on_host.py);
+its FIRST hardware run is this file, hence the non-strict xfail marker (an XPASS line = verified on hardware; remove the marker
+then).  Sorted last on purpose: it cannot shadow the long-verified tests under `-x`."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -14,8 +19,8 @@ import torch.nn.functional as F
 from oracle_util import check_grad_digests, load_golden, oracle_clip_run
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason="first hardware run of the ModifiedResNet path (round 1 GPU budget was spent "
-                                                     "before it was written); verified through the host emulation on CPU")]
+              pytest.mark.xfail(strict=False, reason="first hardware run (the round-1 GPU budget was spent before this was written); "
+                                                     "verified through the host emulation of the kernels on the CPU")]
 DTYPES = [torch.float32, torch.bfloat16]
 
 
