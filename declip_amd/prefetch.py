@@ -72,11 +72,24 @@ class DataPrefetcher(object):
             # the reference's batches carry a list of captions per sample and use the first one (clip.py:110-111)
             texts = [c if isinstance(c, str) else c[0] for c in caps]
             out["captions"] = bpe.tokenize(self.tokenizer, texts, self.context_length)
+        caps = out.get("captions")
+        if torch.is_tensor(caps) and caps.dtype == torch.int64 and not caps.is_cuda:
+            # packed captions (DH_TEXT_PACKED, engine.PackedCaptions) size their buffers by the number of caption rows up to
+            # <|endoftext|>: counted HERE, on the host copy, so that the step never reads it back from the device
+            out["_caption_rows"] = int((caps.argmax(dim=-1) + 1).sum())
         if self._cuda:
             for k, v in out.items():
                 if torch.is_tensor(v) and not v.is_cuda and not v.is_pinned():
                     out[k] = v.pin_memory()
         return out
+
+    @staticmethod
+    def _tag_rows(batch):
+        rows = batch.pop("_caption_rows", None)
+        caps = batch.get("captions")
+        if rows is not None and torch.is_tensor(caps):
+            caps._dh_rows = (caps._version, rows)       # all captions of the tensor ([b, ctx], or every variant of [b, k, ctx])
+        return batch
 
     def _work(self):
         try:
@@ -98,10 +111,11 @@ class DataPrefetcher(object):
             self._staged = item
             return
         if not self._cuda:
-            self._staged = item
+            self._staged = self._tag_rows(item)
             return
         with torch.cuda.stream(self.stream):
             dev = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in item.items()}
+            dev = self._tag_rows(dev)
             dev = crops_on_device(dev, self.image_hw)      # resize / mirror / normalise behind the copy, on the copy stream
             self._event = torch.cuda.Event()
             self._event.record(self.stream)

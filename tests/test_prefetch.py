@@ -68,3 +68,16 @@ def test_solver_wraps_a_user_loader(monkeypatch, tmp_path):
     out = s.train()
     assert isinstance(s._iter, DataPrefetcher) and s.state["last_iter"] == 5 and torch.isfinite(out["loss"]).all()
     assert s._iter.next() is None
+
+
+def test_prefetcher_counts_caption_rows_on_the_host():
+    """packed captions need the number of rows up to <|endoftext|>: the prefetcher counts it on the host copy and tags the tensor"""
+    from declip_amd import synth
+    from declip_amd.prefetch import DataPrefetcher
+    ids = synth.synth_tokens(5, ctx=16, seed=1)
+    two = torch.stack([ids, synth.synth_tokens(5, ctx=16, seed=2)], dim=1)
+    pf = DataPrefetcher([{"captions": ids}, {"captions": two}], device="cpu")
+    a, b = pf.next(), pf.next()
+    assert a["captions"]._dh_rows == (a["captions"]._version, int((ids.argmax(-1) + 1).sum())) and "_caption_rows" not in a
+    assert b["captions"]._dh_rows[1] == int((two.argmax(-1) + 1).sum())
+    assert pf.next() is None
