@@ -71,7 +71,7 @@ PACKED = [
 ]
 
 
-PACKED_MODES = [("1", c) for c in PACKED] + [("2", c) for c in (PACKED[0], PACKED[2])]       # 1: variable-length attention, 2: via the dense layout
+PACKED_MODES = [("1", c) for c in PACKED] + [("2", c) for c in (PACKED[0], PACKED[1])]       # 1: variable-length attention, 2: via the dense layout
 
 
 @pytest.mark.parametrize("mode,case", PACKED_MODES, ids=["packed%s-%s-%d" % (m, c[1], i) for i, (m, c) in enumerate(PACKED_MODES)])
@@ -131,7 +131,6 @@ def test_packed_text_tower_equals_padded_on_edge_lengths(monkeypatch, dtype, mod
 
 POOLED = [
     ({"DH_POOLED_LAST": "1"}, ("test_gpu_clip", "test_clip_fp32_matches_reference_golden", ("clip_tiny",))),
-    ({"DH_POOLED_LAST": "1"}, ("test_gpu_clip", "test_clip_bf16_close_to_reference", ("clip_tiny", 1e-2, 5e-2))),
     ({"DH_POOLED_LAST": "1"}, ("test_gpu_clip", "test_train_steps_flat_adamw_matches_torch_adamw_on_oracle", ())),
     ({"DH_POOLED_LAST": "1", "DH_TEXT_PACKED": "1"}, ("test_gpu_clip", "test_slip_step_matches_reference_golden", ("fp32", 1e-3))),
     ({"DH_POOLED_LAST": "1", "DH_TEXT_PACKED": "1"}, ("test_gpu_clip", "test_clip_fp32_matches_reference_golden", ("clip_tiny_scale5",))),
