@@ -496,8 +496,8 @@ int launch_fwd_mfma(const bf16_t* qkv, bf16_t* out, float* lse, int b, int L, in
                     hipStream_t st, const int* cu = nullptr) {
   constexpr int L16 = NKB * 16, TS = L16 + 8;
   size_t lds = (size_t)(3 * L16 * RS + L16 * TS + 64) * sizeof(bf16_t);
-  hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (cu) hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  else hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
   int grid = attn_cus() * (per_cu < 1 ? 1 : per_cu);
   if (grid > b * heads) grid = b * heads;
@@ -510,8 +510,8 @@ int launch_bwd_mfma(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
                     int L, int heads, int causal, float scale, hipStream_t st, const int* cu = nullptr) {
   constexpr int L16 = NKB * 16, TS = L16 + 8;
   size_t lds = (size_t)(4 * L16 * RS + 2 * L16 * TS + 64) * sizeof(bf16_t) + L16 * sizeof(float);
-  hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NKB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (cu) hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  else hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NKB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
   int grid = attn_cus() * (per_cu < 1 ? 1 : per_cu);
   if (grid > b * heads) grid = b * heads;
