@@ -384,3 +384,29 @@ avgpool_fwd = _emulated("avgpool_fwd")
 avgpool_bwd = _emulated("avgpool_bwd")
 attnpool_tokens_fwd = _emulated("attnpool_tokens_fwd")
 attnpool_tokens_bwd = _emulated("attnpool_tokens_bwd")
+
+
+# ---------------------------------------------------------------------------------------------
+# packed captions / pooled last block (DH_TEXT_PACKED, DH_POOLED_LAST): likewise the real wrappers on the host-emulated kernels
+# ---------------------------------------------------------------------------------------------
+_SEQ_SYMS = ["dh_text_embed_packed_fwd", "dh_text_embed_bwd", "dh_packed_pos_grad", "dh_attn_varlen_fwd", "dh_attn_varlen_bwd",
+             "dh_attn_pooled_fwd", "dh_attn_pooled_bwd"]
+_SEQ_ORIG = {n: getattr(_real_ops, n) for n in ("text_embed_packed_fwd", "text_embed_packed_bwd", "attn_varlen_fwd", "attn_varlen_bwd",
+                                                "attn_pooled_fwd", "attn_pooled_bwd")}
+
+
+def _emulated_seq(name):
+    def call(*args, **kwargs):
+        from hipemu_util import emu_ops
+        with emu_ops(["embed.hip", "attention.hip"], _SEQ_SYMS):
+            return _SEQ_ORIG[name](*args, **kwargs)
+    call.__name__ = name
+    return call
+
+
+text_embed_packed_fwd = _emulated_seq("text_embed_packed_fwd")
+text_embed_packed_bwd = _emulated_seq("text_embed_packed_bwd")
+attn_varlen_fwd = _emulated_seq("attn_varlen_fwd")
+attn_varlen_bwd = _emulated_seq("attn_varlen_bwd")
+attn_pooled_fwd = _emulated_seq("attn_pooled_fwd")
+attn_pooled_bwd = _emulated_seq("attn_pooled_bwd")

@@ -106,6 +106,25 @@ def _w_clip(rank, world, port, out):
         out.put("ok")
 
 
+def _w_clip_packed_pooled(rank, world, port, out):
+    """the data-parallel CLIP step with packed captions and the pooled last block switched on (their kernels on the host
+    emulation): still the golden of the TWO reference ranks, and the bucketed reducer still covers the flat buffer once."""
+    os.environ["DH_TEXT_PACKED"], os.environ["DH_POOLED_LAST"] = "1", "1"
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import cpu_ops_mock
+    calls = {"pooled": 0, "packed": 0}
+    for key, name in (("pooled", "attn_pooled_fwd"), ("packed", "text_embed_packed_fwd")):
+        orig = getattr(cpu_ops_mock, name)
+        setattr(cpu_ops_mock, name, (lambda o, k: lambda *a, **kw: (calls.__setitem__(k, calls[k] + 1), o(*a, **kw))[1])(orig, key))
+
+    class Q:                                   # rank 0 reports "ok" only if both switches really took their paths
+        def put(self, v):
+            assert calls["pooled"] == 2 and calls["packed"] == 1, calls
+            out.put(v)
+    _w_clip(rank, world, port, Q())
+
+
 def _w_clip_r50(rank, world, port, out):
     """Data-parallel CLIP-R50 step (ModifiedResNet tower on the host-emulated kernels, per-rank BatchNorm statistics, flat
     bucket reducer fed by resnet_engine's grads_ready calls) against the golden of TWO reference ranks; the BatchNorm
@@ -240,7 +259,7 @@ def _w_zero_shot(rank, world, port, out):
         out.put("ok")
 
 
-@pytest.mark.parametrize("fn", [_w_gather, _w_reducer, _w_clip, _w_clip_r50, _w_clip_r50_syncbn, _w_zero_shot])
+@pytest.mark.parametrize("fn", [_w_gather, _w_reducer, _w_clip, _w_clip_packed_pooled, _w_clip_r50, _w_clip_r50_syncbn, _w_zero_shot])
 def test_world2(fn):
     port = _free_port()
     ctx = mp.get_context("spawn")
