@@ -109,7 +109,8 @@ class DECLIP(CLIP):
         dev = flat.flat_p.device
         b = images.shape[0]
         ids_cat = torch.cat([engine.to_device_async(ids, dev), engine.to_device_async(ids_aug, dev)], dim=0).long().contiguous()
-        tag = getattr(caps, "_dh_rows", None) if torch.is_tensor(caps) and caps.dim() == 3 and "mlm_labels" in input else None
+        tag = (getattr(caps, "_dh_rows", None)
+               if torch.is_tensor(caps) and caps.dim() == 3 and caps.shape[1] == 2 and "mlm_labels" in input else None)   # exactly the 2 variants used
         if tag is not None and tag[0] == caps._version:
             ids_cat._dh_rows = (ids_cat._version, tag[1])        # both variants of every caption: the row count the prefetcher took on the host
         want_words = self.text_mask_type is not None
