@@ -561,6 +561,8 @@ class PackedCaptions:
         else:
             total = int(lens.sum())                                      # one host read for this tensor object
             ids._dh_rows = (ids._version, total)
+        if tag is not None and tag[0] == ids._version and hasattr(torch, "_assert_async"):
+            torch._assert_async(lens.sum() == total)                     # a host-side count that does not match fails loudly (device-side assert, no read-back)
         self.b, self.L, self.rows = b, L, total
         self.rows_pad = (total + tile - 1) // tile * tile
         cu = torch.zeros(b + 1, device=ids.device, dtype=torch.int64)
