@@ -459,9 +459,12 @@ __global__ __launch_bounds__(256) void image_resized_crop_u8_kernel(const uint8_
     const bool mir = flip && flip[bi];
     // position of this output pixel inside the Wf x Hf image the crop box is resized to
     const int fx = ox + (mir ? W - 1 - x : x), fy = oy + y;
-    const float sx = (float)bw / (float)Wf, sy = (float)bh / (float)Hf;
+    // correctly rounded fp32 quotients (through fp64): this file is built with -ffast-math, whose v_rcp_f32 quotient is ~1 ulp
+    // off, and (j - cx + 0.5) below cancels ~3 digits at source coordinates of several hundred pixels -- on the MI355X that was
+    // 1.4e-4 of a normalised pixel against the oracle (torch's antialiased resize divides in IEEE fp32), i.e. rounding flips
+    const float sx = (float)((double)bw / (double)Wf), sy = (float)((double)bh / (double)Hf);
     const float supx = sx >= 1.f ? sx : 1.f, supy = sy >= 1.f ? sy : 1.f;
-    const float isx = sx >= 1.f ? 1.f / sx : 1.f, isy = sy >= 1.f ? 1.f / sy : 1.f;
+    const float isx = sx >= 1.f ? (float)(1.0 / (double)sx) : 1.f, isy = sy >= 1.f ? (float)(1.0 / (double)sy) : 1.f;
     const float cx = ((float)fx + 0.5f) * sx, cy = ((float)fy + 0.5f) * sy;
     int x_lo = (int)(cx - supx + 0.5f), x_hi = (int)(cx + supx + 0.5f);
     int y_lo = (int)(cy - supy + 0.5f), y_hi = (int)(cy + supy + 0.5f);
@@ -484,10 +487,10 @@ __global__ __launch_bounds__(256) void image_resized_crop_u8_kernel(const uint8_
       }
       acc[0] += wy * r[0]; acc[1] += wy * r[1]; acc[2] += wy * r[2];
     }
-    const float norm = 1.f / (wsx * wsy);
+    const double norm = 1.0 / ((double)wsx * (double)wsy);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      float v = acc[c] * norm;
+      float v = (float)((double)acc[c] * norm);
       if (round_u8) v = fminf(fmaxf(floorf(v + 0.5f), 0.f), 255.f);   // the PIL image between resize and ToTensor is uint8
       dst[(((long)bi * c_total + c0 + c) * H + y) * W + x] = (v / 255.f - mean[c]) * inv[c];
     }

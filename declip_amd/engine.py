@@ -267,10 +267,25 @@ def block_bwd(dx_out, r, saved, b, L, heads, causal):
     return ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
 
 
-def pooled_last_block():
-    """DH_POOLED_LAST=1: the last block of a tower runs its query / attention / out_proj / MLP for the POOLED rows only."""
+def pooled_last_block(width=None, heads=None, L=0):
+    """The last block of a tower runs its query / attention / out_proj / MLP for the POOLED rows only (default since round 2:
+    measured +4 % pairs/s alone, +18.6 % together with packed captions, profiles/r02_ab_switches.txt); DH_POOLED_LAST=0 restores
+    the reference's dense schedule (same outputs)."""
     import os
-    return os.environ.get("DH_POOLED_LAST", "0") == "1"
+    if os.environ.get("DH_POOLED_LAST", "1") != "1":
+        return False
+    # dh_attn_pooled_*: one wave per (sequence, head), lane = head dimension -> head dim 64, at most 128 keys; other geometries
+    # (test-sized towers) keep the dense last block
+    return width is None or (width == 64 * heads and L <= 128)
+
+
+def text_packed_mode():
+    """0 = padded captions as the reference computes them; 1 (default since round 2: +14 % pairs/s on the synthetic caption
+    lengths, same outputs) = the text tower on the rows up to <|endoftext|> only with variable-length attention; 2 = packed rows,
+    attention through the dense layout.  Environment DH_TEXT_PACKED."""
+    import os
+    m = os.environ.get("DH_TEXT_PACKED", "1")
+    return int(m) if m in ("0", "1", "2") else 1
 
 
 def block_fwd_pooled(x, r, sel, row0, nkeys, Lmax, heads, save):
@@ -366,7 +381,7 @@ class VisionTowerFn(torch.autograd.Function):
         refs = [BlockRefs(flat, blk) for blk in tower.transformer.resblocks]
         saved_blocks = []
         pool = None
-        if pooled_last_block() and not want_dense and refs:
+        if pooled_last_block(width, heads, L) and not want_dense and refs:
             # the last block only for the CLS rows (their keys: the L rows of the image)
             seq = torch.arange(b, device=images.device)
             pool = ((seq * L).contiguous(), (seq * L).to(torch.int32).contiguous(), torch.full((b,), L, device=images.device, dtype=torch.int32))
@@ -464,7 +479,7 @@ class TextTowerFn(torch.autograd.Function):
         save = bool(ctx.needs_input_grad[0])
         eot = ids.argmax(dim=-1)                                    # text_transformer.py:203 (index arithmetic)
         pool = None
-        if pooled_last_block() and not want_dense and refs:
+        if pooled_last_block(width, heads, L) and not want_dense and refs:
             # the last block only for the <|endoftext|> rows (their keys: the rows up to and including EOT: the causal mask)
             seq = torch.arange(b, device=ids.device)
             pool = ((seq * L + eot).contiguous(), (seq * L).to(torch.int32).contiguous(), (eot + 1).to(torch.int32).contiguous())
@@ -537,7 +552,7 @@ class TextTowerFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
-# text tower on PACKED captions (opt-in: DH_TEXT_PACKED=1)
+# text tower on PACKED captions (the default; DH_TEXT_PACKED=0 for the padded layout)
 # ---------------------------------------------------------------------------------------------
 class PackedCaptions:
     """Row bookkeeping of a caption batch in which only the tokens up to and including <|endoftext|> are rows.
@@ -632,7 +647,7 @@ def packed_captions(ids, dtype):
     """PackedCaptions of a device id tensor (kept on the tensor object: a batch that is used again keeps its bookkeeping)."""
     import os
     tile = 256 if dtype == torch.bfloat16 else 8                        # whole tiles of the persistent GEMM in bf16
-    varlen = os.environ.get("DH_TEXT_PACKED", "1") != "2"               # 2: attention through the dense layout (gathers)
+    varlen = text_packed_mode() != 2                                    # 2: attention through the dense layout (gathers)
     cached = getattr(ids, "_dh_packed", None)
     if cached is not None and cached[0] == (ids._version, tile, varlen):
         return cached[1]
@@ -656,7 +671,7 @@ class TextTowerPackedFn(torch.autograd.Function):
         save = bool(ctx.needs_input_grad[0])
         saved_blocks = []
         pool = None
-        if pooled_last_block() and not want_words and refs:
+        if pooled_last_block(tower.width, tower.heads, ids.shape[1]) and not want_words and refs:
             pool = (pk.eot_rows, pk.cu[:-1].contiguous(), (pk.cu[1:] - pk.cu[:-1]).contiguous())     # EOT rows; keys = the caption's rows
         for r in (refs[:-1] if pool is not None else refs):
             x, s = block_fwd_packed(x, r, pk, tower.heads, save)

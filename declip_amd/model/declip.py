@@ -117,7 +117,7 @@ class DECLIP(CLIP):
         side = self._fork(images)                # text tower on the side stream, both image views on the caller's (clip.py)
         # DH_TEXT_PACKED: only the caption rows up to <|endoftext|> are computed (engine.PackedCaptions); not when a subclass needs
         # the per-token features of the padded layout (DeFILIP's token selection ranks the padding too)
-        packed = os.environ.get("DH_TEXT_PACKED", "0") in ("1", "2") and not getattr(self, "return_filip", False)
+        packed = engine.text_packed_mode() != 0 and not getattr(self, "return_filip", False)
         with self._on(side):
             if packed:
                 tout = engine.TextTowerPackedFn.apply(flat.anchor, ids_cat, et, want_words)

@@ -181,7 +181,7 @@ class TextTransformer(_Tower):
         flat = self._flat()
         dev = flat.flat_p.device
         want_dense = return_dense or mask_type is not None
-        packed = not want_dense and os.environ.get("DH_TEXT_PACKED", "0") in ("1", "2")
+        packed = not want_dense and engine.text_packed_mode() != 0
         host_rows = None
         if packed and not ids.is_cuda and getattr(ids, "_dh_rows", None) is None:
             host_rows = int((ids.argmax(dim=-1) + 1).sum())         # counted on the host copy: no device read in the step

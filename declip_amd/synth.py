@@ -259,6 +259,9 @@ R50_FC = dict(vision="resnet", r_width=64, r_layers=(1, 1, 1, 1), r_heads=32, re
 # filip_res50: 49 dense tokens of width*32 channels; >= 16 text tokens (v_width = the dense image width the FILIP heads see)
 R50_TINY_FILIP = dict(R50_TINY, ctx=24, v_width=16 * 32)
 
+# the shipped FILIP ViT-B/32 (experiments/filip_experiments/yfcc15m/yfcc15m_vit_filip/config.yaml:5,13: embed_dim 768)
+FILIP_VITB32 = dict(VITB32, embed_dim=768)
+
 # FILIP needs >= 16 image tokens and >= 16 text tokens: 160 px / 32 = 25 patches, 24-token context
 FILIP_SMALL = dict(v_width=128, v_layers=2, v_heads=2, patch=32, res=160,
                    t_width=128, t_layers=2, t_heads=2, ctx=24, embed_dim=64, vocab=VOCAB)

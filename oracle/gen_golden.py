@@ -34,6 +34,18 @@ def grad_digest(named_grads):
     return out
 
 
+def logits_digest(l, label0=0):
+    """compact record of a [b, B] logits matrix for the full-width fixtures (b >= 128: the matrix itself would be the bulk of the
+    file): 48 x 48 corner, the label diagonal, row log-sum-exp, absolute maximum, a seeded projection."""
+    l = l.detach().double()
+    b, B = l.shape
+    gen = torch.Generator().manual_seed(777)
+    r = torch.randn(b, B, generator=gen, dtype=torch.float64)
+    idx = torch.arange(b)
+    return dict(shape=(b, B), corner=l[:48, :48].float().clone(), diag=l[idx, idx + label0].float().clone(),
+                lse=torch.logsumexp(l, dim=1).float(), absmax=float(l.abs().max()), proj=float((l * r).sum() / (b * B) ** 0.5))
+
+
 def build_ref_clip(ref, cfg, use_allgather):
     vt = ref.modules["prototype.model.image_encoder.visual_transformer"]
     tt = ref.modules["prototype.model.text_encoder.text_transformer"]
@@ -103,9 +115,11 @@ def run_clip_rank(rank, world, cfg, b, seed, logit_scale, ret):
     if world > 1:
         dist.all_reduce(total)
     if rank == 0:
-        ret.update(loss=float(total), loss_rank0=float(loss.detach() * world),
-                   logits_i=logits_i.detach().clone(), logits_t=logits_t.detach().clone(),
-                   labels=labels.clone(), grads=grad_digest(grads))
+        ret.update(loss=float(total), loss_rank0=float(loss.detach() * world), labels=labels.clone(), grads=grad_digest(grads))
+        if b >= 128:
+            ret.update(logits_i_digest=logits_digest(logits_i, int(labels[0])), logits_t_digest=logits_digest(logits_t, int(labels[0])))
+        else:
+            ret.update(logits_i=logits_i.detach().clone(), logits_t=logits_t.detach().clone())
         if cfg.get("vision") == "resnet":
             # BatchNorm side effects of the training forward, then the eval-mode tower (running statistics) on the same images
             bufs = dict(model.named_buffers())
@@ -265,13 +279,19 @@ def gen_slip(name, cfg, b, seed=0):
     print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
 
 
-def gen_filip(name, cfg, b, seed=0):
-    """Reference FILIP (model/filip.py) + filip_solver.py loss composition (clip 0.0, dense 1.0), one rank."""
+def run_filip_rank(rank, world, cfg, b, seed, ret):
+    """One reference FILIP rank (model/filip.py) + filip_solver.py loss composition (clip 0.0, dense 1.0): local rows
+    [rank*b, (rank+1)*b) of the global batch; world > 1 exercises B > b and label0 = rank*b != 0 in the dense logits."""
     import contextlib
     import io
-    os.environ["SLURM_PROCID"], os.environ["SLURM_NTASKS"] = "0", "1"
+    os.environ["SLURM_PROCID"], os.environ["SLURM_NTASKS"] = str(rank), str(world)
     ref = ref_harness.load_reference()
-    ref_harness.ensure_gloo_group()
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world, init_method="tcp://127.0.0.1:29543")
+        torch.set_num_threads(max(1, (os.cpu_count() or 2) // world))
+    else:
+        ref_harness.ensure_gloo_group()
     rf = ref.modules["prototype.model.filip"]
     vt = ref.modules["prototype.model.image_encoder.visual_transformer"]
     tt = ref.modules["prototype.model.text_encoder.text_transformer"]
@@ -292,26 +312,66 @@ def gen_filip(name, cfg, b, seed=0):
         sd = synth.synth_state(synth.filip_shapes(cfg), seed=seed)
         model.load_state_dict(sd, strict=True)
         model.train()
-    images = synth.synth_images(b, views=2, res=cfg["res"], seed=seed)
-    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+    B = b * world
+    images = synth.synth_images(B, views=2, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
     ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+    sl = slice(rank * b, (rank + 1) * b)
 
     def tokenize(texts, context_length=77, return_length=False, mask_type=None):
         keys = [int(t) for t in texts]
         assert mask_type is not None
         return torch.stack([ids_masked[k] for k in keys]), torch.stack([labels[k] for k in keys])
     model.encode_text.tokenize = tokenize
-    out = model({"images": images, "captions": [[i] for i in range(b)]}, return_dict=True)
+    out = model({"images": images[sl], "captions": [[i] for i in range(rank * b, (rank + 1) * b)]}, return_dict=True)
     crit = ref.modules["prototype.loss_functions.loss"].ClipInfoCELoss()
     li, lt = out["logits"]
     dli, dlt = out["dense_logits"]
     clip_loss, _ = crit(li, lt)
-    dense_loss, _ = crit(dli, dlt)
-    total = 0.0 * clip_loss + 1.0 * dense_loss                           # yfcc15m_vit_filip/config.yaml:32-37
+    dense_loss, dlabels = crit(dli, dlt)
+    total = (0.0 * clip_loss + 1.0 * dense_loss) / world                 # yfcc15m_vit_filip/config.yaml:32-37; filip_solver.py (/ world_size)
     total.backward()
-    ret = dict(kind="filip", cfg=cfg, b=b, seed=seed, loss=float(total), parts=dict(clip=float(clip_loss), dense=float(dense_loss)),
-               dense_logits_i=dli.detach().clone(), dense_logits_t=dlt.detach().clone(),
-               grads=grad_digest([(n, p.grad) for n, p in model.named_parameters()]), torch_version=torch.__version__)
+    grads = []
+    for name, p in model.named_parameters():
+        g = p.grad
+        if g is not None and world > 1:
+            dist.all_reduce(g)                                           # utils/dist.py:71-74 (SUM)
+        grads.append((name, g))
+    tot = total.detach().clone()
+    parts = torch.tensor([float(clip_loss), float(dense_loss)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tot)
+        dist.all_reduce(parts)
+        parts /= world
+    if rank == 0:
+        ret.update(loss=float(tot), parts=dict(clip=float(parts[0]), dense=float(parts[1])), grads=grad_digest(grads))
+        if b >= 128:
+            ret.update(dense_logits_i_digest=logits_digest(dli, int(dlabels[0])), dense_logits_t_digest=logits_digest(dlt, int(dlabels[0])))
+        else:
+            ret.update(dense_logits_i=dli.detach().clone(), dense_logits_t=dlt.detach().clone())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _spawn_filip(rank, world, cfg, b, seed, path):
+    ret = {}
+    run_filip_rank(rank, world, cfg, b, seed, ret)
+    if rank == 0:
+        torch.save(ret, path)
+
+
+def gen_filip(name, cfg, b, seed=0, world=1):
+    if world == 1:
+        ret = {}
+        run_filip_rank(0, 1, cfg, b, seed, ret)
+    else:
+        import torch.multiprocessing as mp
+        tmp = "/tmp/_golden_%s.pt" % name
+        mp.spawn(_spawn_filip, args=(world, cfg, b, seed, tmp), nprocs=world, join=True)
+        ret = torch.load(tmp, weights_only=False)
+        os.remove(tmp)
+    ret.update(kind="filip", cfg=cfg, b=b, seed=seed, world=world, torch_version=torch.__version__)
     path = os.path.join(GOLDEN_DIR, name + ".pt")
     torch.save(ret, path)
     print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
@@ -457,6 +517,13 @@ FIXTURES = {
     "filip_small": lambda: gen_filip("filip_small", synth.FILIP_SMALL, b=5, seed=6),
     "filip_r50_tiny": lambda: gen_filip("filip_r50_tiny", synth.R50_TINY_FILIP, b=4, seed=13),
     "defilip_small": lambda: gen_defilip("defilip_small", synth.FILIP_SMALL, b=4, seed=7),
+    # full-width fixtures at the smallest batches whose GEMMs are whole 256-row tiles, i.e. that run on the benchmarked
+    # gemm_v4 kernel in bf16; minutes of CPU and up to ~40 GB each, logits kept as digests
+    "clip_vitb32_b256": lambda: gen_clip("clip_vitb32_b256", synth.VITB32, b=256, seed=21),
+    "declip_vitb32_b128": lambda: gen_declip("declip_vitb32_b128", synth.VITB32, b=128, seed=22, nn_size=4096),
+    "slip_vitb32_b128": lambda: gen_slip("slip_vitb32_b128", synth.VITB32, b=128, seed=23),
+    "filip_vitb32_e768_b256": lambda: gen_filip("filip_vitb32_e768_b256", synth.FILIP_VITB32, b=256, seed=24),
+    "filip_vitb32_e768_b256_w2": lambda: gen_filip("filip_vitb32_e768_b256_w2", synth.FILIP_VITB32, b=256, seed=25, world=2),
     "zeroshot_tiny": lambda: gen_zeroshot("zeroshot_tiny", synth.TINY, label_num=7, prompts_num=3, b=5, batches=2, seed=8),
 }
 

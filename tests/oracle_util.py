@@ -21,17 +21,20 @@ def grad_digest_of(name, idx, g):
                 proj=float((g * r).sum() / max(1.0, g.numel() ** 0.5)))
 
 
-def oracle_clip_run(cfg, b, world=1, seed=0, logit_scale=None):
-    """Run the restated CLIP step on CPU fp32; returns loss, per-rank logits, grads by name."""
+def oracle_clip_run(cfg, b, world=1, seed=0, logit_scale=None, dtype=torch.float32):
+    """Run the restated CLIP step on CPU (fp32 as the reference; fp64 = the same inputs / parameters in double, used to measure
+    how far fp32 rounding alone moves an ill-conditioned gradient); returns loss, per-rank logits, grads by name."""
     shapes = synth.clip_shapes(cfg)
     sd = synth.synth_state(shapes, seed=seed, logit_scale=logit_scale)
+    if dtype != torch.float32:
+        sd = {k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in sd.items()}
     resnet = cfg.get("vision") == "resnet"
     frozen = set() if resnet else {"visual.conv1.weight"}  # visual_transformer.py:45-51 (the ResNet stem trains)
     for k, v in sd.items():
         if v.dtype.is_floating_point and "running_" not in k:
             v.requires_grad_(k not in frozen)
     B = b * world
-    images = synth.synth_images(B, res=cfg["res"], seed=seed)
+    images = synth.synth_images(B, res=cfg["res"], seed=seed).to(dtype)
     ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
     new_stats = {} if resnet else None
     total, per_rank, feats, metrics = restated.clip_step_loss(images, ids, sd, cfg, world, new_stats=new_stats)

@@ -7,20 +7,18 @@ Also here, for the same reason (written after the GPU budget was gone): the on-G
 variable-length attention kernels and the packed-caption text tower (DH_TEXT_PACKED), the pooled-query attention and the
 last-block-for-the-pooled-rows path (DH_POOLED_LAST).
 
-STATUS: everything in this file was written after round 1's GPU budget had been spent.  It is verified on the CPU by running the
-same C entry points through the host emulation of the kernels (tests/test_hipemu_resnet.py, tests/test_hipemu_kernels.py,
-tests/test_engine_cpu_mock.py, and THIS file's own tests on the emulation: tests/test_hipemu_step.py, tools/run_gpu_test_on_host.py);
-its FIRST hardware run is this file, hence the non-strict xfail marker (an XPASS line = verified on hardware; remove the marker
-then).  Sorted last on purpose: it cannot shadow the long-verified tests under `-x`."""
+STATUS: written after round 1's GPU budget was gone and first run on the MI355X by the round-1 driver suite under a non-strict
+xfail marker: 54 of 56 passed there; the two that did not were diagnosed on hardware in round 2 (tools/diag_hw.py) -- the full-size
+ResNet-50 gradient bound tested the fp32 oracle's own rounding noise (see that test's docstring), and the resized crop lost ~3
+digits to the fast-math reciprocal in its scale / centre arithmetic (fixed in csrc/embed.hip).  The marker is gone: every test
+here must pass."""
 import pytest
 import torch
 import torch.nn.functional as F
 
 from oracle_util import check_grad_digests, load_golden, oracle_clip_run
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason="first hardware run (the round-1 GPU budget was spent before this was written); "
-                                                     "verified through the host emulation of the kernels on the CPU")]
+pytestmark = [pytest.mark.gpu]
 DTYPES = [torch.float32, torch.bfloat16]
 
 
@@ -254,18 +252,44 @@ def test_clip_r50_bf16_close_to_reference():
 
 def test_clip_r50_full_size_fp32_against_oracle():
     """BASELINE.json configs[0]: CLIP ResNet-50 + 12-layer text transformer, fp32 (batch 8 here so that the CPU oracle
-    finishes in seconds; the batch-32 step itself is exercised below)."""
+    finishes in seconds; the batch-32 step itself is exercised below).
+
+    Forward (loss, logits): the north_star 1e-3 against the fp32 oracle (measured on the MI355X: 2e-6 / 1.4e-4).
+    Gradients: this 50-layer ReLU / batch-8 BatchNorm network at random init is ill-conditioned -- the reference arithmetic
+    itself, run in fp32 and in fp64 on the same inputs, disagrees by 1.7e-2...2.6e-2 on the stem / layer1 / layer2 gradients
+    (median 2.7e-3 over all parameters; an fp32 rounding flips ReLU masks, and the BatchNorm backward sums cancelling terms), while
+    the head (attention pool, text tower) agrees at 1e-4.  A fixed tolerance against the fp32 oracle would therefore test the
+    oracle's own rounding noise (first hardware run: 2.04e-2 on `visual.conv1.weight` against a 2e-2 bound, with the forward exact
+    to 2e-6).  The bar used instead: against the EXACT (fp64) gradient, the HIP path may be at most 3x as far away as the
+    reference's own fp32 arithmetic is, per parameter (floor 2e-3), over EVERY parameter of the model."""
     from declip_amd import synth
     cfg, b, seed = synth.R50, 8, 3
     ref = oracle_clip_run(cfg, b, 1, seed, None)
+    exact = oracle_clip_run(cfg, b, 1, seed, None, dtype=torch.float64)
     _, out = run_engine(cfg, b, seed, "fp32")
     assert abs(out["loss"] - float(ref["loss"])) <= 1e-3 * abs(float(ref["loss"]))
     li = ref["per_rank"][0][0].detach()
     assert float((out["logits_i"] - li).abs().max()) <= 1e-3 * float(li.abs().max())
-    for n in ("visual.attnpool.c_proj.weight", "visual.layer4.2.conv3.weight", "visual.layer1.0.conv1.weight", "visual.conv1.weight",
-              "encode_text.text_projection.weight"):
+    gmax = max(float(v.norm()) for v in exact["grads"].values() if v is not None)
+    bad, checked = [], 0
+    for n, e in exact["grads"].items():
+        r, g = ref["grads"][n], out["grads"][n]
+        if e is None:
+            assert g is None or float(g.abs().max()) == 0.0, n
+            continue
+        en = float(e.norm())
+        if en < 1e-6 * gmax:                      # analytically-zero gradients (a bias in front of a softmax over keys): noise only
+            assert float(g.double().norm()) < 1e-4 * gmax, n
+            continue
+        noise = float((r.double() - e).norm()) / en
+        err = float((g.double() - e).norm()) / en
+        checked += 1
+        if err > max(3.0 * noise, 2e-3):
+            bad.append((n, err, noise))
+    assert checked > 300 and not bad, bad[:8]
+    for n in ("visual.attnpool.c_proj.weight", "encode_text.text_projection.weight"):      # well-conditioned: tight, vs the fp32 oracle
         r = ref["grads"][n]
-        assert float((out["grads"][n] - r).norm()) <= 2e-2 * float(r.norm()), n
+        assert float((out["grads"][n] - r).norm()) <= 1e-3 * float(r.norm()), n
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

@@ -21,17 +21,17 @@ CASES = [
     ("test_gpu_clip", "test_slip_step_matches_reference_golden", ("fp32", 1e-3)),
     ("test_gpu_clip", "test_filip_step_matches_reference_golden", ("fp32", 1e-3)),
     ("test_gpu_zeroshot", "test_zero_shot_fp32_matches_reference_evaluate", (8,)),
-    ("test_gpu_zz_first_hw_run", "test_clip_r50_fp32_matches_reference_golden", ()),
-    ("test_gpu_zz_first_hw_run", "test_clip_r50_fc_head_fp32_matches_reference_golden", ()),
+    ("test_gpu_resnet_intake_packed", "test_clip_r50_fp32_matches_reference_golden", ()),
+    ("test_gpu_resnet_intake_packed", "test_clip_r50_fc_head_fp32_matches_reference_golden", ()),
 ]
 # minutes each on the emulation (bf16 GEMMs = emulated MFMA tiles over 37 k pixel rows / a 49 k-word vocabulary): run on demand with
 # HIPEMU_SLOW=1 (all four passed when this file was written: 690 s, 160 s, 170 s, 40 s)
 SLOW = [
-    ("test_gpu_zz_first_hw_run", "test_clip_r50_bf16_close_to_reference", ()),
+    ("test_gpu_resnet_intake_packed", "test_clip_r50_bf16_close_to_reference", ()),
     ("test_gpu_clip", "test_declip_step_matches_reference_golden", ("bf16", 2e-2)),
     ("test_gpu_clip", "test_defilip_step_matches_reference_golden", ("bf16", 3e-2)),
-    ("test_gpu_zz_first_hw_run", "test_declip_r50_fp32_matches_reference_golden", ()),
-    ("test_gpu_zz_first_hw_run", "test_filip_r50_fp32_matches_reference_golden", ()),
+    ("test_gpu_resnet_intake_packed", "test_declip_r50_fp32_matches_reference_golden", ()),
+    ("test_gpu_resnet_intake_packed", "test_filip_r50_fp32_matches_reference_golden", ()),
 ]
 
 
