@@ -24,32 +24,123 @@ GFLOP_PER_PAIR_R50 = 53.9       # CLIP ResNet-50 (configs[0]): trunk 10.73 + att
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(batch=16, steps=2, cfg=None, label="CLIP ViT-B/32"):
-    """The oracle restatement (kind "port") of the same step on the host cores, bounded sample."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def _host_cpu():
+    """(model string, physical cores) of the host this runs on."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:
+        cores = os.cpu_count() or 1
+    return model, int(cores)
+
+
+def _cpu_sample(cfg, label, batch, steps, use_reference):
+    """pairs/s of ONE configuration on the host cores: the reference's own modules (kind "reference": only where /root/reference
+    exists, i.e. the build container) or the oracle restatement of them (kind "port": the GPU box), fp32, fwd + bwd + AdamW."""
     from declip_amd import synth
     from oracle import restated
-    cfg = cfg or synth.VITB32
-    threads = torch.get_num_threads()
     sd = synth.synth_state(synth.clip_shapes(cfg), seed=0)
-    frozen = set() if cfg.get("vision") == "resnet" else {"visual.conv1.weight"}
-    for k, v in sd.items():
-        if v.dtype.is_floating_point and "running_" not in k:
-            v.requires_grad_(k not in frozen)
-    opt = torch.optim.AdamW([v for v in sd.values() if v.requires_grad], lr=1e-4, betas=(0.9, 0.98), weight_decay=0.1)
     images = synth.synth_images(batch, seed=0)
     ids = synth.synth_tokens(batch, seed=0)
+    if use_reference:
+        import contextlib
+        import io
+        from oracle import gen_golden, ref_harness
+        ref = ref_harness.load_reference()
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = gen_golden.build_ref_clip(ref, cfg, use_allgather=False)
+            model.load_state_dict(sd, strict=True)
+            model.train()
+        gen_golden.patch_tokenize(model.encode_text, {i: ids[i] for i in range(batch)})
+        crit = ref.modules["prototype.loss_functions.loss"].ClipInfoCELoss()
+        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.98), weight_decay=0.1)
+        feed = {"images": images, "captions": [[i] for i in range(batch)]}
+
+        def one():
+            opt.zero_grad()
+            li, lt = model(feed)
+            loss, _ = crit(li, lt)
+            loss.backward()
+            opt.step()
+    else:
+        frozen = set() if cfg.get("vision") == "resnet" else {"visual.conv1.weight"}
+        for k, v in sd.items():
+            if v.dtype.is_floating_point and "running_" not in k:
+                v.requires_grad_(k not in frozen)
+        opt = torch.optim.AdamW([v for v in sd.values() if v.requires_grad], lr=1e-4, betas=(0.9, 0.98), weight_decay=0.1)
+
+        def one():
+            opt.zero_grad()
+            total, _, _, _ = restated.clip_step_loss(images, ids, sd, cfg, 1)
+            total.backward()
+            opt.step()
     times = []
-    for i in range(steps + 1):
+    for _ in range(steps + 1):
         t0 = time.time()
-        opt.zero_grad()
-        total, _, _, _ = restated.clip_step_loss(images, ids, sd, cfg, 1)
-        total.backward()
-        opt.step()
+        one()
         times.append(time.time() - t0)
     dt = sorted(times[1:])[len(times[1:]) // 2]
-    return dict(value=round(batch / dt, 3), unit="pairs/s", cores=threads, kind="port",
-                sample="%s fp32 fwd+bwd+AdamW, batch %d, 1 warm-up + %d timed steps (median), torch CPU oracle restatement" % (label, batch, steps))
+    return dict(config=label, value=round(batch / dt, 3), unit="pairs/s", batch=batch, timed_steps=steps, s_per_step=round(dt, 3))
+
+
+def cpu_baseline(batch=32, steps=3, r50=True):
+    """the reference's CPU path beside the GPU number -- CLIP ViT-B/32 (the metric's model) and CLIP ResNet-50
+    (BASELINE.json configs[0], the reference's own CPU-runnable case), batch 32, fp32, 1 warm-up + 3 timed steps (median), torch
+    threads = physical cores.  Bounded: ~10-30 s of CPU work on the GPU box's host."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from declip_amd import synth
+    from oracle import ref_harness
+    model, cores = _host_cpu()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    use_ref = ref_harness.reference_available()
+    try:
+        main_s = _cpu_sample(synth.VITB32, "CLIP ViT-B/32", batch, steps, use_ref)
+        also = [_cpu_sample(synth.R50, "CLIP ResNet-50 (BASELINE.json configs[0])", batch, steps, use_ref)] if r50 else []
+    finally:
+        torch.set_num_threads(prev)
+    return dict(value=main_s["value"], unit="pairs/s", cores=cores, cpu=model, kind="reference" if use_ref else "port",
+                sample="%s fp32 fwd+bwd+AdamW, batch %d, 1 warm-up + %d timed steps (median), torch CPU, %d threads (= physical cores); "
+                       "%s" % (main_s["config"], batch, steps, cores,
+                               "the unmodified reference's modules (oracle/ref_harness.py)" if use_ref else
+                               "oracle/restated.py, the CPU restatement of the reference (the reference tree is not on this box)"),
+                s_per_step=main_s["s_per_step"], also=also)
+
+
+def loss_delta_vs_cpu_ref(dev):
+    """BASELINE.json metric, second half ("loss delta vs CPU ref"): the engine's loss on the inputs + seeded weights of the fixture
+    tests/golden/clip_vitb32_b256.pt against the loss the UNMODIFIED reference computed for them on the CPU in fp32 (fixture
+    generated by oracle/gen_golden.py; b = 256 = the smallest batch whose tower GEMMs all run on the benchmarked gemm_v4 kernel)."""
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.testing import build_clip
+    path = os.path.join(ROOT, "tests", "golden", "clip_vitb32_b256.pt")
+    if not os.path.exists(path):
+        return None
+    g = torch.load(path, weights_only=False)
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    images = synth.synth_images(b, res=cfg["res"], seed=seed).to(dev)
+    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"]).to(dev)
+    out = dict(reference_loss=round(g["loss"], 6), batch=b, source="tests/golden/clip_vitb32_b256.pt (reference CPU fp32, oracle/gen_golden.py)")
+    for dtype in ("fp32", "bf16"):
+        model = build_clip(cfg, dtype=dtype, seed=seed)
+        with torch.no_grad():
+            li, lt = model({"images": images, "captions": ids})
+            loss, _ = ClipInfoCELoss()(li, lt)
+        val = float(loss)
+        out[dtype] = dict(loss=round(val, 6), rel_delta=float("%.3e" % (abs(val - g["loss"]) / abs(g["loss"]))))
+        del model
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -63,10 +154,11 @@ def main():
                     help="clip = BASELINE.json metric; declip = configs[2] variant; clip_r50 = configs[0] (CLIP ResNet-50, batch 32; add --dtype fp32)")
     ap.add_argument("--text-packed", choices=["0", "1", "2"], default=None,
                     help="text tower on the caption rows up to <|endoftext|> only (DESIGN.md s11; 1 = variable-length attention, "
-                         "2 = attention via the dense layout); default: the DH_TEXT_PACKED environment variable, else 0 (padded, as the reference)")
+                         "2 = attention via the dense layout, 0 = padded as the reference computes them); default: DH_TEXT_PACKED, else 1")
     ap.add_argument("--pooled-last", choices=["0", "1"], default=None,
-                    help="last block of each tower for the pooled row only (DESIGN.md s12); default: DH_POOLED_LAST, else 0")
+                    help="last block of each tower for the pooled row only (DESIGN.md s12); default: DH_POOLED_LAST, else 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-loss-delta", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -75,6 +167,7 @@ def main():
     if args.pooled_last is not None:
         os.environ["DH_POOLED_LAST"] = args.pooled_last
     from declip_amd import dist as dh_dist
+    from declip_amd import engine as eng_mod
     from declip_amd import ops, synth
     from declip_amd.loss import ClipInfoCELoss
     from declip_amd.optim import build_adamw
@@ -89,6 +182,7 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", torch.cuda.current_device())
 
+    torch.manual_seed(1234 + rank)            # random-init weights, reproducible from run to run (the loss in the line is then too)
     cfg = synth.R50 if args.model == "clip_r50" else synth.VITB32
     b = args.batch if args.batch is not None else (32 if args.model == "clip_r50" else 512)
     crit = ClipInfoCELoss()
@@ -220,19 +314,25 @@ def main():
                     fh.write("%6d %5d %6d %d %d %d %d %d | %4d %8.1f %6.0f %7.3f\n" % (k + (c // nprof, tms / c * 1e3, fl / tms / 1e9, tms / nprof)))
         # HBM-side traffic of the same kernels from the rocprofv3 PMC passes of tools/profile_step.sh (committed summary):
         # per-launch average next to the algorithmic bytes per launch (operands once + outputs once)
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s_b%d.json" % (args.model, b))
-        if os.path.exists(pmc_file):
-            with open(pmc_file) as fh:
-                pm = json.load(fh)
-            traffic = round((pm["gemm_read_bytes_per_step"] + pm["gemm_write_bytes_per_step"]) / max(pm["gemm_launches_per_step"], 1), 1)
+        traffic, traffic_source = None, None
+        for rnd in ("r02", "r01"):                # a COMMITTED rocprofv3 --pmc summary of this configuration (tools/profile_step.sh):
+            pmc_file = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s_b%d.json" % (rnd, args.model, b))   # not measured by this run
+            if os.path.exists(pmc_file):
+                with open(pmc_file) as fh:
+                    pm = json.load(fh)
+                traffic = round((pm["gemm_read_bytes_per_step"] + pm["gemm_write_bytes_per_step"]) / max(pm["gemm_launches_per_step"], 1), 1)
+                traffic_source = "profiles/%s (committed rocprofv3 --pmc passes of this configuration; NOT re-measured by this run)" % os.path.basename(pmc_file)
+                break
         roofline = dict(bound="mfma", kernel="v4::gemm_v4_kernel family (every tower GEMM of a step: fwd, dX, dW)", achieved=round(achieved, 2),
                         peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic,
-                        traffic_unit="bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE; profiles/r01_v4_pmc_summary.txt)",
+                        traffic_unit="bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)", traffic_source=traffic_source,
                         algorithmic_bytes_per_launch=round(sum(gemm_bytes) / max(len(gemm_bytes), 1), 1),
                         launches_per_step=len(records) // nprof, gemm_ms_per_step=round(ms / nprof, 3),
                         note="kernel durations measured with both towers on one stream (no co-running launches)",
                         gemm_gflop_per_step=round(flops / nprof / 1e9, 1),
+                        executed_gemm_gflop_per_pair=round(flops / nprof / 1e9 / b, 2),
+                        dense_gflop_per_pair={"clip": GFLOP_PER_PAIR, "clip_r50": GFLOP_PER_PAIR_R50}.get(args.model, 89.9),
+                        step_mfma_frac_executed=round(pairs_per_s / b * (flops / nprof) / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
                         step_mfma_frac=round(pairs_per_s * {"clip": GFLOP_PER_PAIR, "clip_r50": GFLOP_PER_PAIR_R50}.get(args.model, 89.9) / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
 
     name = {"clip": "CLIP ViT-B/32", "declip": "DeCLIP ViT-B/32", "clip_r50": "CLIP ResNet-50"}[args.model]
@@ -250,12 +350,14 @@ def main():
                config=dict(workload=workloads[args.model],
                            global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world,
                            tower_streams=1 + len(model.__dict__["_flat_store"].side_streams),
-                           text_packed=int(os.environ.get("DH_TEXT_PACKED", "0")), pooled_last=int(os.environ.get("DH_POOLED_LAST", "0"))),   # 1 / 2: captions computed up to <|endoftext|> only (opt-in)
+                           text_packed=eng_mod.text_packed_mode(), pooled_last=int(eng_mod.pooled_last_block())),   # captions computed up to <|endoftext|> only; last block for the pooled rows only (same outputs, fewer executed flops: see roofline.executed_gemm_gflop_per_pair)
                loss=round(float(loss.detach()) * world, 5))
     if roofline is not None:
         out["roofline"] = roofline
+    if rank == 0 and world == 1 and args.model == "clip" and not args.no_loss_delta:
+        out["loss_delta_vs_cpu_ref"] = loss_delta_vs_cpu_ref(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(batch=8, cfg=synth.R50, label="CLIP ResNet-50") if args.model == "clip_r50" else cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

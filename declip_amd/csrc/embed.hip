@@ -223,7 +223,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 // Segmented variant: hyper-parameters (lr, weight decay) vary per contiguous segment of the flat
 // buffer (param groups of utils/misc.py:267-412 `param_group_all`); ONE launch for the whole model.
-// seg_start[nseg+1] (element offsets, multiples of 4, ascending), seg_lr[nseg], seg_wd[nseg].
+// seg_start[nseg+1] (element offsets, multiples of 4, ascending), seg_lr[nseg], seg_wd[nseg].  seg_lr < 0 marks a segment the
+// optimizer does not own or whose gradient is None (frozen / off-path parameters): values and moments untouched, as
+// torch.optim.AdamW skips them -- an lr that a schedule legitimately drives to 0 still updates the moments.
 __global__ __launch_bounds__(256) void adamw_seg_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, bf16_t* __restrict__ pb, long n4,
                                                         const long* __restrict__ seg_start, const float* __restrict__ seg_lr,
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void adamw_seg_kernel(float* __restrict__ p, c
     int lo = 0, hi = nseg - 1;
     while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (seg_start[mid] <= e) lo = mid; else hi = mid - 1; }
     const float lr = seg_lr[lo], wd = seg_wd[lo];
-    if (lr == 0.f && wd == 0.f) { if (pb) { float4 q = reinterpret_cast<float4*>(p)[i]; reinterpret_cast<uint2*>(pb)[i] = make_uint2(pack2bf(q.x, q.y), pack2bf(q.z, q.w)); } continue; }
+    if (lr < 0.f) { if (pb) { float4 q = reinterpret_cast<float4*>(p)[i]; reinterpret_cast<uint2*>(pb)[i] = make_uint2(pack2bf(q.x, q.y), pack2bf(q.z, q.w)); } continue; }
     float4 pv = reinterpret_cast<float4*>(p)[i], gv = reinterpret_cast<const float4*>(g)[i];
     float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
     float pp[4] = {pv.x, pv.y, pv.z, pv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};

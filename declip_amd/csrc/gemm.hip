@@ -317,6 +317,15 @@ bool dh_gemm_try_glds(const dh_gemm_args* a, int split, hipStream_t st);  // gem
 bool dh_gemm_try_v3(const dh_gemm_args* a, int split, hipStream_t st);    // gemm_v3.hip
 bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st);    // gemm_v4.hip
 
+// launches per kernel family since the last reset: [0] v4 persistent 256x256, [1] v3, [2] v2 LDS-DMA 128x128, [3] v1 MFMA tiles,
+// [4] generic (VALU).  The parity tests assert with it that a fixture really ran on the benchmarked kernel.
+static long long g_gemm_family_calls[5] = {0, 0, 0, 0, 0};
+extern "C" int dh_gemm_stats(long long* out5, int reset) {
+  if (out5) for (int i = 0; i < 5; ++i) out5[i] = g_gemm_family_calls[i];
+  if (reset) for (int i = 0; i < 5; ++i) g_gemm_family_calls[i] = 0;
+  return DH_OK;
+}
+
 extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   DH_REQUIRE(a && a->A && a->B && a->C, "dh_gemm: null pointer");
@@ -339,15 +348,18 @@ extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
   if (a->a_colsum) DH_REQUIRE(a->a_kmajor, "dh_gemm: a_colsum needs a_kmajor");
   // v2 (LDS-DMA + transpose-read) kernel when shapes/alignments allow it (fuses a_colsum)
   if ((a->force_generic == 0 || a->force_generic == 4) && dh_gemm_try_v4(a, split, st)) {
+    ++g_gemm_family_calls[0];
     DH_CHECK_LAUNCH();
     return DH_OK;
   }
   DH_REQUIRE(a->force_generic != 4, "dh_gemm: the v4 kernel does not support this problem");
   if (a->force_generic == 0 && dh_gemm_try_v3(a, split, st)) {
+    ++g_gemm_family_calls[1];
     DH_CHECK_LAUNCH();
     return DH_OK;
   }
   if ((a->force_generic == 0 || a->force_generic == 3) && dh_gemm_try_glds(a, split, st)) {
+    ++g_gemm_family_calls[2];
     DH_CHECK_LAUNCH();
     return DH_OK;
   }
@@ -365,6 +377,7 @@ extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
     if (!a->b_kmajor && a->K % 8) mfma = false;
     if (a->b_kmajor && (a->N % 8 || a->N < 8)) mfma = false;
   }
+  ++g_gemm_family_calls[mfma ? 3 : 4];
   if (mfma) {
     int kps = ((a->K + split - 1) / split + BK - 1) / BK * BK;
     split = (a->K + kps - 1) / kps;

@@ -68,9 +68,17 @@ def initialize(backend="nccl"):
     tdist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
 
 
+def step_barrier():
+    """Inside the training step nothing needs linklink.barrier (linklink/__init__.py:30-34): every collective of the step is
+    stream-ordered.  The engine's own call sites use this no-op."""
+    return None
+
+
 def barrier():
-    """linklink.barrier (linklink/__init__.py:30-34) without the host round trip: collectives are
-    stream-ordered, so inside the step this is a no-op; kept for API compatibility."""
+    """linklink.barrier as reference-style callers use it for HOST-side ordering (rank 0 writes a file the other ranks read,
+    result dumps of evaluate(), checkpoint hand-off): a real barrier over the process group when one is initialised."""
+    if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+        tdist.barrier()
     return None
 
 
@@ -131,7 +139,7 @@ class FlatReducer:
     reduces everything that is left (small/odd ranges, parameters handled by torch autograd) as
     maximal contiguous runs and waits for all collectives (stream-ordered: no host sync)."""
 
-    SLACK = 64   # alignment padding between consecutive parameters (engine.ALIGN)
+    # ranges arrive as whole ALIGN-padded parameter slots (FlatParams.grads_ready): neighbours touch exactly, nothing is bridged
 
     def __init__(self, flat, bucket_bytes=48 << 20):
         self.flat = flat
@@ -143,6 +151,10 @@ class FlatReducer:
 
     def begin(self):
         self.done, self.runs, self.works, self.events = [], [], [], []
+
+    @staticmethod
+    def distributed():
+        return is_dist()
 
     def _launch(self, lo, hi):
         if hi <= lo:
@@ -166,7 +178,7 @@ class FlatReducer:
         runs = sorted(self.runs + [(lo, hi)])
         merged = [list(runs[0])]
         for a, b in runs[1:]:
-            if a <= merged[-1][1] + self.SLACK:
+            if a <= merged[-1][1]:
                 merged[-1][1] = max(merged[-1][1], b)
             else:
                 merged.append([a, b])

@@ -40,6 +40,8 @@ class FlatParams:
         self.names = {}
         self.side_streams = []       # extra HIP streams that towers run on (see side_stream); joined wherever params/grads are consumed
         self._zero_event = None
+        self._pending_uses = {}      # id(tower) -> forwards of this step whose backward has not run yet (see tower_forward)
+        self._early_ok = True        # may grads_ready() hand ranges to the reducer in the backward that is running now?
 
     # ------------------------------------------------------------------ construction
     def attach(self):
@@ -133,6 +135,10 @@ class FlatParams:
     def begin_step(self):
         """Call at the start of every forward in training: parameters may have changed."""
         self.ensure()
+        if self._in_backward:        # a backward that raised never reached its end-of-pass callback: do not carry its state over
+            self._in_backward = False
+            self._zero_event = None
+            self._pending_uses = {}
         self.join_streams()
         self.mirror_fresh = False
         self.refresh_mirror()
@@ -147,6 +153,12 @@ class FlatParams:
         self._in_backward = True
         base, end = self.flat_g.data_ptr(), self.flat_g.data_ptr() + 4 * self.total
         live = [p for p in self.params if p.grad is not None and base <= p.grad.data_ptr() < end]
+        if live and self.reducer is not None and self.reducer.distributed():
+            # these gradients were all-reduced at the end of the previous backward(): reducing the running sum again would count
+            # the earlier micro-batch once per rank
+            self._in_backward = False
+            raise DeclipHipError("gradient accumulation over several backward() calls is not supported with data parallelism: "
+                                 "call optimizer.zero_grad() before every backward()")
         if not live:
             self.flat_g.zero_()                  # the common case: optimizer.zero_grad() ran -> one memset
         else:                                    # accumulate semantics: keep live views, zero the rest
@@ -163,6 +175,8 @@ class FlatParams:
     def _end_backward(self):
         self._in_backward = False
         self._zero_event = None
+        self._pending_uses = {}
+        self._early_ok = True
         self.join_streams()                      # gradients written on the side streams are final from here on
         for p in self.params:
             if not p.requires_grad or getattr(p, "_dh_grad_none", False):   # parameters off the path keep grad None (torch semantics)
@@ -176,12 +190,28 @@ class FlatParams:
         if self.reducer is not None:
             self.reducer.finish()
 
+    def tower_forward(self, tower, needs_grad):
+        """A tower Function ran forward and will run backward: one more pending use of its parameters in this step."""
+        if needs_grad:
+            self._pending_uses[id(tower)] = self._pending_uses.get(id(tower), 0) + 1
+
+    def tower_backward(self, tower):
+        """Start of a tower Function's backward.  A tower that ran forward more than once in this step (encode_image called per view,
+        ...) accumulates into the same gradient ranges once per use: only the LAST of those backwards may release ranges to the
+        bucketed all-reduce (an earlier release would reduce a partial gradient and add the rest on top of the reduced values).
+        Autograd runs the Functions of one device on one thread, so the flag set here holds for this Function's grads_ready calls."""
+        left = self._pending_uses.get(id(tower), 1) - 1
+        self._pending_uses[id(tower)] = left
+        self._early_ok = left <= 0
+
     def grads_ready(self, params):
-        """gradients of `params` are final for this backward pass (bucketed reduction may start)."""
-        if self.reducer is not None:
+        """gradients of `params` are final for this backward pass (bucketed reduction may start).  The range handed over is the
+        parameter's whole ALIGN-padded slot: slots of neighbouring parameters then touch exactly, and the reducer never has to
+        bridge a gap (bridging used to sweep a not-yet-final small parameter sitting in such a gap into an early bucket)."""
+        if self.reducer is not None and self._early_ok:
             for p in params:
                 o, n = self.index[id(p)]
-                self.reducer.ready(o, o + n)
+                self.reducer.ready(o, o + (n + ALIGN - 1) // ALIGN * ALIGN)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -368,6 +398,7 @@ class VisionTowerFn(torch.autograd.Function):
         npatch = (images.shape[2] // P) * (images.shape[3] // P)
         L = npatch + 1
         save = bool(ctx.needs_input_grad[0])
+        flat.tower_forward(tower, save)
         if n_views == 1:
             rows = ops.im2row(images, c0, P, dtype)
         else:
@@ -411,6 +442,7 @@ class VisionTowerFn(torch.autograd.Function):
         tower = ctx.tower
         flat = tower._flat()
         flat.begin_backward()
+        flat.tower_backward(tower)
         dtype = flat.act_dtype
         b, L, npatch, rows, x0, mean0, rstd0, pooled, mean_p, rstd_p, feat, x_final = ctx.misc
         width, heads = tower.width, tower.heads
@@ -477,6 +509,7 @@ class TextTowerFn(torch.autograd.Function):
         refs = [BlockRefs(flat, blk) for blk in tower.transformer.resblocks]
         saved_blocks = []
         save = bool(ctx.needs_input_grad[0])
+        flat.tower_forward(tower, save)
         eot = ids.argmax(dim=-1)                                    # text_transformer.py:203 (index arithmetic)
         pool = None
         if pooled_last_block(width, heads, L) and not want_dense and refs:
@@ -513,6 +546,7 @@ class TextTowerFn(torch.autograd.Function):
         tower = ctx.tower
         flat = tower._flat()
         flat.begin_backward()
+        flat.tower_backward(tower)
         dtype = flat.act_dtype
         b, L, ids, eot, x_final, pooled, mean_f, rstd_f, feat, want_dense = ctx.misc
         width, heads = tower.width, tower.heads
@@ -669,6 +703,7 @@ class TextTowerPackedFn(torch.autograd.Function):
                                       pk.rows, pk.rows_pad)
         refs = [BlockRefs(flat, blk) for blk in tower.transformer.resblocks]
         save = bool(ctx.needs_input_grad[0])
+        flat.tower_forward(tower, save)
         saved_blocks = []
         pool = None
         if pooled_last_block(tower.width, tower.heads, ids.shape[1]) and not want_words and refs:
@@ -701,6 +736,7 @@ class TextTowerPackedFn(torch.autograd.Function):
         tower, pk = ctx.tower, ctx.pk
         flat = tower._flat()
         flat.begin_backward()
+        flat.tower_backward(tower)
         dtype = flat.act_dtype
         x_final, pooled, mean_f, rstd_f, feat, want_words = ctx.misc
         dout = grads[0]

@@ -48,6 +48,7 @@ _PROTOS = {
     "dh_device_info": (c_int, [c_int, POINTER(c_int)]),
     "dh_gemm": (c_int, [POINTER(GemmArgs), _P]),
     "dh_gemm_v4_enable": (c_int, [c_int]),
+    "dh_gemm_stats": (c_int, [_P, c_int]),
     "dh_colsum": (c_int, [c_int, _P, c_int64, c_int, c_int, _P, c_int, _P]),
     "dh_layernorm_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "dh_layernorm_bwd_ws_bytes": (c_int64, [c_int, c_int]),

@@ -61,6 +61,13 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, 
     return out
 
 
+def gemm_stats(reset=False):
+    """dh_gemm launches per kernel family since the last reset (test instrumentation, include/declip_hip.h)."""
+    out = (ctypes.c_longlong * 5)()
+    check(L.load().dh_gemm_stats(out, int(reset)), "dh_gemm_stats")
+    return dict(v4=out[0], v3=out[1], glds=out[2], mfma_tiles=out[3], generic=out[4])
+
+
 def colsum(X, out, accumulate=True):
     assert X.dim() == 2 and X.stride(1) == 1 and out.dtype == torch.float32 and out.numel() == X.shape[1]
     check(L.load().dh_colsum(dt(X), ptr(X), X.stride(0), X.shape[0], X.shape[1], ptr(out), int(accumulate), stream()),

@@ -40,7 +40,7 @@ class FlatAdamW(torch.optim.Optimizer):
             gi = self._param_group.get(pid)
             p = self._by_id[pid]
             if gi is None or not p.requires_grad or getattr(p, "_dh_grad_none", False):   # torch.optim.AdamW skips grad-None parameters
-                lrs.append(0.0), wds.append(0.0)
+                lrs.append(-1.0), wds.append(0.0)       # lr < 0 = inactive segment (dh_adamw_segmented)
             else:
                 g = self.param_groups[gi]
                 lrs.append(float(g["lr"])), wds.append(float(g["weight_decay"]))
@@ -49,6 +49,51 @@ class FlatAdamW(torch.optim.Optimizer):
             self._seg_lr.copy_(torch.tensor(lrs, dtype=torch.float32), non_blocking=True)
             self._seg_wd.copy_(torch.tensor(wds, dtype=torch.float32), non_blocking=True)
             self._cached_hp = hp
+
+    # ---- checkpoint layout of torch.optim.AdamW (what the reference writes under 'optimizer', clip_solver.py:655): parameters are
+    # numbered in param_groups order; per parameter 'step', 'exp_avg', 'exp_avg_sq'
+    def state_dict(self):
+        flat, state, groups, idx = self.flat, {}, [], 0
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                o, n = flat.index[id(p)]
+                state[idx] = dict(step=torch.tensor(float(self.step_count)), exp_avg=self.m[o:o + n].view(p.shape).detach().cpu().clone(),
+                                  exp_avg_sq=self.v[o:o + n].view(p.shape).detach().cpu().clone())
+                ids.append(idx)
+                idx += 1
+            groups.append(dict({k: v for k, v in g.items() if k != "params"}, params=ids))
+        return dict(state=state, param_groups=groups)
+
+    def load_state_dict(self, sd):
+        """accepts the torch.optim.AdamW layout (a reference / model-zoo checkpoint, or state_dict() above); anything that does
+        not line up with this optimizer's parameters raises instead of silently dropping the moments."""
+        flat = self.flat
+        if len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError("optimizer state has %d param groups, this optimizer %d" % (len(sd["param_groups"]), len(self.param_groups)))
+        steps = set()
+        with torch.no_grad():
+            for g, sg in zip(self.param_groups, sd["param_groups"]):
+                if len(sg["params"]) != len(g["params"]):
+                    raise ValueError("optimizer state: a param group has %d parameters, expected %d" % (len(sg["params"]), len(g["params"])))
+                for k, v in sg.items():
+                    if k != "params":
+                        g[k] = tuple(v) if k == "betas" else v
+                for p, idx in zip(g["params"], sg["params"]):
+                    st = sd["state"].get(idx)
+                    if st is None:                      # torch keeps no state for a parameter that never had a gradient
+                        continue
+                    if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                        raise ValueError("optimizer state %d has shape %s, parameter %s has %s" % (
+                            idx, tuple(st["exp_avg"].shape), flat.names.get(id(p), "?"), tuple(p.shape)))
+                    o, n = flat.index[id(p)]
+                    self.m[o:o + n].view(p.shape).copy_(st["exp_avg"])
+                    self.v[o:o + n].view(p.shape).copy_(st["exp_avg_sq"])
+                    steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("optimizer state with per-parameter step counts %s: the fused update keeps ONE step count" % sorted(steps))
+        self.step_count = steps.pop() if steps else 0
+        self._cached_hp = None
 
     def zero_grad(self, set_to_none=True):
         # gradients live in flat_g; the engine zeroes it at the start of the next backward
@@ -63,6 +108,10 @@ class FlatAdamW(torch.optim.Optimizer):
         self._refresh_table()
         self.step_count += 1
         g0 = self.param_groups[0]
+        for g in self.param_groups[1:]:                 # ONE fused launch: betas / eps are launch constants, lr / weight decay per segment
+            if tuple(g["betas"]) != tuple(g0["betas"]) or g["eps"] != g0["eps"]:
+                raise NotImplementedError("per-group betas / eps overrides (pconfig) are not supported by the fused AdamW: "
+                                          "group has betas %s eps %s, group 0 betas %s eps %s" % (g["betas"], g["eps"], g0["betas"], g0["eps"]))
         b1, b2 = g0["betas"]
         ops.adamw_segmented(flat.flat_p, flat.flat_g, self.m, self.v, flat.flat_b, self._seg_start, self._seg_lr,
                             self._seg_wd, b1, b2, g0["eps"], self.step_count, grad_scale)

@@ -196,6 +196,7 @@ class ResNetTowerFn(torch.autograd.Function):
         flat = tower._flat()
         training = tower.training
         save = bool(ctx.needs_input_grad[0])
+        flat.tower_forward(tower, save)
         passes, feats, denses = [], [], []
         for v in range(n_views):
             st = _forward_pass(flat, tower, images, c0 + 3 * v, training)
@@ -214,6 +215,7 @@ class ResNetTowerFn(torch.autograd.Function):
         tower = ctx.tower
         flat = tower._flat()
         flat.begin_backward()
+        flat.tower_backward(tower)
         dout = grads[0]
         ddense = grads[1] if ctx.want_dense else None
         V = len(ctx.passes)

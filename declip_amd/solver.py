@@ -56,24 +56,30 @@ def parse_config(path):
 
 
 # --------------------------------------------------------------------------------------- lr schedule
-class CosineLRScheduler(object):
-    """lr_scheduler/scheduler.py:68-84,200-246: linear warm-up base_lr -> warmup_lr over warmup_steps, then cosine to
-    min_lr at max_iter; every param group is scaled relative to its own initial lr."""
+class WarmUpLRScheduler(object):
+    """lr_scheduler/scheduler.py:7-84: linear warm-up base_lr -> warmup_lr over warmup_steps, then `_after_warmup()` (the target
+    learning rate as a function of last_iter); every param group is scaled by target / base_lr relative to its own initial lr.
+    The four shipped laws differ only in that function: Step (:87-144), StepDecay (:147-197), Cosine (:200-249), Poly (:252-300)."""
 
-    def __init__(self, optimizer, max_iter, min_lr, base_lr, warmup_lr, warmup_steps, last_iter=0):
+    def __init__(self, optimizer, base_lr, warmup_lr, warmup_steps, max_iter=None, last_iter=0, **law):
         assert warmup_steps >= 2 or warmup_steps == 0
-        self.optimizer, self.max_iter, self.min_lr = optimizer, max_iter, min_lr
+        if warmup_steps == 0:
+            assert base_lr == warmup_lr
+        self.optimizer, self.max_iter = optimizer, max_iter
         self.base_lr, self.warmup_lr, self.warmup_steps, self.last_iter = base_lr, warmup_lr, warmup_steps, last_iter
+        self.law = law
         for g in optimizer.param_groups:
             g.setdefault("initial_lr", g["lr"])
         self.base_lrs = [g["initial_lr"] for g in optimizer.param_groups]
+
+    def _after_warmup(self):
+        raise NotImplementedError
 
     def _target(self):
         it = self.last_iter
         if self.warmup_steps >= 2 and it < self.warmup_steps:
             return (self.warmup_lr - self.base_lr) / (self.warmup_steps - 1) * (it - 1) + self.base_lr
-        ratio = (it - self.warmup_steps) / (self.max_iter - self.warmup_steps)
-        return self.min_lr + (self.warmup_lr - self.min_lr) * (1 + math.cos(math.pi * ratio)) / 2
+        return self._after_warmup()
 
     def step(self, this_iter=None):
         self.last_iter = self.last_iter + 1 if this_iter is None else this_iter
@@ -85,11 +91,64 @@ class CosineLRScheduler(object):
         return [g["lr"] for g in self.optimizer.param_groups]
 
 
+class CosineLRScheduler(WarmUpLRScheduler):
+    def __init__(self, optimizer, max_iter, min_lr, base_lr, warmup_lr, warmup_steps, last_iter=0):
+        super().__init__(optimizer, base_lr, warmup_lr, warmup_steps, max_iter, last_iter)
+        self.min_lr = min_lr
+
+    def _after_warmup(self):
+        ratio = (self.last_iter - self.warmup_steps) / (self.max_iter - self.warmup_steps)
+        return self.min_lr + (self.warmup_lr - self.min_lr) * (1 + math.cos(math.pi * ratio)) / 2
+
+
+class StepLRScheduler(WarmUpLRScheduler):
+    def __init__(self, optimizer, lr_steps, lr_mults, base_lr, warmup_lr, warmup_steps, max_iter, last_iter=0):
+        super().__init__(optimizer, base_lr, warmup_lr, warmup_steps, max_iter, last_iter)
+        if len(lr_steps) != len(lr_mults) or list(lr_steps) != sorted(lr_steps):
+            raise ValueError("lr_steps must be increasing and match lr_mults: %s vs %s" % (lr_steps, lr_mults))
+        self.lr_steps, self.cum = list(lr_steps), [1.0]
+        for m in lr_mults:
+            self.cum.append(self.cum[-1] * m)
+
+    def _after_warmup(self):
+        import bisect
+        return self.warmup_lr * self.cum[bisect.bisect_right(self.lr_steps, self.last_iter)]
+
+
+class StepDecayLRScheduler(WarmUpLRScheduler):
+    def __init__(self, optimizer, step_size, decay, base_lr, warmup_lr, warmup_steps, max_iter, last_iter=0):
+        super().__init__(optimizer, base_lr, warmup_lr, warmup_steps, max_iter, last_iter)
+        self.step_size, self.decay = step_size, decay
+
+    def _after_warmup(self):
+        return self.decay ** ((self.last_iter - self.warmup_steps) // self.step_size) * self.warmup_lr
+
+
+class PolynomialLRScheduler(WarmUpLRScheduler):
+    def __init__(self, optimizer, power, max_iter, base_lr, warmup_lr, warmup_steps, last_iter=0):
+        super().__init__(optimizer, base_lr, warmup_lr, warmup_steps, max_iter, last_iter)
+        self.power = power
+
+    def _after_warmup(self):
+        return (1 - (self.last_iter - self.warmup_steps) / float(self.max_iter)) ** self.power * self.warmup_lr
+
+
+_SCHEDULERS = {"Cosine": CosineLRScheduler, "Step": StepLRScheduler, "StepDecay": StepDecayLRScheduler, "Poly": PolynomialLRScheduler}
+
+
 def scheduler_entry(cfg):
-    """lr_scheduler/__init__.py:18-22."""
-    if cfg["type"] != "Cosine":
-        raise NotImplementedError("lr_scheduler type %s (shipped configs use Cosine)" % cfg["type"])
-    return CosineLRScheduler(**cfg["kwargs"])
+    """lr_scheduler/__init__.py:4-22 (incl. the *Epoch variants: epochs -> iterations by max_iter / max_epoch)."""
+    typ, kw = cfg["type"], dict(cfg["kwargs"])
+    if typ in ("StepEpoch", "CosineEpoch"):
+        typ = typ.replace("Epoch", "")
+        ratio = kw["max_iter"] / kw.pop("max_epoch")
+        if "lr_epochs" in kw:
+            kw["lr_steps"] = [round(e * ratio) for e in kw.pop("lr_epochs")]
+        if "warmup_epoch" in kw:
+            kw["warmup_steps"] = max(round(kw.pop("warmup_epoch") * ratio), 2)
+    if typ not in _SCHEDULERS:
+        raise NotImplementedError("lr_scheduler type %s (the reference ships %s)" % (typ, sorted(_SCHEDULERS)))
+    return _SCHEDULERS[typ](**kw)
 
 
 # --------------------------------------------------------------------------------------- optimizer groups
@@ -99,7 +158,11 @@ def param_groups(model, opt_cfg):
     Linear weights into 'linear_w' only when pconfig names it, parameters whose name contains 'logit_scale' into
     'logit_scale'; everything else (incl. MultiheadAttention.in_proj_*, embeddings, projections) is the default
     group.  Groups named in pconfig get its overrides; the others the optimizer defaults."""
-    pconfig = dict(opt_cfg.get("pconfig", {}) or {})
+    pconfig = {}
+    if opt_cfg.get("no_wd", False):                                   # clip_solver.py:248-254
+        for k in ("conv_b", "linear_b", "bn_w", "bn_b", "ln_w", "ln_b"):
+            pconfig[k] = {"weight_decay": 0.0}
+    pconfig.update(dict(opt_cfg.get("pconfig", {}) or {}))
     keys = ["bn_w", "bn_b", "conv_b", "linear_b", "ln_w", "ln_b"] + [k for k in ("linear_w", "logit_scale", "bias") if k in pconfig]
     pg, taken = {k: [] for k in keys}, set()
 
@@ -135,10 +198,13 @@ def param_groups(model, opt_cfg):
     return groups
 
 
-def optim_entry(model, opt_cfg):
-    """optimizer/__init__.py:18-26: AdamW -> the engine's fused flat AdamW; other torch optimizers by name."""
+def optim_entry(model, opt_cfg, base_lr=None):
+    """optimizer/__init__.py:18-26: AdamW -> the engine's fused flat AdamW; other torch optimizers by name.  `base_lr`:
+    clip_solver.py:243 overwrites optimizer.kwargs.lr with lr_scheduler.kwargs.base_lr before anything is built."""
     groups = param_groups(model, opt_cfg)
     kw = dict(opt_cfg.get("kwargs", {}))
+    if base_lr is not None:
+        kw["lr"] = base_lr
     if opt_cfg["type"] in ("AdamW", "FusedFP16AdamW"):
         kw["betas"] = tuple(kw.get("betas", (0.9, 0.999)))
         return FlatAdamW(groups, model.__dict__["_flat_store"], **kw)
@@ -212,12 +278,18 @@ class ClsSolver(object):
             h.setFormatter(logging.Formatter("%(asctime)s %(message)s"))
             self.logger.addHandler(h)
         self.logger.setLevel(logging.INFO if self.rank == 0 else logging.WARNING)
+        self.save_many = bool(saver.get("save_many", False))
         self.state = {"last_iter": 0}
-        if (saver.get("pretrain", None) or {}).get("auto_resume", False):       # saver.pretrain.auto_resume (clip_solver.py:120-137)
+        pre = saver.get("pretrain", None) or {}
+        path = pre.get("path", None)
+        if pre.get("auto_resume", False):                                        # clip_solver.py:128-133: the last checkpoint wins
             cands = sorted(glob.glob(os.path.join(self.save_dir, "ckpt*.pth.tar")), key=os.path.getmtime)
             if cands:
-                self.state = torch.load(cands[-1], map_location="cpu")
-                self.logger.info("auto-resumed from %s (iter %d)" % (cands[-1], self.state["last_iter"]))
+                path = cands[-1]
+        if path:                                                                 # clip_solver.py:134-137
+            self.state = torch.load(path, map_location="cpu", weights_only=False)
+            self.state.setdefault("last_iter", 0)
+            self.logger.info("Recovering from %s, keys=%s (iter %d)" % (path, list(self.state.keys()), self.state["last_iter"]))
 
     # ---- clip_solver.py:187-234
     def build_model(self):
@@ -227,16 +299,27 @@ class ClsSolver(object):
         self.model.train()
         if "model" in self.state:
             sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in self.state["model"].items()}
-            self.model.load_state_dict(sd, strict=False)
+            res = self.model.load_state_dict(sd, strict=False)                   # utils/misc.py:441-452: non-strict, every miss logged
+            for k in res.missing_keys:
+                self.logger.warning("missing key: %s" % k)
+            for k in res.unexpected_keys:
+                self.logger.warning("unexpected key: %s" % k)
+            if sd and len(res.missing_keys) == len(self.model.state_dict()):
+                raise RuntimeError("checkpoint 'model' shares no key with the model (wrong checkpoint?)")
         sync = bool(self.config.get("dist", {}).get("sync", False))
         self.model = dh_dist.DistModule(self.model, sync)
 
     def build_optimizer(self):
-        self.optimizer = optim_entry(self.model.module, self.config.optimizer)
-        if "optimizer_flat" in self.state and isinstance(self.optimizer, FlatAdamW):
+        base_lr = (self.config.get("lr_scheduler", None) or {}).get("kwargs", {}).get("base_lr", None)
+        self.optimizer = optim_entry(self.model.module, self.config.optimizer, base_lr=base_lr)
+        if "optimizer" in self.state:            # torch.optim.AdamW layout: the reference's checkpoints and our own (clip_solver.py:655)
+            self.optimizer.load_state_dict(self.state["optimizer"])              # raises if it does not line up: never silently dropped
+        elif "optimizer_flat" in self.state and isinstance(self.optimizer, FlatAdamW):     # round-1 checkpoints of this engine
             st = self.state["optimizer_flat"]
             self.optimizer.m.copy_(st["m"]), self.optimizer.v.copy_(st["v"])
             self.optimizer.step_count = st["step"]
+        elif self.state.get("last_iter", 0) > 0:
+            self.logger.warning("resuming at iter %d WITHOUT optimizer state (none in the checkpoint)" % self.state["last_iter"])
 
     def build_lr_scheduler(self):
         cfg = AttrDict(self.config.lr_scheduler)
@@ -276,7 +359,7 @@ class ClsSolver(object):
             w = dict(self.config.get("clip_simsiam_loss_weight", steps.DEFILIP_WEIGHTS if self.kind == "defilip" else steps.DECLIP_WEIGHTS))
             tv = self.config.get("data", {}).get("train", {})
             return steps.declip_loss(self.model, batch, self.criterion, self.simsiam_criterion, self.nt_xent_criterion, weights=w,
-                                     world_size=W, image_text_two_view=tv.get("image_text_two_view", True),
+                                     world_size=W, image_text_two_view=tv.get("image_text_two_view", False),   # declip_solver.py:447-452
                                      only_image_two_view=tv.get("only_image_two_view", False))
         if self.kind == "slip":
             return steps.slip_loss(self.model, batch, self.criterion, self.simclr_criterion, self.nt_xent_criterion,
@@ -284,26 +367,80 @@ class ClsSolver(object):
         return steps.filip_loss(self.model, batch, self.criterion,
                                 weights=dict(self.config.get("clip_simsiam_loss_weight", steps.FILIP_WEIGHTS)), world_size=W)
 
-    def _clamp_params(self):
-        """grad_clip.type == logit_scale_param_value: clamp the log-space temperature before and after the step
-        (clip_solver.py:507-508,521-522; filip also clamps logit_scale_dense, filip_solver.py:646,661)."""
+    # ---- grad_clip (clip_solver.py:489-530): parameter clips around the step, gradient clips before optimizer.step().  Everything
+    # stays on the device (no .item()): the reference's host reads are replaced by tensor arithmetic with the same result.
+    def _gc(self):
         gc = self.config.get("grad_clip", None)
-        if gc and gc.get("type") == "logit_scale_param_value":
-            m = self.model.module
-            m.logit_scale.data.clamp_(min=gc.value, max=gc.max_value)
-            if hasattr(m, "logit_scale_dense"):
-                m.logit_scale_dense.data.clamp_(min=gc.value, max=gc.max_value)
+        return (gc.get("type"), gc) if gc else (None, None)
+
+    def _scales(self):
+        m = self.model.module
+        out = [m.logit_scale]
+        if hasattr(m, "logit_scale_dense"):                 # filip_solver.py:646,661 clamps the dense temperature too
+            out.append(m.logit_scale_dense)
+        return out
+
+    def _param_clip_before(self):
+        typ, gc = self._gc()
+        if typ == "constant":
+            self.model.module.logit_scale.requires_grad = False
+        elif typ == "logit_scale_param":
+            self._scale_before = self.model.module.logit_scale.data.clone()
+        elif typ == "logit_scale_param_abs_min":
+            self.model.module.logit_scale.data.clamp_(min=gc.value)
+        elif typ == "logit_scale_param_value":
+            for p in self._scales():
+                p.data.clamp_(min=gc.value, max=gc.max_value)
+
+    def _param_clip_after(self):
+        typ, gc = self._gc()
+        if typ == "logit_scale_param":                      # the step may move the temperature by at most `value`
+            p, before = self.model.module.logit_scale, self._scale_before
+            p.data.copy_(torch.minimum(torch.maximum(p.data, before - gc.value), before + gc.value))
+        elif typ == "logit_scale_param_abs_min":
+            self.model.module.logit_scale.data.clamp_(min=gc.value)
+        elif typ == "logit_scale_param_value":
+            for p in self._scales():
+                p.data.clamp_(min=gc.value, max=gc.max_value)
+
+    def _grad_clip_before(self):
+        typ, gc = self._gc()
+        if typ not in ("norm", "value", "logit_scale_grad"):
+            return
+        flat = self.model.module.__dict__["_flat_store"]
+        flat.join_streams()
+        if typ == "norm":                                   # utils/grad_clip.py:10-44 on the flat gradient buffer (one norm, one scale)
+            total = flat.flat_g.norm(2)                     # alignment padding and grad-None slots are zeros
+            flat.flat_g.mul_(torch.clamp(float(gc.value) / (total + 1e-6), max=1.0))
+        elif typ == "value":
+            flat.flat_g.clamp_(min=-float(gc.value), max=float(gc.value))
+        else:
+            g = self.model.module.logit_scale.grad
+            if g is not None:
+                g.clamp_(min=-float(gc.value), max=float(gc.value))
+
+    def _clamp_params(self):                                # kept for callers of the round-1 name
+        self._param_clip_after()
 
     def train_step(self, curr_step):
-        batch = self.loader.get(curr_step) if hasattr(self.loader, "get") else next(self._iter)
+        if hasattr(self.loader, "get"):
+            batch = self.loader.get(curr_step)
+        else:
+            try:
+                batch = next(self._iter)
+            except StopIteration:
+                raise RuntimeError("train_loader is exhausted at iteration %d of %d: the solver is iteration-based, hand it an "
+                                   "infinite / iteration-sized sampler (data/sampler.py DistributedGivenIterationSampler in the "
+                                   "reference)" % (curr_step, self.max_iter)) from None
         self.lr_scheduler.step(curr_step)
         out = self._loss(batch)
         self.optimizer.zero_grad()
-        self._clamp_params()
+        self._param_clip_before()
         out["loss"].backward()
         self.model.sync_gradients()
+        self._grad_clip_before()
         self.optimizer.step()
-        self._clamp_params()
+        self._param_clip_after()
         return out
 
     def train(self, max_steps=None):
@@ -356,16 +493,20 @@ class ClsSolver(object):
         return out
 
     def save(self, curr_step):
-        """clip_solver.py:649-668 key layout ('module.'-prefixed model state, optimizer, last_iter)."""
+        """clip_solver.py:649-668: {'model' ('module.'-prefixed), 'optimizer' (torch.optim.AdamW layout), 'last_iter'} to
+        ckpt.pth.tar (ckpt_<iter>.pth.tar with saver.save_many).  Written to a temporary name and renamed into place: a crash in
+        mid-save never leaves a truncated file where auto_resume would pick it up."""
         if self.rank != 0:
-            return
+            return None
         os.makedirs(self.save_dir, exist_ok=True)
-        st = {"model": {"module." + k: v.detach().cpu() for k, v in self.model.module.state_dict().items()}, "last_iter": curr_step}
-        if isinstance(self.optimizer, FlatAdamW):
-            st["optimizer_flat"] = {"m": self.optimizer.m.cpu(), "v": self.optimizer.v.cpu(), "step": self.optimizer.step_count}
-        else:
-            st["optimizer"] = self.optimizer.state_dict()
-        torch.save(st, os.path.join(self.save_dir, "ckpt.pth.tar"))
+        st = {"model": {"module." + k: v.detach().cpu() for k, v in self.model.module.state_dict().items()},
+              "optimizer": self.optimizer.state_dict(), "last_iter": curr_step}
+        name = "ckpt_%d.pth.tar" % curr_step if self.save_many else "ckpt.pth.tar"
+        path = os.path.join(self.save_dir, name)
+        tmp = path + ".tmp%d" % os.getpid()
+        torch.save(st, tmp)
+        os.replace(tmp, path)
+        return path
 
     @torch.no_grad()
     def evaluate(self, val_data=None):

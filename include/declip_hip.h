@@ -90,6 +90,10 @@ int dh_gemm(const dh_gemm_args* args, dh_stream_t stream);
 /* Auto-dispatch switch for the 256 x 256 persistent kernel (on by default; DH_GEMM_V4=0 in the environment turns it off).
  * Returns the previous setting (-1 = default).  Used by the parity tests to run one model through both GEMM families. */
 int dh_gemm_v4_enable(int on);
+/* dh_gemm launches per kernel family since the last reset: out5[0] persistent 256x256 (gemm_v4.hip), [1] gemm_v3.hip, [2] LDS-DMA
+ * 128x128 (gemm_glds.hip), [3] MFMA-builtin tiles, [4] generic VALU kernel (gemm.hip).  Test instrumentation: lets a parity test
+ * assert that a fixture ran on the kernel that bench.py measures.  Host counters, not thread-safe. */
+int dh_gemm_stats(long long* out5, int reset);
 
 /* out[n] (+)= sum_m X[m,n]  (fp32 out; bias gradients).  X: dtype, [M][N] with ldx. */
 int dh_colsum(int dtype, const void* X, int64_t ldx, int M, int N, float* out, int accumulate, dh_stream_t stream);
@@ -287,7 +291,8 @@ int dh_adamw(float* p, const float* g, float* m, float* v, void* p_bf16_or_null,
              float beta2, float eps, float weight_decay, int step, float grad_scale, dh_stream_t stream);
 /* Same update with per-segment (lr, weight_decay): the parameter groups of utils/misc.py:267-412 laid out
  * over the flat buffer; seg_start[nseg] ascending element offsets (multiples of 4) in DEVICE memory.
- * Segments with lr == 0 and wd == 0 are left untouched (frozen parameters, alignment padding). */
+ * Segments with seg_lr < 0 are left untouched (parameters the optimizer does not own, frozen or gradient-less ones: what
+ * torch.optim.AdamW skips); lr == 0 is an ordinary value (the moments still move, as in torch). */
 int dh_adamw_segmented(float* p, const float* g, float* m, float* v, void* p_bf16_or_null, int64_t n,
                        const int64_t* seg_start_dev, const float* seg_lr_dev, const float* seg_wd_dev, int nseg,
                        float beta1, float beta2, float eps, int step, float grad_scale, dh_stream_t stream);

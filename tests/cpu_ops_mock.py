@@ -244,7 +244,7 @@ def adamw_segmented(p, g, m, v, p_bf16, seg_start, seg_lr, seg_wd, beta1, beta2,
     for i in range(len(starts) - 1):
         lo, hi = starts[i], starts[i + 1]
         lr, wd = float(seg_lr[i]), float(seg_wd[i])
-        if lr == 0.0 and wd == 0.0:
+        if lr < 0.0:
             continue
         adamw(p[lo:hi], g[lo:hi], m[lo:hi], v[lo:hi], None, lr, beta1, beta2, eps, wd, step, grad_scale)
     if p_bf16 is not None:

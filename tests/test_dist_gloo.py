@@ -61,10 +61,89 @@ def _w_reducer(rank, world, port, out):
     red = dd.FlatReducer(Flat, bucket_bytes=4 * 200)
     red.begin()
     red.ready(800, 1000)
-    red.ready(600, 790)      # contiguous up to alignment slack -> coalesced
+    red.ready(600, 790)      # a gap of 10 elements: NOT bridged (ranges arrive as whole padded slots); finish() covers it
     red.ready(100, 300)      # disjoint -> separate launch
     red.finish()             # tail: everything else
     assert torch.allclose(Flat.flat_g, torch.full((1000,), float(sum(range(1, world + 1)))))
+    if rank == 0:
+        out.put("ok")
+
+
+def _w_reducer_gap(rank, world, port, out):
+    """a small parameter slot that sits between two ready ranges and is NOT final yet must not be swept into
+    an early bucket -- its late gradient (a parameter torch autograd handles itself, added in the end-of-backward callback)
+    has to be reduced exactly once, by finish()."""
+    _init(rank, world, port)
+    from declip_amd import dist as dd
+
+    class Flat:
+        total = 448
+        flat_g = torch.zeros(448)
+    Flat.flat_g[0:128] = float(rank + 1)
+    Flat.flat_g[192:448] = float(rank + 1)
+    red = dd.FlatReducer(Flat, bucket_bytes=4 * 64)        # every ready range is launched at once
+    red.begin()
+    red.ready(0, 128)          # a parameter that fills its slots exactly
+    red.ready(192, 448)        # the next-but-one; [128, 192) = the slot of a 1-element parameter in between
+    assert all(not (lo < 192 and hi > 128) for lo, hi in red.done), red.done
+    for w in red.works:
+        w.wait()
+    Flat.flat_g[128] = 10.0 * (rank + 1)                   # the late gradient
+    red.finish()
+    tot = float(sum(range(1, world + 1)))
+    assert torch.allclose(Flat.flat_g[0:128], torch.full((128,), tot)) and torch.allclose(Flat.flat_g[192:], torch.full((256,), tot))
+    assert float(Flat.flat_g[128]) == 10.0 * tot, float(Flat.flat_g[128])
+    if rank == 0:
+        out.put("ok")
+
+
+def _w_clip_tower_twice(rank, world, port, out):
+    """encode_image called TWICE in one step (half the images each) under data parallelism.  The first
+    backward through the tower holds only part of the gradient: nothing may be all-reduced before the second one has run.
+    Same arithmetic as one call (no cross-sample op in the ViT), so the two-rank reference golden must still be met -- with
+    buckets small enough that every block's range would be launched at once."""
+    _init(rank, world, port)
+    import cpu_ops_mock
+    from declip_amd import dist as dd
+    from declip_amd import engine, ops, synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.model.clip import LazyLogits
+    from declip_amd.testing import build_clip
+    from oracle_util import check_grad_digests, load_golden
+    for name in dir(cpu_ops_mock):
+        if not name.startswith("_") and callable(getattr(cpu_ops_mock, name)) and hasattr(ops, name):
+            setattr(ops, name, getattr(cpu_ops_mock, name))
+    engine._require_gpu = lambda p, name: None
+    g = load_golden("clip_tiny_w2")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_clip(cfg, dtype="fp32", use_allgather=True, seed=seed, device="cpu")
+    dd.DistModule(model, sync=False, bucket_bytes=1 << 10)
+    B = b * world
+    images = synth.synth_images(B, res=cfg["res"], seed=seed)[rank * b:(rank + 1) * b]
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])[rank * b:(rank + 1) * b]
+    f1 = model.encode_image(images[:1].contiguous())
+    f2 = model.encode_image(images[1:].contiguous())
+    img = engine.L2NormFn.apply(torch.cat([f1, f2], dim=0), 0.0)
+    txt = engine.L2NormFn.apply(model.encode_text(ids), 1e-10)
+    g_img, g_txt = dd.all_gather_cat_many([img, txt])
+    scale = model.logit_scale_value()
+    li, lt = LazyLogits(img, g_txt, scale, rank * b), LazyLogits(txt, g_img, scale, rank * b)
+    loss, _ = ClipInfoCELoss()(li, lt)
+    (loss / world).backward()
+    total = (loss / world).detach().clone()
+    torch.distributed.all_reduce(total)
+    if rank == 0:
+        assert abs(float(total) - g["loss"]) <= 1e-4 * abs(g["loss"])
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+        check_grad_digests(g["grads"], grads, rtol=5e-4)
+    # a second backward() without zero_grad would re-reduce reduced gradients: refused under data parallelism
+    f = model.encode_image(images)
+    try:
+        f.sum().backward()
+        raised = False
+    except Exception as e:                       # DeclipHipError, surfaced by autograd
+        raised = "accumulation" in str(e)
+    assert raised
     if rank == 0:
         out.put("ok")
 
@@ -259,7 +338,7 @@ def _w_zero_shot(rank, world, port, out):
         out.put("ok")
 
 
-@pytest.mark.parametrize("fn", [_w_gather, _w_reducer, _w_clip, _w_clip_packed_pooled, _w_clip_r50, _w_clip_r50_syncbn, _w_zero_shot])
+@pytest.mark.parametrize("fn", [_w_gather, _w_reducer, _w_reducer_gap, _w_clip, _w_clip_tower_twice, _w_clip_packed_pooled, _w_clip_r50, _w_clip_r50_syncbn, _w_zero_shot])
 def test_world2(fn):
     port = _free_port()
     ctx = mp.get_context("spawn")

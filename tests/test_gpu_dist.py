@@ -143,3 +143,73 @@ def test_one_rank_rccl_collectives_are_the_identity():
         pytest.fail("RCCL worker timed out")
     assert p.exitcode == 0
     assert q.get() == "ok"
+
+
+def _filip_w2_worker(rank, world, port, dtype, out):
+    """FILIP ViT-B/32 (embed 768), two ranks x b = 256 on the one GPU: B = 512 > b gathered token sets, label0 = 256 on rank 1,
+    every tower GEMM on the persistent 256 x 256 kernel in bf16 -- against TWO reference ranks (filip_vitb32_e768_b256_w2)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from declip_amd import dist as dd
+    from declip_amd import ops, synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.steps import filip_loss
+    from declip_amd.testing import build_filip
+    from oracle_util import check_grad_digests, load_golden
+    from test_gpu_golden_fullwidth import assert_ran_on_v4, check_bf16_grad_norms, check_logits_digest, named_grads
+    g = load_golden("filip_vitb32_e768_b256_w2")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_filip(cfg, dtype=dtype, seed=seed)
+    wrapped = dd.DistModule(model, sync=False)
+    B = b * world
+    sl = slice(rank * b, (rank + 1) * b)
+    images = synth.synth_images(B, views=2, res=cfg["res"], seed=seed)[sl].cuda()
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+    ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+    batch = {"images": images, "captions": ids_masked[sl].cuda(), "mlm_labels": labels[sl]}
+    ops.gemm_stats(reset=True)
+    o = filip_loss(wrapped, batch, ClipInfoCELoss(), world_size=world)
+    o["loss"].backward()
+    wrapped.sync_gradients()
+    torch.cuda.synchronize()
+    stats = ops.gemm_stats()
+    total = o["loss"].detach().clone()
+    dist.all_reduce(total)
+    tol = 1e-3 if dtype == "fp32" else 3e-2
+    if rank == 0:
+        assert abs(float(total) - g["loss"]) <= tol * abs(g["loss"]), (float(total), g["loss"])
+        dli, dlt = o["outputs"]["dense_logits"]
+        check_logits_digest(dli, g["dense_logits_i_digest"], tol)
+        check_logits_digest(dlt, g["dense_logits_t_digest"], tol)
+        if dtype == "fp32":
+            check_grad_digests(g["grads"], named_grads(model), rtol=1e-3)
+        else:
+            assert_ran_on_v4(stats, 200)
+            check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04)
+    dist.barrier()
+    if rank == 0:
+        out.put("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_filip_two_ranks_on_one_gpu_match_two_reference_ranks(dtype):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_filip_w2_worker, args=(r, 2, port, dtype, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(420)
+        if p.is_alive():
+            p.terminate()
+            p.join(10)
+            pytest.fail("rank timed out")
+        assert p.exitcode == 0
+    assert q.get() == "ok"

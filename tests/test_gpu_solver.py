@@ -17,6 +17,7 @@ def _config(kind):
         cfg["model"]["kwargs"]["clip"]["feature_dim"] = 128
     if kind == "declip":
         cfg["model"]["kwargs"]["clip"] = dict(use_allgather=True, text_mask_type="MLM", return_nn_bank=True, feature_dim=32, nn_size=64)
+        cfg["data"]["train"] = dict(image_text_two_view=True)             # yfcc15m_vit_declip/config.yaml:101
     return cfg
 
 

@@ -138,3 +138,137 @@ def test_solver_zero_shot_evaluate_synthetic(mocked, tmp_path):
     assert s.model.training
     for k, v in s.model.module.state_dict().items():
         assert torch.equal(v, before[k]), k
+
+
+def test_other_schedules_match_reference_formulas():
+    """Step / StepDecay / Poly (lr_scheduler/scheduler.py:87-300) and the *Epoch variants (lr_scheduler/__init__.py:4-22)."""
+    from declip_amd.solver import scheduler_entry
+
+    def run(typ, **kw):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([dict(params=[p], lr=0.1), dict(params=[torch.nn.Parameter(torch.zeros(1))], lr=0.05)], lr=0.1)
+        s = scheduler_entry(dict(type=typ, kwargs=dict(optimizer=opt, base_lr=0.1, warmup_lr=0.4, warmup_steps=5, **kw)))
+        out = []
+        for it in range(1, 41):
+            s.step(it)
+            out.append(s.get_lr())
+        return out
+    st = run("Step", lr_steps=[10, 20], lr_mults=[0.1, 0.5], max_iter=40)
+    assert st[2][0] == pytest.approx((0.4 - 0.1) / 4 * 2 + 0.1) and st[2][1] == pytest.approx(st[2][0] / 2)      # warm-up, second group scaled
+    assert st[8][0] == pytest.approx(0.4) and st[9][0] == pytest.approx(0.04) and st[19][0] == pytest.approx(0.02)
+    sd = run("StepDecay", step_size=10, decay=0.5, max_iter=40)
+    assert sd[5][0] == pytest.approx(0.4) and sd[14][0] == pytest.approx(0.2) and sd[24][0] == pytest.approx(0.1)
+    po = run("Poly", power=2.0, max_iter=40)
+    assert po[19][0] == pytest.approx((1 - 15 / 40.0) ** 2 * 0.4)
+    ep = scheduler_entry(dict(type="StepEpoch", kwargs=dict(optimizer=torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1),
+                                                            base_lr=0.1, warmup_lr=0.4, warmup_epoch=1, lr_epochs=[2, 3], lr_mults=[0.1, 0.1],
+                                                            max_iter=40, max_epoch=4)))
+    assert ep.lr_steps == [20, 30] and ep.warmup_steps == 10
+    with pytest.raises(NotImplementedError):
+        scheduler_entry(dict(type="Exponential", kwargs={}))
+
+
+def test_checkpoint_has_the_reference_layout_and_resumes_from_a_torch_adamw_state(mocked, tmp_path):
+    """'model' / 'optimizer' / 'last_iter' (clip_solver.py:649-668) with the optimizer in torch.optim.AdamW's own layout: a
+    checkpoint whose 'optimizer' was written by torch.optim.AdamW over the same param groups (what the reference saves) resumes
+    with its moments and step count; saver.pretrain.path is honoured; the save is atomic (no temporary left behind)."""
+    import yaml
+    from declip_amd.solver import ClsSolver
+    cfg = _config("clip")
+    cfg["saver"].update(save_freq=2, pretrain=dict(auto_resume=False))
+    cfgp = tmp_path / "config.yaml"
+    cfgp.write_text(yaml.safe_dump(cfg))
+    s = ClsSolver(str(cfgp), device="cpu")
+    s.train(max_steps=2)
+    ckdir = os.path.join(str(tmp_path), "checkpoints")
+    assert sorted(os.listdir(ckdir)) == ["ckpt.pth.tar"]
+    ck = torch.load(os.path.join(ckdir, "ckpt.pth.tar"), weights_only=False)
+    assert set(ck) == {"model", "optimizer", "last_iter"} and ck["last_iter"] == 2
+    osd = ck["optimizer"]
+    assert set(osd) == {"state", "param_groups"} and all(set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in osd["state"].values())
+    # the same layout loads into a real torch.optim.AdamW over the same groups ...
+    groups = [dict(params=list(g["params"]), **{k: v for k, v in g.items() if k != "params"}) for g in s.optimizer.param_groups]
+    ref_opt = torch.optim.AdamW(groups, lr=1e-4)
+    ref_opt.load_state_dict(osd)
+    # ... and what torch.optim.AdamW writes resumes here (moments perturbed so that the copy is visible)
+    tsd = ref_opt.state_dict()
+    for v in tsd["state"].values():
+        v["exp_avg"] = v["exp_avg"] + 1.0
+    ck2 = dict(ck, optimizer=tsd)
+    p2 = os.path.join(str(tmp_path), "zoo.pth.tar")
+    torch.save(ck2, p2)
+    cfg["saver"]["pretrain"] = dict(auto_resume=False, path=p2)
+    cfgp.write_text(yaml.safe_dump(cfg))
+    s2 = ClsSolver(str(cfgp), device="cpu")
+    assert s2.state["last_iter"] == 2 and s2.optimizer.step_count == 2
+    p = s2.optimizer.param_groups[0]["params"][0]
+    o, n = s2.optimizer.flat.index[id(p)]
+    assert torch.allclose(s2.optimizer.m[o:o + n].view(p.shape).cpu(), tsd["state"][0]["exp_avg"])
+    # a state that does not line up is refused, not dropped
+    bad = dict(ck, optimizer=dict(state=tsd["state"], param_groups=tsd["param_groups"][:-1]))
+    torch.save(bad, p2)
+    with pytest.raises(ValueError):
+        ClsSolver(str(cfgp), device="cpu")
+
+
+@pytest.mark.parametrize("typ", ["norm", "value", "logit_scale_grad", "logit_scale_param", "logit_scale_param_abs_min", "constant"])
+def test_grad_clip_types(mocked, tmp_path, typ):
+    """every grad_clip.type of clip_solver.py:489-530 acts (round 1 honoured logit_scale_param_value only and dropped the rest)."""
+    from declip_amd.solver import ClsSolver
+    cfg = _config("clip")
+    cfg["saver"] = dict(print_freq=100, save_freq=0, pretrain=dict(auto_resume=False))
+    value = {"norm": 1e-3, "value": 1e-5, "logit_scale_grad": 1e-6, "logit_scale_param": 1e-6, "logit_scale_param_abs_min": 2.7, "constant": 0}[typ]
+    cfg["grad_clip"] = dict(type=typ, value=value)
+    s = ClsSolver(cfg, device="cpu")
+    m = s.model.module
+    flat = m.__dict__["_flat_store"]
+    seen = {}
+    orig_step = s.optimizer.step
+
+    def spy(*a, **kw):
+        seen["gnorm"] = float(flat.flat_g.norm())
+        seen["gmax"] = float(flat.flat_g.abs().max())
+        seen["dscale"] = None if m.logit_scale.grad is None else float(m.logit_scale.grad.abs().max())
+        return orig_step(*a, **kw)
+    s.optimizer.step = spy
+    before = float(m.logit_scale.detach())
+    s.train(max_steps=1)
+    after = float(m.logit_scale.detach())
+    if typ == "norm":
+        assert seen["gnorm"] <= 1e-3 * 1.001
+    elif typ == "value":
+        assert seen["gmax"] <= 1e-5 * 1.001
+    elif typ == "logit_scale_grad":
+        assert seen["dscale"] <= 1e-6 * 1.001
+    elif typ == "logit_scale_param":
+        assert 0 < abs(after - before) <= 1e-6 * 1.01                  # AdamW's first step would move it by lr = 1e-4
+    elif typ == "logit_scale_param_abs_min":
+        assert after >= 2.7 - 1e-6
+    else:
+        assert after == before and not m.logit_scale.requires_grad
+
+
+def test_optimizer_lr_is_base_lr_and_no_wd(mocked):
+    """clip_solver.py:243 (optimizer.kwargs.lr := lr_scheduler.kwargs.base_lr) and :248-254 (optimizer.no_wd)."""
+    from declip_amd.solver import ClsSolver
+    cfg = _config("clip")
+    cfg["saver"] = dict(print_freq=100, save_freq=0, pretrain=dict(auto_resume=False))
+    cfg["optimizer"]["kwargs"]["lr"] = 0.5                                # contradicts base_lr 1e-4: must be overridden
+    cfg["optimizer"].pop("pconfig")
+    cfg["optimizer"]["no_wd"] = True
+    s = ClsSolver(cfg, device="cpu")
+    assert all(g["initial_lr"] == 1e-4 for g in s.optimizer.param_groups)
+    assert s.optimizer.param_groups[0]["weight_decay"] == 0.1
+    assert len(s.optimizer.param_groups) > 1 and all(g["weight_decay"] == 0.0 for g in s.optimizer.param_groups[1:])
+
+
+def test_exhausted_loader_is_reported(mocked):
+    from declip_amd.solver import ClsSolver
+    cfg = _config("clip")
+    cfg["saver"] = dict(print_freq=100, save_freq=0, pretrain=dict(auto_resume=False))
+    cfg["data"]["prefetch"] = False
+    probe = ClsSolver(cfg, device="cpu")
+    one = probe.loader.get(1)
+    s = ClsSolver(cfg, train_loader=[one], device="cpu")
+    with pytest.raises(RuntimeError, match="exhausted"):
+        s.train(max_steps=3)

@@ -11,6 +11,9 @@ import sys
 from collections import defaultdict
 
 
+XCDS = 8        # MI355X: 8 XCDs, one GRBM each
+
+
 def short(name):
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(.*$", "", name)
@@ -47,10 +50,13 @@ def main(root):
         if "SQ_VALU_MFMA_BUSY_CYCLES" not in a:
             continue
         # SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD summed; GRBM_GUI_ACTIVE = wall cycles of the dispatch
-        gui = a.get("GRBM_GUI_ACTIVE", 0.0)
+        # GRBM_GUI_ACTIVE arrives SUMMED over the 8 XCDs (one GRBM per XCD, each counting the dispatch's wall cycles): the wall clock
+        # of the dispatch is gui / 8.  Round 1 divided by the raw sum and printed 5.5 % for a GEMM whose matrix pipes were busy 44 %
+        # of the time.  MfmaUtil = MFMA-busy cycles / (wall cycles x 1024 SIMDs).
+        gui = a.get("GRBM_GUI_ACTIVE", 0.0) / XCDS
         mfma = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
         util = mfma / (gui * 1024) if gui else 0.0          # 256 CUs x 4 SIMDs
-        print("%-70s MFMA busy %.3g cyc, GUI active %.3g cyc -> MfmaUtil %.1f%%  (waves: wait_any %.0f%%, wait_inst %.0f%%, active %.0f%% of wave cycles)" % (
+        print("%-70s MFMA busy %.3g cyc, wall (GUI active / 8 XCDs) %.3g cyc -> MfmaUtil %.1f%%  (waves: wait_any %.0f%%, wait_inst %.0f%%, active %.0f%% of wave cycles)" % (
             k, mfma, gui, 100 * util, 100 * a.get("SQ_WAIT_ANY", 0) / max(a.get("SQ_WAVE_CYCLES", 1), 1),
             100 * a.get("SQ_WAIT_INST_ANY", 0) / max(a.get("SQ_WAVE_CYCLES", 1), 1), 100 * a.get("SQ_ACTIVE_INST_ANY", 0) / max(a.get("SQ_WAVE_CYCLES", 1), 1)))
     for k in sorted(agg, key=lambda k: -agg[k].get("TCC_HIT_sum", 0))[:15]:
