@@ -326,6 +326,30 @@ extern "C" int dh_gemm_stats(long long* out5, int reset) {
   return DH_OK;
 }
 
+bool dh_gemm_try_v4_group(const dh_gemm_args* a, int n, hipStream_t st);   // gemm_v4.hip
+
+// Several weight-gradient GEMMs with the same contraction length (the dW problems of one transformer block) as one launch of the
+// persistent kernel + one reduce pass; any group the kernel cannot take is issued as n dh_gemm calls (same results).
+extern "C" int dh_gemm_group(const dh_gemm_args* a, int n, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(a && n >= 1, "dh_gemm_group: bad args");
+  for (int i = 0; i < n; ++i) {
+    DH_REQUIRE(a[i].A && a[i].B && a[i].C && a[i].M > 0 && a[i].N > 0 && a[i].K > 0, "dh_gemm_group: problem %d: null pointer / bad shape", i);
+    DH_REQUIRE(a[i].accumulate && a[i].c_dtype == DH_F32 && a[i].a_kmajor && a[i].b_kmajor,
+               "dh_gemm_group: problem %d is not a weight gradient (a_kmajor, b_kmajor, fp32 accumulate)", i);
+  }
+  if (a[0].force_generic == 0 && n >= 2 && dh_gemm_try_v4_group(a, n, st)) {
+    g_gemm_family_calls[0] += n;
+    DH_CHECK_LAUNCH();
+    return DH_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    const int rc = dh_gemm(&a[i], stream);
+    if (rc != DH_OK) return rc;
+  }
+  return DH_OK;
+}
+
 extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   DH_REQUIRE(a && a->A && a->B && a->C, "dh_gemm: null pointer");

@@ -36,6 +36,7 @@
 //   contraction-major [64 k][128 out] 256-B rows, 16-B chunk c of row k at slot c ^ ((k&3)<<2)
 #include "dh_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 #ifndef V4_ABL
 #define V4_ABL 0
@@ -104,12 +105,30 @@ struct EpiParams {
 // opaque pointer to the kernarg segment, right where a value is needed (prologue of the launch, start of each epilogue).
 // Passed as ordinary by-value arguments, these ~45 scalars were preloaded and kept (then spilled: 150-280 SGPR spills, with
 // v_readlane reloads inside the K loop of the dW kernel) across the main loop, which itself needs only four strides.
+// MODE_GROUP: several weight-gradient problems with the same contraction length (the four dW GEMMs of a transformer block:
+// dY^T X for in_proj, out_proj, c_fc, c_proj) as ONE persistent launch.  A problem on its own has 9-36 tiles for 256 CUs, so it
+// was cut into 7-64 K-slices (28 slices of 14 K-tiles for a 768 x 768 weight: prologue / epilogue bound, 120-275 TFLOP/s) and
+// every slice wrote a 256 KB fp32 partial tile; together the four have 108 (vision) / 48 (text) tiles, fill the chip with 5-7
+// slices of >= 57 K-tiles, write 4x fewer partial tiles and need one reduce pass instead of four.
+constexpr int MAX_GROUP = 4;
+struct GProb {
+  const bf16_t* A; const bf16_t* B;      // dY [K][M] and X [K][N] (both contraction-major)
+  long lda, ldb;
+  long ws_off;                            // float offset of this problem's [M][N] block inside one K-slice slab of the workspace
+  long cs_off;                            // float offset of its [ntx][M] bias-gradient block inside one slab of the colsum area
+  float* a_colsum;                        // bias gradient (or null)
+  int M, N, ntx, nty, tile0, pad_;        // tile0: index of its first tile in the concatenated tile list (INT_MAX: unused entry)
+};
 struct KArgs {
   const bf16_t* A; long lda;
   const bf16_t* B; long ldb;
   int M, N, K, k_per_split, ntx, nty, nitems, n_full, S, dyn;   // dyn: 0 static partition, 1 dynamic after the first item, 2 fully dynamic + stealing
   int* sched;
   EpiParams e;
+  // MODE_GROUP only
+  int T, ngrp;                            // tiles of all problems together; problems
+  long zs, cs_zs;                         // floats per K-slice slab: partial tiles (sum M*N), bias-gradient partials (sum ntx*M)
+  GProb gp[MAX_GROUP];
 };
 typedef const __attribute__((address_space(4))) unsigned char* kargp_t;
 template <typename T> __device__ __forceinline__ T karg_load(kargp_t kp, int off) {
@@ -117,6 +136,7 @@ template <typename T> __device__ __forceinline__ T karg_load(kargp_t kp, int off
   return *(P)(kp + off);
 }
 #define KARG(kp, T, field) karg_load<T>((kp), (int)offsetof(KArgs, field))
+#define GPARG(kp, p, T, field) karg_load<T>((kp), (int)(offsetof(KArgs, gp) + offsetof(GProb, field)) + (p) * (int)sizeof(GProb))
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;          // 16 KiB
@@ -127,7 +147,7 @@ constexpr int SCHED_OFF = BIAS_OFF + MAX_BIAS_N * 4;   // one word: the work ite
 constexpr int LDS_BYTES = SCHED_OFF + 16;            // 144 KiB + 16 B
 // MODE: what happens to the finished tile.  The bf16 epilogue flavours are separate instantiations (straight-line code:
 // the kernel lives at the 256-VGPR cap, runtime epilogue switches cost spills).
-constexpr int MODE_STORE = 0, MODE_STORE_GELU = 1, MODE_STORE_DGELU = 2, MODE_STORE_RES = 3, MODE_ATOMIC = 4, MODE_PARTIAL = 5;
+constexpr int MODE_STORE = 0, MODE_STORE_GELU = 1, MODE_STORE_DGELU = 2, MODE_STORE_RES = 3, MODE_ATOMIC = 4, MODE_PARTIAL = 5, MODE_GROUP = 6;
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -246,7 +266,7 @@ __device__ __forceinline__ void tile_from_logical(int b, int ntx, int nty, int& 
 // scheduling: when other kernels -- RCCL during the overlapped gradient all-reduce -- hold some CUs, the workgroups that do
 // run simply take more tiles; with a static partition a 4-CU hog slowed this GEMM by 39 %), with stealing from the other
 // XCDs' lists once the own one is exhausted.  Without a scheduler buffer the partition is static (l += workgroups on x).
-struct Item { int tile_x, tile_y, z, kbeg, nk, slice; };
+struct Item { int tile_x, tile_y, z, kbeg, nk, slice, p; };
 __device__ __forceinline__ void chunk_of(int n, int x, int& start, int& len) {
   const int q = n >> 3, r = n & 7;
   len = q + (x < r ? 1 : 0);
@@ -263,6 +283,7 @@ __device__ __forceinline__ bool decode_pos(int x, int l, int ntx, int nty, int n
     it.kbeg = it.z * k_per_split;
     it.nk = (min(K, it.kbeg + k_per_split) - it.kbeg) / BK;
     it.slice = -1;
+    it.p = 0;
     return true;
   }
   if (S == 0) return false;
@@ -274,7 +295,27 @@ __device__ __forceinline__ bool decode_pos(int x, int l, int ntx, int nty, int n
   const int j = ss + j0, lt = j / S, sl = j - lt * S, nkt = K / BK;
   tile_from_logical(n_full + lt, ntx, nty, it.tile_x, it.tile_y);
   const int k0 = sl * nkt / S, k1 = (sl + 1) * nkt / S;
-  it.z = 0; it.kbeg = k0 * BK; it.nk = k1 - k0; it.slice = j;
+  it.z = 0; it.kbeg = k0 * BK; it.nk = k1 - k0; it.slice = j; it.p = 0;
+  return true;
+}
+// MODE_GROUP: position l of XCD x's chunk of the (K-slice, tile) list -> item.  Tiles of all problems are concatenated; inside a
+// problem the usual grouped order (tile_from_logical), so the ~32 items an XCD runs together share the dY / X panels of one
+// K-slice in its L2.
+__device__ __forceinline__ bool decode_group(kargp_t kp, int x, int l, int nitems, int T, int K, int k_per_split, Item& it) {
+  int sf, lf;
+  chunk_of(nitems, x, sf, lf);
+  if (l >= lf) return false;
+  const int logical = sf + l;
+  it.z = logical / T;
+  const int t = logical - it.z * T;
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < MAX_GROUP; ++q) p = t >= GPARG(kp, q, int, tile0) ? q : p;
+  it.p = p;
+  tile_from_logical(t - GPARG(kp, p, int, tile0), GPARG(kp, p, int, ntx), GPARG(kp, p, int, nty), it.tile_x, it.tile_y);
+  it.kbeg = it.z * k_per_split;
+  it.nk = (min(K, it.kbeg + k_per_split) - it.kbeg) / BK;
+  it.slice = -1;
   return true;
 }
 __device__ __forceinline__ int wgs_on_xcd(int x, int grid) { return x < grid ? ((grid - 1 - x) >> 3) + 1 : 0; }
@@ -297,6 +338,19 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool SWAP = MODE != MODE_ATOMIC;
   constexpr bool STORE = MODE <= MODE_STORE_RES;
+  constexpr bool GROUP = MODE == MODE_GROUP;
+  // item decoding and the per-problem operands (MODE_GROUP: from the problem table, read late like everything else)
+#define DECODE(x_, l_, it_) (GROUP ? decode_group(kp, (x_), (l_), nitems, KARG(kp, int, T), K, k_per_split, (it_)) \
+                                   : decode_pos((x_), (l_), ntx, nty, n_fullitems, n_full, S, K, k_per_split, (it_)))
+#define LOAD_PROBLEM(kq_, p_)                                                                   \
+  do {                                                                                          \
+    if (GROUP) {                                                                                \
+      A = GPARG(kq_, p_, const bf16_t*, A); B = GPARG(kq_, p_, const bf16_t*, B);               \
+      lda = GPARG(kq_, p_, long, lda); ldb = GPARG(kq_, p_, long, ldb);                         \
+      M = GPARG(kq_, p_, int, M); N = GPARG(kq_, p_, int, N);                                   \
+      astep = (long)BK * lda; bstep = (long)BK * ldb;                                           \
+    }                                                                                           \
+  } while (0)
   // ROLES: waves 4-7 issue ALL LDS-DMA and never store; waves 0-3 do all global stores of the epilogue and never wait on
   // vmcnt in the main loop.  A wave's vmcnt retires in order, so a wave with epilogue stores in flight cannot wait for a
   // younger load without also waiting for those stores to reach HBM; with the roles split the stores of tile i drain during
@@ -313,8 +367,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
   const bool issuer = !ROLES || wm == 1;
   unsigned char* const wdst = smem + (ROLES ? (wave & 3) * 4096 : wave * 2048);   // this wave's slice of a half-tile
   const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
-  const long astep = TA ? (long)BK * lda : BK;
-  const long bstep = TB ? (long)BK * ldb : BK;
+  long astep = TA ? (long)BK * lda : BK;             // (MODE_GROUP: per problem, LOAD_PROBLEM)
+  long bstep = TB ? (long)BK * ldb : BK;
 
   // DMA sources.  Shapes are whole tiles (host-checked).  Each wave stages pieces 2w, 2w+1 of every half-tile: two per-lane
   // pointers per operand (the source swizzle of a K-contiguous piece depends on the piece), half +1 = a wave-uniform offset
@@ -429,10 +483,10 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     }
     __syncthreads();
     const int p0 = __builtin_amdgcn_readfirstlane(sched_lds[1]);
-    have = p0 >= 0 && decode_pos(p0 >> 24, p0 & 0xffffff, ntx, nty, n_fullitems, n_full, S, K, k_per_split, nxt);
+    have = p0 >= 0 && DECODE(p0 >> 24, p0 & 0xffffff, nxt);
   } else {
     const int my_l = blockIdx.x >> 3;                                    // position in XCD `xcd`'s list
-    have = decode_pos(xcd, my_l, ntx, nty, n_fullitems, n_full, S, K, k_per_split, nxt);   // grid <= items: always true
+    have = DECODE(xcd, my_l, nxt);                                       // grid <= items: always true
     if (t == 0) {
       int v;
       if (dyn) { int r0, sa[8]; FETCH_ISSUE(r0, sa); FETCH_WAIT(0, r0, sa); v = fetch_finish(r0, sa); }
@@ -441,6 +495,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     }
   }
   if (have) {   // first tile: the four half-tiles of its K-tile 0, in steady-state FIFO order
+    LOAD_PROBLEM(kp, nxt.p);
     SETUP_SRC(nxt.tile_y * BM, nxt.tile_x * BN, nxt.kbeg);
     ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, b_dh, 3, 0); ISSUE_H(ap, a_dh, 1, 0);
   }
@@ -472,7 +527,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     const int zcur = nxt.z;
     const int txcur = nxt.tile_x;
     const int cur_slice = nxt.slice;
-    const int ntx_cs = ntx;
+    const int pcur = nxt.p;
+    const int ntx_cs = GROUP ? GPARG(kp, pcur, int, ntx) : ntx;
 
     // fragment addressing restarts from an opaque lane id per tile, so its ~12 address registers are not kept live across
     // the epilogue of the previous tile (same trick as `te` below)
@@ -489,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     f32x16_t cs;                     // bias-gradient accumulator: column c = row-tile c of this wave (TA only)
 #pragma unroll
     for (int r = 0; r < 16; ++r) cs[r] = 0.f;
-    const bool want_cs = TA && e.a_colsum != nullptr;
+    const bool want_cs = TA && (GROUP ? GPARG(kp, pcur, float*, a_colsum) != nullptr : e.a_colsum != nullptr);
     int cs_ctr = 0;                  // K-tiles with cs_ctr == tile_x contribute (spreads the extra MFMAs over the tile columns)
 
     // ---- rest of the prologue: A0, B0 of K-tile 1 go to ring buffer 1 (free: every wave is past the epilogue)
@@ -678,7 +734,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     RELOAD_ARGS();
     n_fullitems = S ? n_full : nitems;
     const int packed = __builtin_amdgcn_readfirstlane(sched_lds[0]);       // published before this tile's prologue barrier
-    have = packed >= 0 && decode_pos(packed >> 24, packed & 0xffffff, ntx, nty, n_fullitems, n_full, S, K, k_per_split, nxt);
+    have = packed >= 0 && DECODE(packed >> 24, packed & 0xffffff, nxt);
     int fut = -1;                                // thread 0: the item after that (published at the end of this epilogue)
     int fut_raw = 1 << 22, fut_sn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (have) {
@@ -686,6 +742,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
         if (dyn) FETCH_ISSUE(fut_raw, fut_sn);   // no control flow depends on it until the end of the epilogue
         else { const int x = packed >> 24, l = (packed & 0xffffff) + wgs_on_xcd(x, grid); fut = (x << 24) | l; }
       }
+      LOAD_PROBLEM(kp, nxt.p);
       SETUP_SRC(nxt.tile_y * BM, nxt.tile_x * BN, nxt.kbeg);
       ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, b_dh, 3, 0); ISSUE_H(ap, a_dh, 1, 0);
     }
@@ -719,7 +776,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       V4_BARRIER();
       if (te < 256) {
         const float v = (csl[te] + csl[256 + te]) + (csl[512 + te] + csl[768 + te]);
-        if (MODE == MODE_PARTIAL) e.ws_cs[((long)zcur * ntx + txcur) * M + m0 + te] = v;
+        if (GROUP) e.ws_cs[(long)zcur * KARG(kp, long, cs_zs) + GPARG(kp, pcur, long, cs_off) + (long)txcur * GPARG(kp, pcur, int, M) + m0 + te] = v;
+        else if (MODE == MODE_PARTIAL) e.ws_cs[((long)zcur * ntx + txcur) * M + m0 + te] = v;
         else atomicAdd(e.a_colsum + m0 + te, v);
       }
       wait_lgkm0();
@@ -748,13 +806,17 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
 
     unsigned char* Cs = smem + STAGE_BYTES;  // ring buffer 1 (buffer 0 is receiving the next tile)
     constexpr bool SLICEABLE = MODE == MODE_STORE || MODE == MODE_STORE_RES;   // the N = d GEMMs (few tiles) use these flavours
-    if (MODE == MODE_PARTIAL || (SLICEABLE && cur_slice >= 0)) {
+    if (MODE == MODE_PARTIAL || GROUP || (SLICEABLE && cur_slice >= 0)) {
       // fp32 partial tile: MODE_PARTIAL -> ws[z][m][n]; tail slice -> its private [256][256] tile of the workspace.
       // 4 passes of 64 rows: pass (i, ii) holds rows i*128 + wm*64 + ii*32 + 0..31 of both wave groups; staging row =
       // wm*32 + (lane&31), 1024 B per row, 16-byte unit u of row r stored at unit u ^ (r & 7).
       float* Wp;
       long wld;
-      if (MODE == MODE_PARTIAL) { Wp = e.ws + (long)zcur * M * N + (long)m0 * N + n0; wld = N; }
+      if (GROUP) {   // this item's problem (M, N above already belong to the NEXT item)
+        const int Nc = GPARG(kp, pcur, int, N);
+        Wp = e.ws + (long)zcur * KARG(kp, long, zs) + GPARG(kp, pcur, long, ws_off) + (long)m0 * Nc + n0; wld = Nc;
+      }
+      else if (MODE == MODE_PARTIAL) { Wp = e.ws + (long)zcur * M * N + (long)m0 * N + n0; wld = N; }
       else { Wp = e.ws + (long)cur_slice * (BM * BN); wld = BN; }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -934,6 +996,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
 #undef FETCH_WAIT
 #undef ADVANCE_SRC
 #undef WAITV
+#undef DECODE
+#undef LOAD_PROBLEM
 }
 
 // out[m][n] (+)= sum_z ws[z][m][n]   (the split-K partial tiles of MODE_PARTIAL)
@@ -1158,6 +1222,14 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
     static int tail = -1;
     if (tail < 0) { const char* ev = getenv("DH_V4_TAIL"); tail = ev ? atoi(ev) : 1; }
     const int T = dh_cdiv(a->N, BN) * dh_cdiv(a->M, BM), G = num_cus(), rem = T % G, nkt = a->K / BK;
+    if (tail && T <= G / 2 && nkt >= 8) {
+      // FEW tiles (the M = b GEMMs of the pooled last block: 6-24 tiles of 12-48 K-tiles ran on 6-24 CUs, 20-68 us each at 12-90
+      // TFLOP/s): every tile is cut in K over the whole chip, the fix-up kernel sums the slices and applies the epilogue
+      int s_ = G / T;
+      if (s_ > 32) s_ = 32;
+      if (s_ > nkt / 2) s_ = nkt / 2;
+      if (s_ >= 2 && a->ws_bytes >= (int64_t)T * s_ * BM * BN * 4) { S = s_; n_full = 0; }
+    } else
     if (tail && T > G && rem > 0 && rem <= G / 2 && nkt >= 24) {   // short-K tiles: the slice overheads eat the gain (measured)
       int s_ = G / rem;
       if (s_ > 8) s_ = 8;
@@ -1194,5 +1266,138 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a->ws, (float*)a->C, (long)a->ldc, a->M,
                        a->N, split, 1, (const float*)e.ws_cs, a->a_colsum, split * dh_cdiv(a->N, BN));
   }
+  return true;
+}
+
+// ---- grouped weight gradients (MODE_GROUP) -------------------------------------------------------------------------------------
+namespace v4 {
+struct GReduce {
+  float* out[MAX_GROUP];          // gradient [M][N], contiguous (ldc == N)
+  float* colsum[MAX_GROUP];       // bias gradient [M] or null
+  long ws_off[MAX_GROUP + 1];     // float offsets inside a slab (ascending; [n] = zs)
+  long cs_off[MAX_GROUP];
+  int M[MAX_GROUP], ntx[MAX_GROUP];
+  int n;
+};
+// out_p[i] += sum_z ws[z][ws_off_p + i]  for every problem of the group; bias gradients: colsum_p[m] += sum_{z, tx} cs[z][cs_off_p + tx*M_p + m]
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const float* __restrict__ ws, const float* __restrict__ cs, long zs, long cs_zs,
+                                                                  int nsplit, GReduce g) {
+  const long n4 = zs / 4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long i = tid; i < n4; i += stride) {
+    const long e = i * 4;
+    f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int zz = 0;
+    for (; zz + 2 <= nsplit; zz += 2) {
+      s0 += *reinterpret_cast<const f32x4_t*>(ws + (long)zz * zs + e);
+      s1 += *reinterpret_cast<const f32x4_t*>(ws + (long)(zz + 1) * zs + e);
+    }
+    if (zz < nsplit) s0 += *reinterpret_cast<const f32x4_t*>(ws + (long)zz * zs + e);
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < MAX_GROUP; ++q) p = (q < g.n && e >= g.ws_off[q]) ? q : p;
+    float* op = nullptr;
+    long off = 0;
+#pragma unroll
+    for (int q = 0; q < MAX_GROUP; ++q) if (q == p) { op = g.out[q]; off = g.ws_off[q]; }
+    f32x4_t* o = reinterpret_cast<f32x4_t*>(op + (e - off));
+    *o = *o + (s0 + s1);
+  }
+  if (cs) {
+    // the LAST threads of the grid take the (short) bias-gradient job: one thread per (problem, row)
+    long gt = (long)gridDim.x * blockDim.x - 1 - tid;
+#pragma unroll
+    for (int q = 0; q < MAX_GROUP; ++q) {
+      if (q >= g.n) break;
+      const int Mq = g.M[q];
+      if (g.colsum[q] && gt >= 0 && gt < Mq) {
+        float a = 0.f;
+        for (int z = 0; z < nsplit; ++z)
+          for (int tx = 0; tx < g.ntx[q]; ++tx) a += cs[(long)z * cs_zs + g.cs_off[q] + (long)tx * Mq + gt];
+        g.colsum[q][gt] += a;
+      }
+      gt -= Mq;
+    }
+  }
+}
+}  // namespace v4
+
+// The n weight-gradient problems C_p[M_p][N_p] += A_p^T B_p (dh_gemm_args with a_kmajor = b_kmajor = accumulate = 1, fp32 C, same K)
+// as one launch + one reduce pass.  Returns false (nothing launched) if the group does not fit the kernel: the caller then issues
+// the problems one by one.
+bool dh_gemm_try_v4_group(const dh_gemm_args* a, int n, hipStream_t st) {
+  using namespace v4;
+  if (g_v4_mode == -2) { const char* ev = getenv("DH_GEMM_V4"); g_v4_mode = ev ? atoi(ev) : -1; }
+  if (g_v4_mode == 0) return false;
+  static int grp_on = -1;
+  if (grp_on < 0) { const char* ev = getenv("DH_V4_GROUP"); grp_on = ev ? atoi(ev) : 1; }
+  if (!grp_on || n < 2 || n > MAX_GROUP) return false;
+  const int K = a[0].K;
+  if (K % BK || K < 8 * BK || !a[0].ws || ((uintptr_t)a[0].ws & 15)) return false;
+  KArgs ka;
+  memset(&ka, 0, sizeof(ka));
+  GReduce gr;
+  memset(&gr, 0, sizeof(gr));
+  int T = 0;
+  long zs = 0, cs_zs = 0;
+  bool any_cs = false;
+  for (int p = 0; p < MAX_GROUP; ++p) ka.gp[p].tile0 = 0x7fffffff;
+  for (int p = 0; p < n; ++p) {
+    const dh_gemm_args& q = a[p];
+    if (q.dtype != DH_BF16 || q.c_dtype != DH_F32 || !q.a_kmajor || !q.b_kmajor || !q.accumulate || q.K != K) return false;
+    if (q.bias || q.residual || q.epilogue != DH_EPI_NONE || q.alpha != 1.f) return false;
+    if ((q.lda % 8) || (q.ldb % 8) || ((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15) || ((uintptr_t)q.C & 15)) return false;
+    if ((q.M % BM) || (q.N % BN) || q.ldc != q.N) return false;
+    GProb& g = ka.gp[p];
+    g.A = (const bf16_t*)q.A; g.B = (const bf16_t*)q.B; g.lda = q.lda; g.ldb = q.ldb; g.M = q.M; g.N = q.N;
+    g.ntx = q.N / BN; g.nty = q.M / BM; g.tile0 = T; g.ws_off = zs; g.cs_off = cs_zs; g.a_colsum = (float*)q.a_colsum;
+    gr.out[p] = (float*)q.C; gr.colsum[p] = (float*)q.a_colsum; gr.ws_off[p] = zs; gr.cs_off[p] = cs_zs; gr.M[p] = q.M; gr.ntx[p] = g.ntx;
+    T += g.ntx * g.nty;
+    zs += (long)q.M * q.N;
+    cs_zs += (long)g.ntx * q.M;
+    any_cs = any_cs || q.a_colsum;
+  }
+  gr.n = n;
+  for (int p = n; p <= MAX_GROUP; ++p) gr.ws_off[p] = zs;
+  // K-slices: minimise  rounds x (K-tiles per slice + epilogue) + reduce traffic   [unit: one K-tile of one CU, ~1.3 us]
+  const int G = num_cus(), nkt = K / BK;
+  const double epi = 8.0, red = (double)zs * 4.0 / 5.3e6;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int S = 1; S <= 16 && nkt / S >= 8; ++S) {
+    const int rounds = (T * S + G - 1) / G;
+    const int per = (nkt + S - 1) / S;
+    if (nkt - (S - 1) * per < 2) continue;              // short tail slice
+    const double cost = rounds * (per + epi) + (S > 1 ? S * red : 0.0);
+    if (a[0].ws_bytes < (int64_t)S * (zs + cs_zs) * 4) break;
+    if (cost < best_cost) { best_cost = cost; best = S; }
+  }
+  static int force_s = -1;
+  if (force_s < 0) { const char* ev = getenv("DH_V4_GROUP_SPLIT"); force_s = ev ? atoi(ev) : 0; }
+  int split = force_s > 0 ? force_s : best;
+  int kps = ((nkt + split - 1) / split) * BK;
+  split = (K + kps - 1) / kps;
+  if (K - (split - 1) * kps < 2 * BK || kps < 2 * BK) return false;
+  if (a[0].ws_bytes < (int64_t)split * (zs + cs_zs) * 4) return false;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_v4_kernel<true, true, MODE_GROUP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  ka.K = K; ka.k_per_split = kps; ka.nitems = T * split; ka.T = T; ka.ngrp = n; ka.zs = zs; ka.cs_zs = cs_zs;
+  ka.A = ka.gp[0].A; ka.B = ka.gp[0].B; ka.lda = ka.gp[0].lda; ka.ldb = ka.gp[0].ldb; ka.M = ka.gp[0].M; ka.N = ka.gp[0].N;
+  ka.ntx = ka.gp[0].ntx; ka.nty = ka.gp[0].nty;
+  ka.sched = sched_slot(st, &ka.dyn);
+  ka.e.alpha = 1.f;
+  ka.e.ws = (float*)a[0].ws;
+  ka.e.ws_cs = any_cs ? (float*)a[0].ws + (int64_t)split * zs : nullptr;
+  ka.e.a_colsum = any_cs ? ka.gp[0].a_colsum : nullptr;
+  int grid = G;
+  if (grid > ka.nitems) grid = ka.nitems;
+  hipLaunchKernelGGL((gemm_v4_kernel<true, true, MODE_GROUP, false>), dim3(grid), dim3(512), LDS_BYTES, st, ka);
+  int blocks = (int)((zs / 4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a[0].ws, (const float*)ka.e.ws_cs, zs, cs_zs, split, gr);
   return true;
 }

@@ -245,9 +245,9 @@ def _split_k(mg, ng, kg):
 _GEMM_WS = {}
 
 
-def gemm_workspace(device, nbytes=128 << 20):
-    """Scratch for the split-K partial tiles of the weight-gradient GEMMs (one per device and stream; 128 MiB covers
-    32 slices of the largest tower weight)."""
+def gemm_workspace(device, nbytes=256 << 20):
+    """Scratch for the split-K partial tiles of the weight-gradient GEMMs (one per device and stream; 256 MiB covers 32 slices of
+    the largest tower weight, or 8 K-slices of the four weight gradients of a ViT-B block issued as one group)."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _GEMM_WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
@@ -262,6 +262,33 @@ def weight_grad(dy, x, gw, gb=None):
     ws = gemm_workspace(dy.device) if dy.is_cuda and dy.dtype == torch.bfloat16 else None
     ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=gw, accumulate=True,
              split_k=_split_k(gw.shape[0], gw.shape[1], dy.shape[0]), a_colsum=gb, ws=ws)
+
+
+class DwGroup:
+    """The weight-gradient problems of one transformer block, issued together at the end of the block's backward: problems with
+    the same contraction length (= row count of dy / x) go to ONE launch of the persistent GEMM (ops.gemm_dw_group, dh_gemm_group):
+    a single 768 x 768 weight has 9 output tiles for 256 CUs, the four weights of a ViT-B block 108.  The dy / x tensors are
+    kept alive until flush()."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, dy, x, gw, gb=None):
+        self.items.append((dy, x, gw, gb))
+
+    def flush(self):
+        by_rows = {}
+        for it in self.items:
+            by_rows.setdefault((it[0].shape[0], it[0].dtype), []).append(it)
+        self.items = []
+        for (_, dtype), grp in by_rows.items():
+            ws = gemm_workspace(grp[0][0].device) if grp[0][0].is_cuda and dtype == torch.bfloat16 else None
+            for i in range(0, len(grp), 4):
+                chunk = grp[i:i + 4]
+                if len(chunk) == 1:
+                    weight_grad(*chunk[0])
+                else:
+                    ops.gemm_dw_group(chunk, ws=ws)
 
 
 def block_fwd(x, r, b, L, heads, causal, save):
@@ -282,19 +309,22 @@ def block_fwd(x, r, b, L, heads, causal, save):
 def block_bwd(dx_out, r, saved, b, L, heads, causal):
     x, mean1, rstd1, h1, qkv, a, lse, x_mid, mean2, rstd2, h2, u, g = saved
     # MLP: x_out = x_mid + gelu(h2 Wfc^T + bfc) Wproj^T + bproj
-    weight_grad(dx_out, g, r.g_w_proj, r.g_b_proj)
+    dw = DwGroup()
+    dw.add(dx_out, g, r.g_w_proj, r.g_b_proj)
     du = ops.gemm(dx_out, r.w_proj, b_kmajor=True, epilogue=EPI_DGELU, aux=u)
-    weight_grad(du, h2, r.g_w_fc, r.g_b_fc)
+    dw.add(du, h2, r.g_w_fc, r.g_b_fc)
     ws = gemm_workspace(du.device) if du.is_cuda and du.dtype == torch.bfloat16 else None
     dh2 = ops.gemm(du, r.w_fc, b_kmajor=True, ws=ws)
     dx_mid = ops.layernorm_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)
     # attention: x_mid = x + attn(h1) Wout^T + bout
-    weight_grad(dx_mid, a, r.g_w_out, r.g_b_out)
+    dw.add(dx_mid, a, r.g_w_out, r.g_b_out)
     da = ops.gemm(dx_mid, r.w_out, b_kmajor=True, ws=ws)
     dqkv = ops.attn_bwd(qkv, a, da, lse, b, L, heads, causal)
-    weight_grad(dqkv, h1, r.g_w_in, r.g_b_in)
+    dw.add(dqkv, h1, r.g_w_in, r.g_b_in)
     dh1 = ops.gemm(dqkv, r.w_in, b_kmajor=True, ws=ws)
-    return ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
+    dx = ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
+    dw.flush()                         # the block's four weight gradients: one grouped launch (all inputs are final here)
+    return dx
 
 
 def pooled_last_block(width=None, heads=None, L=0):
@@ -329,14 +359,14 @@ def block_fwd_pooled(x, r, sel, row0, nkeys, Lmax, heads, save):
     ws = gemm_workspace(x.device) if x.is_cuda and x.dtype == torch.bfloat16 else None
     kv = ops.gemm(h1, r.w_in[d:], bias=r.b_in[d:], ws=ws)                 # k | v of every row
     h1s = ops.gather_rows(h1, sel)
-    q = ops.gemm(h1s, r.w_in[:d], bias=r.b_in[:d])                        # the pooled rows' queries
+    q = ops.gemm(h1s, r.w_in[:d], bias=r.b_in[:d], ws=ws)                 # the pooled rows' queries (ws: few tiles -> cut in K over the chip)
     a, lse = ops.attn_pooled_fwd(q, kv, row0, nkeys, heads, Lmax)
     xs = ops.gather_rows(x, sel)
-    x_mid = ops.gemm(a, r.w_out, bias=r.b_out, residual=xs)
+    x_mid = ops.gemm(a, r.w_out, bias=r.b_out, residual=xs, ws=ws)
     h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, r.ln2_w, r.ln2_b, r.eps2)
     u = torch.empty(x_mid.shape[0], r.w_fc.shape[0], device=x.device, dtype=x.dtype) if save else None
     g = ops.gemm(h2, r.w_fc, bias=r.b_fc, epilogue=EPI_GELU, aux=u)
-    x_out = ops.gemm(g, r.w_proj, bias=r.b_proj, residual=x_mid)
+    x_out = ops.gemm(g, r.w_proj, bias=r.b_proj, residual=x_mid, ws=ws)
     saved = (x, mean1, rstd1, h1, kv, h1s, q, a, lse, x_mid, mean2, rstd2, h2, u, g) if save else None
     return x_out, saved
 
@@ -345,21 +375,23 @@ def block_bwd_pooled(dx_out, r, saved, sel, row0, nkeys, Lmax, heads):
     """dx_out [b, d] (gradient of the pooled rows' block output) -> gradient of the block input x [R, d]."""
     x, mean1, rstd1, h1, kv, h1s, q, a, lse, x_mid, mean2, rstd2, h2, u, g = saved
     d = x.shape[1]
-    weight_grad(dx_out, g, r.g_w_proj, r.g_b_proj)
+    dw = DwGroup()                     # four problems over the b pooled rows + the k|v projection over all rows
+    dw.add(dx_out, g, r.g_w_proj, r.g_b_proj)
     du = ops.gemm(dx_out, r.w_proj, b_kmajor=True, epilogue=EPI_DGELU, aux=u)
-    weight_grad(du, h2, r.g_w_fc, r.g_b_fc)
-    dh2 = ops.gemm(du, r.w_fc, b_kmajor=True)
-    dx_mid = ops.layernorm_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)       # [b, d]
-    weight_grad(dx_mid, a, r.g_w_out, r.g_b_out)
-    da = ops.gemm(dx_mid, r.w_out, b_kmajor=True)
-    dq, dkv = ops.attn_pooled_bwd(q, kv, da, lse, row0, nkeys, heads, Lmax)
-    weight_grad(dq, h1s, r.g_w_in[:d], r.g_b_in[:d])
-    weight_grad(dkv, h1, r.g_w_in[d:], r.g_b_in[d:])
+    dw.add(du, h2, r.g_w_fc, r.g_b_fc)
     ws = gemm_workspace(x.device) if x.is_cuda and x.dtype == torch.bfloat16 else None
+    dh2 = ops.gemm(du, r.w_fc, b_kmajor=True, ws=ws)
+    dx_mid = ops.layernorm_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)       # [b, d]
+    dw.add(dx_mid, a, r.g_w_out, r.g_b_out)
+    da = ops.gemm(dx_mid, r.w_out, b_kmajor=True, ws=ws)
+    dq, dkv = ops.attn_pooled_bwd(q, kv, da, lse, row0, nkeys, heads, Lmax)
+    dw.add(dq, h1s, r.g_w_in[:d], r.g_b_in[:d])
+    dw.add(dkv, h1, r.g_w_in[d:], r.g_b_in[d:])
     dh1 = ops.gemm(dkv, r.w_in[d:], b_kmajor=True, ws=ws)                 # [R, d]
-    ops.scatter_rows_add(ops.gemm(dq, r.w_in[:d], b_kmajor=True), sel, dh1)
+    ops.scatter_rows_add(ops.gemm(dq, r.w_in[:d], b_kmajor=True, ws=ws), sel, dh1)
     dx = ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b)
     ops.scatter_rows_add(dx_mid, sel, dx)                                 # the residual path of the pooled rows (x_mid = x[sel] + ...)
+    dw.flush()
     return dx
 
 
@@ -654,13 +686,14 @@ def block_fwd_packed(x, r, pk, heads, save):
 
 def block_bwd_packed(dx_out, r, saved, pk, heads):
     x, mean1, rstd1, h1, att_saved, a, lse, x_mid, mean2, rstd2, h2, u, g = saved
-    weight_grad(dx_out, g, r.g_w_proj, r.g_b_proj)
+    dw = DwGroup()
+    dw.add(dx_out, g, r.g_w_proj, r.g_b_proj)
     du = ops.gemm(dx_out, r.w_proj, b_kmajor=True, epilogue=EPI_DGELU, aux=u)
-    weight_grad(du, h2, r.g_w_fc, r.g_b_fc)
+    dw.add(du, h2, r.g_w_fc, r.g_b_fc)
     ws = gemm_workspace(du.device) if du.is_cuda and du.dtype == torch.bfloat16 else None
     dh2 = ops.gemm(du, r.w_fc, b_kmajor=True, ws=ws)
     dx_mid = ops.layernorm_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)
-    weight_grad(dx_mid, a, r.g_w_out, r.g_b_out)
+    dw.add(dx_mid, a, r.g_w_out, r.g_b_out)
     da = ops.gemm(dx_mid, r.w_out, b_kmajor=True, ws=ws)
     if pk.varlen:
         qkv, a_p = att_saved
@@ -672,9 +705,11 @@ def block_bwd_packed(dx_out, r, saved, pk, heads):
         ops.scatter_rows_add(da[:pk.rows], pk.pack_idx, da_d)
         dqkv_d = ops.attn_bwd(qkv_d, a_d, da_d, lse, pk.b, pk.L, heads, True)
         dqkv = ops.gather_rows(dqkv_d, pk.pack_idx, pk.rows_pad)
-    weight_grad(dqkv, h1, r.g_w_in, r.g_b_in)
+    dw.add(dqkv, h1, r.g_w_in, r.g_b_in)
     dh1 = ops.gemm(dqkv, r.w_in, b_kmajor=True, ws=ws)
-    return ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
+    dx = ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
+    dw.flush()
+    return dx
 
 
 def packed_captions(ids, dtype):

@@ -47,6 +47,7 @@ _PROTOS = {
     "dh_version": (c_int, []),
     "dh_device_info": (c_int, [c_int, POINTER(c_int)]),
     "dh_gemm": (c_int, [POINTER(GemmArgs), _P]),
+    "dh_gemm_group": (c_int, [POINTER(GemmArgs), c_int, _P]),
     "dh_gemm_v4_enable": (c_int, [c_int]),
     "dh_gemm_stats": (c_int, [_P, c_int]),
     "dh_colsum": (c_int, [c_int, _P, c_int64, c_int, c_int, _P, c_int, _P]),

@@ -61,6 +61,29 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, 
     return out
 
 
+def gemm_dw_group(problems, ws=None):
+    """problems: list of (dy [rows, out], x [rows, in], gw [out, in] fp32, gb [out] fp32 or None), all with the same `rows`:
+    gw += dy^T x and gb += colsum(dy) for every problem in ONE launch of the persistent kernel (dh_gemm_group)."""
+    n = len(problems)
+    arr = (GemmArgs * n)()
+    for a, (dy, x, gw, gb) in zip(arr, problems):
+        assert dy.dim() == 2 and x.dim() == 2 and dy.shape[0] == x.shape[0] and dy.dtype == x.dtype
+        assert gw.dtype == torch.float32 and gw.shape == (dy.shape[1], x.shape[1]) and gw.stride(1) == 1
+        assert dy.stride(1) == 1 and x.stride(1) == 1
+        a.dtype, a.c_dtype = dt(dy), DH_F32
+        a.a_kmajor, a.b_kmajor = 1, 1
+        a.M, a.N, a.K = dy.shape[1], x.shape[1], dy.shape[0]
+        a.A, a.lda, a.B, a.ldb, a.C, a.ldc = ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(gw), gw.stride(0)
+        a.accumulate, a.alpha = 1, 1.0
+        a.split_k = max(1, min(1024 // max(((a.M + 127) // 128) * ((a.N + 127) // 128), 1), a.K // 512))   # used only on the one-by-one path
+        if gb is not None:
+            assert gb.dtype == torch.float32 and gb.numel() == a.M
+            a.a_colsum = ptr(gb)
+        if ws is not None:
+            a.ws, a.ws_bytes = ptr(ws), ws.numel() * ws.element_size()
+    check(L.load().dh_gemm_group(arr, n, stream()), "dh_gemm_group")
+
+
 def gemm_stats(reset=False):
     """dh_gemm launches per kernel family since the last reset (test instrumentation, include/declip_hip.h)."""
     out = (ctypes.c_longlong * 5)()

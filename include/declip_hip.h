@@ -87,6 +87,12 @@ typedef struct dh_gemm_args {
                             atomics from every split (needs split*M*N*4 bytes; ignored when too small or NULL) */
 } dh_gemm_args;
 int dh_gemm(const dh_gemm_args* args, dh_stream_t stream);
+/* n weight-gradient problems with the SAME contraction length K -- args[i] with a_kmajor = b_kmajor = accumulate = 1, fp32 C --
+ * as one launch: the dW GEMMs of one ResidualAttentionBlock (in_proj, out_proj, c_fc, c_proj of base_transformer.py:29-48, i.e. what
+ * autograd computes as four separate `grad_output.t() @ input` matmuls).  On their own these problems have 9-36 output tiles for
+ * 256 CUs; together they fill the chip with 2-7 K-slices instead of 7-64.  Uses args[0].ws / ws_bytes as the split-K workspace.
+ * Same results as n dh_gemm calls (which is also what happens whenever the group does not fit the persistent kernel). */
+int dh_gemm_group(const dh_gemm_args* args, int n, dh_stream_t stream);
 /* Auto-dispatch switch for the 256 x 256 persistent kernel (on by default; DH_GEMM_V4=0 in the environment turns it off).
  * Returns the previous setting (-1 = default).  Used by the parity tests to run one model through both GEMM families. */
 int dh_gemm_v4_enable(int on);

@@ -238,6 +238,13 @@ def cast(src, dst):
     return dst
 
 
+def gemm_dw_group(problems, ws=None):
+    for dy, x, gw, gb in problems:
+        gw.add_(dy.float().t() @ x.float())
+        if gb is not None:
+            gb.add_(dy.float().sum(0))
+
+
 def adamw_segmented(p, g, m, v, p_bf16, seg_start, seg_lr, seg_wd, beta1, beta2, eps, step, grad_scale=1.0):
     n = p.numel()
     starts = seg_start.tolist() + [n]

@@ -8,3 +8,4 @@
 bool dh_gemm_try_glds(const dh_gemm_args*, int, hipStream_t) { return false; }
 bool dh_gemm_try_v3(const dh_gemm_args*, int, hipStream_t) { return false; }
 bool dh_gemm_try_v4(const dh_gemm_args*, int, hipStream_t) { return false; }
+bool dh_gemm_try_v4_group(const dh_gemm_args*, int, hipStream_t) { return false; }

@@ -44,8 +44,13 @@ def oracle_clip_run(cfg, b, world=1, seed=0, logit_scale=None, dtype=torch.float
                 images=images, ids=ids, metrics=metrics, new_stats=new_stats)
 
 
-def check_grad_digests(golden_grads, grads, rtol, atol_frac=1e-4, only=None):
-    """Compare gradient digests: norm, 8-element head, seeded projection (`only`: predicate selecting the names to check)."""
+def check_grad_digests(golden_grads, grads, rtol, atol_frac=1e-4, only=None, head_rtol=None):
+    """Compare gradient digests: norm, 8-element head, seeded projection (`only`: predicate selecting the names to check).
+    `head_rtol`: tolerance of the 8 single elements when it has to differ from `rtol` -- at full width an element of a weight
+    gradient is a sum of 10^4...10^5 cancelling products, and the accumulation ORDER alone (the reference's CPU GEMM blocking vs
+    any other fp32 order) moves single elements by ~1e-2 of their size while norms and projections agree at 1e-3."""
+    if head_rtol is None:
+        head_rtol = rtol
     names = list(golden_grads.keys())
     bad = []
     gmax = max((v["norm"] for v in golden_grads.values() if v is not None), default=1.0)
@@ -67,7 +72,7 @@ def check_grad_digests(golden_grads, grads, rtol, atol_frac=1e-4, only=None):
             bad.append((name, "norm", d["norm"], ref["norm"]))
         if abs(d["proj"] - ref["proj"]) > rtol * scale + atol_frac * scale:
             bad.append((name, "proj", d["proj"], ref["proj"]))
-        head_tol = rtol * max(float(ref["head"].abs().max()), scale / max(1.0, g.numel() ** 0.5)) + 1e-12
+        head_tol = head_rtol * max(float(ref["head"].abs().max()), scale / max(1.0, g.numel() ** 0.5)) + 1e-12
         if float((d["head"] - ref["head"]).abs().max()) > head_tol * 4:
             bad.append((name, "head", d["head"].tolist(), ref["head"].tolist()))
     assert not bad, "gradient digest mismatches (first 5): %s" % (bad[:5],)

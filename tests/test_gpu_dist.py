@@ -187,7 +187,7 @@ def _filip_w2_worker(rank, world, port, dtype, out):
         check_logits_digest(dli, g["dense_logits_i_digest"], tol)
         check_logits_digest(dlt, g["dense_logits_t_digest"], tol)
         if dtype == "fp32":
-            check_grad_digests(g["grads"], named_grads(model), rtol=1e-3)
+            check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
         else:
             assert_ran_on_v4(stats, 200)
             check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04)

@@ -141,3 +141,51 @@ def test_v4_refuses_partial_tiles():
         ops.gemm(A, B, force_generic=4)
     out = ops.gemm(A, B)                      # auto dispatch falls back to the 128 x 128 kernel
     assert rel_err(out, A.double().cpu() @ B.double().cpu().t()) < TOL
+
+
+@pytest.mark.parametrize("K,shapes", [
+    (2048, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),       # the four weights of a ViT-B/32 vision block (c_proj, c_fc, out_proj, in_proj)
+    (22016, [(512, 2048), (2048, 512), (512, 512), (1536, 512)]),      # text block over a packed caption batch (86 x 256 rows)
+    (512, [(768, 3072), (3072, 768), (768, 768), (768, 768)]),         # the pooled last block: K = b rows, one K-slice
+    (1024, [(256, 256), (512, 256)]),                                  # two problems
+])
+def test_v4_grouped_weight_gradients(K, shapes):
+    """dh_gemm_group: the dW problems of one block in ONE persistent launch + one reduce pass (MODE_GROUP) == the problems one
+    by one, against an fp64 reference; gradients accumulate into non-zero buffers, one problem carries no bias gradient."""
+    ops = _ops()
+    probs, refs = [], []
+    for i, (M, N) in enumerate(shapes):
+        dy, x = rnd(K, M, seed=10 + i).to(bf), rnd(K, N, seed=20 + i).to(bf)
+        gw0, gb0 = rnd(M, N, seed=30 + i), rnd(M, seed=40 + i)
+        with_bias = i != 1
+        probs.append((dy.to(cuda), x.to(cuda), gw0.clone().to(cuda), gb0.clone().to(cuda) if with_bias else None))
+        refs.append((gw0.double() + dy.double().t() @ x.double(), gb0.double() + dy.double().sum(0) if with_bias else None))
+    ops.gemm_stats(reset=True)
+    ops.gemm_dw_group(probs, ws=_ws())
+    torch.cuda.synchronize()
+    st = ops.gemm_stats()
+    assert st["v4"] == len(shapes) and sum(st.values()) == len(shapes), st      # taken by the grouped kernel, no fall-back launches
+    for (dy, x, gw, gb), (rw, rb) in zip(probs, refs):
+        assert rel_err(gw, rw) < 2e-5
+        if gb is not None:
+            assert rel_err(gb, rb) < 2e-5
+    # twice in a row on the same buffers: the partial workspace of the first call must not leak into the second
+    ops.gemm_dw_group(probs, ws=_ws())
+    torch.cuda.synchronize()
+    dy, x, gw, gb = probs[0]
+    rw = refs[0][0] + dy.double().cpu().t() @ x.double().cpu()
+    assert rel_err(gw, rw) < 2e-5
+
+
+def test_v4_group_falls_back_for_shapes_it_cannot_take():
+    """a problem that is not whole 256-tiles: the group is issued one by one (same results, other kernels)."""
+    ops = _ops()
+    K = 512
+    probs, refs = [], []
+    for i, (M, N) in enumerate([(384, 256), (256, 128)]):
+        dy, x = rnd(K, M, seed=50 + i).to(bf), rnd(K, N, seed=60 + i).to(bf)
+        probs.append((dy.to(cuda), x.to(cuda), torch.zeros(M, N, device=cuda), torch.zeros(M, device=cuda)))
+        refs.append((dy.double().t() @ x.double(), dy.double().sum(0)))
+    ops.gemm_dw_group(probs, ws=_ws())
+    for (dy, x, gw, gb), (rw, rb) in zip(probs, refs):
+        assert rel_err(gw, rw) < 2e-5 and rel_err(gb, rb) < 2e-5

@@ -83,7 +83,7 @@ def test_clip_vitb32_b256_matches_reference_golden(dtype):
     check_logits_digest(li.materialize(), g["logits_i_digest"], ltol)
     check_logits_digest(lt.materialize(), g["logits_t_digest"], ltol)
     if dtype == "fp32":
-        check_grad_digests(g["grads"], named_grads(model), rtol=1e-3)
+        check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
     else:
         assert_ran_on_v4(stats, 200)
         check_bf16_grad_norms(g["grads"], named_grads(model))
@@ -116,7 +116,7 @@ def test_declip_vitb32_b128_matches_reference_golden(dtype):
     li1 = out["outputs"]["logits"][0].materialize().detach().cpu()
     assert float((li1 - g["logits_i1"]).abs().max()) <= (1e-3 if dtype == "fp32" else 3e-2) * float(g["logits_i1"].abs().max())
     if dtype == "fp32":
-        check_grad_digests(g["grads"], named_grads(model), rtol=1e-3)
+        check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
         assert abs(float(model.nn_replacer_text.bank.double().sum()) - g["bank_sum"]) <= 1e-3 * max(1.0, abs(g["bank_sum"]))
     else:
         assert_ran_on_v4(stats, 200)
@@ -142,7 +142,7 @@ def test_slip_vitb32_b128_matches_reference_golden(dtype):
     for k in ("clip", "simclr", "nt_xent"):
         assert abs(float(out["parts"][k]) - g["parts"][k]) <= tol * max(1.0, abs(g["parts"][k])), k
     if dtype == "fp32":
-        check_grad_digests(g["grads"], named_grads(model), rtol=1e-3)
+        check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
     else:
         assert_ran_on_v4(stats, 200)
         check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04)
@@ -169,7 +169,7 @@ def test_filip_vitb32_e768_b256_matches_reference_golden(dtype):
     check_logits_digest(dli, g["dense_logits_i_digest"], tol)
     check_logits_digest(dlt, g["dense_logits_t_digest"], tol)
     if dtype == "fp32":
-        check_grad_digests(g["grads"], named_grads(model), rtol=1e-3)
+        check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
     else:
         assert_ran_on_v4(stats, 200)
         check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04)
