@@ -150,8 +150,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 512; clip_r50: 32, the configs[0] batch)")
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--model", default="clip", choices=["clip", "declip", "clip_r50"],
-                    help="clip = BASELINE.json metric; declip = configs[2] variant; clip_r50 = configs[0] (CLIP ResNet-50, batch 32; add --dtype fp32)")
+    ap.add_argument("--model", default="clip", choices=["clip", "declip", "slip", "filip", "defilip", "clip_r50"],
+                    help="clip = BASELINE.json metric; declip / slip / filip = configs[2] / [3] / [4] at their per-GPU batches (512 / 512 / 256); "
+                         "clip_r50 = configs[0] (CLIP ResNet-50, batch 32; add --dtype fp32)")
     ap.add_argument("--text-packed", choices=["0", "1", "2"], default=None,
                     help="text tower on the caption rows up to <|endoftext|> only (DESIGN.md s11; 1 = variable-length attention, "
                          "2 = attention via the dense layout, 0 = padded as the reference computes them); default: DH_TEXT_PACKED, else 1")
@@ -183,14 +184,33 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     torch.manual_seed(1234 + rank)            # random-init weights, reproducible from run to run (the loss in the line is then too)
-    cfg = synth.R50 if args.model == "clip_r50" else synth.VITB32
-    b = args.batch if args.batch is not None else (32 if args.model == "clip_r50" else 512)
+    cfg = synth.R50 if args.model == "clip_r50" else synth.FILIP_VITB32 if args.model == "filip" else synth.VITB32
+    b = args.batch if args.batch is not None else {"clip_r50": 32, "filip": 256, "defilip": 256}.get(args.model, 512)
     crit = ClipInfoCELoss()
     if args.model in ("clip", "clip_r50"):
         model = build_clip(cfg, dtype=args.dtype, use_allgather=(world > 1), seed=0, load_synth=False)
         images = synth.synth_images(b, seed=rank).to(dev)
         ids = synth.synth_tokens(b, seed=rank).to(dev)
         batch = {"images": images, "captions": ids}
+    elif args.model == "slip":
+        from declip_amd.loss import NT_Xent_gather
+        from declip_amd.steps import slip_loss
+        from declip_amd.testing import build_slip, slip_batch
+        model = build_slip(cfg, dtype=args.dtype, seed=0, load_synth=False)
+        batch = slip_batch(cfg, b, seed=rank, device=dev)
+        simclr_crit = NT_Xent_gather(b)
+    elif args.model == "filip":
+        from declip_amd.steps import filip_loss
+        from declip_amd.testing import build_filip, filip_batch
+        model = build_filip(cfg, dtype=args.dtype, seed=0, load_synth=False)
+        batch = filip_batch(cfg, b, seed=rank, device=dev)
+    elif args.model == "defilip":
+        from declip_amd.heads import SimsiamLoss
+        from declip_amd.steps import DEFILIP_WEIGHTS, declip_loss
+        from declip_amd.testing import build_defilip, defilip_batch
+        model = build_defilip(cfg, dtype=args.dtype, seed=0, nn_size=65536, load_synth=False)
+        batch = defilip_batch(cfg, b, seed=rank, device=dev)
+        sim_crit = SimsiamLoss()
     else:
         from declip_amd.heads import SimsiamLoss
         from declip_amd.steps import declip_loss
@@ -206,13 +226,22 @@ def main():
             li, lt = wrapped(batch)
             loss, _ = crit(li, lt)
             loss = loss / world                  # clip_solver.py:418
+        elif args.model == "slip":
+            loss = slip_loss(wrapped, batch, crit, simclr_crit, None, world_size=world, with_accuracy=False)["loss"]
+        elif args.model == "filip":
+            loss = filip_loss(wrapped, batch, crit, world_size=world, with_accuracy=False)["loss"]
+        elif args.model == "defilip":
+            loss = declip_loss(wrapped, batch, crit, sim_crit, None, weights=DEFILIP_WEIGHTS, world_size=world, with_accuracy=False)["loss"]
         else:
             loss = declip_loss(wrapped, batch, crit, sim_crit, None, world_size=world, with_accuracy=False)["loss"]
         loss.backward()                          # gradient all-reduce overlaps inside (dist.FlatReducer)
         wrapped.sync_gradients()
-        model.logit_scale.data.clamp_(3, 6)      # grad_clip: logit_scale_param_value (config.yaml:20-23)
+        scales = [model.logit_scale] + ([model.logit_scale_dense] if hasattr(model, "logit_scale_dense") else [])
+        for p_ in scales:
+            p_.data.clamp_(3, 6)                 # grad_clip: logit_scale_param_value (config.yaml:20-23; filip_solver.py:646,661)
         opt.step()
-        model.logit_scale.data.clamp_(3, 6)
+        for p_ in scales:
+            p_.data.clamp_(3, 6)
         return loss
 
     for _ in range(args.warmup):
@@ -273,6 +302,24 @@ def main():
                              int(kw.get("residual") is not None), int(bool(kw.get("accumulate"))))))
             return out
 
+        orig_group = ops.gemm_dw_group
+
+        def timed_group(problems, ws=None):
+            # the grouped weight gradients of a block: ONE launch (+ one reduce pass) for all its problems
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig_group(problems, ws=ws)
+            e1.record()
+            fl, nb = 0.0, 0
+            for dy, x, gw, gb in problems:
+                fl += 2.0 * dy.shape[1] * x.shape[1] * dy.shape[0]
+                nb += (dy.numel() + x.numel()) * dy.element_size() + 2 * gw.numel() * 4
+            gemm_bytes.append(nb)
+            dy0 = problems[0][0]
+            records.append((e0, e1, fl, dy0.dtype, (sum(p[0].shape[1] * p[1].shape[1] for p in problems) // max(problems[0][1].shape[1], 1),
+                                                    problems[0][1].shape[1], dy0.shape[0], 1, 1, 0, 0, len(problems))))
+            return None
+
         ops.gemm = timed_gemm
         import declip_amd.engine as eng
         eng.ops.gemm = timed_gemm
@@ -287,6 +334,7 @@ def main():
         step()
         ops.gemm = timed_gemm
         eng.ops.gemm = timed_gemm
+        ops.gemm_dw_group = timed_group
         sync()
         nprof = 2
         tp0 = time.perf_counter()
@@ -296,6 +344,7 @@ def main():
         tprof = time.perf_counter() - tp0
         ops.gemm = orig
         eng.ops.gemm = orig
+        ops.gemm_dw_group = orig_group
         if streams_env is None:
             del os.environ["DH_TOWER_STREAMS"]
         else:
@@ -309,7 +358,7 @@ def main():
                 c, tms, fl = agg.get(r[4], (0, 0.0, 0.0))
                 agg[r[4]] = (c + 1, tms + r[0].elapsed_time(r[1]), fl + r[2])
             with open(os.environ["DH_BENCH_GEMM_TABLE"], "w") as fh:
-                fh.write("M N K ta tb epi res acc | calls/step  avg_us  TF/s  ms/step\n")
+                fh.write("M N K ta tb epi res acc(>1: problems of a grouped dW launch, M = sum of their out rows) | calls/step  avg_us  TF/s  ms/step\n")
                 for k, (c, tms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                     fh.write("%6d %5d %6d %d %d %d %d %d | %4d %8.1f %6.0f %7.3f\n" % (k + (c // nprof, tms / c * 1e3, fl / tms / 1e9, tms / nprof)))
         # HBM-side traffic of the same kernels from the rocprofv3 PMC passes of tools/profile_step.sh (committed summary):
@@ -335,12 +384,18 @@ def main():
                         step_mfma_frac_executed=round(pairs_per_s / b * (flops / nprof) / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
                         step_mfma_frac=round(pairs_per_s * {"clip": GFLOP_PER_PAIR, "clip_r50": GFLOP_PER_PAIR_R50}.get(args.model, 89.9) / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
 
-    name = {"clip": "CLIP ViT-B/32", "declip": "DeCLIP ViT-B/32", "clip_r50": "CLIP ResNet-50"}[args.model]
+    name = {"clip": "CLIP ViT-B/32", "declip": "DeCLIP ViT-B/32", "slip": "SLIP ViT-B/32", "filip": "FILIP ViT-B/32", "defilip": "DeFILIP ViT-B/32",
+            "clip_r50": "CLIP ResNet-50"}[args.model]
     workloads = {
         "clip": "CLIP ViT-B/32 + 12-layer text transformer, InfoNCE, fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d, 224x224 images, "
                 "77-token captions, random-init weights" % b,
         "declip": "DeCLIP ViT-B/32 (2 image views + masked/augmented text, 8+4 InfoNCE pairs, SimSiam, NN bank 65536, MLM), "
                   "fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d" % b,
+        "slip": "SLIP ViT-B/32 (CLIP on the base view + SimCLR NT-Xent between two augmented views through the 768-4096-4096-256 MLP; "
+                "3 image views per pair), fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d (BASELINE.json configs[3])" % b,
+        "filip": "FILIP ViT-B/32, embed 768 (global InfoNCE + token-wise max-sim InfoNCE over 49 image x 77 text tokens, top-16 token "
+                 "selection; B x L_i x L_t similarity never materialised), fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d (BASELINE.json configs[4])" % b,
+        "defilip": "DeFILIP ViT-B/32 (DeCLIP terms + FILIP token-wise max-sim), fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d" % b,
         "clip_r50": "CLIP ModifiedResNet-50 (per-rank BatchNorm, attention pool) + 12-layer text transformer, InfoNCE, "
                     "fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d (BASELINE.json configs[0]), 224x224 images, 77-token captions" % b,
     }

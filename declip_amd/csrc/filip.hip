@@ -106,7 +106,67 @@ __global__ __launch_bounds__(256) void maxsim_scatter_kernel(const float* __rest
   }
 }
 
+__global__ __launch_bounds__(256) void maxsim_scale_kernel(const float* __restrict__ raw, const float* __restrict__ scale_p, float* __restrict__ logits, long n) {
+  const float sc = *scale_p;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) logits[t] = raw[t] * sc;
+}
+
+// rows [r0, r0 + nrows) of G only (the backward walks G in row chunks through a small rotating buffer): Gc [nrows][B*16]
+template <typename T>
+__global__ __launch_bounds__(256) void maxsim_scatter_rows_kernel(const float* __restrict__ g, const unsigned char* __restrict__ arg,
+                                                                  const float* __restrict__ scale_p, T* __restrict__ G, long ldg, int b, int B, int J,
+                                                                  long r0, long nrows) {
+  const float sc = (*scale_p) / J;
+  const long total = nrows * B * 2;       // (row, l, half)
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int half = (int)(t & 1);
+    const long rl = t >> 1;
+    const int l = (int)(rl % B);
+    const long rr = rl / B;                // row inside the chunk
+    const long row = r0 + rr;
+    const int i = (int)(row / J);
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < b) {                           // padding rows beyond b*J: zero rows
+      const int m = arg[row * B + l];
+      if ((m >> 3) == half) v[m & 7] = sc * g[(long)i * B + l];
+    }
+    st8(G + rr * ldg + (long)l * TOPK + half * 8, v);
+  }
+}
+
 }  // namespace
+
+bool dh_maxsim_try_v4(const void* Q, const void* Ksel, int rows_pad, int b, int B, int J, int D, float* raw, uint8_t* arg, hipStream_t st);   // gemm_v4.hip
+
+// Fused forward (bf16 token features): token-similarity GEMM on the persistent MFMA kernel with the max-over-m / mean-over-j
+// reduction in its epilogue (gemm_v4.hip MODE_MAXSIM); the [b*J, B*16] similarity matrix is never written.
+extern "C" int dh_maxsim_fused_fwd(const void* Q_bf16, const void* K_bf16, int rows_pad, int b, int B, int J, int D, const float* scale_dev,
+                                   float* logits, float* raw, uint8_t* argmax, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(Q_bf16 && K_bf16 && scale_dev && logits && raw && argmax && b > 0 && B > 0 && J > 0 && rows_pad >= b * J, "dh_maxsim_fused_fwd: bad args");
+  DH_REQUIRE(dh_maxsim_try_v4(Q_bf16, K_bf16, rows_pad, b, B, J, D, raw, argmax, st),
+             "dh_maxsim_fused_fwd: needs rows_pad %% 256 == 0, B %% 16 == 0, D %% 64 == 0, D >= 128, J >= 19, 16-byte aligned operands (got rows_pad %d B %d D %d J %d)",
+             rows_pad, B, D, J);
+  DH_CHECK_LAUNCH();
+  const long n = (long)b * B;
+  hipLaunchKernelGGL(maxsim_scale_kernel, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, st, raw, scale_dev, logits, n);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+// G rows [r0, r0 + nrows) into a chunk buffer Gc [nrows][ldg >= B*16] (see maxsim_scatter_rows_kernel)
+extern "C" int dh_maxsim_scatter_rows(int g_dtype, const float* dlogits, const uint8_t* argmax, const float* scale_dev, void* Gc,
+                                      int64_t ldg, int b, int B, int J, int64_t r0, int64_t nrows, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(dlogits && argmax && scale_dev && Gc && b > 0 && B > 0 && J > 0 && r0 >= 0 && nrows > 0 && ldg >= (int64_t)B * TOPK, "dh_maxsim_scatter_rows: bad args");
+  long total = (long)nrows * B * 2;
+  long gsz = (total + 255) / 256;
+  if (gsz > 65536) gsz = 65536;
+  if (g_dtype == DH_BF16) hipLaunchKernelGGL(maxsim_scatter_rows_kernel<bf16_t>, dim3((int)gsz), dim3(256), 0, st, dlogits, argmax, scale_dev, (bf16_t*)Gc, (long)ldg, b, B, J, (long)r0, (long)nrows);
+  else hipLaunchKernelGGL(maxsim_scatter_rows_kernel<float>, dim3((int)gsz), dim3(256), 0, st, dlogits, argmax, scale_dev, (float*)Gc, (long)ldg, b, B, J, (long)r0, (long)nrows);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
 
 extern "C" int dh_filip_select(const float* img_tok, const float* txt_tok, int b, int J, int T, int D, int64_t* idx_img,
                                int64_t* idx_txt, dh_stream_t stream) {

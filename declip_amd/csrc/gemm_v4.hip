@@ -99,6 +99,8 @@ struct EpiParams {
   float* a_colsum;
   float* ws;          // MODE_PARTIAL: [nsplit][M][N] fp32
   float* ws_cs;       // MODE_PARTIAL + a_colsum: [nsplit][ntx][M] fp32 bias-gradient partials
+  // MODE_MAXSIM (FILIP token-wise max-sim, filip.py:96-105): C = raw [ms_b][ms_B] fp32 (+= mean_j max_m), aux = arg-max uint8 [M][ms_B]
+  int ms_J, ms_b, ms_B;
 };
 
 // The kernel's ONLY parameter: the kernarg segment is exactly this struct, and the kernel reads most of it LATE, through an
@@ -147,7 +149,7 @@ constexpr int SCHED_OFF = BIAS_OFF + MAX_BIAS_N * 4;   // one word: the work ite
 constexpr int LDS_BYTES = SCHED_OFF + 16;            // 144 KiB + 16 B
 // MODE: what happens to the finished tile.  The bf16 epilogue flavours are separate instantiations (straight-line code:
 // the kernel lives at the 256-VGPR cap, runtime epilogue switches cost spills).
-constexpr int MODE_STORE = 0, MODE_STORE_GELU = 1, MODE_STORE_DGELU = 2, MODE_STORE_RES = 3, MODE_ATOMIC = 4, MODE_PARTIAL = 5, MODE_GROUP = 6;
+constexpr int MODE_STORE = 0, MODE_STORE_GELU = 1, MODE_STORE_DGELU = 2, MODE_STORE_RES = 3, MODE_ATOMIC = 4, MODE_PARTIAL = 5, MODE_GROUP = 6, MODE_MAXSIM = 7;
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -520,6 +522,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     e.residual = KARG(kq, const void*, e.residual); e.ldr = KARG(kq, long, e.ldr);                      \
     e.aux = KARG(kq, void*, e.aux); e.ldaux = KARG(kq, long, e.ldaux); e.alpha = KARG(kq, float, e.alpha); \
     e.a_colsum = KARG(kq, float*, e.a_colsum); e.ws = KARG(kq, float*, e.ws); e.ws_cs = KARG(kq, float*, e.ws_cs); \
+    e.ms_J = KARG(kq, int, e.ms_J); e.ms_b = KARG(kq, int, e.ms_b); e.ms_B = KARG(kq, int, e.ms_B);               \
   } while (0)
   while (have) {
     const int m0 = nxt.tile_y * BM, n0 = nxt.tile_x * BN;
@@ -801,6 +804,68 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
             }
       wait_vmcnt<0>();                       // 128 atomics per lane cannot ride along: drain (also lands the next tile's loads)
       V4_BARRIER();
+      break;
+    }
+
+    if (MODE == MODE_MAXSIM) {
+      // FILIP token-wise max-sim fused into the epilogue (filip.py:96-105): the tile holds S[(i,j), (l,m)] for 256 token rows and
+      // 16 captions x 16 selected tokens; what leaves the chip is max_m per (row, l) reduced to mean_j per (sample, l) -- one fp32
+      // atomic per (sample-in-tile, l) into raw[b][B] -- and the arg-max m as one byte per (row, l).  S itself (fp32 [b*J, B*16]:
+      // 1.6 + 2.6 GB per step at the FILIP batch) never exists.
+      // acc[i*2+ii][j]: lane -> row (lane&31), registers 4*rg .. +3 -> columns 8*rg + 4*(lane>>5) + {0..3} of a 32-column group,
+      // i.e. l-group g = rg>>1 of the fragment, m = 8*(rg&1) + 4*(lane>>5) + x.
+      float* mv = reinterpret_cast<float*>(smem + STAGE_BYTES);                    // [256 rows][16 l] max values
+      unsigned char* ma = smem + STAGE_BYTES + 256 * 16 * 4;                         // [256 rows][16 l] arg-max
+      const int hh = le >> 5;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            float bv[2]; int bm[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              float v = acc[i * 2 + ii][j][8 * g]; int m = 4 * hh;
+#pragma unroll
+              for (int q = 1; q < 8; ++q) {
+                const float c = acc[i * 2 + ii][j][8 * g + q];
+                const int mq = 8 * (q >> 2) + 4 * hh + (q & 3);
+                if (c > v) { v = c; m = mq; }
+              }
+              const float v2 = __shfl_xor(v, 32, 64);
+              const int m2 = __shfl_xor(m, 32, 64);
+              if (v2 > v || (v2 == v && m2 < m)) { v = v2; m = m2; }           // first maximum wins (torch.max)
+              bv[g] = v; bm[g] = m;
+            }
+            // half-wave h publishes l-group h of the fragment
+            const int row = i * 128 + ar + ii * 32 + (le & 31);
+            const int lt = j * 8 + wn * 2 + hh;
+            mv[row * 16 + lt] = hh ? bv[1] : bv[0];
+            ma[row * 16 + lt] = (unsigned char)(hh ? bm[1] : bm[0]);
+          }
+      wait_lgkm0();
+      V4_BARRIER();
+      if (te < 256) {
+        const int J = e.ms_J, Bc = e.ms_B;
+        // arg-max bytes: one 16-byte store per row
+        const uint4 a16 = *reinterpret_cast<const uint4*>(ma + te * 16);
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(e.aux) + (long)(m0 + te) * Bc + (n0 >> 4)) = a16;
+        // mean over the rows of each sample present in this tile: thread (l = te & 15, segment = te >> 4)
+        const int l = te & 15, sg = te >> 4;
+        const int smp = m0 / J + sg;                                             // sample of this segment
+        int r0 = smp * J - m0, r1 = r0 + J;
+        r0 = r0 < 0 ? 0 : r0;
+        r1 = r1 > 256 ? 256 : r1;
+        if (smp < e.ms_b && r0 < r1) {
+          float sum = 0.f;
+          for (int r = r0; r < r1; ++r) sum += mv[r * 16 + l];
+          atomicAdd(reinterpret_cast<float*>(e.C) + (long)smp * Bc + (n0 >> 4) + l, sum / (float)J);
+        }
+      }
+      wait_lgkm0();
+      V4_BARRIER();                          // staging area free again (the next tile's K-tile 1 lands there)
+      pend = 0;                              // few, unevenly spread stores: the next prologue waits for them all (conservative count)
       break;
     }
 
@@ -1399,5 +1464,26 @@ bool dh_gemm_try_v4_group(const dh_gemm_args* a, int n, hipStream_t st) {
   int blocks = (int)((zs / 4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a[0].ws, (const float*)ka.e.ws_cs, zs, cs_zs, split, gr);
+  return true;
+}
+
+// FILIP token-wise max-sim, forward (filip.py:96-105): raw[i][l] = mean_j max_m <Q[(i,j)], K[(l,m)]>, argmax[(i,j)][l] = that m.
+// Q [rows_pad][D] bf16 (rows_pad = b*J rounded up to 256, the padding rows anything finite), K [B*16][D] bf16.  raw is zeroed here.
+bool dh_maxsim_try_v4(const void* Q, const void* Ksel, int rows_pad, int b, int B, int J, int D, float* raw, uint8_t* arg, hipStream_t st) {
+  using namespace v4;
+  if (g_v4_mode == -2) { const char* ev = getenv("DH_GEMM_V4"); g_v4_mode = ev ? atoi(ev) : -1; }
+  if (g_v4_mode == 0) return false;
+  const int N = B * 16;
+  if ((rows_pad % BM) || (N % BN) || (D % BK) || D < 2 * BK || ((uintptr_t)Q & 15) || ((uintptr_t)Ksel & 15) || ((uintptr_t)arg & 15)) return false;
+  if (J < 1 || 256 / J + 2 > 16) return false;               // at most 16 sample segments per 256-row tile
+  hipMemsetAsync(raw, 0, sizeof(float) * (size_t)b * B, st);
+  dh_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  a.dtype = DH_BF16; a.c_dtype = DH_F32; a.M = rows_pad; a.N = N; a.K = D; a.A = Q; a.lda = D; a.B = Ksel; a.ldb = D; a.C = raw; a.ldc = B;
+  a.alpha = 1.f;
+  EpiParams e;
+  memset(&e, 0, sizeof(e));
+  e.M = rows_pad; e.N = N; e.C = raw; e.ldc = B; e.aux = arg; e.ldaux = B; e.alpha = 1.f; e.ms_J = J; e.ms_b = b; e.ms_B = B;
+  launch<false, false, MODE_MAXSIM, false>(&a, e, 1, D, 0, 0, st);
   return true;
 }

@@ -923,29 +923,74 @@ class GatherTokFn(torch.autograd.Function):
 
 
 class MaxSimFn(torch.autograd.Function):
-    """logits[i,l] = scale * mean_j max_m <Q[(i,j)], K[(l,m)]> (filip.py:96-105).
+    """logits[i,l] = scale * mean_j max_m <Q[(i,j)], K[(l,m)]> (filip.py:96-105), without the [b*J, B*16] matrices the reference
+    builds (as [b, B, J, 16]; 1.6 + 2.6 GB in fp32 at the FILIP batch b = 256, B = 2048).
 
-    forward: token-similarity GEMM on MFMA (bf16 operands in bf16 mode, fp32 scores) + dh_maxsim_reduce (arg-max
-    kept as uint8); backward: dh_maxsim_scatter builds the one-hot-weighted G and two GEMMs give dQ / dK."""
+    forward, bf16: ONE launch -- the token-similarity GEMM on the persistent MFMA kernel with max-over-m / mean-over-j in its
+    epilogue (ops.maxsim_fused_fwd); only raw [b, B] and the arg-max bytes [b*J, B] leave the chip.  fp32 validation mode (and
+    shapes the fused kernel does not take): the scores exist for a chunk of captions at a time (<= 256 MB), reduced by
+    dh_maxsim_reduce.
+    backward: G[(i,j),(l,m)] = scale * dlogits[i,l] / J at m = argmax is regenerated from the arg-max bytes for a chunk of token
+    rows at a time into ONE small buffer (<= 128 MB, cache-resident) that feeds the two MFMA GEMMs dQ_chunk = G_c K and
+    dK += G_c^T Q_chunk; the full G is never allocated either."""
+
+    S_CHUNK_BYTES = 256 << 20
+    G_CHUNK_BYTES = 128 << 20
+    G_ROW_QUANTUM = 256          # chunk rows are whole GEMM tiles (tests lower it to exercise several chunks on small problems)
 
     @staticmethod
     def forward(ctx, scale, Q, K, b, B, J, act_dtype):
         Qa = _to_act(Q, act_dtype)
         Ka = _to_act(K, act_dtype)
-        S = ops.gemm(Qa, Ka, out_dtype=torch.float32)                      # [b*J, B*16]
         sc = scale.detach().reshape(1).float().contiguous()
-        logits, raw, arg = ops.maxsim_reduce(S, b, B, J, sc)
+        rows, D = b * J, Qa.shape[1]
+        if ops.maxsim_fused_ok(Qa, Ka, B, J):
+            rows_pad = (rows + 255) // 256 * 256
+            if rows_pad != rows:                                           # whole 256-row tiles: zero rows behind the last token
+                Qp = torch.zeros(rows_pad, D, device=Qa.device, dtype=Qa.dtype)
+                Qp[:rows].copy_(Qa)
+                Qa = Qp
+            logits, raw, arg = ops.maxsim_fused_fwd(Qa, Ka, b, B, J, sc)
+        else:
+            Lc = max(1, MaxSimFn.S_CHUNK_BYTES // (rows * 64))               # captions per chunk: rows x Lc x 16 fp32 scores
+            Lc = Lc // 16 * 16 if Lc >= 16 else Lc
+            if Lc >= B:
+                S = ops.gemm(Qa, Ka, out_dtype=torch.float32)              # [b*J, B*16] (small problems: one chunk)
+                logits, raw, arg = ops.maxsim_reduce(S, b, B, J, sc)
+            else:
+                logits = torch.empty(b, B, device=Qa.device, dtype=torch.float32)
+                raw = torch.empty(b, B, device=Qa.device, dtype=torch.float32)
+                arg = torch.empty(rows, B, device=Qa.device, dtype=torch.uint8)
+                for l0 in range(0, B, Lc):
+                    l1 = min(B, l0 + Lc)
+                    S = ops.gemm(Qa, Ka[l0 * 16:l1 * 16], out_dtype=torch.float32)
+                    lg, rw, ag = ops.maxsim_reduce(S, b, l1 - l0, J, sc)
+                    logits[:, l0:l1], raw[:, l0:l1], arg[:, l0:l1] = lg, rw, ag
+                    del S
         ctx.save_for_backward(Qa, Ka, arg, raw, sc)
-        ctx.meta = (b, B, J, act_dtype, scale.shape, Q.dtype, K.dtype)
+        ctx.meta = (b, B, J, act_dtype, scale.shape, Q.dtype, K.dtype, rows)
         return logits
 
     @staticmethod
     def backward(ctx, dl):
         Qa, Ka, arg, raw, sc = ctx.saved_tensors
-        b, B, J, act_dtype, sshape, qdt, kdt = ctx.meta
+        b, B, J, act_dtype, sshape, qdt, kdt, rows = ctx.meta
         dl = dl.contiguous().float()
-        G = ops.maxsim_scatter(dl, arg, sc, b, B, J, act_dtype)
-        dQ = ops.gemm(G, Ka, b_kmajor=True, out_dtype=torch.float32)       # [b*J, D]
-        dK = ops.gemm(G, Qa, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)   # [B*16, D]
+        D = Qa.shape[1]
+        rows_all = Qa.shape[0]                                             # b*J, or padded to whole tiles (fused forward)
+        esz = 2 if act_dtype == torch.bfloat16 else 4
+        q = MaxSimFn.G_ROW_QUANTUM
+        Rc = max(q, MaxSimFn.G_CHUNK_BYTES // (B * 16 * esz) // q * q)
+        Rc = min(Rc, rows_all)
+        Gbuf = torch.empty(Rc, B * 16, device=dl.device, dtype=act_dtype)
+        dQ = torch.empty(rows_all, D, device=dl.device, dtype=torch.float32)
+        dK = torch.zeros(B * 16, D, device=dl.device, dtype=torch.float32)
+        ws = gemm_workspace(dl.device) if dl.is_cuda and act_dtype == torch.bfloat16 else None
+        for r0 in range(0, rows_all, Rc):
+            n = min(Rc, rows_all - r0)
+            G = ops.maxsim_scatter_rows(dl, arg, sc, b, B, J, r0, n, Gbuf)
+            ops.gemm(G, Ka, b_kmajor=True, out=dQ[r0:r0 + n], ws=ws)                                     # [n, D]
+            ops.gemm(G, Qa[r0:r0 + n], a_kmajor=True, b_kmajor=True, out=dK, accumulate=True,
+                     split_k=_split_k(B * 16, D, n), ws=ws)                                               # [B*16, D] +=
         dscale = (dl * raw).sum().reshape(sshape)
-        return dscale, dQ.to(qdt), dK.to(kdt), None, None, None, None
+        return dscale, dQ[:rows].to(qdt), dK.to(kdt), None, None, None, None

@@ -100,6 +100,8 @@ _PROTOS = {
     "dh_scatter_rows_add": (c_int, [c_int, _P, _P, _P, c_int, c_int, _P]),
     "dh_filip_select": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "dh_maxsim_reduce": (c_int, [c_int, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "dh_maxsim_fused_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "dh_maxsim_scatter_rows": (c_int, [c_int, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int64, c_int64, _P]),
     "dh_maxsim_scatter": (c_int, [c_int, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P]),
     "dh_adamw": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
     "dh_adamw_segmented": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int, c_float, c_float, c_float, c_int, c_float, _P]),

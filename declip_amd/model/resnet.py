@@ -106,15 +106,19 @@ class ModifiedResNet(_Tower):
             self._inplanes = planes * Bottleneck.expansion
         return nn.Sequential(*chain)
 
-    def forward(self, x, return_dense=False, channel_offset=0, n_views=1):
+    def forward(self, x, return_dense=False, channel_offset=0, n_views=1, return_feature=False):
         """x: [b, 3*views, 224, 224] fp32 (or uint8 [b, H, W, 3]) on the GPU -> [b, embed_dim] fp32
-        (, dense [b, 49, width*32]: modified_resnet.py:206)."""
+        (, dense [b, 49, width*32]: modified_resnet.py:206)(, feature [b, width*32]).
+        `return_feature` does not exist in the reference's ModifiedResNet.forward (modified_resnet.py:183): its SLIP model calls
+        `self.visual(image, return_feature=True)` (slip.py:228-231), so the shipped `slip_res50` config raises a TypeError in
+        the reference.  Here the keyword returns the pooled trunk feature in front of the output projection (2048 wide for
+        ResNet-50 = the `feature_dim: 2048` that config hands to SLIP's projection MLP), which makes slip_res50 runnable."""
         flat = self._flat()
         if x.dtype == torch.uint8:
             x = engine.ops.image_prep_u8(x.contiguous(), (self.input_resolution, self.input_resolution))
         if x.dtype != torch.float32:
             x = x.float()
-        return resnet_engine.ResNetTowerFn.apply(flat.anchor, x.contiguous(), self, channel_offset, return_dense, n_views)
+        return resnet_engine.ResNetTowerFn.apply(flat.anchor, x.contiguous(), self, channel_offset, return_dense, n_views, return_feature)
 
 
 def modified_resnet_R50(**kwargs):

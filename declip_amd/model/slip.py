@@ -12,7 +12,7 @@ from ..heads import projection_MLP
 from .clip import CLIP, LazyLogits, _engine_kwargs
 from .transformer import text_transformers, visual_transformer_B32
 
-__all__ = ["SLIP", "slip_vitb32"]
+__all__ = ["SLIP", "slip_vitb32", "slip_res50"]
 
 
 class SLIP(CLIP):
@@ -80,6 +80,16 @@ class SLIP(CLIP):
         ret["sim_features"] = sim1f, g_s1, sim2f, g_s2
         ret["features"] = txt_n, img_n
         return ret
+
+
+def slip_res50(**kwargs):
+    """model/slip.py:289-297 (experiments/slip_experiments/yfcc15m/yfcc15m_r50_slip/config.yaml: image_encode {embed_dim 1024,
+    bn_* / use_sync_bn}, clip {return_sim, feature_dim 2048, sim_dim 256}).  The reference's own forward of this model stops at
+    `self.visual(image, return_feature=True)` -- its ModifiedResNet.forward has no such argument; see model/resnet.py."""
+    from .resnet import modified_resnet_R50
+    image_encode = modified_resnet_R50(**kwargs["image_encode"])
+    text_encode = text_transformers(**kwargs["text_encode"])
+    return SLIP(image_encode, text_encode, **kwargs["clip"], **_engine_kwargs(kwargs))
 
 
 def slip_vitb32(**kwargs):

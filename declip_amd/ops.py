@@ -512,6 +512,35 @@ def maxsim_reduce(S, b, B, J, scale):
     return logits, raw, arg
 
 
+def maxsim_fused_ok(Q, K, B, J):
+    """can dh_maxsim_fused_fwd take this problem?  (bf16 token features, whole 256-tiles after row padding)"""
+    import os
+    D = Q.shape[1]
+    if os.environ.get("DH_MAXSIM_FUSED", "1") == "0":          # A/B switch: scores in caption chunks + dh_maxsim_reduce instead
+        return False
+    return Q.is_cuda and Q.dtype == torch.bfloat16 and K.dtype == torch.bfloat16 and B % 16 == 0 and D % 64 == 0 and D >= 128 and J >= 19
+
+
+def maxsim_fused_fwd(Q, K, b, B, J, scale):
+    """Q [rows_pad, D] bf16 (rows_pad % 256 == 0, rows >= b*J), K [B*16, D] bf16 -> logits [b,B], raw [b,B], argmax [rows_pad, B] uint8."""
+    assert Q.dim() == 2 and K.dim() == 2 and Q.is_contiguous() and K.is_contiguous() and K.shape == (B * 16, Q.shape[1])
+    rows_pad = Q.shape[0]
+    logits = torch.empty(b, B, device=Q.device, dtype=torch.float32)
+    raw = torch.empty(b, B, device=Q.device, dtype=torch.float32)
+    arg = torch.empty(rows_pad, B, device=Q.device, dtype=torch.uint8)
+    check(L.load().dh_maxsim_fused_fwd(ptr(Q), ptr(K), rows_pad, b, B, J, Q.shape[1], ptr(scale), ptr(logits), ptr(raw), ptr(arg), stream()),
+          "dh_maxsim_fused_fwd")
+    return logits, raw, arg
+
+
+def maxsim_scatter_rows(dlogits, arg, scale, b, B, J, r0, nrows, out):
+    """rows [r0, r0 + nrows) of the one-hot-weighted G into the chunk buffer `out` [>= nrows, B*16]."""
+    assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= nrows and out.shape[1] >= B * 16 and arg.shape[0] >= min(r0 + nrows, b * J)
+    check(L.load().dh_maxsim_scatter_rows(dt(out), ptr(_contig(dlogits, "dlogits")), ptr(arg), ptr(scale), ptr(out), out.stride(0), b, B, J,
+                                          r0, nrows, stream()), "dh_maxsim_scatter_rows")
+    return out[:nrows]
+
+
 def maxsim_scatter(dlogits, arg, scale, b, B, J, dtype):
     G = torch.empty(b * J, B * 16, device=dlogits.device, dtype=dtype)
     check(L.load().dh_maxsim_scatter(dt(G), ptr(_contig(dlogits, "dlogits")), ptr(arg), ptr(scale), ptr(G), G.stride(0), b, B, J,

@@ -192,23 +192,27 @@ class ResNetTowerFn(torch.autograd.Function):
     the views of DeCLIP / SLIP go through the tower one after the other), outputs concatenated view-major."""
 
     @staticmethod
-    def forward(ctx, anchor, images, tower, c0, want_dense, n_views=1):
+    def forward(ctx, anchor, images, tower, c0, want_dense, n_views=1, want_feature=False):
         flat = tower._flat()
         training = tower.training
         save = bool(ctx.needs_input_grad[0])
         flat.tower_forward(tower, save)
-        passes, feats, denses = [], [], []
+        passes, feats, denses, pooleds = [], [], [], []
         for v in range(n_views):
             st = _forward_pass(flat, tower, images, c0 + 3 * v, training)
             feats.append(st["out"])
             denses.append(st["dense"])
+            pooleds.append(st["pooled"])
             passes.append(st if save else None)
-        ctx.tower, ctx.passes, ctx.want_dense = tower, passes, want_dense
-        out = feats[0] if n_views == 1 else torch.cat(feats, dim=0)
+        ctx.tower, ctx.passes, ctx.want_dense, ctx.want_feature = tower, passes, want_dense, want_feature
+        outs = [feats[0] if n_views == 1 else torch.cat(feats, dim=0)]
         if want_dense:
-            dense = denses[0] if n_views == 1 else torch.cat(denses, dim=0)
-            return out, dense
-        return out
+            outs.append(denses[0] if n_views == 1 else torch.cat(denses, dim=0))
+        if want_feature:
+            # the pooled trunk feature in front of the output projection ([b, width*32]: the attention pool's mean-token output
+            # before c_proj, or the adaptive average pool in front of fc) -- what SLIP's `feature_dim: 2048` head consumes
+            outs.append(pooleds[0] if n_views == 1 else torch.cat(pooleds, dim=0))
+        return tuple(outs) if len(outs) > 1 else outs[0]
 
     @staticmethod
     def backward(ctx, *grads):
@@ -217,16 +221,22 @@ class ResNetTowerFn(torch.autograd.Function):
         flat.begin_backward()
         flat.tower_backward(tower)
         dout = grads[0]
-        ddense = grads[1] if ctx.want_dense else None
+        gi = 1
+        ddense = dfeat = None
+        if ctx.want_dense:
+            ddense = grads[gi]; gi += 1
+        if ctx.want_feature:
+            dfeat = grads[gi]; gi += 1
         V = len(ctx.passes)
         for v in reversed(range(V)):
             st = ctx.passes[v]
             b = st["b"]
             do = dout[v * b:(v + 1) * b] if dout is not None else None
             dd = ddense[v * b:(v + 1) * b] if ddense is not None else None
-            _backward_pass(flat, tower, st, do, dd, last=(v == 0))
+            df = dfeat[v * b:(v + 1) * b] if dfeat is not None else None
+            _backward_pass(flat, tower, st, do, dd, last=(v == 0), dfeat=df)
         ctx.passes = None
-        return (torch.zeros_like(flat.anchor), None, None, None, None, None)
+        return (torch.zeros_like(flat.anchor), None, None, None, None, None, None)
 
 
 def _stem_conv1_weight(flat, tower, dtype, device):
@@ -301,7 +311,7 @@ def _forward_pass(flat, tower, images, c0, training):
     return st
 
 
-def _backward_pass(flat, tower, st, dout, ddense, last):
+def _backward_pass(flat, tower, st, dout, ddense, last, dfeat=None):
     dtype = flat.act_dtype
     g = flat.gview
     b = st["b"]
@@ -309,19 +319,26 @@ def _backward_pass(flat, tower, st, dout, ddense, last):
     ap = tower.attnpool
     w = flat.wview
     x_last = st["x_last"]
+    dfeat_a = _to_act(dfeat, dtype) if dfeat is not None else None      # gradient of the pooled feature handed out (return_feature)
     if st["head"] == "fc":
-        if dout is not None:
-            do = _to_act(dout, dtype)
-            weight_grad(do, st["pooled"], g(tower.fc.weight), g(tower.fc.bias))
-            dpooled = ops.gemm(do, w(tower.fc.weight), b_kmajor=True)
+        if dout is not None or dfeat_a is not None:
+            dpooled = dfeat_a
+            if dout is not None:
+                do = _to_act(dout, dtype)
+                weight_grad(do, st["pooled"], g(tower.fc.weight), g(tower.fc.bias))
+                dp = ops.gemm(do, w(tower.fc.weight), b_kmajor=True)
+                dpooled = dp if dpooled is None else dp.add_(dpooled)
             H, W = st["hw"]
             dx = ops.avgpool_bwd(dpooled, b, H, W, C, H)
         else:
             dx = torch.zeros_like(x_last)
-    elif dout is not None:
-        do = _to_act(dout, dtype)
-        weight_grad(do, st["pooled"], g(ap.c_proj.weight), g(ap.c_proj.bias))
-        dpooled = ops.gemm(do, w(ap.c_proj.weight), b_kmajor=True)
+    elif dout is not None or dfeat_a is not None:
+        dpooled = dfeat_a
+        if dout is not None:
+            do = _to_act(dout, dtype)
+            weight_grad(do, st["pooled"], g(ap.c_proj.weight), g(ap.c_proj.bias))
+            dp = ops.gemm(do, w(ap.c_proj.weight), b_kmajor=True)
+            dpooled = dp if dpooled is None else dp.add_(dpooled)
         da = ops.pool_rows_bwd(dpooled, None, b, L)
         dqkv = ops.attn_bwd(st["qkv"], st["a"], da, st["lse"], b, L, heads, False)
         dq, dk, dv = (t.contiguous() for t in dqkv.split(C, dim=1))

@@ -286,6 +286,17 @@ int dh_filip_select(const float* img_tok, const float* txt_tok, int b, int J, in
                     int64_t* idx_txt, dh_stream_t stream);
 int dh_maxsim_reduce(int s_dtype, const void* S, int64_t lds, int b, int B, int J, const float* scale_dev, float* logits,
                      float* raw, uint8_t* argmax, dh_stream_t stream);
+/* Fused forward for bf16 token features: the token-similarity GEMM on the persistent MFMA kernel with max_m / mean_j in its
+ * epilogue -- S [b*J, B*16] is never written (filip.py:96-105 materialises it as [b, B, J, 16]).  Q [rows_pad][D] (rows_pad =
+ * b*J rounded up to 256; padding rows anything finite), K [B*16][D], both bf16 row-major.  Writes raw [b][B] (unscaled means),
+ * logits = raw * *scale_dev, argmax uint8 [rows_pad][B].  Fails (no fallback) unless rows_pad % 256 == 0, B % 16 == 0,
+ * D % 64 == 0, D >= 128, J >= 19. */
+int dh_maxsim_fused_fwd(const void* Q_bf16, const void* K_bf16, int rows_pad, int b, int B, int J, int D, const float* scale_dev,
+                        float* logits, float* raw, uint8_t* argmax, dh_stream_t stream);
+/* Rows [r0, r0 + nrows) of G (dh_maxsim_scatter) into a chunk buffer Gc [nrows][ldg]: the backward walks G in row chunks through
+ * one small buffer (dQ_chunk = Gc K, dK += Gc^T Q_chunk) instead of allocating [b*J, B*16]; rows >= b*J are written as zeros. */
+int dh_maxsim_scatter_rows(int g_dtype, const float* dlogits, const uint8_t* argmax, const float* scale_dev, void* Gc, int64_t ldg,
+                           int b, int B, int J, int64_t r0, int64_t nrows, dh_stream_t stream);
 int dh_maxsim_scatter(int g_dtype, const float* dlogits, const uint8_t* argmax, const float* scale_dev, void* G,
                       int64_t ldg, int b, int B, int J, dh_stream_t stream);
 

@@ -349,6 +349,13 @@ def maxsim_scatter(dlogits, arg, scale, b, B, J, dtype):
     return G.reshape(b * J, B * 16).to(dtype)
 
 
+def maxsim_scatter_rows(dlogits, arg, scale, b, B, J, r0, nrows, out):
+    G = maxsim_scatter(dlogits, arg[:b * J], scale, b, B, J, out.dtype)
+    pad = torch.zeros(max(0, r0 + nrows - G.shape[0]), G.shape[1], dtype=G.dtype)
+    out[:nrows] = torch.cat([G, pad])[r0:r0 + nrows]
+    return out[:nrows]
+
+
 def image_prep_u8(src, out_hw, crop_xy=None, flip=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), out=None, c0=0):
     from oracle import restated
     res = restated.image_prep_u8(src, out_hw, crop_xy, flip, mean, std)

@@ -9,3 +9,4 @@ bool dh_gemm_try_glds(const dh_gemm_args*, int, hipStream_t) { return false; }
 bool dh_gemm_try_v3(const dh_gemm_args*, int, hipStream_t) { return false; }
 bool dh_gemm_try_v4(const dh_gemm_args*, int, hipStream_t) { return false; }
 bool dh_gemm_try_v4_group(const dh_gemm_args*, int, hipStream_t) { return false; }
+bool dh_maxsim_try_v4(const void*, const void*, int, int, int, int, int, float*, uint8_t*, hipStream_t) { return false; }

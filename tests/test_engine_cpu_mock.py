@@ -372,6 +372,39 @@ def test_slip_engine_composition_matches_golden(mocked_engine):
     check_grad_digests(g["grads"], grads, rtol=1e-3)
 
 
+def test_slip_res50_registers_and_trains(mocked_engine):
+    """`type: slip_res50` (model/__init__.py:9, slip.py:289-297; VERDICT r1 missing #2) through model_entry.  The reference's own
+    forward of this model raises (ModifiedResNet.forward has no return_feature, slip.py:228-231), so there is no reference golden:
+    what is pinned here is the wiring -- the `feature` the SimCLR head sees is the pooled trunk feature in front of c_proj
+    (proj == c_proj(feature)), three views go through the tower, the loss is finite and reaches the trunk and the SimCLR MLP."""
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss, NT_Xent, NT_Xent_gather
+    from declip_amd.steps import slip_loss
+    from prototype.model import model_entry
+    b = 2
+    cfg = dict(type="slip_res50", kwargs=dict(
+        image_encode=dict(embed_dim=32, layers=[1, 1, 1, 1], width=16, heads=8, bn_group_size=16, bn_sync_stats=True, use_sync_bn=False),
+        text_encode=dict(embed_dim=32, context_length=16, transformer_width=64, transformer_heads=2, transformer_layers=2,
+                         text_encode_type="Transformer", bpe_path=None, text_model_utils=dict(random=False, freeze=False), vocab_size=49409),
+        clip=dict(use_allgather=True, return_sim=True, feature_dim=16 * 32, sim_dim=16), engine=dict(dtype="fp32")))
+    torch.manual_seed(0)
+    model = model_entry(cfg)
+    model.train()
+    images = synth.synth_images(b, views=3, res=224, seed=1)
+    ids = synth.synth_tokens(b, ctx=16, seed=1)
+    proj, feat = model.visual(images, return_feature=True, n_views=3)
+    ap = model.visual.attnpool
+    assert feat.shape == (3 * b, 16 * 32) and proj.shape == (3 * b, 32)
+    assert torch.allclose(proj, feat.float() @ ap.c_proj.weight.t() + ap.c_proj.bias, rtol=1e-4, atol=1e-5)
+    out = slip_loss(model, {"images": images, "captions": ids}, ClipInfoCELoss(), NT_Xent_gather(b), NT_Xent(b))
+    out["loss"].backward()
+    assert torch.isfinite(out["loss"]).all() and float(out["parts"]["simclr"]) > 0
+    g = {n: p.grad for n, p in model.named_parameters()}
+    for n in ("visual.conv1.weight", "visual.layer4.0.downsample.0.weight", "visual.layer4.0.bn3.weight", "visual.attnpool.c_proj.weight", "predictor_sim.linear1.weight",
+              "text_encoder.text_projection.weight"):
+        assert g[n] is not None and float(g[n].abs().max()) > 0, n
+
+
 def test_filip_engine_composition_matches_golden(mocked_engine):
     from declip_amd.loss import ClipInfoCELoss
     from declip_amd.steps import filip_loss
@@ -387,6 +420,28 @@ def test_filip_engine_composition_matches_golden(mocked_engine):
     dli, dlt = out["outputs"]["dense_logits"]
     assert float((dli.detach() - g["dense_logits_i"]).abs().max()) <= 1e-4 * float(g["dense_logits_i"].abs().max())
     assert float((dlt.detach() - g["dense_logits_t"]).abs().max()) <= 1e-4 * float(g["dense_logits_t"].abs().max())
+    grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+    check_grad_digests(g["grads"], grads, rtol=1e-3)
+
+
+def test_filip_maxsim_in_chunks_matches_golden(mocked_engine, monkeypatch):
+    """MaxSimFn never holds the [b*J, B*16] matrices: scores per chunk of captions (unfused path), G per chunk of token rows.
+    With chunk sizes forced down to 1 caption group / 32 rows the reference golden must still be met."""
+    from declip_amd import engine
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.steps import filip_loss
+    from declip_amd.testing import build_filip, filip_batch
+    monkeypatch.setattr(engine.MaxSimFn, "S_CHUNK_BYTES", 1)
+    monkeypatch.setattr(engine.MaxSimFn, "G_CHUNK_BYTES", 1)
+    monkeypatch.setattr(engine.MaxSimFn, "G_ROW_QUANTUM", 32)
+    g = load_golden("filip_small")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_filip(cfg, dtype="fp32", seed=seed, device="cpu")
+    out = filip_loss(model, filip_batch(cfg, b, seed=seed, device="cpu"), ClipInfoCELoss())
+    out["loss"].backward()
+    assert abs(float(out["loss"]) - g["loss"]) <= 1e-4 * abs(g["loss"])
+    dli, dlt = out["outputs"]["dense_logits"]
+    assert float((dli.detach() - g["dense_logits_i"]).abs().max()) <= 1e-4 * float(g["dense_logits_i"].abs().max())
     grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
     check_grad_digests(g["grads"], grads, rtol=1e-3)
 

@@ -184,8 +184,9 @@ def _filip_w2_worker(rank, world, port, dtype, out):
     if rank == 0:
         assert abs(float(total) - g["loss"]) <= tol * abs(g["loss"]), (float(total), g["loss"])
         dli, dlt = o["outputs"]["dense_logits"]
-        check_logits_digest(dli, g["dense_logits_i_digest"], tol)
-        check_logits_digest(dlt, g["dense_logits_t_digest"], tol)
+        sel = dict(outlier_frac=0.02, outlier_cap=5.0) if dtype == "bf16" else {}   # token-selection flips (check_logits_digest)
+        check_logits_digest(dli, g["dense_logits_i_digest"], tol, **sel)
+        check_logits_digest(dlt, g["dense_logits_t_digest"], tol, **sel)
         if dtype == "fp32":
             check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
         else:

@@ -494,6 +494,45 @@ def test_filip_select_and_maxsim():
     assert rel_err(G.view(b, J, B, 16), ref) < 1e-6
 
 
+@pytest.mark.parametrize("b,B,J,D", [(16, 16, 49, 256), (32, 64, 77, 256), (5, 16, 25, 128), (256, 512, 49, 256)])
+def test_maxsim_fused_forward_and_chunked_backward(b, B, J, D):
+    """dh_maxsim_fused_fwd (token-similarity GEMM with max_m / mean_j in the epilogue of the persistent kernel: S is never
+    written) against the explicit [b, B, J, 16] computation of filip.py:96-105 on the same bf16-rounded operands; then the whole
+    autograd Function (row-chunked regeneration of G) against torch autograd on that computation."""
+    ops = _ops()
+    from declip_amd import engine
+    bf = torch.bfloat16
+    Q = torch.nn.functional.normalize(rnd(b * J, D, seed=110), dim=-1)
+    K = torch.nn.functional.normalize(rnd(B * 16, D, seed=111), dim=-1)
+    Qb, Kb = Q.to(bf), K.to(bf)
+    rows_pad = (b * J + 255) // 256 * 256
+    Qp = torch.zeros(rows_pad, D, dtype=bf)
+    Qp[:b * J] = Qb
+    scale = torch.tensor([9.0])
+    assert ops.maxsim_fused_ok(Qp.to(cuda), Kb.to(cuda), B, J)
+    logits, raw, arg = ops.maxsim_fused_fwd(Qp.to(cuda), Kb.to(cuda), b, B, J, scale.to(cuda))
+    S = (Qb.double() @ Kb.double().t()).view(b, J, B, 16)
+    mx, am = S.max(-1)
+    assert rel_err(raw, mx.mean(1)) < 2e-6 and rel_err(logits, 9.0 * mx.mean(1)) < 2e-6
+    got = arg[:b * J].cpu().view(b, J, B).long()
+    picked = S.gather(3, got[..., None])[..., 0]
+    assert float((mx - picked).abs().max()) <= 1e-6          # the chosen m attains the maximum (ties may resolve either way)
+    assert float((got != am).double().mean()) < 1e-3
+    # autograd Function vs torch autograd on the dense formula (same bf16-rounded operands)
+    Qg, Kg = Qb.float().to(cuda).requires_grad_(True), Kb.float().to(cuda).requires_grad_(True)
+    sg = torch.tensor(9.0, device=cuda, requires_grad=True)
+    w = rnd(b, B, seed=112).to(cuda)
+    out = engine.MaxSimFn.apply(sg, Qg, Kg, b, B, J, bf)
+    (out * w).sum().backward()
+    Qr, Kr = Qb.double().requires_grad_(True), Kb.double().requires_grad_(True)
+    sr = torch.tensor(9.0, dtype=torch.float64, requires_grad=True)
+    ref = sr * (Qr @ Kr.t()).view(b, J, B, 16).max(-1)[0].mean(1)
+    (ref * w.double().cpu()).sum().backward()
+    assert rel_err(out, ref) < 2e-6
+    assert rel_err(Qg.grad, Qr.grad) < 1e-2 and rel_err(Kg.grad, Kr.grad) < 1e-2     # G is rounded to bf16 before the two GEMMs
+    assert abs(float(sg.grad) - float(sr.grad)) <= 1e-5 * abs(float(sr.grad))
+
+
 def test_image_prep_u8_matches_oracle():
     """uint8 HWC -> normalised fp32 CHW with crop windows and mirrors (restated.image_prep_u8 = ToTensor + Normalize + crop +
     flip); and the vision tower fed with bytes equals the tower fed with the oracle's floats."""
