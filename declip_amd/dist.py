@@ -121,14 +121,60 @@ def all_gather_cat(x):
 
 def all_gather_cat_many(tensors):
     """Gather several [b, D_k] feature tensors with ONE collective (packed along the feature dim)."""
+    return all_gather_cat_many_async(tensors).result()
+
+
+# ---- the feature all-gather as an asynchronous step on an engine-owned communication stream --------------------------------
+_COMM_STREAMS = {}
+
+
+def comm_stream(device):
+    """The engine's communication stream of `device`: feature all-gathers (and, through autograd, their reduce-scatter backward)
+    are enqueued here, so that independent work of the step -- DeCLIP's masked-LM head, its projector / predictor MLPs, the other
+    tower -- keeps the compute stream busy while the collective crosses xGMI.  Ordered against the compute streams with events
+    only (wait_stream), never a host sync."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _COMM_STREAMS.get(key)
+    if st is None:
+        st = _COMM_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+class GatherHandle:
+    """all_gather_cat_many_async(): the packed all-gather is in flight; result() orders the CALLER's current stream behind it and
+    hands out the gathered tensors (rank-major rows).  Not distributed / CPU tensors: the inputs / a synchronous gather."""
+
+    def __init__(self, tensors=None, gathered=None, dims=None, stream=None):
+        self._tensors, self._gathered, self._dims, self._stream = tensors, gathered, dims, stream
+
+    def result(self):
+        if self._tensors is not None:
+            return self._tensors
+        g = self._gathered
+        if self._stream is not None:
+            cur = torch.cuda.current_stream(g.device)
+            cur.wait_stream(self._stream)
+            g.record_stream(cur)                       # allocated on the comm stream, consumed on this one
+        self._tensors = list(torch.split(g, self._dims, dim=1)) if len(self._dims) > 1 else [g]
+        return self._tensors
+
+
+def all_gather_cat_many_async(tensors):
+    """all_gather_cat_many whose collective runs on the communication stream; call .result() where the gathered rows are first
+    needed and put the work that does not need them in between."""
+    tensors = list(tensors)
     if not is_dist():
-        return list(tensors)
-    if len(tensors) == 1:
-        return [all_gather_cat(tensors[0])]
-    dims = [t.shape[1] for t in tensors]
-    packed = torch.cat([t.reshape(t.shape[0], -1) for t in tensors], dim=1)
-    gathered = _AllGatherPacked.apply(packed)
-    return list(torch.split(gathered, dims, dim=1))
+        return GatherHandle(tensors=tensors)
+    dims = [t[0].numel() for t in tensors]
+    packed = tensors[0].reshape(tensors[0].shape[0], -1) if len(tensors) == 1 else torch.cat([t.reshape(t.shape[0], -1) for t in tensors], dim=1)
+    if not packed.is_cuda or os.environ.get("DH_COMM_STREAM", "1") == "0":
+        return GatherHandle(gathered=_AllGatherPacked.apply(packed), dims=dims)
+    comm = comm_stream(packed.device)
+    comm.wait_stream(torch.cuda.current_stream(packed.device))
+    with torch.cuda.stream(comm):
+        packed.record_stream(comm)
+        gathered = _AllGatherPacked.apply(packed)      # autograd replays the backward (reduce-scatter) on this stream as well
+    return GatherHandle(gathered=gathered, dims=dims, stream=comm)
 
 
 class FlatReducer:
@@ -141,16 +187,23 @@ class FlatReducer:
 
     # ranges arrive as whole ALIGN-padded parameter slots (FlatParams.grads_ready): neighbours touch exactly, nothing is bridged
 
-    def __init__(self, flat, bucket_bytes=48 << 20):
+    def __init__(self, flat, bucket_bytes=48 << 20, grad_dtype=None):
         self.flat = flat
         self.bucket_elems = max(1, bucket_bytes // 4)
+        # grad_dtype torch.bfloat16 (DistModule(grad_dtype=...) / DH_GRAD_BF16=1): every bucket crosses xGMI as bf16 -- cast, SUM
+        # all-reduce, cast back into the fp32 gradient (half the 605 MB per step of CLIP ViT-B/32; the sum over W ranks is
+        # rounded to 8 mantissa bits once per hop, so this is opt-in: ~2e-3 relative error on a gradient)
+        if grad_dtype is None and os.environ.get("DH_GRAD_BF16", "0") == "1":
+            grad_dtype = torch.bfloat16
+        self.grad_dtype = grad_dtype
+        self.staged = []     # (work, lo, hi, low-precision copy): written back in finish()
         self.done = []       # launched [lo, hi)
         self.runs = []       # coalesced ready-but-not-launched [lo, hi)
         self.works = []
         self.events = []     # (lo, hi, stream id, event): ranges finished on a tower side stream (FlatParams.side_stream)
 
     def begin(self):
-        self.done, self.runs, self.works, self.events = [], [], [], []
+        self.done, self.runs, self.works, self.events, self.staged = [], [], [], [], []
 
     @staticmethod
     def distributed():
@@ -167,7 +220,12 @@ class FlatReducer:
                 if sid != cur.cuda_stream and a < hi and b > lo:
                     cur.wait_event(ev)
         if is_dist():
-            self.works.append(tdist.all_reduce(self.flat.flat_g[lo:hi], op=tdist.ReduceOp.SUM, async_op=True))
+            seg = self.flat.flat_g[lo:hi]
+            if self.grad_dtype is not None and self.grad_dtype != seg.dtype:
+                low = seg.to(self.grad_dtype)
+                self.staged.append((tdist.all_reduce(low, op=tdist.ReduceOp.SUM, async_op=True), lo, hi, low))
+            else:
+                self.works.append(tdist.all_reduce(seg, op=tdist.ReduceOp.SUM, async_op=True))
 
     def ready(self, lo, hi):
         if getattr(self.flat, "side_streams", None):
@@ -201,6 +259,10 @@ class FlatReducer:
         for w in self.works:
             w.wait()
         self.works = []
+        for w, lo, hi, low in self.staged:
+            w.wait()
+            self.flat.flat_g[lo:hi].copy_(low)
+        self.staged = []
 
 
 class DistModule(torch.nn.Module):
@@ -208,7 +270,7 @@ class DistModule(torch.nn.Module):
     arranges gradient averaging (the loss is pre-divided by world size, clip_solver.py:418, so
     SUM == mean).  `sync` is accepted for config compatibility; both modes reduce flat buckets."""
 
-    def __init__(self, module, sync=False, bucket_bytes=48 << 20):
+    def __init__(self, module, sync=False, bucket_bytes=48 << 20, grad_dtype=None):
         super().__init__()
         self.module = module
         self.sync = sync
@@ -219,9 +281,9 @@ class DistModule(torch.nn.Module):
         if torch.cuda.is_available() and next(module.parameters()).is_cuda:
             flat.ensure()
             self.broadcast_params()
-            flat.reducer = FlatReducer(flat, bucket_bytes)
+            flat.reducer = FlatReducer(flat, bucket_bytes, grad_dtype)
         else:
-            flat.reducer = FlatReducer(flat, bucket_bytes)
+            flat.reducer = FlatReducer(flat, bucket_bytes, grad_dtype)
 
     def forward(self, *inputs, **kwargs):
         return self.module(*inputs, **kwargs)

@@ -207,9 +207,10 @@ class NNMemoryBankModule(nn.Module):
             self.bank_ptr = ptr + b
 
     @torch.no_grad()
-    def forward(self, output, update=False, query=True):
+    def forward(self, output, update=False, query=True, enqueue=None):
         """returns [nearest neighbours [b, D] fp32]; the search sees the bank BEFORE this call's enqueue
-        (memory_bank.py:117-122).  query=False skips the (discarded) search of an update-only call."""
+        (memory_bank.py:117-122).  query=False skips the (discarded) search of an update-only call.  `enqueue`: rows to put into
+        the queue instead of `output` (the GLOBAL queue of DECLIP(global_nn_bank=True): every rank's features, gathered)."""
         output = output.detach().float().contiguous()
         if self.bank is None:
             self.init_bank(output.shape[1], output.device)
@@ -218,7 +219,7 @@ class NNMemoryBankModule(nn.Module):
             _, feats = ops.nn_bank_query(output, self.bank)
             res = [feats]
         if update:
-            self._enqueue(output)
+            self._enqueue(output if enqueue is None else enqueue.detach().float().contiguous())
         return res
 
 

@@ -146,17 +146,31 @@ class DECLIP(CLIP):
         nn_feats = []
         if self.return_nn_bank:
             bank = self.nn_replacer_text
+            enq_t = enq_aug = None
+            if self.global_nn_bank and dh_dist.is_dist():
+                # north_star: "the NN feature queue is likewise gathered" -- every rank enqueues ALL ranks' caption features, so the
+                # W banks stay identical and hold W x more distinct neighbours per step (the reference keeps W independent per-rank
+                # queues, memory_bank.py:66; that stays the default).  One extra small gather, off the gradient path.
+                enq_t, enq_aug = dh_dist.all_gather_cat_many([t.detach(), t_aug.detach()])
             nn_t = bank(t, update=False)[0]
-            nn_t_aug = bank(t_aug, update=True)[0]
-            bank(t, update=True, query=False)               # the reference's third call only enqueues
+            nn_t_aug = bank(t_aug, update=True, enqueue=enq_aug)[0]
+            bank(t, update=True, query=False, enqueue=enq_t)               # the reference's third call only enqueues
             nn_t = engine.L2NormFn.apply(nn_t, 1e-10)
             nn_t_aug = engine.L2NormFn.apply(nn_t_aug, 1e-10)
             nn_feats = [nn_t, nn_t_aug]
-        # ---- ONE packed all-gather for everything that is gathered (reference: 4 + 2 all_gathers + 2 barriers)
-        gathered = dh_dist.all_gather_cat_many([i1, i2, t, t_aug] + nn_feats)
+        # ---- ONE packed all-gather for everything that is gathered (reference: 4 + 2 all_gathers + 2 barriers), in flight on the
+        # communication stream while the masked-LM head (three vocabulary-wide GEMMs) runs on the compute stream
+        pending = dh_dist.all_gather_cat_many_async([i1, i2, t, t_aug] + nn_feats)
+        ret = {}
+        if self.text_mask_type is not None:
+            if packed:
+                ret["text_self_supervised"] = mlm_loss_packed(words, engine.packed_captions(ids_cat, flat.act_dtype), b, labels,
+                                                              self.text_label_predictor, flat)
+            else:
+                ret["text_self_supervised"] = mlm_loss(words[:b], labels, self.text_label_predictor, flat)
+        gathered = pending.result()
         g_i1, g_i2, g_t, g_t_aug = gathered[:4]
         L = lambda q, k: LazyLogits(q, k, scale, label0)
-        ret = {}
         ret["logits"] = L(i1, g_t), L(i2, g_t), L(t, g_i1), L(t, g_i2)
         ret["logits_aug"] = L(i1, g_t_aug), L(i2, g_t_aug), L(t_aug, g_i1), L(t_aug, g_i2)
         ret["simsiam_features"] = p1, p2, z1, z2
@@ -164,12 +178,6 @@ class DECLIP(CLIP):
         if self.return_nn_bank:
             g_nn, g_nn_aug = gathered[4], gathered[5]
             ret["nn_text_logits"] = L(i1, g_nn), L(i2, g_nn), L(i1, g_nn_aug), L(i2, g_nn_aug)
-        if self.text_mask_type is not None:
-            if packed:
-                ret["text_self_supervised"] = mlm_loss_packed(words, engine.packed_captions(ids_cat, flat.act_dtype), b, labels,
-                                                              self.text_label_predictor, flat)
-            else:
-                ret["text_self_supervised"] = mlm_loss(words[:b], labels, self.text_label_predictor, flat)
         self._extra_outputs(ret, dict(b=b, dense=dense_cat, words=words, label0=label0))
         if not self.fused_loss:
             for k in ("logits", "logits_aug", "nn_text_logits"):

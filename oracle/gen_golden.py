@@ -160,13 +160,21 @@ def gen_clip(name, cfg, b, world=1, seed=0, logit_scale=None):
     print("wrote %s  loss=%.6f  (%d KB)" % (path, ret["loss"], os.path.getsize(path) // 1024))
 
 
-def gen_declip(name, cfg, b, seed=0, nn_size=256):
-    """Reference DECLIP (model/declip.py) + the solver's loss composition (declip_solver.py:435-533), one rank."""
+def run_declip_rank(rank, world, cfg, b, seed, nn_size, ret):
+    """One reference DECLIP rank (model/declip.py) + the solver's loss composition (declip_solver.py:435-533, every term divided by
+    world_size): local rows [rank*b, (rank+1)*b) of the global batch.  world > 1: the six gathered feature tensors (image x2, text,
+    augmented text, NN text x2) span B = world*b columns, label0 = rank*b; every rank owns its NN bank (memory_bank.py:66), seeded
+    per rank."""
     import contextlib
     import io
-    os.environ["SLURM_PROCID"], os.environ["SLURM_NTASKS"] = "0", "1"
+    os.environ["SLURM_PROCID"], os.environ["SLURM_NTASKS"] = str(rank), str(world)
     ref = ref_harness.load_reference()
-    ref_harness.ensure_gloo_group()
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world, init_method="tcp://127.0.0.1:29545")
+        torch.set_num_threads(max(1, (os.cpu_count() or 2) // world))
+    else:
+        ref_harness.ensure_gloo_group()
     rd = ref.modules["prototype.model.declip"]
     vt = ref.modules["prototype.model.image_encoder.visual_transformer"]
     tt = ref.modules["prototype.model.text_encoder.text_transformer"]
@@ -187,14 +195,16 @@ def gen_declip(name, cfg, b, seed=0, nn_size=256):
         sd = synth.synth_state(synth.declip_shapes(cfg), seed=seed)
         model.load_state_dict(sd, strict=True)
         model.train()
-    images = synth.synth_images(b, views=2, res=cfg["res"], seed=seed)
-    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
-    ids_aug = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"])
+    B = b * world
+    images = synth.synth_images(B, views=2, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
+    ids_aug = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"])
     ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
-    bank = synth.synth_bank(nn_size, cfg["embed_dim"], seed=seed)
+    bank = synth.synth_bank(nn_size, cfg["embed_dim"], seed=seed + rank)  # per-rank bank
     model.nn_replacer_text.bank = bank.t().clone()                       # reference layout [D, size]
     model.nn_replacer_text.bank_ptr = torch.LongTensor([0])
     off = ref_harness.AUG_KEY_OFFSET
+    sl = slice(rank * b, (rank + 1) * b)
 
     def tokenize(texts, context_length=77, return_length=False, mask_type=None):
         keys = [int(t) for t in texts]
@@ -202,7 +212,7 @@ def gen_declip(name, cfg, b, seed=0, nn_size=256):
             return torch.stack([ids_masked[k] for k in keys]), torch.stack([labels[k] for k in keys])
         return torch.stack([ids_aug[k - off] if k >= off else ids[k] for k in keys])
     model.encode_text.tokenize = tokenize
-    out = model({"images": images, "captions": [[i] for i in range(b)]}, return_dict=True)
+    out = model({"images": images[sl], "captions": [[i] for i in range(rank * b, (rank + 1) * b)]}, return_dict=True)
     L = ref.modules["prototype.loss_functions.loss"]
     crit, sim_crit = L.ClipInfoCELoss(), L.SimsiamLoss()
     ntx = ref.modules["prototype.loss_functions.nt_xent_ConVIRT"].NTXentLoss(b)
@@ -216,19 +226,54 @@ def gen_declip(name, cfg, b, seed=0, nn_size=256):
     mlm = out["text_self_supervised"]
     tf, if1, if2 = out["features"]
     monitor = ntx(if1, tf) + ntx(if2, tf)
-    total = 0.4 * clip_loss + 0.2 * sim_loss + 0.2 * mlm + 0.2 * nn_loss        # yfcc15m_vit_declip/config.yaml:28-32
+    total = (0.4 * clip_loss + 0.2 * sim_loss + 0.2 * mlm + 0.2 * nn_loss) / world   # yfcc15m_vit_declip/config.yaml:28-32; every term / world_size
     total.backward()
-    ret = dict(kind="declip", cfg=cfg, b=b, seed=seed, nn_size=nn_size, loss=float(total),
-               parts=dict(clip=float(clip_loss), nn=float(nn_loss), simsiam=float(sim_loss), mlm=float(mlm), convirt=float(monitor)),
-               logits_i1=li1.detach().clone(), nn_logits_i1=n1.detach().clone(),
-               grads=grad_digest([(n, p.grad) for n, p in model.named_parameters()]),
-               bank_ptr=int(model.nn_replacer_text.bank_ptr), bank_sum=float(model.nn_replacer_text.bank.double().sum()),
-               bn1_running_mean=model.projector.bn1.running_mean.clone(), bn1_running_var=model.projector.bn1.running_var.clone(),
-               torch_version=torch.__version__)
-    if cfg.get("vision") == "resnet":          # the tower saw two views: its BatchNorm buffers moved twice
-        bufs = dict(model.named_buffers())
-        ret["bn_buffers"] = {k: bufs[k].detach().clone() for k in ("visual.bn1.running_mean", "visual.layer4.0.bn3.running_var",
-                                                                   "visual.bn2.num_batches_tracked")}
+    grads = []
+    for name, p in model.named_parameters():
+        g = p.grad
+        if g is not None and world > 1:
+            dist.all_reduce(g)                                           # utils/dist.py:71-74 (SUM)
+        grads.append((name, g))
+    tot = total.detach().clone()
+    parts = torch.tensor([float(clip_loss), float(nn_loss), float(sim_loss), float(mlm), float(monitor)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tot)
+        dist.all_reduce(parts)
+        parts /= world
+    if rank == 0:
+        ret.update(loss=float(tot), parts=dict(clip=float(parts[0]), nn=float(parts[1]), simsiam=float(parts[2]), mlm=float(parts[3]),
+                                                convirt=float(parts[4])),
+                   logits_i1=li1.detach().clone(), nn_logits_i1=n1.detach().clone(), grads=grad_digest(grads),
+                   bank_ptr=int(model.nn_replacer_text.bank_ptr), bank_sum=float(model.nn_replacer_text.bank.double().sum()),
+                   bn1_running_mean=model.projector.bn1.running_mean.clone(), bn1_running_var=model.projector.bn1.running_var.clone())
+        if cfg.get("vision") == "resnet":          # the tower saw two views: its BatchNorm buffers moved twice
+            bufs = dict(model.named_buffers())
+            ret["bn_buffers"] = {k: bufs[k].detach().clone() for k in ("visual.bn1.running_mean", "visual.layer4.0.bn3.running_var",
+                                                                       "visual.bn2.num_batches_tracked")}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _spawn_declip(rank, world, cfg, b, seed, nn_size, path):
+    ret = {}
+    run_declip_rank(rank, world, cfg, b, seed, nn_size, ret)
+    if rank == 0:
+        torch.save(ret, path)
+
+
+def gen_declip(name, cfg, b, seed=0, nn_size=256, world=1):
+    """Reference DECLIP (model/declip.py) + the solver's loss composition (declip_solver.py:435-533)."""
+    if world == 1:
+        ret = {}
+        run_declip_rank(0, 1, cfg, b, seed, nn_size, ret)
+    else:
+        import torch.multiprocessing as mp
+        tmp = "/tmp/_golden_%s.pt" % name
+        mp.spawn(_spawn_declip, args=(world, cfg, b, seed, nn_size, tmp), nprocs=world, join=True)
+        ret = torch.load(tmp, weights_only=False)
+        os.remove(tmp)
+    ret.update(kind="declip", cfg=cfg, b=b, seed=seed, nn_size=nn_size, world=world, torch_version=torch.__version__)
     path = os.path.join(GOLDEN_DIR, name + ".pt")
     torch.save(ret, path)
     print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
@@ -513,6 +558,8 @@ FIXTURES = {
     "clip_r50_tiny_w2": lambda: gen_clip("clip_r50_tiny_w2", synth.R50_TINY, b=2, world=2, seed=10),
     "declip_tiny": lambda: gen_declip("declip_tiny", synth.TINY, b=6, seed=2),
     "declip_r50_tiny": lambda: gen_declip("declip_r50_tiny", synth.R50_TINY, b=4, seed=12),
+    "declip_tiny_w2": lambda: gen_declip("declip_tiny_w2", synth.TINY, b=4, seed=31, world=2),
+    "filip_small_w2": lambda: gen_filip("filip_small_w2", synth.FILIP_SMALL, b=4, seed=32, world=2),
     "slip_tiny": lambda: gen_slip("slip_tiny", synth.TINY, b=5, seed=4),
     "filip_small": lambda: gen_filip("filip_small", synth.FILIP_SMALL, b=5, seed=6),
     "filip_r50_tiny": lambda: gen_filip("filip_r50_tiny", synth.R50_TINY_FILIP, b=4, seed=13),

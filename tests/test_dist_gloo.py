@@ -304,6 +304,170 @@ def _w_clip_r50_syncbn(rank, world, port, out):
         out.put("ok")
 
 
+def _mock_ops():
+    import cpu_ops_mock
+    from declip_amd import engine, ops
+    for name in dir(cpu_ops_mock):
+        if not name.startswith("_") and callable(getattr(cpu_ops_mock, name)) and hasattr(ops, name):
+            setattr(ops, name, getattr(cpu_ops_mock, name))
+    engine._require_gpu = lambda p, name: None
+
+
+def _w_declip(rank, world, port, out):
+    """DeCLIP data-parallel step (SIX feature tensors in one packed gather: two image views, caption, augmented caption, two
+    nearest-neighbour sets; per-rank NN bank; masked-LM head between the gather and its use) against TWO reference ranks
+    (tests/golden/declip_tiny_w2.pt)."""
+    _init(rank, world, port)
+    _mock_ops()
+    from declip_amd import dist as dd
+    from declip_amd import synth
+    from declip_amd.heads import SimsiamLoss
+    from declip_amd.loss import ClipInfoCELoss, NTXentLoss
+    from declip_amd.steps import declip_loss
+    from declip_amd.testing import build_declip
+    from oracle_util import check_grad_digests, load_golden
+    g = load_golden("declip_tiny_w2")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_declip(cfg, dtype="fp32", seed=seed, nn_size=g["nn_size"], device="cpu")
+    model.nn_replacer_text.bank = synth.synth_bank(g["nn_size"], cfg["embed_dim"], seed=seed + rank)     # per-rank bank, as the golden
+    wrapped = dd.DistModule(model, sync=False, bucket_bytes=1 << 14)
+    B = b * world
+    sl = slice(rank * b, (rank + 1) * b)
+    images = synth.synth_images(B, views=2, res=cfg["res"], seed=seed)[sl]
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
+    ids_aug = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"])
+    ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+    batch = {"images": images, "captions": torch.stack([ids_masked[sl], ids_aug[sl]], dim=1), "mlm_labels": labels[sl]}
+    o = declip_loss(wrapped, batch, ClipInfoCELoss(), SimsiamLoss(), NTXentLoss(b), world_size=world)
+    o["loss"].backward()
+    total = o["loss"].detach().clone()
+    parts = torch.stack([o["parts"][k].detach().reshape(()) for k in ("clip", "nn", "simsiam", "mlm")])
+    torch.distributed.all_reduce(total)
+    torch.distributed.all_reduce(parts)                  # every term is already divided by world_size: the sum is the mean over ranks
+    if rank == 0:
+        assert abs(float(total) - g["loss"]) <= 1e-4 * abs(g["loss"]), (float(total), g["loss"])
+        for v, k in zip(parts.tolist(), ("clip", "nn", "simsiam", "mlm")):
+            assert abs(v - g["parts"][k]) <= 2e-4 * max(1.0, abs(g["parts"][k])), (k, v, g["parts"][k])
+        li1 = o["outputs"]["logits"][0].materialize().detach()
+        assert li1.shape == (b, B)
+        assert float((li1 - g["logits_i1"]).abs().max()) <= 1e-4 * float(g["logits_i1"].abs().max())
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+        check_grad_digests(g["grads"], grads, rtol=1e-3)
+        out.put("ok")
+
+
+def _w_declip_global_bank(rank, world, port, out):
+    """DECLIP(global_nn_bank=True): after a step every rank's queue holds the SAME rows -- both ranks' augmented-caption features,
+    then both ranks' caption features -- and the pointer advanced by 2 * world * b."""
+    _init(rank, world, port)
+    _mock_ops()
+    from declip_amd import dist as dd
+    from declip_amd import synth
+    from declip_amd.heads import SimsiamLoss
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.steps import declip_loss
+    from declip_amd.testing import build_declip
+    cfg, b, seed, nn = synth.TINY, 3, 41, 64
+    model = build_declip(cfg, dtype="fp32", seed=seed, nn_size=nn, device="cpu")
+    model.global_nn_bank = True
+    wrapped = dd.DistModule(model, sync=False)
+    B = b * world
+    sl = slice(rank * b, (rank + 1) * b)
+    images = synth.synth_images(B, views=2, res=cfg["res"], seed=seed)[sl]
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
+    ids_aug = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"])
+    ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+    batch = {"images": images, "captions": torch.stack([ids_masked[sl], ids_aug[sl]], dim=1), "mlm_labels": labels[sl]}
+    o = declip_loss(wrapped, batch, ClipInfoCELoss(), SimsiamLoss(), None, world_size=world)
+    o["loss"].backward()
+    bank = model.nn_replacer_text
+    assert bank.bank_ptr == 2 * B
+    mine = bank.bank.clone()
+    other = mine.clone()
+    torch.distributed.broadcast(other, 0)
+    assert torch.equal(mine, other)
+    t_local = o["outputs"]["features"][0].detach()                     # this rank's caption features
+    assert torch.allclose(mine[B + rank * b:B + (rank + 1) * b], t_local, atol=1e-6)
+    if rank == 0:
+        out.put("ok")
+
+
+def _w_filip(rank, world, port, out):
+    """FILIP data-parallel step: the gathered top-16 token sets span B = 2b captions, the dense labels start at rank*b; against
+    TWO reference ranks (tests/golden/filip_small_w2.pt)."""
+    _init(rank, world, port)
+    _mock_ops()
+    from declip_amd import dist as dd
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.steps import filip_loss
+    from declip_amd.testing import build_filip
+    from oracle_util import check_grad_digests, load_golden
+    g = load_golden("filip_small_w2")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_filip(cfg, dtype="fp32", seed=seed, device="cpu")
+    wrapped = dd.DistModule(model, sync=False, bucket_bytes=1 << 14)
+    B = b * world
+    sl = slice(rank * b, (rank + 1) * b)
+    images = synth.synth_images(B, views=2, res=cfg["res"], seed=seed)[sl]
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+    ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+    o = filip_loss(wrapped, {"images": images, "captions": ids_masked[sl], "mlm_labels": labels[sl]}, ClipInfoCELoss(), world_size=world)
+    o["loss"].backward()
+    total = o["loss"].detach().clone()
+    torch.distributed.all_reduce(total)
+    dli, dlt = o["outputs"]["dense_logits"]
+    assert dli.shape == (b, B) and dlt.shape == (b, B)
+    if rank == 0:
+        assert abs(float(total) - g["loss"]) <= 1e-4 * abs(g["loss"]), (float(total), g["loss"])
+        assert float((dli.detach() - g["dense_logits_i"]).abs().max()) <= 1e-4 * float(g["dense_logits_i"].abs().max())
+        assert float((dlt.detach() - g["dense_logits_t"]).abs().max()) <= 1e-4 * float(g["dense_logits_t"].abs().max())
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+        check_grad_digests(g["grads"], grads, rtol=1e-3)
+        out.put("ok")
+
+
+def _w_clip_bf16_buckets(rank, world, port, out):
+    """gradient buckets cross the wire as bf16 (DistModule(grad_dtype=torch.bfloat16) / DH_GRAD_BF16=1): the two-rank reference
+    golden at the bf16 tolerance -- every gradient norm within 1 % (one rounding of each rank's addend and of the sum), and the
+    result identical on both ranks."""
+    _init(rank, world, port)
+    _mock_ops()
+    from declip_amd import dist as dd
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.testing import build_clip
+    from oracle_util import load_golden
+    g = load_golden("clip_tiny_w2")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_clip(cfg, dtype="fp32", use_allgather=True, seed=seed, device="cpu")
+    wrapped = dd.DistModule(model, sync=False, bucket_bytes=1 << 14, grad_dtype=torch.bfloat16)
+    B = b * world
+    images = synth.synth_images(B, res=cfg["res"], seed=seed)[rank * b:(rank + 1) * b]
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])[rank * b:(rank + 1) * b]
+    li, lt = wrapped({"images": images, "captions": ids})
+    loss, _ = ClipInfoCELoss()(li, lt)
+    (loss / world).backward()
+    flat = model.__dict__["_flat_store"]
+    mine = flat.flat_g.clone()
+    other = mine.clone()
+    torch.distributed.broadcast(other, 0)
+    assert torch.equal(mine, other)                      # every rank holds the same reduced gradient
+    assert len(flat.reducer.staged) == 0
+    bad = []
+    gmax = max(v["norm"] for v in g["grads"].values() if v is not None)
+    for n, p in model.named_parameters():
+        ref = g["grads"][n]
+        if ref is None or ref["norm"] < 1e-3 * gmax:
+            continue
+        got = float(p.grad.double().norm())
+        if abs(got - ref["norm"]) > 1e-2 * ref["norm"]:
+            bad.append((n, got, ref["norm"]))
+    assert not bad, bad[:5]
+    if rank == 0:
+        out.put("ok")
+
+
 def _w_zero_shot(rank, world, port, out):
     """Zero-shot evaluate sharded over two ranks: each rank classifies its own batches, the hit counters are summed, and
     every rank reports the metrics of the whole set (== a one-rank run over all batches)."""
@@ -338,7 +502,8 @@ def _w_zero_shot(rank, world, port, out):
         out.put("ok")
 
 
-@pytest.mark.parametrize("fn", [_w_gather, _w_reducer, _w_reducer_gap, _w_clip, _w_clip_tower_twice, _w_clip_packed_pooled, _w_clip_r50, _w_clip_r50_syncbn, _w_zero_shot])
+@pytest.mark.parametrize("fn", [_w_gather, _w_reducer, _w_reducer_gap, _w_clip, _w_clip_tower_twice, _w_clip_packed_pooled, _w_clip_r50, _w_clip_r50_syncbn, _w_zero_shot, _w_declip, _w_declip_global_bank, _w_filip,
+                                _w_clip_bf16_buckets])
 def test_world2(fn):
     port = _free_port()
     ctx = mp.get_context("spawn")

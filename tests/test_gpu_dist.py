@@ -214,3 +214,72 @@ def test_filip_two_ranks_on_one_gpu_match_two_reference_ranks(dtype):
             pytest.fail("rank timed out")
         assert p.exitcode == 0
     assert q.get() == "ok"
+
+
+def _declip_w2_worker(rank, world, port, out):
+    """DeCLIP, two ranks on the one GPU, fp32: the six-tensor packed gather in flight on the engine's communication stream while
+    the masked-LM head runs on the compute stream (dist.all_gather_cat_many_async), its reduce-scatter backward replayed there by
+    autograd -- against TWO reference ranks (tests/golden/declip_tiny_w2.pt, 1e-3)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from declip_amd import dist as dd
+    from declip_amd import synth
+    from declip_amd.heads import SimsiamLoss
+    from declip_amd.loss import ClipInfoCELoss, NTXentLoss
+    from declip_amd.steps import declip_loss
+    from declip_amd.testing import build_declip
+    from oracle_util import check_grad_digests, load_golden
+    g = load_golden("declip_tiny_w2")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_declip(cfg, dtype="fp32", seed=seed, nn_size=g["nn_size"])
+    model.nn_replacer_text.bank = synth.synth_bank(g["nn_size"], cfg["embed_dim"], seed=seed + rank).cuda()
+    wrapped = dd.DistModule(model, sync=False, bucket_bytes=1 << 16)
+    B = b * world
+    sl = slice(rank * b, (rank + 1) * b)
+    images = synth.synth_images(B, views=2, res=cfg["res"], seed=seed)[sl].cuda()
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
+    ids_aug = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"])
+    ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+    batch = {"images": images, "captions": torch.stack([ids_masked[sl], ids_aug[sl]], dim=1).cuda(), "mlm_labels": labels[sl]}
+    for it in range(2):                       # twice: stream / event state of the first step must not leak into the second
+        for p in model.parameters():
+            p.grad = None
+        model.nn_replacer_text.bank = synth.synth_bank(g["nn_size"], cfg["embed_dim"], seed=seed + rank).cuda()
+        model.nn_replacer_text.bank_ptr = 0
+        o = declip_loss(wrapped, batch, ClipInfoCELoss(), SimsiamLoss(), NTXentLoss(b), world_size=world)
+        o["loss"].backward()
+        torch.cuda.synchronize()
+        assert len(dd._COMM_STREAMS) == 1     # the gather really went through the communication stream
+        total = o["loss"].detach().clone()
+        dist.all_reduce(total)
+        if rank == 0:
+            assert abs(float(total) - g["loss"]) <= 1e-3 * abs(g["loss"]), (float(total), g["loss"])
+            li1 = o["outputs"]["logits"][0].materialize().detach().cpu()
+            assert float((li1 - g["logits_i1"]).abs().max()) <= 1e-3 * float(g["logits_i1"].abs().max())
+            grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
+            check_grad_digests(g["grads"], grads, rtol=1e-3)
+    dist.barrier()
+    if rank == 0:
+        out.put("ok")
+    dist.destroy_process_group()
+
+
+def test_declip_two_ranks_on_one_gpu_match_two_reference_ranks():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_declip_w2_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        if p.is_alive():
+            p.terminate()
+            p.join(10)
+            pytest.fail("rank timed out")
+        assert p.exitcode == 0
+    assert q.get() == "ok"
