@@ -161,6 +161,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-loss-delta", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", choices=["0", "1"], default=None,
+                    help="capture forward + loss + backward of the step in ONE HIP graph (declip_amd/graph.py), the fused AdamW stays "
+                         "a separate launch; default: DH_STEP_GRAPH, else 1 for clip / clip_r50 on one GPU (measured +1.4 % / +10 %), 0 for the models "
+                         "whose step carries host-side state (NN-bank pointer) and for multi-GPU runs")
     args = ap.parse_args()
 
     if args.text_packed is not None:
@@ -220,8 +224,9 @@ def main():
     wrapped = dh_dist.DistModule(model, sync=False)
     opt = build_adamw(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
 
-    def step():
-        opt.zero_grad()
+    use_graph = (args.graph if args.graph is not None else os.environ.get("DH_STEP_GRAPH", "1" if args.model in ("clip", "clip_r50") else "0")) == "1" and world == 1
+
+    def fwd_bwd():
         if args.model in ("clip", "clip_r50"):
             li, lt = wrapped(batch)
             loss, _ = crit(li, lt)
@@ -235,6 +240,14 @@ def main():
         else:
             loss = declip_loss(wrapped, batch, crit, sim_crit, None, world_size=world, with_accuracy=False)["loss"]
         loss.backward()                          # gradient all-reduce overlaps inside (dist.FlatReducer)
+        return loss.detach()
+
+    from declip_amd.graph import GraphedStep
+    graphed = GraphedStep(fwd_bwd, warmup=2, enabled=use_graph)
+
+    def step():
+        opt.zero_grad()
+        loss = graphed()
         wrapped.sync_gradients()
         scales = [model.logit_scale] + ([model.logit_scale_dense] if hasattr(model, "logit_scale_dense") else [])
         for p_ in scales:
@@ -279,6 +292,7 @@ def main():
         # events on the launch stream; achieved = algorithmic 2*M*N*K flops / measured kernel time.
         records = []
         gemm_bytes = []
+        graphed.enabled = False            # the instrumented steps run eagerly (a graph replay does not pass through ops.gemm)
         orig = ops.gemm
 
         def timed_gemm(A, B, **kw):
@@ -404,7 +418,7 @@ def main():
                scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                config=dict(workload=workloads[args.model],
                            global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world,
-                           tower_streams=1 + len(model.__dict__["_flat_store"].side_streams),
+                           tower_streams=1 + len(model.__dict__["_flat_store"].side_streams), step_graph=int(use_graph),
                            text_packed=eng_mod.text_packed_mode(), pooled_last=int(eng_mod.pooled_last_block())),   # captions computed up to <|endoftext|> only; last block for the pooled rows only (same outputs, fewer executed flops: see roofline.executed_gemm_gflop_per_pair)
                loss=round(float(loss.detach()) * world, 5))
     if roofline is not None:

@@ -1,5 +1,7 @@
 """Loss functions of the contrastive path on the HIP engine.
 Reference: prototype/loss_functions/loss.py:24-47 (ClipInfoCELoss), utils/misc.py:415-428 (accuracy)."""
+import weakref
+
 import torch
 from torch import nn
 
@@ -17,7 +19,9 @@ class ClipInfoCELoss(nn.Module):
     Accepts LazyLogits handles (fused streaming kernel, nothing materialised) or plain
     tensors (row-wise CE kernel on the materialised logits).  Returns (loss, labels) like the
     reference; the per-row top-1/top-5 hits of logits_per_image are kept in `.last_correct`
-    so `accuracy()` needs no second pass."""
+    so `accuracy()` needs no second pass.  `.last_correct` identifies the logits it belongs to by a WEAK reference: a strong one
+    kept the previous step's whole autograd graph alive (features -> towers -> AccumulateGrad nodes), and an AccumulateGrad node
+    that survives from an eager iteration carries that iteration's stream into a later hipGraph capture (declip_amd/graph.py)."""
 
     def __init__(self):
         super().__init__()
@@ -34,12 +38,12 @@ class ClipInfoCELoss(nn.Module):
             if same_scale:
                 row_loss, c1, c5 = engine.InfoNCEFn.apply(li.scale, label0, 2, li.Q, li.K, lt.Q, lt.K)
                 loss = row_loss.mean()          # mean over 2b rows == (mean_i + mean_t) / 2
-                self.last_correct = (li, c1[0], c5[0])
+                self.last_correct = (weakref.ref(li), c1[0].detach(), c5[0].detach())
             else:
                 rl_i, c1, c5 = engine.InfoNCEFn.apply(li.scale, label0, 1, li.Q, li.K)
                 rl_t, _, _ = engine.InfoNCEFn.apply(lt.scale, label0, 1, lt.Q, lt.K)
                 loss = (rl_i.mean() + rl_t.mean()) / 2
-                self.last_correct = (li, c1[0], c5[0])
+                self.last_correct = (weakref.ref(li), c1[0].detach(), c5[0].detach())
             return loss, labels
         if _is_lazy(logits_per_image):
             logits_per_image = logits_per_image.materialize()
@@ -51,7 +55,7 @@ class ClipInfoCELoss(nn.Module):
             labels = dh_dist.get_rank() * bs + torch.arange(bs, device=dev, dtype=torch.long)
         rl_i, c1, c5 = engine.RowCEFn.apply(logits_per_image, labels)
         rl_t, _, _ = engine.RowCEFn.apply(logits_per_text, labels)
-        self.last_correct = (logits_per_image, c1, c5)
+        self.last_correct = (weakref.ref(logits_per_image), c1.detach(), c5.detach())
         return (rl_i.mean() + rl_t.mean()) / 2, labels
 
 
@@ -60,7 +64,7 @@ def accuracy(output, target, topk=(1,), criterion=None):
     just saw `output`) the hit flags come from the fused loss kernel; otherwise from the
     row-CE kernel on the materialised logits.  Only k in {1, 5} exist on the hot path."""
     c1 = c5 = None
-    if criterion is not None and criterion.last_correct is not None and criterion.last_correct[0] is output:
+    if criterion is not None and criterion.last_correct is not None and criterion.last_correct[0]() is output:
         _, c1, c5 = criterion.last_correct
     elif _is_lazy(output):
         with torch.no_grad():

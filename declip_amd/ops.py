@@ -11,6 +11,12 @@ from . import lib as L
 from .lib import DH_BF16, DH_F32, EPI_DGELU, EPI_GELU, EPI_NONE, GemmArgs, NcePair, check, dt, ptr, stream
 
 
+def _req(cond, what):
+    """argument check in front of a raw-pointer hand-over to the library: a real exception (bare asserts vanish under python -O)"""
+    if not cond:
+        raise L.DeclipHipError("bad argument: %s" % (what,))
+
+
 def _contig(t, name):
     if not t.is_contiguous():
         raise L.DeclipHipError("%s must be contiguous" % name)
@@ -23,36 +29,36 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, 
     """C[M,N] = epi(alpha * sum_k A(m,k) B(n,k) + bias).  A: [M,K] (or [K,M] if a_kmajor);
     B: [N,K] (or [K,N] if b_kmajor).  See include/declip_hip.h."""
     lib = L.load()
-    assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype
+    _req(A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype, 'A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype')
     M, K = (A.shape[1], A.shape[0]) if a_kmajor else (A.shape[0], A.shape[1])
     N, Kb = (B.shape[1], B.shape[0]) if b_kmajor else (B.shape[0], B.shape[1])
     if dims is not None:            # logical (M, N, K) smaller/larger than the buffers (padded layouts, pad_ok)
         M, N, K = dims
     else:
-        assert K == Kb, "contraction mismatch %d vs %d" % (K, Kb)
-    assert (A.shape[1] == 1 or A.stride(1) == 1) and (B.shape[1] == 1 or B.stride(1) == 1)      # (a 1-wide dim may report any stride)
+        _req(K == Kb, "contraction mismatch %d vs %d" % (K, Kb))
+    _req((A.shape[1] == 1 or A.stride(1) == 1) and (B.shape[1] == 1 or B.stride(1) == 1), '(A.shape[1] == 1 or A.stride(1) == 1) and (B.shape[1] == 1 or B.stride(1) == 1)')  # (a 1-wide dim may report any stride)
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=out_dtype or A.dtype)
-    assert (dims is not None or out.shape == (M, N)) and out.stride(1) == 1
+    _req((dims is not None or out.shape == (M, N)) and out.stride(1) == 1, '(dims is not None or out.shape == (M, N)) and out.stride(1) == 1')
     a = GemmArgs()
     a.dtype, a.c_dtype = dt(A), dt(out)
     a.a_kmajor, a.b_kmajor = int(a_kmajor), int(b_kmajor)
     a.M, a.N, a.K = M, N, K
     a.A, a.lda, a.B, a.ldb, a.C, a.ldc = ptr(A), max(A.stride(0), A.shape[1]), ptr(B), max(B.stride(0), B.shape[1]), ptr(out), out.stride(0)
     if bias is not None:
-        assert bias.dtype == torch.float32 and (dims is not None or bias.numel() == N)
+        _req(bias.dtype == torch.float32 and (dims is not None or bias.numel() == N), 'bias.dtype == torch.float32 and (dims is not None or bias.numel() == N)')
     a.bias = ptr(bias)
     a.epilogue = epilogue
     if residual is not None:
-        assert residual.dtype == out.dtype and residual.shape == out.shape
+        _req(residual.dtype == out.dtype and residual.shape == out.shape, 'residual.dtype == out.dtype and residual.shape == out.shape')
         a.residual, a.ldr = ptr(residual), residual.stride(0)
     if aux is not None:
-        assert aux.shape == (M, N)
-        assert aux.dtype == (out.dtype if epilogue == EPI_GELU else A.dtype)
+        _req(aux.shape == (M, N), 'aux.shape == (M, N)')
+        _req(aux.dtype == (out.dtype if epilogue == EPI_GELU else A.dtype), 'aux.dtype == (out.dtype if epilogue == EPI_GELU else A.dtype)')
         a.aux, a.ldaux = ptr(aux), aux.stride(0)
     a.accumulate, a.split_k, a.alpha, a.force_generic = int(accumulate), int(split_k), float(alpha), int(force_generic)
     if a_colsum is not None:
-        assert a_kmajor and a_colsum.dtype == torch.float32 and a_colsum.numel() == M
+        _req(a_kmajor and a_colsum.dtype == torch.float32 and a_colsum.numel() == M, 'a_kmajor and a_colsum.dtype == torch.float32 and a_colsum.numel() == M')
         a.a_colsum = ptr(a_colsum)
     a.pad_ok = int(pad_ok)
     if ws is not None:              # caller scratch for the split-K partial tiles (v4 kernel)
@@ -67,9 +73,9 @@ def gemm_dw_group(problems, ws=None):
     n = len(problems)
     arr = (GemmArgs * n)()
     for a, (dy, x, gw, gb) in zip(arr, problems):
-        assert dy.dim() == 2 and x.dim() == 2 and dy.shape[0] == x.shape[0] and dy.dtype == x.dtype
-        assert gw.dtype == torch.float32 and gw.shape == (dy.shape[1], x.shape[1]) and gw.stride(1) == 1
-        assert dy.stride(1) == 1 and x.stride(1) == 1
+        _req(dy.dim() == 2 and x.dim() == 2 and dy.shape[0] == x.shape[0] and dy.dtype == x.dtype, 'dy.dim() == 2 and x.dim() == 2 and dy.shape[0] == x.shape[0] and dy.dtype == x.dtype')
+        _req(gw.dtype == torch.float32 and gw.shape == (dy.shape[1], x.shape[1]) and gw.stride(1) == 1, 'gw.dtype == torch.float32 and gw.shape == (dy.shape[1], x.shape[1]) and gw.stride(1) == 1')
+        _req(dy.stride(1) == 1 and x.stride(1) == 1, 'dy.stride(1) == 1 and x.stride(1) == 1')
         a.dtype, a.c_dtype = dt(dy), DH_F32
         a.a_kmajor, a.b_kmajor = 1, 1
         a.M, a.N, a.K = dy.shape[1], x.shape[1], dy.shape[0]
@@ -77,7 +83,7 @@ def gemm_dw_group(problems, ws=None):
         a.accumulate, a.alpha = 1, 1.0
         a.split_k = max(1, min(1024 // max(((a.M + 127) // 128) * ((a.N + 127) // 128), 1), a.K // 512))   # used only on the one-by-one path
         if gb is not None:
-            assert gb.dtype == torch.float32 and gb.numel() == a.M
+            _req(gb.dtype == torch.float32 and gb.numel() == a.M, 'gb.dtype == torch.float32 and gb.numel() == a.M')
             a.a_colsum = ptr(gb)
         if ws is not None:
             a.ws, a.ws_bytes = ptr(ws), ws.numel() * ws.element_size()
@@ -92,7 +98,7 @@ def gemm_stats(reset=False):
 
 
 def colsum(X, out, accumulate=True):
-    assert X.dim() == 2 and X.stride(1) == 1 and out.dtype == torch.float32 and out.numel() == X.shape[1]
+    _req(X.dim() == 2 and X.stride(1) == 1 and out.dtype == torch.float32 and out.numel() == X.shape[1], 'X.dim() == 2 and X.stride(1) == 1 and out.dtype == torch.float32 and out.numel() == X.shape[1]')
     check(L.load().dh_colsum(dt(X), ptr(X), X.stride(0), X.shape[0], X.shape[1], ptr(out), int(accumulate), stream()),
           "dh_colsum")
     return out
@@ -146,7 +152,7 @@ def attn_bwd(qkv, out, dout, lse, b, Lq, heads, causal):
 def attn_varlen_fwd(qkv, cu, rows, b, Lmax, heads, causal):
     """attention on packed sequences: qkv [rows_pad, 3d], sequence i = rows cu[i] .. cu[i+1]; out [rows_pad, d] (tail rows zero)."""
     _contig(qkv, "qkv")
-    assert cu.dtype == torch.int32 and cu.numel() == b + 1
+    _req(cu.dtype == torch.int32 and cu.numel() == b + 1, 'cu.dtype == torch.int32 and cu.numel() == b + 1')
     d = qkv.shape[-1] // 3
     out = torch.empty(qkv.shape[0], d, device=qkv.device, dtype=qkv.dtype)
     if qkv.shape[0] > rows:
@@ -172,7 +178,7 @@ def attn_pooled_fwd(q, kv, row0, nkeys, heads, Lmax):
     """one query per sequence: q [b, d], kv [rows, 2d]; keys of sequence i = kv rows row0[i] .. row0[i] + nkeys[i] - 1."""
     _contig(q, "q"), _contig(kv, "kv")
     b, d = q.shape
-    assert kv.shape[1] == 2 * d and row0.dtype == torch.int32 and nkeys.dtype == torch.int32 and row0.numel() == b == nkeys.numel()
+    _req(kv.shape[1] == 2 * d and row0.dtype == torch.int32 and nkeys.dtype == torch.int32 and row0.numel() == b == nkeys.numel(), 'kv.shape[1] == 2 * d and row0.dtype == torch.int32 and nkeys.dtype == torch.int32 and row0.numel() == b == nkeys.numel()')
     out = torch.empty_like(q)
     lse = torch.empty(b, heads, device=q.device, dtype=torch.float32)
     check(L.load().dh_attn_pooled_fwd(dt(q), ptr(q), ptr(kv), ptr(out), ptr(lse), ptr(_contig(row0, "row0")), ptr(_contig(nkeys, "nkeys")), b,
@@ -209,7 +215,7 @@ def text_embed_bwd(ids, dx, dtable, dpos, hot_ids=(0,)):
 
 def text_embed_packed_fwd(ids_p, pos_idx, table, pos, dtype, rows, rows_pad):
     """packed captions: x [rows_pad, d], x[r] = table[ids_p[r]] + pos[pos_idx[r]] for r < rows, zero rows after."""
-    assert ids_p.dtype == torch.int64 and pos_idx.dtype == torch.int32 and ids_p.numel() >= rows and pos_idx.numel() >= rows
+    _req(ids_p.dtype == torch.int64 and pos_idx.dtype == torch.int32 and ids_p.numel() >= rows and pos_idx.numel() >= rows, 'ids_p.dtype == torch.int64 and pos_idx.dtype == torch.int32 and ids_p.numel() >= rows and pos_idx.numel() >= rows')
     d = table.shape[1]
     x = torch.empty(rows_pad, d, device=table.device, dtype=dtype)
     check(L.load().dh_text_embed_packed_fwd(dt(x), ptr(_contig(ids_p, "ids")), ptr(_contig(pos_idx, "pos_idx")), ptr(table), ptr(pos), ptr(x),
@@ -225,7 +231,7 @@ def text_embed_packed_bwd(ids_p, cu, dx, dtable, dpos, rows, Lmax, hot_ids=()):
         check(L.load().dh_text_embed_bwd(dt(dx), ptr(_contig(ids_p, "ids")), ptr(_contig(dx, "dx")), ptr(dtable), None, rows, 1, d, hot,
                                          len(hot_ids), stream()), "dh_text_embed_bwd")
     if dpos is not None:
-        assert cu.dtype == torch.int32
+        _req(cu.dtype == torch.int32, 'cu.dtype == torch.int32')
         check(L.load().dh_packed_pos_grad(dt(dx), ptr(dx), ptr(_contig(cu, "cu")), cu.numel() - 1, Lmax, d, ptr(dpos), stream()),
               "dh_packed_pos_grad")
 
@@ -236,17 +242,17 @@ IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)     #
 def image_prep_u8(src, out_hw, crop_xy=None, flip=None, mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None, c0=0):
     """uint8 [b, Hs, Ws, 3] on the GPU -> fp32 [b, C, H, W] channels c0..c0+2 (crop window, optional mirror, normalise).
     crop_xy: int32 [b, 2] (x0, y0) device tensor or None; flip: uint8/bool [b] device tensor or None."""
-    assert src.dtype == torch.uint8 and src.dim() == 4 and src.shape[3] == 3 and src.is_contiguous()
+    _req(src.dtype == torch.uint8 and src.dim() == 4 and src.shape[3] == 3 and src.is_contiguous(), 'src.dtype == torch.uint8 and src.dim() == 4 and src.shape[3] == 3 and src.is_contiguous()')
     b, Hs, Ws, _ = src.shape
     H, W = out_hw
     if out is None:
         out = torch.empty(b, 3, H, W, device=src.device, dtype=torch.float32)
-    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == b and tuple(out.shape[2:]) == (H, W)
+    _req(out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == b and tuple(out.shape[2:]) == (H, W), 'out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == b and tuple(out.shape[2:]) == (H, W)')
     if crop_xy is not None:
-        assert crop_xy.dtype == torch.int32 and crop_xy.shape == (b, 2) and crop_xy.is_contiguous()
+        _req(crop_xy.dtype == torch.int32 and crop_xy.shape == (b, 2) and crop_xy.is_contiguous(), 'crop_xy.dtype == torch.int32 and crop_xy.shape == (b, 2) and crop_xy.is_contiguous()')
     if flip is not None:
         flip = flip.to(torch.uint8).contiguous()
-        assert flip.shape == (b,)
+        _req(flip.shape == (b,), 'flip.shape == (b,)')
     m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
     check(L.load().dh_image_prep_u8(ptr(src), b, Hs, Ws, ptr(crop_xy), ptr(flip), m3, s3, ptr(out), out.shape[1], c0, H, W, stream()),
           "dh_image_prep_u8")
@@ -257,16 +263,16 @@ def image_resized_crop_u8(src, params, out_hw, flip=None, mean=IMAGENET_MEAN, st
     """uint8 canvas [b, Hs, Ws, 3] on the GPU -> fp32 [b, C, H, W] channels c0..c0+2: crop box -> antialiased bilinear resize -> window
     -> optional mirror -> ToTensor -> Normalize.  params: int32 [b, 8] device tensor (x0, y0, w, h, Wf, Hf, ox, oy), see
     include/declip_hip.h; flip: uint8/bool [b] device tensor or None."""
-    assert src.dtype == torch.uint8 and src.dim() == 4 and src.shape[3] == 3 and src.is_contiguous()
+    _req(src.dtype == torch.uint8 and src.dim() == 4 and src.shape[3] == 3 and src.is_contiguous(), 'src.dtype == torch.uint8 and src.dim() == 4 and src.shape[3] == 3 and src.is_contiguous()')
     b, Hs, Ws, _ = src.shape
     H, W = out_hw
-    assert params.dtype == torch.int32 and params.shape == (b, 8) and params.is_contiguous()
+    _req(params.dtype == torch.int32 and params.shape == (b, 8) and params.is_contiguous(), 'params.dtype == torch.int32 and params.shape == (b, 8) and params.is_contiguous()')
     if out is None:
         out = torch.empty(b, 3, H, W, device=src.device, dtype=torch.float32)
-    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == b and tuple(out.shape[2:]) == (H, W)
+    _req(out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == b and tuple(out.shape[2:]) == (H, W), 'out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == b and tuple(out.shape[2:]) == (H, W)')
     if flip is not None:
         flip = flip.to(torch.uint8).contiguous()
-        assert flip.shape == (b,)
+        _req(flip.shape == (b,), 'flip.shape == (b,)')
     m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
     check(L.load().dh_image_resized_crop_u8(ptr(src), b, Hs, Ws, ptr(params), ptr(flip), m3, s3, ptr(out), out.shape[1], c0, H, W,
                                             int(round_u8), stream()), "dh_image_resized_crop_u8")
@@ -275,10 +281,10 @@ def image_resized_crop_u8(src, params, out_hw, flip=None, mean=IMAGENET_MEAN, st
 
 def im2row(images, c0, patch, dtype, out=None):
     _contig(images, "images")
-    assert images.dtype == torch.float32
+    _req(images.dtype == torch.float32, 'images.dtype == torch.float32')
     b, ctot, H, W = images.shape
     rows = out if out is not None else torch.empty(b * (H // patch) * (W // patch), 3 * patch * patch, device=images.device, dtype=dtype)
-    assert rows.is_contiguous() and rows.shape == (b * (H // patch) * (W // patch), 3 * patch * patch)
+    _req(rows.is_contiguous() and rows.shape == (b * (H // patch) * (W // patch), 3 * patch * patch), 'rows.is_contiguous() and rows.shape == (b * (H // patch) * (W // patch), 3 * patch * patch)')
     check(L.load().dh_im2row(dt(rows), ptr(images), ctot, c0, ptr(rows), b, H, W, patch, stream()), "dh_im2row")
     return rows
 
@@ -337,7 +343,7 @@ def _pair_array(pairs):
 def _int_array(vals, n):
     if vals is None:
         return None
-    assert len(vals) == n
+    _req(len(vals) == n, 'len(vals) == n')
     return (ctypes.c_int * n)(*[int(v) for v in vals])
 
 
@@ -348,7 +354,7 @@ def infonce_fwd(pairs, scale, label0, want_logits=False, label0s=None, excl0s=No
     b, D = Q0.shape
     B = K0.shape[0]
     for q, k in pairs:
-        assert q.dtype == torch.float32 and k.dtype == torch.float32 and q.shape == (b, D) and k.shape == (B, D)
+        _req(q.dtype == torch.float32 and k.dtype == torch.float32 and q.shape == (b, D) and k.shape == (B, D), 'q.dtype == torch.float32 and k.dtype == torch.float32 and q.shape == (b, D) and k.shape == (B, D)')
         _contig(q, "Q"), _contig(k, "K")
     P = len(pairs)
     mk = lambda: torch.empty(P, b, device=Q0.device, dtype=torch.float32)
@@ -380,7 +386,7 @@ def infonce_bwd(pairs, scale, label0, row_lse, g_row, need=None, label0s=None, e
 
 
 def ce_rows_fwd(logits, labels):
-    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1
+    _req(logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1, 'logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1')
     rows, C = logits.shape
     mk = lambda: torch.empty(rows, device=logits.device, dtype=torch.float32)
     row_loss, row_lse, c1, c5 = mk(), mk(), mk(), mk()
@@ -412,7 +418,7 @@ def adamw_segmented(p, g, m, v, p_bf16, seg_start, seg_lr, seg_wd, beta1, beta2,
 
 
 def cast(src, dst):
-    assert src.numel() == dst.numel()
+    _req(src.numel() == dst.numel(), 'src.numel() == dst.numel()')
     check(L.load().dh_cast(dt(src), ptr(src), dt(dst), ptr(dst), src.numel(), stream()), "dh_cast")
     return dst
 
@@ -503,7 +509,7 @@ def filip_select(img_tok, txt_tok):
 
 def maxsim_reduce(S, b, B, J, scale):
     """S [b*J, B*16] -> logits [b,B] (scaled), raw [b,B], argmax [b*J, B] uint8."""
-    assert S.dim() == 2 and S.stride(1) == 1 and S.shape[0] == b * J and S.shape[1] >= B * 16
+    _req(S.dim() == 2 and S.stride(1) == 1 and S.shape[0] == b * J and S.shape[1] >= B * 16, 'S.dim() == 2 and S.stride(1) == 1 and S.shape[0] == b * J and S.shape[1] >= B * 16')
     logits = torch.empty(b, B, device=S.device, dtype=torch.float32)
     raw = torch.empty(b, B, device=S.device, dtype=torch.float32)
     arg = torch.empty(b * J, B, device=S.device, dtype=torch.uint8)
@@ -523,7 +529,7 @@ def maxsim_fused_ok(Q, K, B, J):
 
 def maxsim_fused_fwd(Q, K, b, B, J, scale):
     """Q [rows_pad, D] bf16 (rows_pad % 256 == 0, rows >= b*J), K [B*16, D] bf16 -> logits [b,B], raw [b,B], argmax [rows_pad, B] uint8."""
-    assert Q.dim() == 2 and K.dim() == 2 and Q.is_contiguous() and K.is_contiguous() and K.shape == (B * 16, Q.shape[1])
+    _req(Q.dim() == 2 and K.dim() == 2 and Q.is_contiguous() and K.is_contiguous() and K.shape == (B * 16, Q.shape[1]), 'Q.dim() == 2 and K.dim() == 2 and Q.is_contiguous() and K.is_contiguous() and K.shape == (B * 16, Q.shape[1])')
     rows_pad = Q.shape[0]
     logits = torch.empty(b, B, device=Q.device, dtype=torch.float32)
     raw = torch.empty(b, B, device=Q.device, dtype=torch.float32)
@@ -535,7 +541,7 @@ def maxsim_fused_fwd(Q, K, b, B, J, scale):
 
 def maxsim_scatter_rows(dlogits, arg, scale, b, B, J, r0, nrows, out):
     """rows [r0, r0 + nrows) of the one-hot-weighted G into the chunk buffer `out` [>= nrows, B*16]."""
-    assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= nrows and out.shape[1] >= B * 16 and arg.shape[0] >= min(r0 + nrows, b * J)
+    _req(out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= nrows and out.shape[1] >= B * 16 and arg.shape[0] >= min(r0 + nrows, b * J), 'out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= nrows and out.shape[1] >= B * 16 and arg.shape[0] >= min(r0 + nrows, b * J)')
     check(L.load().dh_maxsim_scatter_rows(dt(out), ptr(_contig(dlogits, "dlogits")), ptr(arg), ptr(scale), ptr(out), out.stride(0), b, B, J,
                                           r0, nrows, stream()), "dh_maxsim_scatter_rows")
     return out[:nrows]
@@ -555,11 +561,11 @@ def conv_rows(x, N, H, W, C, stride=1, pad=1, out=None):
     """3x3 patches of an NHWC activation x [N*H*W, C] -> rows [N*Ho*Wo, 9*C], inner order (c, ky, kx)
     (== conv.weight.view(Cout, Cin*9))."""
     _contig(x, "x")
-    assert x.shape == (N * H * W, C)
+    _req(x.shape == (N * H * W, C), 'x.shape == (N * H * W, C)')
     Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
     if out is None:
         out = torch.empty(N * Ho * Wo, 9 * C, device=x.device, dtype=x.dtype)
-    assert out.shape == (N * Ho * Wo, 9 * C) and out.is_contiguous() and out.dtype == x.dtype
+    _req(out.shape == (N * Ho * Wo, 9 * C) and out.is_contiguous() and out.dtype == x.dtype, 'out.shape == (N * Ho * Wo, 9 * C) and out.is_contiguous() and out.dtype == x.dtype')
     check(L.load().dh_conv_rows(dt(x), ptr(x), 0, C, 0, ptr(out), N, H, W, C, 3, stride, pad, 9 * C, stream()), "dh_conv_rows")
     return out, Ho, Wo
 
@@ -567,12 +573,12 @@ def conv_rows(x, N, H, W, C, stride=1, pad=1, out=None):
 def conv_rows_image(images, c0, dtype, stride=2, pad=1, out=None):
     """3x3 patches of the fp32 NCHW image batch (3 channels from c0) -> rows [N*Ho*Wo, 32] (K = 27 zero-padded)."""
     _contig(images, "images")
-    assert images.dtype == torch.float32 and images.dim() == 4
+    _req(images.dtype == torch.float32 and images.dim() == 4, 'images.dtype == torch.float32 and images.dim() == 4')
     N, ct, H, W = images.shape
     Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
     if out is None:
         out = torch.empty(N * Ho * Wo, 32, device=images.device, dtype=dtype)
-    assert out.shape == (N * Ho * Wo, 32) and out.is_contiguous()
+    _req(out.shape == (N * Ho * Wo, 32) and out.is_contiguous(), 'out.shape == (N * Ho * Wo, 32) and out.is_contiguous()')
     check(L.load().dh_conv_rows(dt(out), ptr(images), 1, ct, c0, ptr(out), N, H, W, 3, 3, stride, pad, 32, stream()), "dh_conv_rows")
     return out, Ho, Wo
 
@@ -597,7 +603,7 @@ def bn2d_fwd(x, w, b, running_mean, running_var, relu, training, residual=None, 
     mean = torch.empty(C, device=x.device, dtype=torch.float32)
     invstd = torch.empty(C, device=x.device, dtype=torch.float32)
     if residual is not None:
-        assert residual.shape == x.shape and residual.dtype == x.dtype and residual.is_contiguous()
+        _req(residual.shape == x.shape and residual.dtype == x.dtype and residual.is_contiguous(), 'residual.shape == x.shape and residual.dtype == x.dtype and residual.is_contiguous()')
     lib = L.load()
     nbytes = lib.dh_bn2d_ws_bytes(R, C)
     ws = _bn_ws(x.device, nbytes)
@@ -611,7 +617,7 @@ def bn2d_bwd(dy, x, y, w, mean, invstd, dw, db, relu, want_dres=False):
     """-> dx (, dres = dy masked by the ReLU: the gradient of the residual branch); dw, db accumulate."""
     _contig(dy, "dy"), _contig(x, "x")
     R, C = x.shape
-    assert dy.shape == x.shape and dy.dtype == x.dtype and dw.dtype == torch.float32 and db.dtype == torch.float32
+    _req(dy.shape == x.shape and dy.dtype == x.dtype and dw.dtype == torch.float32 and db.dtype == torch.float32, 'dy.shape == x.shape and dy.dtype == x.dtype and dw.dtype == torch.float32 and db.dtype == torch.float32')
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     lib = L.load()
@@ -638,7 +644,7 @@ def bn2d_sums(x, dy=None, y=None, mean=None, invstd=None, relu=False):
 def bn2d_fwd_apply(x, w, b, sums, running_mean, running_var, relu, residual=None, eps=1e-5, momentum=0.1):
     _contig(x, "x")
     R, C = x.shape
-    assert sums.dtype == torch.float64 and sums.numel() == 2 * C + 1
+    _req(sums.dtype == torch.float64 and sums.numel() == 2 * C + 1, 'sums.dtype == torch.float64 and sums.numel() == 2 * C + 1')
     y = torch.empty_like(x)
     mean = torch.empty(C, device=x.device, dtype=torch.float32)
     invstd = torch.empty(C, device=x.device, dtype=torch.float32)
@@ -661,7 +667,7 @@ def bn2d_bwd_apply(dy, x, y, w, mean, invstd, sums_local, sums_global, dw, db, r
 
 def avgpool_fwd(x, N, H, W, C, k):
     _contig(x, "x")
-    assert x.shape == (N * H * W, C)
+    _req(x.shape == (N * H * W, C), 'x.shape == (N * H * W, C)')
     y = torch.empty(N * (H // k) * (W // k), C, device=x.device, dtype=x.dtype)
     check(L.load().dh_avgpool_fwd(dt(x), ptr(x), ptr(y), N, H, W, C, k, stream()), "dh_avgpool_fwd")
     return y
@@ -669,7 +675,7 @@ def avgpool_fwd(x, N, H, W, C, k):
 
 def avgpool_bwd(dy, N, H, W, C, k):
     _contig(dy, "dy")
-    assert dy.shape == (N * (H // k) * (W // k), C)
+    _req(dy.shape == (N * (H // k) * (W // k), C), 'dy.shape == (N * (H // k) * (W // k), C)')
     dx = torch.empty(N * H * W, C, device=dy.device, dtype=dy.dtype)
     check(L.load().dh_avgpool_bwd(dt(dy), ptr(dy), ptr(dx), N, H, W, C, k, stream()), "dh_avgpool_bwd")
     return dx
@@ -678,7 +684,7 @@ def avgpool_bwd(dy, N, H, W, C, k):
 def attnpool_tokens_fwd(x, pos, b, HW):
     _contig(x, "x")
     C = x.shape[1]
-    assert x.shape[0] == b * HW and pos.shape == (HW + 1, C) and pos.dtype == torch.float32 and pos.is_contiguous()
+    _req(x.shape[0] == b * HW and pos.shape == (HW + 1, C) and pos.dtype == torch.float32 and pos.is_contiguous(), 'x.shape[0] == b * HW and pos.shape == (HW + 1, C) and pos.dtype == torch.float32 and pos.is_contiguous()')
     tok = torch.empty(b * (HW + 1), C, device=x.device, dtype=x.dtype)
     check(L.load().dh_attnpool_tokens_fwd(dt(x), ptr(x), ptr(pos), ptr(tok), b, HW, C, stream()), "dh_attnpool_tokens_fwd")
     return tok
@@ -687,7 +693,7 @@ def attnpool_tokens_fwd(x, pos, b, HW):
 def attnpool_tokens_bwd(dtok, dpos, b, HW):
     _contig(dtok, "dtok")
     C = dtok.shape[1]
-    assert dtok.shape[0] == b * (HW + 1) and (dpos is None or (dpos.shape == (HW + 1, C) and dpos.dtype == torch.float32))
+    _req(dtok.shape[0] == b * (HW + 1) and (dpos is None or (dpos.shape == (HW + 1, C) and dpos.dtype == torch.float32)), 'dtok.shape[0] == b * (HW + 1) and (dpos is None or (dpos.shape == (HW + 1, C) and dpos.dtype == torch.float32))')
     dx = torch.empty(b * HW, C, device=dtok.device, dtype=dtok.dtype)
     check(L.load().dh_attnpool_tokens_bwd(dt(dtok), ptr(dtok), ptr(dx), ptr(dpos), b, HW, C, stream()), "dh_attnpool_tokens_bwd")
     return dx
