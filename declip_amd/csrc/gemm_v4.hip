@@ -127,6 +127,7 @@ struct KArgs {
   int M, N, K, k_per_split, ntx, nty, nitems, n_full, S, dyn;   // dyn: 0 static partition, 1 dynamic after the first item, 2 fully dynamic + stealing
   int* sched;
   EpiParams e;
+  int group_m;                            // tile order (tile_from_logical)
   // MODE_GROUP only
   int T, ngrp;                            // tiles of all problems together; problems
   long zs, cs_zs;                         // floats per K-slice slab: partial tiles (sum M*N), bias-gradient partials (sum ntx*M)
@@ -246,8 +247,12 @@ __device__ __forceinline__ const bf16_t* piece_src(const bf16_t* P, long ld, int
 // work item w -> (tile_x, tile_y, split z).  Items with the same z are consecutive (they share A/B panels); inside
 // a split the tile order is XCD-aware (workgroup p and all its items w = p + i*grid sit on XCD p % 8 when the grid
 // is a multiple of 8) and grouped so that the tiles an XCD runs concurrently share A and B panels in its 4 MiB L2.
-__device__ __forceinline__ void tile_from_logical(int b, int ntx, int nty, int& tile_x, int& tile_y) {
-  constexpr int GROUP_M = 8;                       // tiles an XCD runs together share GROUP_M A panels and a few B panels
+// GROUP_M (KArgs.group_m): rows of tiles per group.  An XCD owns a CONTIGUOUS chunk of the logical order, so the group shape
+// decides which operand panels two XCDs both fetch from the fabric: with groups of 8 rows and ntx columns, a chunk boundary
+// inside a group hands the same 8 A panels to two (ntx = 3) or three (ntx = 12: 8 x 4 tiles per XCD) XCDs -- the PMC counters
+// showed 2.7x the algorithmic read traffic on the N = 3072 forward GEMM.  group_m = 1 is row-major: all ntx tiles of a row
+// (one A panel) sit on one XCD; only the small weight operand is fetched by every XCD.
+__device__ __forceinline__ void tile_from_logical(int b, int ntx, int nty, int& tile_x, int& tile_y, int GROUP_M = 8) {
   const int in_group = GROUP_M * ntx;
   const int gid = b / in_group;
   const int first_m = gid * GROUP_M;
@@ -275,13 +280,13 @@ __device__ __forceinline__ void chunk_of(int n, int x, int& start, int& len) {
   start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
 }
 __device__ __forceinline__ bool decode_pos(int x, int l, int ntx, int nty, int n_fullitems, int n_full, int S, int K, int k_per_split,
-                                           Item& it) {
+                                           Item& it, int gm = 8) {
   int sf, lf;
   chunk_of(n_fullitems, x, sf, lf);
   if (l < lf) {
     const int logical = sf + l, nb = ntx * nty;
     it.z = logical / nb;
-    tile_from_logical(logical - it.z * nb, ntx, nty, it.tile_x, it.tile_y);
+    tile_from_logical(logical - it.z * nb, ntx, nty, it.tile_x, it.tile_y, gm);
     it.kbeg = it.z * k_per_split;
     it.nk = (min(K, it.kbeg + k_per_split) - it.kbeg) / BK;
     it.slice = -1;
@@ -295,7 +300,7 @@ __device__ __forceinline__ bool decode_pos(int x, int l, int ntx, int nty, int n
   const int j0 = l - lf;
   if (j0 >= ls) return false;
   const int j = ss + j0, lt = j / S, sl = j - lt * S, nkt = K / BK;
-  tile_from_logical(n_full + lt, ntx, nty, it.tile_x, it.tile_y);
+  tile_from_logical(n_full + lt, ntx, nty, it.tile_x, it.tile_y, gm);
   const int k0 = sl * nkt / S, k1 = (sl + 1) * nkt / S;
   it.z = 0; it.kbeg = k0 * BK; it.nk = k1 - k0; it.slice = j; it.p = 0;
   return true;
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
   constexpr bool GROUP = MODE == MODE_GROUP;
   // item decoding and the per-problem operands (MODE_GROUP: from the problem table, read late like everything else)
 #define DECODE(x_, l_, it_) (GROUP ? decode_group(kp, (x_), (l_), nitems, KARG(kp, int, T), K, k_per_split, (it_)) \
-                                   : decode_pos((x_), (l_), ntx, nty, n_fullitems, n_full, S, K, k_per_split, (it_)))
+                                   : decode_pos((x_), (l_), ntx, nty, n_fullitems, n_full, S, K, k_per_split, (it_), KARG(kp, int, group_m)))
 #define LOAD_PROBLEM(kq_, p_)                                                                   \
   do {                                                                                          \
     if (GROUP) {                                                                                \
@@ -1114,12 +1119,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // Tail-sliced launches: C tile = epilogue(sum of the S fp32 slice tiles + bias).  One thread = 8 consecutive columns.
-__global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict__ ws, int S, int n_full, int ntx, int nty, EpiParams e) {
+__global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict__ ws, int S, int n_full, int ntx, int nty, EpiParams e, int gm) {
   const int lt = blockIdx.x >> 5;
   const int id = (blockIdx.x & 31) * 256 + threadIdx.x;
   const int row = id >> 5, cc = id & 31;
   int tile_x, tile_y;
-  tile_from_logical(n_full + lt, ntx, nty, tile_x, tile_y);
+  tile_from_logical(n_full + lt, ntx, nty, tile_x, tile_y, gm);
   const long m = (long)tile_y * BM + row;
   const int n = tile_x * BN + cc * 8;
   float v[8];
@@ -1196,6 +1201,15 @@ static int* sched_slot(hipStream_t st, int* dyn) {
   return buf + (nown++) * 16;
 }
 
+// tile order of a launch (see tile_from_logical): DH_V4_GROUP_M overrides (A/B runs); the weight-gradient layout keeps groups
+// of 8 (its items are ordered K-slice-major, both operands are streamed once per slice)
+static int v4_group_m(bool ta) {
+  static int env = -2;
+  if (env == -2) { const char* ev = getenv("DH_V4_GROUP_M"); env = ev ? atoi(ev) : -1; }
+  if (env > 0) return env;
+  return ta ? 8 : 1;
+}
+
 template <bool TA, bool TB, int MODE, bool ROLES>
 void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, int n_full, int S, hipStream_t st) {
   static bool attr_set = false;
@@ -1211,6 +1225,7 @@ void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, int n
   ka.A = (const bf16_t*)a->A; ka.lda = a->lda; ka.B = (const bf16_t*)a->B; ka.ldb = a->ldb;
   ka.M = a->M; ka.N = a->N; ka.K = a->K; ka.k_per_split = kps; ka.ntx = ntx; ka.nty = nty; ka.nitems = nitems; ka.n_full = n_full; ka.S = S;
   ka.sched = sched_slot(st, &ka.dyn); ka.e = e;
+  ka.group_m = v4_group_m(TA);
   hipLaunchKernelGGL((gemm_v4_kernel<TA, TB, MODE, ROLES>), dim3(grid), dim3(512), LDS_BYTES, st, ka);
 }
 
@@ -1323,7 +1338,7 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
       }
   }
   if (S) hipLaunchKernelGGL(tail_fixup_kernel, dim3((dh_cdiv(a->N, BN) * dh_cdiv(a->M, BM) - n_full) * 32), dim3(256), 0, st,
-                            (const float*)a->ws, S, n_full, dh_cdiv(a->N, BN), dh_cdiv(a->M, BM), e);
+                            (const float*)a->ws, S, n_full, dh_cdiv(a->N, BN), dh_cdiv(a->M, BM), e, v4_group_m(false));
   if (md == MODE_PARTIAL) {
     const long n4 = (long)a->M * a->N / 4;
     int blocks = (int)((n4 + 255) / 256);
@@ -1454,6 +1469,7 @@ bool dh_gemm_try_v4_group(const dh_gemm_args* a, int n, hipStream_t st) {
   ka.A = ka.gp[0].A; ka.B = ka.gp[0].B; ka.lda = ka.gp[0].lda; ka.ldb = ka.gp[0].ldb; ka.M = ka.gp[0].M; ka.N = ka.gp[0].N;
   ka.ntx = ka.gp[0].ntx; ka.nty = ka.gp[0].nty;
   ka.sched = sched_slot(st, &ka.dyn);
+  ka.group_m = 8;
   ka.e.alpha = 1.f;
   ka.e.ws = (float*)a[0].ws;
   ka.e.ws_cs = any_cs ? (float*)a[0].ws + (int64_t)split * zs : nullptr;
