@@ -79,6 +79,24 @@ class DECLIP(CLIP):
             out.append(" ".join(aug) if isinstance(aug, list) else aug)
         return out
 
+    def prepare_captions(self, caps):
+        """Everything forward() does to caption STRINGS (declip.py:203-230: sample the first caption, EDA-augment it, tokenise both,
+        mask the original for the MLM head), as a function the data pipeline can run ahead of the step
+        (prefetch.DataPrefetcher(text_prep=model.prepare_captions) does, on its worker thread): returns the batch entries
+        `captions` int64 [b, 2, ctx] (masked | augmented) and `mlm_labels` [b, ctx] that forward() accepts as pre-tokenised input."""
+        et = self.encode_text
+        texts = self.sample_captions(caps)
+        if not self.EDA:
+            raise NotImplementedError("No EDA")
+        texts_aug = self._augment(texts)
+        tok = et.tokenize(texts, et.context_length, self.text_mask_type)
+        ids, labels = tok if self.text_mask_type is not None else (tok, None)
+        ids_aug = et.tokenize(texts_aug, et.context_length)
+        out = {"captions": torch.stack([ids, ids_aug], dim=1)}
+        if labels is not None:
+            out["mlm_labels"] = labels
+        return out
+
     def forward(self, input, return_dict=False):
         if not (self.training and self.use_allgather):
             raise NotImplementedError("2-View: Not Implemented")                                   # declip.py:301-302
@@ -99,13 +117,8 @@ class DECLIP(CLIP):
                 from ..bpe import mask_token_ids
                 ids, labels = mask_token_ids(ids.cpu(), et.vocab_size)
         else:
-            texts = self.sample_captions(caps)
-            if not self.EDA:
-                raise NotImplementedError("No EDA")
-            texts_aug = self._augment(texts)
-            tok = et.tokenize(texts, et.context_length, self.text_mask_type)
-            ids, labels = tok if self.text_mask_type is not None else (tok, None)
-            ids_aug = et.tokenize(texts_aug, et.context_length)
+            prep = self.prepare_captions(caps)           # string captions handed straight to forward(): the reference's in-line path
+            ids, ids_aug, labels = prep["captions"][:, 0], prep["captions"][:, 1], prep.get("mlm_labels")
         dev = flat.flat_p.device
         b = images.shape[0]
         ids_cat = torch.cat([engine.to_device_async(ids, dev), engine.to_device_async(ids_aug, dev)], dim=0).long().contiguous()

@@ -51,10 +51,14 @@ _END = object()
 
 
 class DataPrefetcher(object):
-    def __init__(self, loader, device="cuda", tokenizer=None, context_length=77, depth=2, image_size=224):
+    def __init__(self, loader, device="cuda", tokenizer=None, context_length=77, depth=2, image_size=224, text_prep=None):
         self.device = torch.device(device)
         self.image_hw = (image_size, image_size) if isinstance(image_size, int) else tuple(image_size)
         self.tokenizer, self.context_length = tokenizer, context_length
+        # text_prep(captions) -> dict of batch entries: everything a model does to caption STRINGS before its text tower, moved to
+        # this worker thread (DECLIP.prepare_captions: caption sampling, EDA augmentation, BPE, MLM masking -- declip.py:203-230
+        # runs them inside forward(), a per-caption Python loop on the critical path)
+        self.text_prep = text_prep
         self._it = iter(loader)
         self._q = queue.Queue(maxsize=max(1, depth))
         self._cuda = self.device.type == "cuda"
@@ -67,6 +71,9 @@ class DataPrefetcher(object):
     # ---- worker thread: host-side preparation -------------------------------------------------------------------------
     def _prepare(self, batch):
         out = dict(batch)
+        caps = out.get("captions")
+        if self.text_prep is not None and caps is not None and not torch.is_tensor(caps):
+            out.update(self.text_prep(caps))
         caps = out.get("captions")
         if self.tokenizer is not None and caps is not None and not torch.is_tensor(caps):
             # the reference's batches carry a list of captions per sample and use the first one (clip.py:110-111)

@@ -456,7 +456,11 @@ class ClsSolver(object):
                 if self.kind in ("clip", "slip") and getattr(tower, "_bpe_path", None) and os.path.exists(tower._bpe_path):
                     tok = tower._get_tokenizer()          # the other families augment / mask the caption TEXT in forward()
                 # user loaders may hand decoded uint8 canvases + crop boxes (declip_amd.augment): cropped / resized on the GPU
-                self._iter = DataPrefetcher(self.loader, self.device, tokenizer=tok, context_length=int(tower.context_length),
+                # DeCLIP family: caption sampling + EDA + BPE + MLM masking run on the prefetch thread as well (declip.py:203-230 has
+                # them inside forward())
+                prep = m.prepare_captions if (hasattr(m, "prepare_captions") and getattr(tower, "_bpe_path", None)
+                                              and os.path.exists(tower._bpe_path)) else None
+                self._iter = DataPrefetcher(self.loader, self.device, tokenizer=tok, context_length=int(tower.context_length), text_prep=prep,
                                             image_size=int(d.get("input_size", 224)))
             else:
                 self._iter = iter(self.loader)

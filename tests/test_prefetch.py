@@ -81,3 +81,55 @@ def test_prefetcher_counts_caption_rows_on_the_host():
     assert a["captions"]._dh_rows == (a["captions"]._version, int((ids.argmax(-1) + 1).sum())) and "_caption_rows" not in a
     assert b["captions"]._dh_rows[1] == int((two.argmax(-1) + 1).sum())
     assert pf.next() is None
+
+
+def test_declip_caption_strings_are_prepared_on_the_prefetch_thread(monkeypatch):
+    """VERDICT r1 missing #8: caption sampling + EDA + BPE + MLM masking of string captions (declip.py:203-230 runs them inside
+    forward()) happen on the prefetcher's worker thread through DECLIP.prepare_captions; forward() then sees pre-tokenised
+    [b, 2, ctx] ids + labels -- the same entries the in-line path builds."""
+    import sys
+    import threading
+    import types
+    import cpu_ops_mock
+    from declip_amd import engine, ops, synth
+    from declip_amd.testing import build_declip
+
+    class StubEDA:                                   # textaugment is not installed: deterministic stand-in with its interface
+        def synonym_replacement(self, s):
+            return s + " indeed"
+
+        random_swap = random_deletion = synonym_replacement
+    monkeypatch.setitem(sys.modules, "textaugment", types.SimpleNamespace(EDA=StubEDA))
+    for name in dir(cpu_ops_mock):
+        if not name.startswith("_") and callable(getattr(cpu_ops_mock, name)) and hasattr(ops, name):
+            monkeypatch.setattr(ops, name, getattr(cpu_ops_mock, name))
+    monkeypatch.setattr(engine, "_require_gpu", lambda p, name: None)
+    cfg = dict(synth.TINY, ctx=16)
+    model = build_declip(cfg, dtype="fp32", seed=0, nn_size=32, device="cpu", load_synth=False)
+    et = model.encode_text
+    et._bpe_path = ref_harness.synthetic_bpe_path()
+    threads = []
+    orig = model.prepare_captions
+
+    def spy(caps):
+        threads.append(threading.current_thread().name)
+        return orig(caps)
+    b = 3
+    batches = [{"images": synth.synth_images(b, views=2, res=cfg["res"], seed=i),
+                "captions": [["a photo of cat number %d" % (i * b + j), "unused"] for j in range(b)]} for i in range(2)]
+    pf = DataPrefetcher(iter(batches), device="cpu", context_length=16, text_prep=spy)
+    got = pf.next()
+    assert threads and all(t == "declip-prefetch" for t in threads)
+    caps, labels = got["captions"], got["mlm_labels"]
+    assert caps.shape == (b, 2, 16) and caps.dtype == torch.long and labels.shape == (b, 16)
+    plain = bpe.tokenize(bpe.SimpleTokenizer(ref_harness.synthetic_bpe_path()), ["a photo of cat number %d indeed" % j for j in range(b)], 16)
+    assert torch.equal(caps[:, 1], plain)                                       # the augmented caption, tokenised
+    assert bool((labels != -100).any()) and torch.equal(caps[:, 0][labels == -100], bpe.tokenize(
+        bpe.SimpleTokenizer(ref_harness.synthetic_bpe_path()), ["a photo of cat number %d" % j for j in range(b)], 16)[labels == -100])
+    assert got["captions"]._dh_rows[1] == int((caps.reshape(-1, 16).argmax(dim=-1) + 1).sum())    # packed row count from the host copy
+    # and the model consumes the prepared entries
+    from declip_amd.heads import SimsiamLoss
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.steps import declip_loss
+    out = declip_loss(model, got, ClipInfoCELoss(), SimsiamLoss(), None)
+    assert torch.isfinite(out["loss"]).all()
