@@ -118,7 +118,13 @@ def filip_loss(model, batch, criterion, weights=None, world_size=1, with_accurac
     w = dict(FILIP_WEIGHTS if weights is None else weights)
     o = model(batch, return_dict=True)
     li, lt = o["logits"]
-    clip, target = criterion(li, lt)
+    if w.get("clip_loss", 0):
+        clip, target = criterion(li, lt)
+    else:
+        # the shipped config gives the global InfoNCE weight 0.0 (yfcc15m_vit_filip/config.yaml:33): the reference still runs its
+        # backward (a gradient of exact zeros into both towers' features); here the term is evaluated for the log only
+        with torch.no_grad():
+            clip, target = criterion(li, lt)
     acc_src = criterion.last_correct
     clip = clip / world_size
     parts = dict(clip=clip)
