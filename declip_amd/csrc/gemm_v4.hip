@@ -101,6 +101,14 @@ struct EpiParams {
   float* ws_cs;       // MODE_PARTIAL + a_colsum: [nsplit][ntx][M] fp32 bias-gradient partials
   // MODE_MAXSIM (FILIP token-wise max-sim, filip.py:96-105): C = raw [ms_b][ms_B] fp32 (+= mean_j max_m), aux = arg-max uint8 [M][ms_B]
   int ms_J, ms_b, ms_B;
+  // MODE_CE_FWD / MODE_CE_BWD (vocabulary cross-entropy of the masked-LM head, declip.py:326-334, without fp32 logits in HBM):
+  // bias = the [V] bias vector (read per tile, V may exceed MAX_BIAS_N), N = V (ragged last tile: columns >= V are masked)
+  const long long* ce_labels;   // [ce_n] target ids
+  const float* ce_lse;          // BWD: [ce_n] log-sum-exp of every row (from the forward)
+  const float* ce_g;            // BWD: [ce_n] upstream gradient of every row loss
+  float* ce_part;               // FWD: [M][ntx][2] per-tile (max, sum exp) partials
+  float* ce_lab;                // FWD: [M] logit at the label column
+  int ce_n, ce_V, ce_ldd;       // valid rows, vocabulary size, row stride of the dl output (BWD; columns >= ce_ldd are not stored)
 };
 
 // The kernel's ONLY parameter: the kernarg segment is exactly this struct, and the kernel reads most of it LATE, through an
@@ -150,7 +158,7 @@ constexpr int SCHED_OFF = BIAS_OFF + MAX_BIAS_N * 4;   // one word: the work ite
 constexpr int LDS_BYTES = SCHED_OFF + 16;            // 144 KiB + 16 B
 // MODE: what happens to the finished tile.  The bf16 epilogue flavours are separate instantiations (straight-line code:
 // the kernel lives at the 256-VGPR cap, runtime epilogue switches cost spills).
-constexpr int MODE_STORE = 0, MODE_STORE_GELU = 1, MODE_STORE_DGELU = 2, MODE_STORE_RES = 3, MODE_ATOMIC = 4, MODE_PARTIAL = 5, MODE_GROUP = 6, MODE_MAXSIM = 7;
+constexpr int MODE_STORE = 0, MODE_STORE_GELU = 1, MODE_STORE_DGELU = 2, MODE_STORE_RES = 3, MODE_ATOMIC = 4, MODE_PARTIAL = 5, MODE_GROUP = 6, MODE_MAXSIM = 7, MODE_CE_FWD = 8, MODE_CE_BWD = 9;
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -528,6 +536,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     e.aux = KARG(kq, void*, e.aux); e.ldaux = KARG(kq, long, e.ldaux); e.alpha = KARG(kq, float, e.alpha); \
     e.a_colsum = KARG(kq, float*, e.a_colsum); e.ws = KARG(kq, float*, e.ws); e.ws_cs = KARG(kq, float*, e.ws_cs); \
     e.ms_J = KARG(kq, int, e.ms_J); e.ms_b = KARG(kq, int, e.ms_b); e.ms_B = KARG(kq, int, e.ms_B);               \
+    e.ce_labels = KARG(kq, const long long*, e.ce_labels); e.ce_lse = KARG(kq, const float*, e.ce_lse);            \
+    e.ce_g = KARG(kq, const float*, e.ce_g); e.ce_part = KARG(kq, float*, e.ce_part); e.ce_lab = KARG(kq, float*, e.ce_lab); \
+    e.ce_n = KARG(kq, int, e.ce_n); e.ce_V = KARG(kq, int, e.ce_V); e.ce_ldd = KARG(kq, int, e.ce_ldd);            \
   } while (0)
   while (have) {
     const int m0 = nxt.tile_y * BM, n0 = nxt.tile_x * BN;
@@ -874,6 +885,117 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       break;
     }
 
+    if (MODE == MODE_CE_FWD || MODE == MODE_CE_BWD) {
+      // Cross-entropy over the vocabulary on the logits tile while it is still in registers (masked-LM head: rows = masked
+      // positions, columns = 49409 vocabulary entries).  Forward: per-row (max, sum exp) of the tile's 256 columns + the label
+      // logit leave the chip (8 bytes per row and tile instead of 1 KB of fp32 logits); a finalize kernel merges the 194 tiles
+      // of a row.  Backward: the tile is recomputed and dl = g (softmax - onehot) is stored as bf16 for the two gradient GEMMs.
+      float* cb = reinterpret_cast<float*>(smem + STAGE_BYTES);                 // [256] bias of the tile's columns
+      int* lb = reinterpret_cast<int*>(smem + STAGE_BYTES + 1024);              // [256] label of the tile's rows (-1: padding row)
+      float* rl = reinterpret_cast<float*>(smem + STAGE_BYTES + 2048);          // BWD: [256] lse, FWD: unused
+      float* rg = reinterpret_cast<float*>(smem + STAGE_BYTES + 3072);          // BWD: [256] upstream gradient
+      float* red = reinterpret_cast<float*>(smem + STAGE_BYTES + 4096);         // FWD: [256 rows][4 wn][2]
+      const int V = e.ce_V, nrows = e.ce_n;
+      if (te < 256) {
+        const int c = n0 + te, r = m0 + te;
+        cb[te] = (c < V && e.bias) ? e.bias[c] : 0.f;
+        lb[te] = r < nrows ? (int)e.ce_labels[r] : -1;
+        if (MODE == MODE_CE_BWD) { rl[te] = r < nrows ? e.ce_lse[r] : 0.f; rg[te] = r < nrows ? e.ce_g[r] : 0.f; }
+      }
+      __syncthreads();
+      const int hh = le >> 5;
+      if (MODE == MODE_CE_FWD) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const int row = i * 128 + ar + ii * 32 + (le & 31);
+            const int lab = lb[row] - n0;                   // label column inside this tile (or out of [0, 256))
+            float mx = -INFINITY;
+            float vals[32];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int q = 0; q < 16; ++q) {
+                const int cl = j * 128 + br + 8 * (q >> 2) + 4 * hh + (q & 3);
+                float v = acc[i * 2 + ii][j][q] + cb[cl];
+                if (cl == lab) e.ce_lab[m0 + row] = v;
+                v = (n0 + cl < V) ? v : -INFINITY;
+                vals[j * 16 + q] = v;
+                mx = fmaxf(mx, v);
+              }
+            float sm = 0.f;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) sm += (mx == -INFINITY) ? 0.f : __expf(vals[q] - mx);
+            // the other half-wave holds the other 32 columns of this wave's 64
+            const float m2 = __shfl_xor(mx, 32, 64), s2 = __shfl_xor(sm, 32, 64);
+            const float mm = fmaxf(mx, m2);
+            const float ss = (mm == -INFINITY) ? 0.f : sm * __expf(mx - mm) + s2 * __expf(m2 - mm);
+            if (hh == 0) { red[(row * 4 + wn) * 2] = mm; red[(row * 4 + wn) * 2 + 1] = ss; }
+          }
+        __syncthreads();
+        if (te < 256) {
+          float mm = -INFINITY;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) mm = fmaxf(mm, red[(te * 4 + w) * 2]);
+          float ss = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { const float mw = red[(te * 4 + w) * 2]; ss += (mw == -INFINITY) ? 0.f : red[(te * 4 + w) * 2 + 1] * __expf(mw - mm); }
+          float2 o2; o2.x = mm; o2.y = ss;
+          *reinterpret_cast<float2*>(e.ce_part + ((long)(m0 + te) * ntx_cs + txcur) * 2) = o2;
+        }
+        __syncthreads();
+      } else {
+        // dl tile, bf16, staged through LDS like the plain bf16 epilogue (two passes of 128 rows, 512-byte staging rows,
+        // 8-byte unit u of row r at unit u ^ (r & 15)); columns >= ce_ldd (beyond the dl buffer's row) are not stored
+        unsigned char* Cd = smem + STAGE_BYTES + 8192;
+        unsigned char* Db = reinterpret_cast<unsigned char*>(e.C) + ((long)m0 * e.ce_ldd + n0) * 2;
+        const int cc = te & 31, r0 = te >> 5;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const int ml = ar + ii * 32 + (le & 31);
+            const int row = i * 128 + ml;
+            const float lse_r = rl[row], g_r = rg[row];
+            const int lab = lb[row] - n0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int rgp = 0; rgp < 4; ++rgp) {
+                const int nl = j * 128 + br + 8 * rgp + 4 * hh;
+                float d[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                  const int cl = nl + x;
+                  const float v = acc[i * 2 + ii][j][rgp * 4 + x] + cb[cl];
+                  const float pr = (n0 + cl < V) ? __expf(v - lse_r) : 0.f;
+                  d[x] = g_r * (pr - (cl == lab ? 1.f : 0.f));
+                }
+                uint2 pk;
+                pk.x = pack2bf_hw(d[0], d[1]); pk.y = pack2bf_hw(d[2], d[3]);
+                *reinterpret_cast<uint2*>(Cd + ml * 512 + (((nl >> 2) ^ (ml & 15)) << 3)) = pk;
+              }
+          }
+          wait_lgkm0();
+          V4_BARRIER();
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int row = r0 + 16 * it;
+            const int pc = cc ^ ((row & 15) >> 1);
+            uint4 raw = *reinterpret_cast<const uint4*>(Cd + row * 512 + pc * 16);
+            if (row & 1) { uint32_t tx = raw.x, ty = raw.y; raw.x = raw.z; raw.y = raw.w; raw.z = tx; raw.w = ty; }
+            if (n0 + cc * 8 < e.ce_ldd)
+              *reinterpret_cast<uint4*>(Db + ((long)(i * 128 + row) * e.ce_ldd + cc * 8) * 2) = raw;
+          }
+          wait_lgkm0();
+          V4_BARRIER();
+        }
+      }
+      pend = 0;
+      break;
+    }
+
     unsigned char* Cs = smem + STAGE_BYTES;  // ring buffer 1 (buffer 0 is receiving the next tile)
     constexpr bool SLICEABLE = MODE == MODE_STORE || MODE == MODE_STORE_RES;   // the N = d GEMMs (few tiles) use these flavours
     if (MODE == MODE_PARTIAL || GROUP || (SLICEABLE && cur_slice >= 0)) {
@@ -1203,7 +1325,9 @@ static int* sched_slot(hipStream_t st, int* dyn) {
 
 // tile order of a launch (see tile_from_logical): DH_V4_GROUP_M overrides (A/B runs); the weight-gradient layout keeps groups
 // of 8 (its items are ordered K-slice-major, both operands are streamed once per slice)
+static int g_group_m_override = 0;   // set around one launch() by entry points whose big operand is B (the vocabulary matrix of the CE modes)
 static int v4_group_m(bool ta) {
+  if (g_group_m_override > 0) return g_group_m_override;
   static int env = -2;
   if (env == -2) { const char* ev = getenv("DH_V4_GROUP_M"); env = ev ? atoi(ev) : -1; }
   if (env > 0) return env;
@@ -1501,5 +1625,76 @@ bool dh_maxsim_try_v4(const void* Q, const void* Ksel, int rows_pad, int b, int 
   memset(&e, 0, sizeof(e));
   e.M = rows_pad; e.N = N; e.C = raw; e.ldc = B; e.aux = arg; e.ldaux = B; e.alpha = 1.f; e.ms_J = J; e.ms_b = b; e.ms_B = B;
   launch<false, false, MODE_MAXSIM, false>(&a, e, 1, D, 0, 0, st);
+  return true;
+}
+
+// ---- masked-LM cross-entropy without fp32 logits (MODE_CE_FWD / MODE_CE_BWD) -----------------------------------------------------
+namespace v4 {
+// row r: merge its ntx (max, sum exp) partials -> lse; loss = lse - label logit
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ part, const float* __restrict__ lab, int n, int ntx,
+                                                          float* __restrict__ row_loss, float* __restrict__ row_lse) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = blockIdx.x * 4 + wave; r < n; r += gridDim.x * 4) {
+    const float* p = part + (long)r * ntx * 2;
+    float mm = -INFINITY, ss = 0.f;
+    for (int t = lane; t < ntx; t += 64) {
+      const float m = p[2 * t], s = p[2 * t + 1];
+      if (m > mm) { ss = ss * __expf(mm - m) + s; mm = m; } else if (m != -INFINITY) ss += s * __expf(m - mm);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float m2 = __shfl_xor(mm, o, 64), s2 = __shfl_xor(ss, o, 64);
+      const float m = fmaxf(mm, m2);
+      ss = (m == -INFINITY) ? 0.f : ss * __expf(mm - m) + s2 * __expf(m2 - m);
+      mm = m;
+    }
+    if (lane == 0) { const float lse = mm + __logf(ss); row_lse[r] = lse; row_loss[r] = lse - lab[r]; }
+  }
+}
+}  // namespace v4
+
+static bool ce_v4_ok(const void* X, const void* W, int n_pad, int V, int K) {
+  using namespace v4;
+  if (g_v4_mode == -2) { const char* ev = getenv("DH_GEMM_V4"); g_v4_mode = ev ? atoi(ev) : -1; }
+  return g_v4_mode != 0 && n_pad % BM == 0 && V >= BN && K % BK == 0 && K >= 2 * BK && !((uintptr_t)X & 15) && !((uintptr_t)W & 15);
+}
+// forward: X [n_pad][K] bf16 (rows >= n zero), W [V][K] bf16, bias [V] fp32 or null, labels [n] int64 -> row_loss / row_lse [n];
+// ws: n_pad * (ceil(V/256) * 2 + 1) floats
+bool dh_ce_try_v4_fwd(const void* X, const void* W, const float* bias, const long long* labels, int n, int n_pad, int V, int K,
+                      float* row_loss, float* row_lse, float* ws, int64_t ws_bytes, hipStream_t st) {
+  using namespace v4;
+  if (!ce_v4_ok(X, W, n_pad, V, K)) return false;
+  const int ntx = dh_cdiv(V, BN);
+  if (ws_bytes < (int64_t)n_pad * (ntx * 2 + 1) * 4) return false;
+  dh_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  a.dtype = DH_BF16; a.c_dtype = DH_F32; a.M = n_pad; a.N = V; a.K = K; a.A = X; a.lda = K; a.B = W; a.ldb = K; a.C = ws; a.ldc = 1; a.alpha = 1.f;
+  EpiParams e;
+  memset(&e, 0, sizeof(e));
+  e.M = n_pad; e.N = V; e.bias = bias; e.alpha = 1.f; e.ce_labels = labels; e.ce_part = ws; e.ce_lab = ws + (int64_t)n_pad * ntx * 2;
+  e.ce_n = n; e.ce_V = V;
+  g_group_m_override = dh_cdiv(n_pad, BM);      // column-major: the 50 MB vocabulary matrix is fetched once, the 6 MB of rows stay in L2
+  launch<false, false, MODE_CE_FWD, false>(&a, e, 1, K, 0, 0, st);
+  g_group_m_override = 0;
+  int blocks = dh_cdiv(n, 4);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(blocks), dim3(256), 0, st, (const float*)e.ce_part, (const float*)e.ce_lab, n, ntx, row_loss, row_lse);
+  return true;
+}
+// backward: dl [n_pad][ldd] bf16 = g[row] * (softmax(X W^T + bias)[row] - onehot(label[row])), zero for rows >= n and columns >= V
+bool dh_ce_try_v4_bwd(const void* X, const void* W, const float* bias, const long long* labels, const float* row_lse, const float* g_row,
+                      int n, int n_pad, int V, int K, void* dl, int64_t ldd, hipStream_t st) {
+  using namespace v4;
+  if (!ce_v4_ok(X, W, n_pad, V, K) || ((uintptr_t)dl & 15) || (ldd % 8) || ldd < V) return false;
+  dh_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  a.dtype = DH_BF16; a.c_dtype = DH_BF16; a.M = n_pad; a.N = V; a.K = K; a.A = X; a.lda = K; a.B = W; a.ldb = K; a.C = dl; a.ldc = ldd; a.alpha = 1.f;
+  EpiParams e;
+  memset(&e, 0, sizeof(e));
+  e.M = n_pad; e.N = V; e.C = dl; e.ldc = ldd; e.bias = bias; e.alpha = 1.f; e.ce_labels = labels; e.ce_lse = row_lse; e.ce_g = g_row;
+  e.ce_n = n; e.ce_V = V; e.ce_ldd = (int)ldd;
+  g_group_m_override = dh_cdiv(n_pad, BM);
+  launch<false, false, MODE_CE_BWD, false>(&a, e, 1, K, 0, 0, st);
+  g_group_m_override = 0;
   return true;
 }

@@ -701,6 +701,36 @@ extern "C" int dh_infonce_bwd(const dh_nce_pair* pairs, int n_pairs, int b, int 
   return DH_OK;
 }
 
+bool dh_ce_try_v4_fwd(const void* X, const void* W, const float* bias, const long long* labels, int n, int n_pad, int V, int K,
+                      float* row_loss, float* row_lse, float* ws, int64_t ws_bytes, hipStream_t st);                      // gemm_v4.hip
+bool dh_ce_try_v4_bwd(const void* X, const void* W, const float* bias, const long long* labels, const float* row_lse, const float* g_row,
+                      int n, int n_pad, int V, int K, void* dl, int64_t ldd, hipStream_t st);
+
+extern "C" int64_t dh_ce_fused_ws_bytes(int n_pad, int V) { return (int64_t)n_pad * (dh_cdiv(V, 256) * 2 + 1) * (int64_t)sizeof(float); }
+
+// Linear(K -> V) + cross-entropy in one pass over the vocabulary, bf16 operands (the masked-LM head, declip.py:326-334): the
+// logits exist only as tiles of the persistent MFMA GEMM; see gemm_v4.hip MODE_CE_FWD / MODE_CE_BWD.
+extern "C" int dh_ce_fused_fwd(const void* X_bf16, const void* W_bf16, const float* bias, const int64_t* labels, int n, int n_pad, int V,
+                               int K, float* row_loss, float* row_lse, void* ws, int64_t ws_bytes, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(X_bf16 && W_bf16 && labels && row_loss && row_lse && ws && n > 0 && n <= n_pad && V > 0 && K > 0, "dh_ce_fused_fwd: bad args");
+  DH_REQUIRE(dh_ce_try_v4_fwd(X_bf16, W_bf16, bias, (const long long*)labels, n, n_pad, V, K, row_loss, row_lse, (float*)ws, ws_bytes, st),
+             "dh_ce_fused_fwd: needs n_pad %% 256 == 0, V >= 256, K %% 64 == 0, K >= 128, 16-byte aligned operands, ws >= dh_ce_fused_ws_bytes (n_pad %d V %d K %d)",
+             n_pad, V, K);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+extern "C" int dh_ce_fused_bwd(const void* X_bf16, const void* W_bf16, const float* bias, const int64_t* labels, const float* row_lse,
+                               const float* g_row, int n, int n_pad, int V, int K, void* dl_bf16, int64_t ldd, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(X_bf16 && W_bf16 && labels && row_lse && g_row && dl_bf16 && n > 0 && n <= n_pad && V > 0 && K > 0, "dh_ce_fused_bwd: bad args");
+  DH_REQUIRE(dh_ce_try_v4_bwd(X_bf16, W_bf16, bias, (const long long*)labels, row_lse, g_row, n, n_pad, V, K, dl_bf16, ldd, st),
+             "dh_ce_fused_bwd: needs n_pad %% 256 == 0, V >= 256, K %% 64 == 0, ldd %% 8 == 0, ldd >= V, 16-byte aligned operands (n_pad %d V %d K %d ldd %ld)",
+             n_pad, V, K, (long)ldd);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
 extern "C" int dh_ce_rows_fwd(const float* logits, int64_t ld, const int64_t* labels, int rows, int C, float* row_loss,
                               float* row_lse, float* correct1, float* correct5, dh_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;

@@ -226,9 +226,14 @@ class NNMemoryBankModule(nn.Module):
 class MlmHeadFn(torch.autograd.Function):
     """text_label_predictor + cross-entropy on the masked positions only (model/declip.py:326-334).
 
-    The reference runs Linear(width -> 49409) on ALL b*77 positions and then selects; here the masked rows
-    are gathered first (same result, ~7x less work).  The vocabulary dimension is handled in a layout padded
-    to a multiple of 64 so that all three GEMMs take the MFMA/LDS-DMA path."""
+    The reference runs Linear(width -> 49409) on ALL b*77 positions and then selects; here the masked rows are gathered first
+    (same result, ~7x less work).
+    bf16: the vocabulary-wide logits [n_masked, 49409] never reach HBM.  Forward = ONE launch of the persistent GEMM with a
+    cross-entropy epilogue (per-tile max / sum-exp partials + the label logit, merged by a finalize kernel:
+    ops.ce_fused_fwd); backward = the same GEMM recomputed with an epilogue that stores dl = g (softmax - onehot) as bf16
+    (ops.ce_fused_bwd), which feeds the two gradient GEMMs.  Round 1 wrote fp32 logits (1.2 GB per DeCLIP step at b = 512), read
+    them twice in the forward cross-entropy and once more in the backward.
+    fp32 validation mode: logits materialised in a layout padded to a multiple of 64 columns, row-wise CE kernels."""
 
     @staticmethod
     def forward(ctx, words, idx, labels_sel, lin, flat):
@@ -236,14 +241,21 @@ class MlmHeadFn(torch.autograd.Function):
         V = lin.weight.shape[0]
         Vp = (V + 63) // 64 * 64
         n = idx.numel()
-        n_pad = max(64, (n + 63) // 64 * 64)
         wflat = words.reshape(-1, width)
-        rows = ops.gather_rows(wflat, idx, n_pad)
-        logits = torch.empty(n_pad, Vp, device=words.device, dtype=torch.float32)
-        ops.gemm(rows, flat.wview(lin.weight), bias=lin.bias.data, out=logits, pad_ok=True, dims=(n_pad, Vp, width))
-        lview = logits[:n, :V]
-        row_loss, row_lse, _, _ = ops.ce_rows_fwd(lview, labels_sel)
-        ctx.lin, ctx.flat, ctx.meta = lin, flat, (n, n_pad, V, Vp, width, words.shape)
+        w = flat.wview(lin.weight)
+        fused = ops.ce_fused_ok(wflat, w)
+        if fused:
+            n_pad = (n + 255) // 256 * 256                       # whole tiles of the persistent GEMM; the padding rows are zero
+            rows = ops.gather_rows(wflat, idx, n_pad)
+            row_loss, row_lse = ops.ce_fused_fwd(rows, w, lin.bias.data, labels_sel, n)
+            logits = None
+        else:
+            n_pad = max(64, (n + 63) // 64 * 64)
+            rows = ops.gather_rows(wflat, idx, n_pad)
+            logits = torch.empty(n_pad, Vp, device=words.device, dtype=torch.float32)
+            ops.gemm(rows, w, bias=lin.bias.data, out=logits, pad_ok=True, dims=(n_pad, Vp, width))
+            row_loss, row_lse, _, _ = ops.ce_rows_fwd(logits[:n, :V], labels_sel)
+        ctx.lin, ctx.flat, ctx.meta = lin, flat, (n, n_pad, V, Vp, width, words.shape, fused)
         ctx.save_for_backward(rows, logits, row_lse, idx, labels_sel)
         return row_loss
 
@@ -251,13 +263,18 @@ class MlmHeadFn(torch.autograd.Function):
     def backward(ctx, g_row):
         rows, logits, row_lse, idx, labels_sel = ctx.saved_tensors
         lin, flat = ctx.lin, ctx.flat
-        n, n_pad, V, Vp, width, wshape = ctx.meta
+        n, n_pad, V, Vp, width, wshape, fused = ctx.meta
         flat.begin_backward()
-        dl = ops.ce_rows_bwd_padded(logits[:n, :V], labels_sel, row_lse, g_row.contiguous().float(), V, rows.dtype, n_pad, Vp)
+        g_row = g_row.contiguous().float()
+        if fused:
+            dl = ops.ce_fused_bwd(rows, flat.wview(lin.weight), lin.bias.data, labels_sel, row_lse, g_row, n, Vp)
+        else:
+            dl = ops.ce_rows_bwd_padded(logits[:n, :V], labels_sel, row_lse, g_row, V, rows.dtype, n_pad, Vp)
         drows = ops.gemm(dl, flat.wview(lin.weight), b_kmajor=True, pad_ok=True, dims=(n_pad, width, Vp))
         if lin.weight.requires_grad:
+            ws = engine.gemm_workspace(dl.device) if dl.is_cuda and dl.dtype == torch.bfloat16 else None
             ops.gemm(dl, rows, a_kmajor=True, b_kmajor=True, out=flat.gview(lin.weight), accumulate=True,
-                     split_k=engine._split_k(V, width, n_pad), a_colsum=flat.gview(lin.bias), pad_ok=True, dims=(V, width, n_pad))
+                     split_k=engine._split_k(V, width, n_pad), a_colsum=flat.gview(lin.bias), pad_ok=True, dims=(V, width, n_pad), ws=ws)
         dwords = torch.zeros(wshape[0] * wshape[1], width, device=rows.device, dtype=rows.dtype)
         ops.scatter_rows_add(drows, idx, dwords)
         return dwords.view(wshape), None, None, None, None

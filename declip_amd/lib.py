@@ -76,6 +76,9 @@ _PROTOS = {
     "dh_infonce_ws_bytes": (c_int64, [c_int, c_int, c_int]),
     "dh_infonce_fwd": (c_int, [POINTER(NcePair), c_int, c_int, c_int, c_int, _P, c_int, POINTER(c_int), POINTER(c_int), _P, _P, _P, _P, _P, _P, c_int64, _P]),
     "dh_infonce_bwd": (c_int, [POINTER(NcePair), c_int, c_int, c_int, c_int, _P, c_int, POINTER(c_int), POINTER(c_int), _P, _P, _P, _P]),
+    "dh_ce_fused_ws_bytes": (c_int64, [c_int, c_int]),
+    "dh_ce_fused_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int64, _P]),
+    "dh_ce_fused_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P]),
     "dh_ce_rows_fwd": (c_int, [_P, c_int64, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "dh_ce_rows_bwd": (c_int, [_P, c_int64, _P, c_int, c_int, _P, _P, _P, c_int64, _P]),
     "dh_ce_rows_bwd_padded": (c_int, [_P, c_int64, _P, c_int, c_int, _P, _P, _P, c_int, c_int64, c_int, c_int, _P]),

@@ -385,6 +385,42 @@ def infonce_bwd(pairs, scale, label0, row_lse, g_row, need=None, label0s=None, e
     return outs, dscale
 
 
+def ce_fused_ok(rows, weight):
+    """can dh_ce_fused_fwd / bwd take the head?  (bf16 features [*, K] with K a multiple of 64; the caller pads the rows to 256)"""
+    import os
+    if os.environ.get("DH_CE_FUSED", "1") == "0":
+        return False
+    return (rows.is_cuda and rows.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+            and rows.shape[1] % 64 == 0 and rows.shape[1] >= 128 and weight.shape[0] >= 256)
+
+
+def ce_fused_fwd(rows, weight, bias, labels, n):
+    """rows [n_pad, K] bf16 (rows >= n zero), weight [V, K] bf16, bias [V] fp32, labels [n] int64 -> row_loss, row_lse [n] fp32."""
+    n_pad, K = rows.shape
+    V = weight.shape[0]
+    _req(rows.is_contiguous() and weight.stride(1) == 1 and weight.stride(0) == K and labels.dtype == torch.int64 and labels.numel() == n, "ce_fused_fwd operands")
+    row_loss = torch.empty(n, device=rows.device, dtype=torch.float32)
+    row_lse = torch.empty(n, device=rows.device, dtype=torch.float32)
+    lib = L.load()
+    nbytes = lib.dh_ce_fused_ws_bytes(n_pad, V)
+    ws = torch.empty(nbytes // 4, device=rows.device, dtype=torch.float32)
+    check(lib.dh_ce_fused_fwd(ptr(rows), ptr(weight), ptr(bias), ptr(labels), n, n_pad, V, K, ptr(row_loss), ptr(row_lse), ptr(ws), nbytes,
+                              stream()), "dh_ce_fused_fwd")
+    return row_loss, row_lse
+
+
+def ce_fused_bwd(rows, weight, bias, labels, row_lse, g_row, n, ldd):
+    """dl [n_pad, ldd] bf16 = g_row * (softmax(rows W^T + bias) - onehot(labels)); zero rows >= n / columns >= V."""
+    n_pad, K = rows.shape
+    V = weight.shape[0]
+    dl = torch.empty(n_pad, ldd, device=rows.device, dtype=torch.bfloat16)
+    if ldd > (V + 255) // 256 * 256:
+        dl.zero_()
+    check(L.load().dh_ce_fused_bwd(ptr(rows), ptr(weight), ptr(bias), ptr(labels), ptr(_contig(row_lse, "lse")), ptr(_contig(g_row, "g")), n, n_pad,
+                                   V, K, ptr(dl), ldd, stream()), "dh_ce_fused_bwd")
+    return dl
+
+
 def ce_rows_fwd(logits, labels):
     _req(logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1, 'logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1')
     rows, C = logits.shape

@@ -235,6 +235,18 @@ int dh_infonce_bwd(const dh_nce_pair* pairs_host, int n_pairs, int b, int B, int
                    const int* label0s, const int* excl0s, const float* row_lse, const float* g_row, float* dscale,
                    dh_stream_t stream);
 
+/* Linear(K -> V) + row-wise cross-entropy in ONE pass over the vocabulary, bf16 operands: the masked-LM head
+ * `text_label_predictor(word_features)` + `F.cross_entropy(pred[mask], labels[mask])` of declip.py:326-334 without the fp32 logits
+ * [n_masked, 49409] (1.2 GB per DeCLIP step at b = 512) ever reaching HBM.  X [n_pad][K] (rows >= n zero; n_pad % 256 == 0),
+ * W [V][K], bias [V] or NULL, labels [n].  Forward: row_loss / row_lse [n] (per-tile max / sum-exp partials in ws, merged by a
+ * finalize kernel).  Backward: dl [n_pad][ldd] bf16 = g_row * (softmax - onehot), recomputed tile by tile (zero for rows >= n
+ * and columns >= V) -- the operand of the two gradient GEMMs (dh_gemm).  Both fail (no fallback) on shapes the persistent kernel
+ * does not take. */
+int64_t dh_ce_fused_ws_bytes(int n_pad, int V);
+int dh_ce_fused_fwd(const void* X_bf16, const void* W_bf16, const float* bias, const int64_t* labels, int n, int n_pad, int V, int K,
+                    float* row_loss, float* row_lse, void* ws, int64_t ws_bytes, dh_stream_t stream);
+int dh_ce_fused_bwd(const void* X_bf16, const void* W_bf16, const float* bias, const int64_t* labels, const float* row_lse,
+                    const float* g_row, int n, int n_pad, int V, int K, void* dl_bf16, int64_t ldd, dh_stream_t stream);
 /* Row-wise softmax cross-entropy on MATERIALISED fp32 logits [rows,C] (leading dim ld): the form
  * loss_functions/loss.py:44-45 sees when handed tensors, and the MLM head CE (model/declip.py:326-334).
  * Rows whose label is outside [0,C) (e.g. -100, mask_tokens.py:17) give loss 0 / zero gradient. */

@@ -601,3 +601,38 @@ def test_infonce_weak_scaling_shape_with_self_pair_exclusion():
     assert rel_err(outs[0][0], tensors[0].grad) < 1e-4 and rel_err(outs[0][1], tensors[1].grad) < 1e-4
     assert rel_err(outs[1][0], tensors[2].grad) < 1e-4
     assert rel_err(dscale, sr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("n,V,K", [(300, 1000, 128), (1, 49409, 512), (5000, 49409, 512), (777, 4097, 256)])
+def test_ce_fused_forward_and_backward(n, V, K):
+    """dh_ce_fused_fwd / bwd (Linear + cross-entropy over the vocabulary in the epilogue of the persistent GEMM: no logits in HBM)
+    against F.cross_entropy on the same bf16-rounded operands: row losses / lse, dl = g (softmax - onehot) incl. the ragged last
+    column tile, the zero padding rows and the columns between V and the padded row length."""
+    ops = _ops()
+    bf = torch.bfloat16
+    n_pad = (n + 255) // 256 * 256
+    ldd = (V + 63) // 64 * 64
+    X = torch.zeros(n_pad, K)
+    X[:n] = rnd(n, K, seed=120)
+    W, bias = rnd(V, K, seed=121, scale=0.2), rnd(V, seed=122)
+    labels = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(123))
+    labels[0] = V - 1                                               # a label in the ragged last tile
+    Xb, Wb = X.to(bf), W.to(bf)
+    assert ops.ce_fused_ok(Xb.to(cuda), Wb.to(cuda))
+    row_loss, row_lse = ops.ce_fused_fwd(Xb.to(cuda), Wb.to(cuda), bias.to(cuda), labels.to(cuda), n)
+    logits = Xb[:n].double() @ Wb.double().t() + bias.double()
+    ref_lse = torch.logsumexp(logits, dim=1)
+    ref_loss = torch.nn.functional.cross_entropy(logits, labels, reduction="none")
+    assert float((row_lse.cpu().double() - ref_lse).abs().max()) <= 2e-5 * float(ref_lse.abs().max())
+    assert float((row_loss.cpu().double() - ref_loss).abs().max()) <= 2e-5 * float(ref_loss.abs().max()) + 1e-5
+    g = rnd(n, seed=124).abs() + 0.1
+    dl = ops.ce_fused_bwd(Xb.to(cuda), Wb.to(cuda), bias.to(cuda), labels.to(cuda), row_lse, g.to(cuda), n, ldd)
+    assert dl.shape == (n_pad, ldd) and dl.dtype == bf
+    ref = torch.softmax(logits, dim=1)
+    ref[torch.arange(n), labels] -= 1.0
+    ref = ref * g.double()[:, None]
+    got = dl.float().cpu().double()
+    assert float((got[:n, :V] - ref).abs().max()) <= 1e-2 * float(ref.abs().max())          # bf16 storage of dl
+    assert float(got[n:].abs().max() if n_pad > n else 0.0) == 0.0 and float(got[:, V:].abs().max() if ldd > V else 0.0) == 0.0
+    # row sums of dl vanish (softmax - onehot), up to bf16 rounding of ~V entries
+    assert float(got[:n].sum(1).abs().max()) <= 0.05 * float(g.max())
