@@ -139,10 +139,14 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    // blocks the masks below turn into -inf entirely (keys beyond the sequence, keys after every query of this wave under the
+    // causal mask) or whose queries are never stored: no MFMAs (wave-uniform test)
+    if (!(kb * 16 >= Lp || qb * 16 >= Lp || (causal && kb > qb))) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t kf = lds_frag(Ks + (kb * 16 + (lane & 15)) * RS + ks * 32 + 8 * (lane >> 4));
-      acc = mfma16(kf, qf[ks], acc);
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t kf = lds_frag(Ks + (kb * 16 + (lane & 15)) * RS + ks * 32 + 8 * (lane >> 4));
+        acc = mfma16(kf, qf[ks], acc);
+      }
     }
     s[kb] = acc;
   }
@@ -181,11 +185,13 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
   }
   __syncthreads();
   // O[q][d] = sum_key P[q][key] V[key][d]: A = P rows (this wave's queries), B = V via transpose reads
+  const int nks_live = qb * 16 >= Lp ? 0 : (causal ? min((Lp + 31) >> 5, ((qb + 1) * 16 + 31) >> 5) : (Lp + 31) >> 5);   // P is zero beyond
 #pragma unroll
   for (int db = 0; db < 4; ++db) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
+      if (ks >= nks_live) continue;
       const bool dead = KTAIL && ks == NKS - 1 && (lane >> 4) >= 2;
       bf16x8_t pf = kmask(lds_frag(Ps + (qb * 16 + (lane & 15)) * TS + ks * 32 + 8 * (lane >> 4)), dead);
       bf16x8_t vf = kmask(frag_tr(Vs, RS, ks * 32, db * 16, dead ? (lane & 31) : lane), dead);
@@ -305,6 +311,16 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
     for (int r = 0; r < 4; ++r) d_r[r] = Dq[qb * 16 + 4 * (lane >> 4) + r];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
+      const int key = kb * 16 + (lane & 15);
+      // a 16 x 16 block that the masks zero entirely -- keys or queries beyond the sequence (captions average 43 of 77 tokens),
+      // keys after every query of the block under the causal mask (10 of 25 blocks at full length) -- is written as zeros
+      // without its MFMAs and exponentials (wave-uniform test)
+      if (kb * 16 >= Lp || qb * 16 >= Lp || (causal && kb > qb)) {
+        const uint2 z = make_uint2(0u, 0u);
+        *reinterpret_cast<uint2*>(Pt + key * TS + qb * 16 + 4 * (lane >> 4)) = z;
+        *reinterpret_cast<uint2*>(dSt + key * TS + qb * 16 + 4 * (lane >> 4)) = z;
+        continue;
+      }
       f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -313,7 +329,6 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
         sacc = mfma16(qf[ks], kf, sacc);  // rows q, cols key
         pacc = mfma16(gf[ks], vf, pacc);  // dP[q][key]
       }
-      const int key = kb * 16 + (lane & 15);
       float p[4], ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -333,14 +348,16 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
   __syncthreads();
 
   // ---- phase 2: wave owns row block rb (keys for dV/dK, queries for dQ); contraction length L16
-  {
+  if (wave * 16 < Lp) {                    // (a row block beyond the sequence stores nothing)
     const int rb = wave;
     bf16_t* dq_g = dqkv + row0 * gs + h * HD;
+    const int nks_live = (Lp + 31) >> 5;   // contraction steps of 32 rows that hold anything: P^T / dS^T are zero beyond the sequence
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       f32x4_t av = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
+        if (ks >= nks_live) continue;
         const bool dead = KTAIL && ks == NKS - 1 && (lane >> 4) >= 2;
         const int ln = dead ? (lane & 31) : lane;           // dead lanes read in-bounds addresses, then get zeroed
         const int ro = (rb * 16 + (lane & 15)) * TS + ks * 32 + 8 * (ln >> 4);
