@@ -8,6 +8,7 @@
 bool dh_gemm_try_glds(const dh_gemm_args*, int, hipStream_t) { return false; }
 bool dh_gemm_try_v3(const dh_gemm_args*, int, hipStream_t) { return false; }
 bool dh_gemm_try_v4(const dh_gemm_args*, int, hipStream_t) { return false; }
+bool dh_gemm_try_v5(const dh_gemm_args*, hipStream_t) { return false; }
 bool dh_gemm_try_v4_group(const dh_gemm_args*, int, hipStream_t) { return false; }
 bool dh_maxsim_try_v4(const void*, const void*, int, int, int, int, int, float*, uint8_t*, hipStream_t) { return false; }
 bool dh_ce_try_v4_fwd(const void*, const void*, const float*, const long long*, int, int, int, int, float*, float*, float*, int64_t, hipStream_t) { return false; }
