@@ -300,18 +300,31 @@ __device__ __forceinline__ void ystage_commit(const YStage& st, float* Ys) {
 #pragma unroll
   for (int q = 0; q < 16; ++q) *reinterpret_cast<float4*>(dst + 4 * q) = st.v[q];
 }
+// D > 512: the 32 X rows no longer fit in LDS next to the Y tile -- only the 128 columns of the current pass are staged
+// ([32][132], re-read from L2 for every Y tile: + 25 % traffic on a kernel that is bound by the fp32 matrix rate)
+__device__ __forceinline__ void xpass_load(float* Xs, const float* __restrict__ X, int r0, int nx, int D, int d0) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = t + 256 * q, rr = idx >> 5, c = (idx & 31) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + rr < nx && d0 + c < D) v = *reinterpret_cast<const float4*>(X + (long)(r0 + rr) * D + d0 + c);
+    *reinterpret_cast<float4*>(Xs + rr * (MW + 4) + c) = v;
+  }
+}
 // Y row (inside the wave's 32) of accumulator register x for a lane in half h
 __device__ __forceinline__ int acc_row(int x, int h) { return (x >> 2) * 8 + h * 4 + (x & 3); }
 
 // S^T-fragment of one pass: sacc[x] += sum over the 128 staged columns of Y[w*32 + acc_row][k] * X[lane & 31][d0 + k]
 // (only the groups of 8 columns that exist: for D not a multiple of 128 the rest of the pass would read the uninitialised pad
 // of the X rows -- NaN bit patterns left in LDS by an earlier kernel times the staged zeros are NaN, not 0)
-__device__ __forceinline__ void logits_pass(f32x16_t& sacc, const float* Xs, int XS, const float* Ys, int d0, int D, int wave, int r, int h) {
+// Xp: column d0 of row 0 of the X rows in LDS (row stride XS)
+__device__ __forceinline__ void logits_pass(f32x16_t& sacc, const float* Xp, int XS, const float* Ys, int d0, int D, int wave, int r, int h) {
   const int ng = min(MW / 8, (D - d0) / 8);
 #pragma unroll 4
   for (int g = 0; g < ng; ++g) {
     const float4 a = *reinterpret_cast<const float4*>(Ys + (wave * 32 + r) * (MW + 4) + 8 * g + 4 * h);
-    const float4 b = *reinterpret_cast<const float4*>(Xs + r * XS + d0 + 8 * g + 4 * h);
+    const float4 b = *reinterpret_cast<const float4*>(Xp + r * XS + 8 * g + 4 * h);
     sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, sacc, 0, 0, 0);
     sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, sacc, 0, 0, 0);
     sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, sacc, 0, 0, 0);
@@ -319,12 +332,13 @@ __device__ __forceinline__ void logits_pass(f32x16_t& sacc, const float* Xs, int
   }
 }
 
+template <bool XRES>
 __global__ __launch_bounds__(256) void nce_fwd_mfma_kernel(PairTable pt, int b, int B, int D, const float* __restrict__ scale_p,
                                                            float* __restrict__ part, float* __restrict__ logits_out, int chunk_cols) {
   const float scale = *scale_p;
   DH_DYN_LDS_A16(float, sm);
-  const int XS = D + 4;
-  float* Xs = sm;                       // [32][D + 4]
+  const int XS = XRES ? D + 4 : MW + 4;
+  float* Xs = sm;                       // XRES: [32][D + 4] whole rows; else [32][132] the columns of the current pass
   float* Ys = Xs + MX * XS;             // [128][132]
   float* lab = Ys + MY * (MW + 4);      // [32] label logits
   float* red = lab + MX;                // [4 waves][32][3]
@@ -336,19 +350,22 @@ __global__ __launch_bounds__(256) void nce_fwd_mfma_kernel(PairTable pt, int b, 
   const float* K = pt.K[pair];
   const int r0 = blockIdx.x * MX;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
-  for (int i = t; i < MX * (D / 4); i += 256) {
-    const int rr = i / (D / 4), k4 = i % (D / 4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r0 + rr < b) v = *reinterpret_cast<const float4*>(Q + (long)(r0 + rr) * D + k4 * 4);
-    *reinterpret_cast<float4*>(Xs + rr * XS + k4 * 4) = v;
+  if (XRES) {
+    for (int i = t; i < MX * (D / 4); i += 256) {
+      const int rr = i / (D / 4), k4 = i % (D / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + rr < b) v = *reinterpret_cast<const float4*>(Q + (long)(r0 + rr) * D + k4 * 4);
+      *reinterpret_cast<float4*>(Xs + rr * XS + k4 * 4) = v;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   {  // label logit: 8 threads per row
     const int rr = t >> 3, part_i = t & 7;
     float a = 0.f;
     if (r0 + rr < b) {
       const float* kr = K + (long)(label0 + r0 + rr) * D;
-      for (int k = part_i; k < D; k += 8) a = fmaf(Xs[rr * XS + k], kr[k], a);
+      const float* xr = XRES ? Xs + rr * XS : Q + (long)(r0 + rr) * D;
+      for (int k = part_i; k < D; k += 8) a = fmaf(xr[k], kr[k], a);
     }
     a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
     if (part_i == 0) lab[rr] = a * scale;
@@ -367,10 +384,11 @@ __global__ __launch_bounds__(256) void nce_fwd_mfma_kernel(PairTable pt, int b, 
     for (int p = 0; p < npass; ++p) {
       __syncthreads();
       ystage_commit(st, Ys);
+      if (!XRES) xpass_load(Xs, Q, r0, b, D, p * MW);
       __syncthreads();
       if (p + 1 < npass) ystage_fetch(st, K, c0, cend, D, (p + 1) * MW);
       else if (c0 + MY < cend) ystage_fetch(st, K, c0 + MY, cend, D, 0);
-      logits_pass(sacc, Xs, XS, Ys, p * MW, D, wave, r, h);
+      logits_pass(sacc, XRES ? Xs + p * MW : Xs, XS, Ys, p * MW, D, wave, r, h);
     }
 #pragma unroll
     for (int x = 0; x < 16; ++x) {
@@ -405,15 +423,18 @@ __global__ __launch_bounds__(256) void nce_fwd_mfma_kernel(PairTable pt, int b, 
 
 // backward on the matrix pipe: per Y tile, 4 passes build the logits fragment, G goes to LDS TRANSPOSED ([y][x]: the lanes of
 // a wave write consecutive x), 4 more passes over the same Y columns accumulate dX[32][D] += G . Y with wave w owning the
-// w-th 32-column chunk of every pass (16 accumulator tiles of 32 x 32 over the 4 waves; D <= 512).
+// w-th 32-column chunk of every pass (16 accumulator tiles of 32 x 32 over the 4 waves = 512 columns of dX per block).  D > 512
+// (!XRES): blockIdx.x = (512-column chunk of dX, row block) -- every chunk's block rebuilds the logits over the whole of D and
+// sweeps its own columns, so the cost is (D / 512 + 1) / 2 of the ideal; still the matrix pipe instead of the VALU tile loop.
+template <bool XRES>
 __global__ __launch_bounds__(256) void nce_bwd_mfma_kernel(PairTable pt, int mode, int b, int B, int D, const float* __restrict__ scale_p,
                                                            const float* __restrict__ row_lse, const float* __restrict__ g_row,
                                                            float* __restrict__ dscale, int chunk_cols) {
   const float scale = *scale_p;
   DH_DYN_LDS_A16(float, sm);
-  const int XS = D + 4;
+  const int XS = XRES ? D + 4 : MW + 4;
   constexpr int GS = MX + 4;
-  float* Xs = sm;                        // [32][D + 4]
+  float* Xs = sm;                        // XRES: [32][D + 4]; else [32][132] the columns of the current logits pass
   float* Ys = Xs + MX * XS;              // [128][132]
   float* Gt = Ys + MY * (MW + 4);        // [128][36]  G transposed
   float* red = Gt + MY * GS;             // [8]
@@ -422,21 +443,25 @@ __global__ __launch_bounds__(256) void nce_bwd_mfma_kernel(PairTable pt, int mod
   const float* X = mode == 0 ? pt.Q[pair] : pt.K[pair];
   const float* Y = mode == 0 ? pt.K[pair] : pt.Q[pair];
   float* dX = mode == 0 ? pt.dQ[pair] : pt.dK[pair];
-  if (dX == nullptr && !(mode == 0 && dscale != nullptr)) return;     // gradient not wanted for this operand
   const int nx = mode == 0 ? b : B, ny_all = mode == 0 ? B : b;
+  const int npass = (D + MW - 1) / MW;
+  const int nrb = (nx + MX - 1) / MX;      // gridDim.x = nrb * (number of 512-column chunks of dX)
+  const int dchunk = XRES ? 0 : blockIdx.x / nrb;
+  const int gp0 = dchunk * 4, np_local = min(4, npass - gp0);       // this block's dX passes: gp0 .. gp0 + np_local
+  if (dX == nullptr && !(mode == 0 && dscale != nullptr && dchunk == 0)) return;     // gradient not wanted for this operand
   const int ybeg = blockIdx.z * chunk_cols, ny = min(ny_all, ybeg + chunk_cols);
   const bool chunked = gridDim.z > 1;
-  const int r0 = blockIdx.x * MX;
+  const int r0 = (XRES ? blockIdx.x : blockIdx.x % nrb) * MX;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
   const float* lse_p = row_lse + (long)pair * b;
   const float* g_p = g_row + (long)pair * b;
-  for (int i = t; i < MX * (D / 4); i += 256) {
-    const int rr = i / (D / 4), k4 = i % (D / 4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r0 + rr < nx) v = *reinterpret_cast<const float4*>(X + (long)(r0 + rr) * D + k4 * 4);
-    *reinterpret_cast<float4*>(Xs + rr * XS + k4 * 4) = v;
-  }
-  const int npass = (D + MW - 1) / MW;     // <= 4
+  if (XRES)
+    for (int i = t; i < MX * (D / 4); i += 256) {
+      const int rr = i / (D / 4), k4 = i % (D / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + rr < nx) v = *reinterpret_cast<const float4*>(X + (long)(r0 + rr) * D + k4 * 4);
+      *reinterpret_cast<float4*>(Xs + rr * XS + k4 * 4) = v;
+    }
   f32x16_t dacc[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p)
@@ -455,9 +480,10 @@ __global__ __launch_bounds__(256) void nce_bwd_mfma_kernel(PairTable pt, int mod
     for (int p = 0; p < npass; ++p) {
       __syncthreads();
       ystage_commit(st, Ys);
+      if (!XRES) xpass_load(Xs, X, r0, nx, D, p * MW);
       __syncthreads();
-      ystage_fetch(st, Y, c0, ny, D, ((p + 1) % npass) * MW);      // next logits pass, or pass 0 again for the dX sweep
-      logits_pass(sacc, Xs, XS, Ys, p * MW, D, wave, r, h);
+      ystage_fetch(st, Y, c0, ny, D, (p + 1 < npass ? p + 1 : gp0) * MW);      // next logits pass, or the first pass of the dX sweep
+      logits_pass(sacc, XRES ? Xs + p * MW : Xs, XS, Ys, p * MW, D, wave, r, h);
     }
     // G for this lane's X row against its 16 Y rows; stored transposed
 #pragma unroll
@@ -477,13 +503,13 @@ __global__ __launch_bounds__(256) void nce_bwd_mfma_kernel(PairTable pt, int mod
     // dX[32][D] += G[32][128] . Y[128][D]: pass p re-stages columns 128p.., wave w multiplies its 32-column chunk
 #pragma unroll
     for (int p = 0; p < 4; ++p) {          // unrolled: dacc[] must stay in registers (no dynamic indexing)
-      if (p < npass) {
+      if (p < np_local) {
         __syncthreads();                  // (p == 0: also publishes Gt)
         ystage_commit(st, Ys);
         __syncthreads();
-        if (p + 1 < npass) ystage_fetch(st, Y, c0, ny, D, (p + 1) * MW);
+        if (p + 1 < np_local) ystage_fetch(st, Y, c0, ny, D, (gp0 + p + 1) * MW);
         else if (c0 + MY < ny) ystage_fetch(st, Y, c0 + MY, ny, D, 0);
-        if (p * MW + wave * 32 < D) {
+        if ((gp0 + p) * MW + wave * 32 < D) {
 #pragma unroll 4
           for (int k0 = 0; k0 < MY; k0 += 8) {
 #pragma unroll
@@ -497,12 +523,12 @@ __global__ __launch_bounds__(256) void nce_bwd_mfma_kernel(PairTable pt, int mod
       }
     }
   }
-  // dacc[p][x] of lane (r, h): X row acc_row(x, h), column 128p + 32*wave + r
+  // dacc[p][x] of lane (r, h): X row acc_row(x, h), column 128 (gp0 + p) + 32*wave + r
   if (dX != nullptr) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int col = p * MW + wave * 32 + r;
-      if (p < npass && col < D) {
+      const int col = (gp0 + p) * MW + wave * 32 + r;
+      if (p < np_local && col < D) {
 #pragma unroll
         for (int x = 0; x < 16; ++x) {
           const int rr = r0 + acc_row(x, h);
@@ -514,7 +540,7 @@ __global__ __launch_bounds__(256) void nce_bwd_mfma_kernel(PairTable pt, int mod
       }
     }
   }
-  if (mode == 0 && dscale) {
+  if (mode == 0 && dscale && dchunk == 0) {
     __syncthreads();
     float tot = block_sum256(ds_acc, red);
     if (t == 0) atomicAdd(dscale, tot);
@@ -529,9 +555,12 @@ static int nce_chunk_cols_mfma(int rows, int cols, int n_pairs) {
   if (chunk < MY) chunk = MY;
   return chunk;
 }
-static bool nce_mfma_ok(int D) { return D % 32 == 0 && D >= 32 && D <= 512; }
-static size_t nce_fwd_mfma_lds(int D) { return (size_t)(MX * (D + 4) + MY * (MW + 4) + MX + 4 * MX * 3) * sizeof(float); }
-static size_t nce_bwd_mfma_lds(int D) { return (size_t)(MX * (D + 4) + MY * (MW + 4) + MY * (MX + 4) + 8) * sizeof(float); }
+// D <= 512: X rows resident in LDS; above (FILIP's embed_dim 768, the 3072 of the DeCLIP-88M configs): X staged per pass
+static bool nce_mfma_ok(int D) { return D % 32 == 0 && D >= 32 && D <= 8192; }
+static bool nce_xres(int D) { return D <= 512; }
+static int nce_xs(int D) { return nce_xres(D) ? D + 4 : MW + 4; }
+static size_t nce_fwd_mfma_lds(int D) { return (size_t)(MX * nce_xs(D) + MY * (MW + 4) + MX + 4 * MX * 3) * sizeof(float); }
+static size_t nce_bwd_mfma_lds(int D) { return (size_t)(MX * nce_xs(D) + MY * (MW + 4) + MY * (MX + 4) + 8) * sizeof(float); }
 
 // ---- plain row-wise softmax cross-entropy on materialised logits [rows, C] (fp32):
 // used for logits handed in as tensors (loss_functions/loss.py:44-45) and for the MLM head
@@ -621,7 +650,7 @@ extern "C" int dh_infonce_fwd(const dh_nce_pair* pairs, int n_pairs, int b, int 
   fill_table(pt, pairs, n_pairs, label0, label0s, excl0s);
   for (int i = 0; i < n_pairs; ++i) DH_REQUIRE(pt.label0[i] >= 0 && pt.label0[i] + b <= B, "dh_infonce_fwd: labels out of range");
   for (int i = 0; i < n_pairs; ++i) DH_REQUIRE(pt.Q[i] && pt.K[i], "dh_infonce_fwd: null feature pointer");
-  DH_REQUIRE(D <= 1024, "dh_infonce_fwd: D=%d > 1024", D);
+  DH_REQUIRE(nce_mfma_ok(D) || D <= 1024, "dh_infonce_fwd: D=%d (multiples of 32 up to 8192, anything up to 1024)", D);
   constexpr int RT = 32;
   int nchunk;
   if (nce_mfma_ok(D)) {                  // matrix-pipe kernel (fewer, larger column chunks: the workspace bound still holds)
@@ -629,9 +658,10 @@ extern "C" int dh_infonce_fwd(const dh_nce_pair* pairs, int n_pairs, int b, int 
     nchunk = dh_cdiv(B, chunk_cols);
     DH_REQUIRE(ws_bytes >= (int64_t)n_pairs * nchunk * b * 4 * (int64_t)sizeof(float), "dh_infonce_fwd: workspace too small");
     const size_t lds = nce_fwd_mfma_lds(D);
-    hipFuncSetAttribute((const void*)nce_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(nce_fwd_mfma_kernel, dim3(dh_cdiv(b, MX), n_pairs, nchunk), dim3(256), lds, st, pt, b, B, D, scale, (float*)ws,
-                       logits_out, chunk_cols);
+    auto kern = nce_xres(D) ? nce_fwd_mfma_kernel<true> : nce_fwd_mfma_kernel<false>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(dh_cdiv(b, MX), n_pairs, nchunk), dim3(256), lds, st, pt, b, B, D, scale, (float*)ws, logits_out,
+                       chunk_cols);
   } else {
     const int chunk_cols = nce_chunk_cols(b, B, n_pairs, RT);
     nchunk = dh_cdiv(B, chunk_cols);
@@ -673,17 +703,19 @@ extern "C" int dh_infonce_bwd(const dh_nce_pair* pairs, int n_pairs, int b, int 
   };
   auto launch_mfma = [&](int mode) {
     const size_t lds = nce_bwd_mfma_lds(D);
-    hipFuncSetAttribute((const void*)nce_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto kern = nce_xres(D) ? nce_bwd_mfma_kernel<true> : nce_bwd_mfma_kernel<false>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int nx = mode == 0 ? b : B, ny = mode == 0 ? B : b;
-    const int chunk_cols = nce_chunk_cols_mfma(nx, ny, n_pairs);
+    const int ndc = nce_xres(D) ? 1 : dh_cdiv(dh_cdiv(D, MW), 4);          // 512-column chunks of dX, one block each
+    const int chunk_cols = nce_chunk_cols_mfma(nx * ndc, ny, n_pairs);
     const int nz = dh_cdiv(ny, chunk_cols);
     if (nz > 1)
       for (int i = 0; i < n_pairs; ++i) {
         void* dst = mode == 0 ? (void*)pt.dQ[i] : (void*)pt.dK[i];
         if (dst) hipMemsetAsync(dst, 0, sizeof(float) * (size_t)nx * D, st);
       }
-    hipLaunchKernelGGL(nce_bwd_mfma_kernel, dim3(dh_cdiv(nx, MX), n_pairs, nz), dim3(256), lds, st, pt, mode, b, B, D, scale, row_lse,
-                       g_row, dscale, chunk_cols);
+    hipLaunchKernelGGL(kern, dim3(dh_cdiv(nx, MX) * ndc, n_pairs, nz), dim3(256), lds, st, pt, mode, b, B, D, scale, row_lse, g_row,
+                       dscale, chunk_cols);
   };
   if (nce_mfma_ok(D)) {
     launch_mfma(0);

@@ -66,6 +66,16 @@ def initialize(backend="nccl"):
     if backend == "nccl" and torch.cuda.is_available():
         kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
     tdist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    if os.environ.get("DH_COMM_NATIVE", "0") == "1" and torch.cuda.is_available():
+        # the step's three collectives on the library's own communicator context (csrc/comm.hip) instead of ProcessGroupNCCL
+        from . import comm_native
+        comm_native.bootstrap(get_local_rank())
+
+
+def native_comm():
+    """The library-owned communicator context (declip_amd.comm_native) when DH_COMM_NATIVE=1 set one up, else None."""
+    from . import comm_native
+    return comm_native.context()
 
 
 def step_barrier():
@@ -116,6 +126,12 @@ def all_gather_cat(x):
     """[b, ...] -> [B, ...] differentiable gather (CLIP.all_gather, clip.py:113-116)."""
     if not is_dist():
         return x
+    comm = native_comm()
+    if comm is not None and x.is_cuda:
+        from .comm_native import AllGatherPackedNative
+        out = AllGatherPackedNative.apply(comm, x)
+        comm.wait(x.device)
+        return out.reshape((out.shape[0],) + tuple(x.shape[1:]))
     return _AllGatherPacked.apply(x)
 
 
@@ -144,14 +160,16 @@ class GatherHandle:
     """all_gather_cat_many_async(): the packed all-gather is in flight; result() orders the CALLER's current stream behind it and
     hands out the gathered tensors (rank-major rows).  Not distributed / CPU tensors: the inputs / a synchronous gather."""
 
-    def __init__(self, tensors=None, gathered=None, dims=None, stream=None):
-        self._tensors, self._gathered, self._dims, self._stream = tensors, gathered, dims, stream
+    def __init__(self, tensors=None, gathered=None, dims=None, stream=None, native=None):
+        self._tensors, self._gathered, self._dims, self._stream, self._native = tensors, gathered, dims, stream, native
 
     def result(self):
         if self._tensors is not None:
             return self._tensors
         g = self._gathered
-        if self._stream is not None:
+        if self._native is not None:
+            self._native.wait(g.device)                # the library's communication stream -> this stream (one event)
+        elif self._stream is not None:
             cur = torch.cuda.current_stream(g.device)
             cur.wait_stream(self._stream)
             g.record_stream(cur)                       # allocated on the comm stream, consumed on this one
@@ -166,6 +184,11 @@ def all_gather_cat_many_async(tensors):
     if not is_dist():
         return GatherHandle(tensors=tensors)
     dims = [t[0].numel() for t in tensors]
+    comm = native_comm()
+    if comm is not None and tensors[0].is_cuda:
+        from .comm_native import AllGatherPackedNative
+        gathered = AllGatherPackedNative.apply(comm, *[t.reshape(t.shape[0], -1) for t in tensors])
+        return GatherHandle(gathered=gathered, dims=dims, native=comm)
     packed = tensors[0].reshape(tensors[0].shape[0], -1) if len(tensors) == 1 else torch.cat([t.reshape(t.shape[0], -1) for t in tensors], dim=1)
     if not packed.is_cuda or os.environ.get("DH_COMM_STREAM", "1") == "0":
         return GatherHandle(gathered=_AllGatherPacked.apply(packed), dims=dims)
@@ -201,9 +224,10 @@ class FlatReducer:
         self.runs = []       # coalesced ready-but-not-launched [lo, hi)
         self.works = []
         self.events = []     # (lo, hi, stream id, event): ranges finished on a tower side stream (FlatParams.side_stream)
+        self.native = None   # the library's communicator context, once a bucket went through it this step
 
     def begin(self):
-        self.done, self.runs, self.works, self.events, self.staged = [], [], [], [], []
+        self.done, self.runs, self.works, self.events, self.staged, self.native = [], [], [], [], [], None
 
     @staticmethod
     def distributed():
@@ -221,7 +245,11 @@ class FlatReducer:
                     cur.wait_event(ev)
         if is_dist():
             seg = self.flat.flat_g[lo:hi]
-            if self.grad_dtype is not None and self.grad_dtype != seg.dtype:
+            comm = native_comm()
+            if comm is not None and seg.is_cuda:
+                comm.allreduce_bucket(seg, bf16=(self.grad_dtype == torch.bfloat16))
+                self.native = comm
+            elif self.grad_dtype is not None and self.grad_dtype != seg.dtype:
                 low = seg.to(self.grad_dtype)
                 self.staged.append((tdist.all_reduce(low, op=tdist.ReduceOp.SUM, async_op=True), lo, hi, low))
             else:
@@ -263,6 +291,9 @@ class FlatReducer:
             w.wait()
             self.flat.flat_g[lo:hi].copy_(low)
         self.staged = []
+        if self.native is not None:
+            self.native.wait(self.flat.flat_g.device)
+            self.native = None
 
 
 class DistModule(torch.nn.Module):

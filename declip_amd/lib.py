@@ -109,6 +109,15 @@ _PROTOS = {
     "dh_adamw": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
     "dh_adamw_segmented": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int, c_float, c_float, c_float, c_int, c_float, _P]),
     "dh_cast": (c_int, [c_int, _P, c_int, _P, c_int64, _P]),
+    "dh_comm_unique_id": (c_int, [_P, c_int64]),
+    "dh_init": (c_void_p, [c_int, c_int, c_int, _P]),
+    "dh_finalize": (c_int, [c_void_p]),
+    "dh_ctx_info": (c_int, [c_void_p, POINTER(c_int)]),
+    "dh_comm_stream": (c_void_p, [c_void_p]),
+    "dh_comm_wait": (c_int, [c_void_p, _P]),
+    "dh_allgather_packed": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int), c_int, c_int, c_int, _P, _P]),
+    "dh_reducescatter_packed": (c_int, [c_void_p, _P, POINTER(c_void_p), POINTER(c_int), c_int, c_int, c_int, _P, _P]),
+    "dh_allreduce_bucket": (c_int, [c_void_p, _P, c_int64, _P, _P]),
 }
 
 _lib = None

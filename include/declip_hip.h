@@ -391,6 +391,35 @@ int dh_bpe_vocab_size(void* handle);
 int dh_bpe_encode(void* handle, const char* texts, const int64_t* offsets /* n + 1 */, int n, int ctx,
                   int64_t* out /* [n][ctx] */, int32_t* status /* [n] */, int n_threads);
 
+/* ---- communicator context: the collectives of the data-parallel step on RCCL / xGMI -----------------
+ * Replaces the `linklink` calls of the step (linklink/__init__.py:13-71): AllGather.forward/backward (model/clip.py:25-49:
+ * one all_gather per feature tensor, backward = all-reduce of the whole gathered gradient + slice) and DistModule's
+ * per-parameter gradient all-reduce hooks (utils/dist.py:49-88).  A context owns the RCCL communicator, a communication stream
+ * and the events ordering it against the caller's streams.  Every call ENQUEUES only: the communication stream first waits for
+ * what `stream` (the producer of the operands) holds at the time of the call; consumers are ordered with dh_comm_wait().
+ * RCCL is bound at run time (dlopen) by dh_comm_unique_id / dh_init; any RCCL error fails the call (dh_last_error()).
+ *   dh_comm_unique_id   rank 0: the 128-byte ncclUniqueId every rank passes to dh_init (exchanged by the launcher's own means)
+ *   dh_init             binds `local_rank`'s device, creates the communicator (collective over all ranks); NULL on error
+ *   dh_allgather_packed n tensors [rows][cols_k] (elem_bytes 2 | 4, rows of 16-byte multiples) -> gathered [world*rows][sum cols]
+ *                       rank-major, ONE all-gather (the own rows are packed straight into the own slot: in-place collective)
+ *   dh_reducescatter_packed  backward of it: grad_gathered [world*rows][sum cols] --reduce-scatter(SUM)--> scratch [rows][sum cols]
+ *                       --split--> dst_k [rows][cols_k]; same sum as the reference's all-reduce + slice, world x less traffic
+ *   dh_allreduce_bucket SUM all-reduce of grad[0..n) (fp32, in place).  bf16_stage != NULL ([n] bf16): the bucket crosses the
+ *                       links as bf16 (cast, all-reduce, cast back -- all on the communication stream) */
+#define DH_COMM_MAX_TENSORS 8
+typedef struct dh_ctx dh_ctx;
+int dh_comm_unique_id(void* id_out, int64_t bytes /* >= 128 */);
+dh_ctx* dh_init(int rank, int world, int local_rank, const void* nccl_unique_id);
+int dh_finalize(dh_ctx* ctx);
+int dh_ctx_info(const dh_ctx* ctx, int* out3 /* rank, world, device */);
+void* dh_comm_stream(const dh_ctx* ctx);                 /* the hipStream_t of the context (for profilers / external events) */
+int dh_comm_wait(dh_ctx* ctx, dh_stream_t stream);       /* `stream` waits for every collective enqueued so far */
+int dh_allgather_packed(dh_ctx* ctx, const void* const* src, const int* cols, int n, int rows, int elem_bytes, void* gathered,
+                        dh_stream_t stream);
+int dh_reducescatter_packed(dh_ctx* ctx, const void* grad_gathered, void* const* dst, const int* cols, int n, int rows, int elem_bytes,
+                            void* scratch, dh_stream_t stream);
+int dh_allreduce_bucket(dh_ctx* ctx, float* grad, int64_t n, void* bf16_stage, dh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,7 +78,10 @@ def emu_ops(sources, symbols):
 ALL_SOURCES = ["embed.hip", "layernorm.hip", "declip_ops.hip", "filip.hip", "infonce.hip", "attention.hip", "gemm.hip", "resnet_ops.hip",
                "emu_stubs.cpp"]
 _NOT_EMULATED = {"dh_bpe_create", "dh_bpe_destroy", "dh_bpe_vocab_size", "dh_bpe_encode", "dh_version", "dh_device_info", "dh_gemm_v4_enable",
-                 "dh_last_error"}
+                 "dh_last_error",
+                 # the communicator context is RCCL + HIP streams / events: nothing of it exists on the host
+                 "dh_comm_unique_id", "dh_init", "dh_finalize", "dh_ctx_info", "dh_comm_stream", "dh_comm_wait", "dh_allgather_packed",
+                 "dh_reducescatter_packed", "dh_allreduce_bucket"}
 
 
 def all_symbols():

@@ -84,12 +84,12 @@ def test_two_ranks_on_one_gpu_match_two_reference_ranks(streams, bucket_bytes):
     assert q.get() == "ok"
 
 
-def _rccl_worker(port, out):
+def _rccl_worker(port, out, native=False):
     """One rank, backend nccl (= RCCL), DH_DIST_FORCE=1: the packed all-gather / reduce-scatter autograd, the flat parameter
     broadcast and the bucketed asynchronous all-reduce launched from both tower streams all go through RCCL; with one rank
     every collective is the identity, so the step must reproduce the non-distributed one."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                      DH_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      DH_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", DH_COMM_NATIVE="1" if native else "0")
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch.distributed as dist
@@ -100,6 +100,9 @@ def _rccl_worker(port, out):
     from declip_amd.testing import build_clip
     dd.initialize("nccl")
     assert dist.get_backend() == "nccl" and dd.is_dist()
+    assert (dd.native_comm() is not None) == native
+    if native:
+        _native_primitives(dd.native_comm())
     cfg, b, seed = synth.VITB32, 256, 4
     images = synth.synth_images(b, res=cfg["res"], seed=seed).cuda()
     ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"]).cuda()
@@ -131,10 +134,46 @@ def _rccl_worker(port, out):
     dist.destroy_process_group()
 
 
-def test_one_rank_rccl_collectives_are_the_identity():
+def _native_primitives(comm):
+    """The communicator context of the C-ABI (dh_init / dh_allgather_packed / dh_reducescatter_packed / dh_allreduce_bucket) with one
+    rank: every collective is the identity, what is checked is the packing, the split, the bf16 staging and the event ordering
+    (operands produced on the compute stream right before the call, results consumed right after dh_comm_wait)."""
+    from declip_amd.comm_native import AllGatherPackedNative
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    for dtype in (torch.float32, torch.bfloat16):
+        srcs = [torch.randn(96, c, generator=g).to(dtype).to(dev).requires_grad_() for c in (512, 24, 16 * 64)]
+        scaled = [t * 2.0 for t in srcs]                       # produced on the compute stream: the gather must wait for it
+        packed = AllGatherPackedNative.apply(comm, *scaled)
+        comm.wait(dev)
+        assert packed.shape == (96, 512 + 24 + 1024)
+        assert torch.equal(packed, torch.cat(scaled, dim=1))
+        w = torch.randn(packed.shape, generator=g).to(dtype).to(dev)
+        (packed * w).sum().backward()                          # reduce-scatter + split, consumed by autograd's accumulation
+        torch.cuda.synchronize()
+        off = 0
+        for t in srcs:
+            assert torch.equal(t.grad, 2.0 * w[:, off:off + t.shape[1]]), dtype
+            off += t.shape[1]
+    flat = torch.randn(3_000_003, generator=g).to(dev)
+    ref = flat.clone()
+    seg = flat[64:64 + 2_000_011]
+    comm.allreduce_bucket(seg, bf16=False)
+    comm.wait(dev)
+    assert torch.equal(flat, ref)
+    comm.allreduce_bucket(seg, bf16=True)                      # crosses as bf16: the bucket comes back rounded, its neighbours untouched
+    comm.wait(dev)
+    assert torch.equal(flat[64:64 + 2_000_011], ref[64:64 + 2_000_011].bfloat16().float())
+    assert torch.equal(flat[:64], ref[:64]) and torch.equal(flat[64 + 2_000_011:], ref[64 + 2_000_011:])
+    with pytest.raises(Exception, match="16 bytes"):
+        comm.all_gather_packed([torch.zeros(4, 3, device=dev)])
+
+
+@pytest.mark.parametrize("native", [False, True], ids=["process_group", "library_context"])
+def test_one_rank_rccl_collectives_are_the_identity(native):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q, native))
     p.start()
     p.join(300)
     if p.is_alive():

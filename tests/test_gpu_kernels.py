@@ -247,8 +247,10 @@ def _poison_lds(ops):
 
 
 @pytest.mark.parametrize("b,B,D,label0", [(8, 8, 64, 0), (40, 120, 512, 40), (70, 70, 256, 0), (33, 99, 768, 66),
-                                          (96, 1160, 128, 1000), (520, 520, 64, 0)])
+                                          (96, 1160, 128, 1000), (520, 520, 64, 0), (130, 260, 1024, 130), (40, 72, 3072, 8)])
 def test_infonce(b, B, D, label0):
+    """D <= 512: X rows resident in LDS; D = 768 / 1024 / 3072 (FILIP's embed_dim, the DeCLIP-88M configs): X staged per pass, dX in
+    512-column chunks over blockIdx.x -- all on the fp32 matrix pipe."""
     ops = _ops()
     P = 2
     scale = torch.tensor([14.3])

@@ -35,6 +35,7 @@ CASES = [
     ("test_infonce", (8, 8, 64, 0)),
     ("test_infonce", (40, 120, 512, 40)),
     ("test_infonce", (33, 99, 768, 66)),
+    ("test_infonce", (40, 140, 1280, 100)),
     ("test_ce_rows", ()),
     ("test_adamw_matches_torch", ()),
     ("test_bn1d_groups", (BF16, True)),
