@@ -62,6 +62,8 @@ _PROTOS = {
     "dh_attn_pooled_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "dh_text_embed_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "dh_text_embed_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, POINTER(c_int64), c_int, _P]),
+    "dh_embed_table_grad_ws_bytes": (c_int64, [c_int, c_int]),
+    "dh_embed_table_grad": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, _P]),
     "dh_text_embed_packed_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "dh_packed_pos_grad": (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P, _P]),
     "dh_image_prep_u8": (c_int, [_P, c_int, c_int, c_int, _P, _P, POINTER(c_float), POINTER(c_float), _P, c_int, c_int, c_int, c_int, _P]),

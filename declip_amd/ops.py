@@ -204,13 +204,35 @@ def text_embed_fwd(ids, table, pos, dtype):
     return x
 
 
+_EMBED_WS = {}
+
+
+def embed_table_grad(ids, dx, dtable):
+    """dtable [vocab, d] += sum over rows r of dx[r] at row ids[r]: sort-by-id segmented reduction (dh_embed_table_grad).  The scratch
+    is cached per device and size (created in the eager warm-up steps, so a captured step replays with it)."""
+    rows, d = ids.numel(), dx.shape[-1]
+    _req(dx.numel() == rows * d and dtable.dim() == 2 and dtable.shape[1] == d and dtable.dtype == torch.float32 and ids.dtype == torch.int64,
+         "embed_table_grad: ids [rows] int64, dx [rows, d], dtable [vocab, d] fp32")
+    vocab = dtable.shape[0]
+    need = L.load().dh_embed_table_grad_ws_bytes(rows, vocab)
+    key = (str(dx.device), need)
+    ws = _EMBED_WS.get(key)
+    if ws is None:
+        ws = _EMBED_WS[key] = torch.empty(need // 4, device=dx.device, dtype=torch.int32)
+    check(L.load().dh_embed_table_grad(dt(dx), ptr(_contig(ids, "ids")), ptr(_contig(dx, "dx")), ptr(_contig(dtable, "dtable")), rows, d, vocab,
+                                       ptr(ws), need, stream()), "dh_embed_table_grad")
+
+
 def text_embed_bwd(ids, dx, dtable, dpos, hot_ids=(0,)):
-    """hot_ids: ids that occur in (almost) every caption (pad, SOT, EOT) -- reduced without atomic contention."""
+    """Token table by the sorted segmented reduction (no per-element atomics; `hot_ids` is kept for callers of the scatter-add entry
+    dh_text_embed_bwd and unused here), positions by the batch reduction."""
     b, Lq = ids.shape
     d = dx.shape[-1]
-    hot = (ctypes.c_int64 * max(1, len(hot_ids)))(*hot_ids)
-    check(L.load().dh_text_embed_bwd(dt(dx), ptr(ids), ptr(dx), ptr(dtable), ptr(dpos), b, Lq, d, hot, len(hot_ids), stream()),
-          "dh_text_embed_bwd")
+    if dtable is not None:
+        embed_table_grad(ids, dx, dtable)
+    if dpos is not None:
+        hot = (ctypes.c_int64 * 1)(0)
+        check(L.load().dh_text_embed_bwd(dt(dx), ptr(ids), ptr(dx), None, ptr(dpos), b, Lq, d, hot, 0, stream()), "dh_text_embed_bwd")
 
 
 def text_embed_packed_fwd(ids_p, pos_idx, table, pos, dtype, rows, rows_pad):
@@ -227,9 +249,7 @@ def text_embed_packed_bwd(ids_p, cu, dx, dtable, dpos, rows, Lmax, hot_ids=()):
     """gradients of the packed embedding: token table by scatter-add over the packed ids, positions by a per-position reduction."""
     d = dx.shape[1]
     if dtable is not None:
-        hot = (ctypes.c_int64 * max(1, len(hot_ids)))(*hot_ids)
-        check(L.load().dh_text_embed_bwd(dt(dx), ptr(_contig(ids_p, "ids")), ptr(_contig(dx, "dx")), ptr(dtable), None, rows, 1, d, hot,
-                                         len(hot_ids), stream()), "dh_text_embed_bwd")
+        embed_table_grad(ids_p[:rows], dx[:rows], dtable)
     if dpos is not None:
         _req(cu.dtype == torch.int32, 'cu.dtype == torch.int32')
         check(L.load().dh_packed_pos_grad(dt(dx), ptr(dx), ptr(_contig(cu, "cu")), cu.numel() - 1, Lmax, d, ptr(dpos), stream()),

@@ -158,6 +158,13 @@ int dh_text_embed_fwd(int dtype, const int64_t* ids, const float* table, const f
                       dh_stream_t stream);
 int dh_text_embed_bwd(int dtype, const int64_t* ids, const void* dx, float* dtable, float* dpos, int b, int L, int d,
                       const int64_t* hot_ids_host, int n_hot, dh_stream_t stream);
+/* The token-table part of it as a sort-by-id segmented reduction: rows counting-sorted by id (one integer atomic per ROW), runs of
+ * equal ids summed in registers by one wave per 16 sorted rows and added to dtable [vocab][d] with plain 16-byte stores; only
+ * runs longer than a wave's chunk (frequent tokens) flush with float atomics, once per 16 rows.  ids outside [0, vocab) are
+ * skipped.  ws: caller scratch of dh_embed_table_grad_ws_bytes(rows, vocab).  d % 8 == 0. */
+int64_t dh_embed_table_grad_ws_bytes(int rows, int vocab);
+int dh_embed_table_grad(int dtype, const int64_t* ids, const void* dx, float* dtable, int rows, int d, int vocab, void* ws,
+                        int64_t ws_bytes, dh_stream_t stream);
 /* Packed (variable-length) captions.  Under the causal mask a token never attends to a later one and only the <|endoftext|>
  * row is pooled (text_encoder/text_transformer.py:136-142,203), so the rows after EOT of the reference's [b][77] layout are dead
  * work; the packed text tower keeps only the rows up to and including EOT: [rows = sum len_i][d], zero rows up to rows_pad

@@ -117,6 +117,10 @@ def text_embed_fwd(ids, table, pos, dtype):
     return (table[ids] + pos).reshape(b * L, -1).to(dtype)
 
 
+def embed_table_grad(ids, dx, dtable):
+    dtable.index_add_(0, ids.reshape(-1), dx.reshape(ids.numel(), -1).float())
+
+
 def text_embed_bwd(ids, dx, dtable, dpos, hot_ids=(0,)):
     b, L = ids.shape
     if dtable is not None:
@@ -403,7 +407,7 @@ attnpool_tokens_bwd = _emulated("attnpool_tokens_bwd")
 # ---------------------------------------------------------------------------------------------
 # packed captions / pooled last block (DH_TEXT_PACKED, DH_POOLED_LAST): likewise the real wrappers on the host-emulated kernels
 # ---------------------------------------------------------------------------------------------
-_SEQ_SYMS = ["dh_text_embed_packed_fwd", "dh_text_embed_bwd", "dh_packed_pos_grad", "dh_attn_varlen_fwd", "dh_attn_varlen_bwd",
+_SEQ_SYMS = ["dh_text_embed_packed_fwd", "dh_text_embed_bwd", "dh_embed_table_grad", "dh_embed_table_grad_ws_bytes", "dh_packed_pos_grad", "dh_attn_varlen_fwd", "dh_attn_varlen_bwd",
              "dh_attn_pooled_fwd", "dh_attn_pooled_bwd"]
 _SEQ_ORIG = {n: getattr(_real_ops, n) for n in ("text_embed_packed_fwd", "text_embed_packed_bwd", "attn_varlen_fwd", "attn_varlen_bwd",
                                                 "attn_pooled_fwd", "attn_pooled_bwd")}

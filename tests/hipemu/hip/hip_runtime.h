@@ -77,6 +77,7 @@ static inline T __shfl(T v, int src, int width = 64) {
 }
 // lanes of a wave run in lockstep on the hardware; here they are independent fibers, so a wave barrier must really wait
 static inline void emu_wave_barrier() { const char c = 0; (void)emu_wave_gather(&c, 1); }
+#define __builtin_amdgcn_readlane(v, l) __shfl((v), (l))
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_s_barrier() emu_syncthreads()

@@ -190,6 +190,29 @@ def test_text_embed(dtype):
     assert rel_err(dp, dx.double().view(b, L, d).sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("rows,d,V,dtype", [(5000, 512, 3000, torch.bfloat16), (700, 520, 90, torch.float32), (33, 768, 49408, torch.bfloat16),
+                                            (22016, 512, 49408, torch.bfloat16)])
+def test_embed_table_grad_sorted_segments(rows, d, V, dtype):
+    """dh_embed_table_grad: counting sort by id + one wave per 16 sorted rows.  Zipf-like ids (runs far longer than a wave's chunk next
+    to ids that occur once), a table that already holds gradient, ids outside the vocabulary (skipped), d not a multiple of 512
+    (lanes masked off in the column loop), twice in a row through the cached workspace."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows + d)
+    u = torch.rand(rows, generator=g)
+    ids = (V * u ** 3).long().clamp_(0, V - 1)             # cubic: a few very frequent ids, a long tail of singletons
+    ids[::97] = 1                                            # one run of ~rows/97 rows
+    ids[5] = -1
+    ids[7] = V + 3
+    dx = rnd(rows, d, seed=3).to(dtype)
+    base = rnd(V, d, seed=4)
+    keep = (ids >= 0) & (ids < V)
+    ref = base.double().index_add_(0, ids[keep], dx.double()[keep])
+    for _ in range(2):
+        dt = base.clone().to(cuda)
+        ops.embed_table_grad(ids.to(cuda), dx.to(cuda), dt)
+        assert rel_err(dt, ref) < 2e-6                       # fp32 sums of at most a few hundred terms
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_vision_embed(dtype):
     ops = _ops()

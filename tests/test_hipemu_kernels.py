@@ -31,6 +31,8 @@ CASES = [
     ("test_attention", (F32, 1, 16, 2, True)),
     ("test_text_embed", (BF16,)),
     ("test_vision_embed", (F32,)),
+    ("test_embed_table_grad_sorted_segments", (700, 520, 90, F32)),
+    ("test_embed_table_grad_sorted_segments", (1500, 512, 3000, BF16)),
     ("test_pool_and_l2norm", (BF16,)),
     ("test_infonce", (8, 8, 64, 0)),
     ("test_infonce", (40, 120, 512, 40)),
