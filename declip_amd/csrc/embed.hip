@@ -407,22 +407,53 @@ __global__ __launch_bounds__(256) void embed_hist_kernel(const int64_t* __restri
     if (id >= 0 && id < V) atomicAdd(count + id, 1);
   }
 }
-// exclusive prefix sum of count[V] -> cursor[V]; one block of 1024 threads, thread t owns a contiguous run of bins
+// exclusive prefix sum of count[V] -> cursor[V]; one block of 1024 threads, thread t owns 64 consecutive bins of every round of
+// 65536 bins (a CLIP vocabulary is one round), read as 16 int4 loads issued back to back (one memory latency, not 64)
 __global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict__ count, int* __restrict__ cursor, int V) {
   __shared__ int part[1024];
-  const int t = threadIdx.x, per = (V + 1023) / 1024, lo = min(V, t * per), hi = min(V, lo + per);
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += count[i];
-  part[t] = s;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan
-    const int v = t >= off ? part[t - off] : 0;
+  __shared__ int carry_s;
+  const int t = threadIdx.x;
+  if (t == 0) carry_s = 0;
+  for (int base = 0; base < V; base += 65536) {
+    const int lo = base + t * 64;
+    int4 c[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i0 = lo + 4 * q;
+      if (i0 + 3 < V) c[q] = *reinterpret_cast<const int4*>(count + i0);       // (V * 4 bytes after a 16-byte aligned base)
+      else c[q] = make_int4(i0 < V ? count[i0] : 0, i0 + 1 < V ? count[i0 + 1] : 0, i0 + 2 < V ? count[i0 + 2] : 0, 0);
+    }
+    int s = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += c[q].x + c[q].y + c[q].z + c[q].w;
+    part[t] = s;
     __syncthreads();
-    part[t] += v;
+    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan
+      const int v = t >= off ? part[t - off] : 0;
+      __syncthreads();
+      part[t] += v;
+      __syncthreads();
+    }
+    int run = carry_s + part[t] - s;                     // exclusive
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i0 = lo + 4 * q;
+      int4 o;
+      o.x = run; run += c[q].x;
+      o.y = run; run += c[q].y;
+      o.z = run; run += c[q].z;
+      o.w = run; run += c[q].w;
+      if (i0 + 3 < V) *reinterpret_cast<int4*>(cursor + i0) = o;
+      else {
+        if (i0 < V) cursor[i0] = o.x;
+        if (i0 + 1 < V) cursor[i0 + 1] = o.y;
+        if (i0 + 2 < V) cursor[i0 + 2] = o.z;
+      }
+    }
+    __syncthreads();
+    if (t == 1023) carry_s += part[1023];
     __syncthreads();
   }
-  int run = part[t] - s;                               // exclusive
-  for (int i = lo; i < hi; ++i) { cursor[i] = run; run += count[i]; }
 }
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ ids, int rows, int V, int* __restrict__ cursor,
                                                             int* __restrict__ perm, int* __restrict__ sid) {
@@ -494,7 +525,8 @@ __global__ __launch_bounds__(256) void embed_segreduce_kernel(const T* __restric
   }
 }
 
-extern "C" int64_t dh_embed_table_grad_ws_bytes(int rows, int vocab) { return (int64_t)(2 * (int64_t)vocab + 2 * (int64_t)rows) * 4; }
+static inline int64_t vocab_slot(int vocab) { return ((int64_t)vocab + 3) / 4 * 4; }      // 16-byte aligned sections
+extern "C" int64_t dh_embed_table_grad_ws_bytes(int rows, int vocab) { return (2 * vocab_slot(vocab) + 2 * (int64_t)rows) * 4; }
 
 extern "C" int dh_embed_table_grad(int dtype, const int64_t* ids, const void* dx, float* dtable, int rows, int d, int vocab, void* ws,
                                    int64_t ws_bytes, dh_stream_t stream) {
@@ -502,9 +534,10 @@ extern "C" int dh_embed_table_grad(int dtype, const int64_t* ids, const void* dx
   DH_REQUIRE(ids && dx && dtable && rows > 0 && vocab > 0 && d > 0 && d % 8 == 0, "dh_embed_table_grad: bad args (d %% 8 == 0)");
   DH_REQUIRE(ws && ws_bytes >= dh_embed_table_grad_ws_bytes(rows, vocab), "dh_embed_table_grad: workspace too small");
   DH_REQUIRE(dtype == DH_BF16 || dtype == DH_F32, "dh_embed_table_grad: bad dtype");
+  DH_REQUIRE(((uintptr_t)ws & 15) == 0, "dh_embed_table_grad: workspace not 16-byte aligned");
   int* count = (int*)ws;
-  int* cursor = count + vocab;
-  int* perm = cursor + vocab;
+  int* cursor = count + vocab_slot(vocab);
+  int* perm = cursor + vocab_slot(vocab);
   int* sid = perm + rows;
   if (hipMemsetAsync(count, 0, sizeof(int) * (size_t)vocab, st) != hipSuccess) DH_FAIL(DH_ERR_LAUNCH, "dh_embed_table_grad: memset failed");
   const int g = grid_for(rows);

@@ -42,6 +42,9 @@
 #define V4_ABL 0
 #endif
 
+#ifndef V4_PIPE_EPI
+#define V4_PIPE_EPI 1     // bf16 epilogue in four pipelined quarter passes (0: the two staged passes of round 1)
+#endif
 #ifndef V4_TRACE
 #define V4_TRACE 0
 #endif
@@ -750,6 +753,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     TRACE();                                 // [1] main loop done
 
     // ---- next work item: request the four half-tiles of its K-tile 0 into ring buffer 0 BEFORE the epilogue
+    constexpr bool STORE_MODE = MODE == MODE_STORE || MODE == MODE_STORE_RES || MODE == MODE_STORE_GELU || MODE == MODE_STORE_DGELU;
+    constexpr bool PIPE = V4_PIPE_EPI && !ROLES && STORE_MODE && !GROUP && do_epi;
+    const bool defer_issue = PIPE && !((MODE == MODE_STORE || MODE == MODE_STORE_RES) && cur_slice >= 0);
     RELOAD_ARGS();
     n_fullitems = S ? n_full : nitems;
     const int packed = __builtin_amdgcn_readfirstlane(sched_lds[0]);       // published before this tile's prologue barrier
@@ -763,7 +769,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       }
       LOAD_PROBLEM(kp, nxt.p);
       SETUP_SRC(nxt.tile_y * BM, nxt.tile_x * BN, nxt.kbeg);
-      ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, b_dh, 3, 0); ISSUE_H(ap, a_dh, 1, 0);
+      // the pipelined bf16 epilogue issues these 8 LDS-DMA pieces between the conversions of its first quarter pass (an LDS-DMA
+      // issue costs the wave ~100 cycles of the shared address path; the conversions are VALU work: ~1000 cycles per tile hidden)
+      if (!defer_issue) { ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, b_dh, 3, 0); ISSUE_H(ap, a_dh, 1, 0); }
     }
     TRACE();                                 // [2] next tile requested
     pend = 0;
@@ -1029,11 +1037,20 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
           V4_BARRIER();
           {
             const int c = te & 63;            // 16-byte unit of the row (4 columns)
+            f32x4_t rb[8];                     // all eight LDS reads first: read -> wait -> store per row was a dependent round trip each
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+              const int rl2 = wave + 8 * it;
+              rb[it] = *reinterpret_cast<const f32x4_t*>(Cs + rl2 * 1024 + ((c ^ (rl2 & 7)) << 4));
+            }
+            wait_lgkm0();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) asm volatile("" : "+v"(rb[it]));
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
               const int rl2 = wave + 8 * it;                                       // staging row 0..63 (wave-uniform)
               const long mr = i * 128 + (rl2 >> 5) * 64 + ii * 32 + (rl2 & 31);    // row inside the tile
-              const f32x4_t v = *reinterpret_cast<const f32x4_t*>(Cs + rl2 * 1024 + ((c ^ (rl2 & 7)) << 4));
+              const f32x4_t v = rb[it];
 #if V4_NT_STORE >= 4
               __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(reinterpret_cast<unsigned char*>(Wp + mr * wld) + (uint32_t)(c * 16)));
 #else
@@ -1053,7 +1070,137 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     // -> 4 consecutive columns 8*rg + 4*(lane>>5) + {0..3}.  Two passes (A-half i = rows i*128 ..): staging tile
     // [128 rows][512 B] in ring buffer 1, 8-byte unit u of row r at unit u ^ (r & 15)  (conflict-free ds_write_b64;
     // ds_read_b128 sees whole 16-byte chunks, halves swapped on odd rows).
-    {
+    if constexpr (PIPE) {
+      // Four quarter passes q = (i, ii): rows i*128 + wm*64 + ii*32 + 0..31 of both wave groups -> staging rows wm*32 + (lane&31)
+      // of buffer q & 1 (two [64 rows][512 B] halves of ring buffer 1).  Phase q converts and stages quarter q (VALU + LDS
+      // writes) right after ISSUING the read-back + global stores of quarter q-1 (LDS reads + the vector-memory path): the two
+      // waves of a SIMD overlap one's store issue with the other's conversions instead of meeting at a barrier between a
+      // VALU-only and a store-only phase.  In-kernel trace (profiles/r02_gemm_trace_epilogue.txt): the two-pass epilogue costs
+      // 2 x (2.3 k stage + 1.7 k store) cycles per tile whether 30 or 256 CUs store at the same time -- issue-bound, not HBM-bound.
+      const int cc = te & 31;                 // 16-byte chunk of the row (8 columns)
+      const int r0 = te >> 5;                 // 0..15
+      unsigned char* Cb = reinterpret_cast<unsigned char*>(e.C) + ((long)m0 * e.ldc + n0) * 2;
+      const uint32_t c_off = ((uint32_t)r0 * (uint32_t)e.ldc + cc * 8) * 2;
+      unsigned char* Xb = reinterpret_cast<unsigned char*>(e.aux) + ((long)m0 * e.ldaux + n0) * 2;
+      const uint32_t x_off = ((uint32_t)r0 * (uint32_t)e.ldaux + cc * 8) * 2;
+      const unsigned char* Rb = reinterpret_cast<const unsigned char*>(e.residual) + ((long)m0 * e.ldr + n0) * 2;
+      const uint32_t r_off = ((uint32_t)r0 * (uint32_t)e.ldr + cc * 8) * 2;
+      constexpr bool is_gelu = MODE == MODE_STORE_GELU, is_dgelu = MODE == MODE_STORE_DGELU;
+      constexpr bool NT_OUT = V4_NT_STORE == 1 || V4_NT_STORE >= 3 || (V4_NT_STORE == 2 && (is_gelu || is_dgelu));
+      constexpr bool NT_IN = V4_NT_STORE >= 3;
+      constexpr bool has_pre = MODE == MODE_STORE_DGELU || MODE == MODE_STORE_RES;
+      const unsigned char* pre_base = is_dgelu ? Xb : Rb;
+      const uint32_t pre_off = is_dgelu ? x_off : r_off;
+      const long pre_ld = is_dgelu ? e.ldaux : e.ldr;
+      // fused-epilogue operands of rows i*128 + 16*x + r0 (x = 0..7): half 0 requested before any store of the tile, half 1 when
+      // the accumulators of half 0 are dead (after quarter 1 is staged; those loads queue behind quarter 0's stores, which is
+      // fine: they are consumed two phases later)
+      uint4 pre0[8], pre1[8];
+      if (has_pre) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) pre0[x] = load_once16<NT_IN>(pre_base + (long)(16 * x) * pre_ld * 2 + pre_off);
+      }
+      const int mlq = wm * 32 + (le & 31);
+      const bool issue_now = defer_issue && have;
+      // the lane's 8 bias quads (columns j*128 + br + 8*rg + 4*(lane>>5) ..+3) are the same for all four quarters: ONE batch of
+      // LDS reads.  (Read next to their use, every conversion group was a dependent LDS round trip -- the compiler cannot move a
+      // read of the bias area across the staging writes -- and 16 of them per half were most of the epilogue's 9.5 k cycles.)
+      float4 bq[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          bq[j][rg] = *reinterpret_cast<const float4*>(smem + BIAS_OFF + 4 * (n0 + j * 128 + br + 8 * rg + 4 * (le >> 5)));
+      wait_lgkm0();
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) asm volatile("" : "+v"(bq[j][rg].x), "+v"(bq[j][rg].y), "+v"(bq[j][rg].z), "+v"(bq[j][rg].w));
+#pragma unroll
+      for (int q = 0; q <= 4; ++q) {
+        if (q >= 1) {                          // read back + store quarter q - 1: the four LDS reads first, then the stores
+          const int qs = q - 1, i = qs >> 1, ii = qs & 1;
+          const unsigned char* Cq = Cs + (qs & 1) * (64 * 512);
+          uint4 raws[4];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int row = r0 + 16 * it;                                        // staging row 0..63
+            const int pc = cc ^ ((row & 15) >> 1);
+            raws[it] = *reinterpret_cast<const uint4*>(Cq + row * 512 + pc * 16);
+          }
+          wait_lgkm0();
+#pragma unroll
+          for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(raws[it].x), "+v"(raws[it].y), "+v"(raws[it].z), "+v"(raws[it].w));
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int row = r0 + 16 * it;
+            const long mu = i * 128 + (it >> 1) * 64 + ii * 32 + 16 * (it & 1);  // wave-uniform part of the tile row (+ r0 in c_off)
+            const int xo = (it >> 1) * 4 + ii * 2 + (it & 1);                    // index of this row group in pre0 / pre1
+            uint4 raw = raws[it];
+            if (row & 1) { uint32_t tx = raw.x, ty = raw.y; raw.x = raw.z; raw.y = raw.w; raw.z = tx; raw.w = ty; }
+            if (MODE == MODE_STORE) {
+              store_c16<NT_OUT>(Cb + mu * e.ldc * 2 + c_off, raw);
+            } else {
+              const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
+              float v[8];
+#pragma unroll
+              for (int x = 0; x < 4; ++x) { v[2 * x] = __uint_as_float(wv[x] << 16); v[2 * x + 1] = __uint_as_float(wv[x] & 0xffff0000u); }
+              if (is_gelu) {
+                store_c16<NT_OUT>(Xb + mu * e.ldaux * 2 + x_off, raw);
+#pragma unroll
+                for (int x = 0; x < 8; ++x) v[x] = quick_gelu_f(v[x]);
+              }
+              if (has_pre) {
+                const uint4 pr = i == 0 ? pre0[xo] : pre1[xo];
+                const uint32_t pw[4] = {pr.x, pr.y, pr.z, pr.w};
+                float pf[8];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { pf[2 * x] = __uint_as_float(pw[x] << 16); pf[2 * x + 1] = __uint_as_float(pw[x] & 0xffff0000u); }
+                if (is_dgelu) {
+#pragma unroll
+                  for (int x = 0; x < 8; ++x) v[x] *= quick_gelu_grad_f(pf[x]);
+                } else {
+#pragma unroll
+                  for (int x = 0; x < 8; ++x) v[x] += pf[x];
+                }
+              }
+              uint4 pk;
+              pk.x = pack2bf_hw(v[0], v[1]); pk.y = pack2bf_hw(v[2], v[3]); pk.z = pack2bf_hw(v[4], v[5]); pk.w = pack2bf_hw(v[6], v[7]);
+              store_c16<NT_OUT>(Cb + mu * e.ldc * 2 + c_off, pk);
+            }
+            if (it & 1) __builtin_amdgcn_sched_barrier(0);      // keep the unrolled iterations from being interleaved (register pressure)
+          }
+        }
+        if (q <= 3) {                          // convert + stage quarter q
+          unsigned char* Cq = Cs + (q & 1) * (64 * 512);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int nl = j * 128 + br + 8 * rg + 4 * (le >> 5);
+              uint2 pk;
+              pk.x = pack2bf_hw(acc[q][j][rg * 4 + 0] * e.alpha + bq[j][rg].x, acc[q][j][rg * 4 + 1] * e.alpha + bq[j][rg].y);
+              pk.y = pack2bf_hw(acc[q][j][rg * 4 + 2] * e.alpha + bq[j][rg].z, acc[q][j][rg * 4 + 3] * e.alpha + bq[j][rg].w);
+              *reinterpret_cast<uint2*>(Cq + mlq * 512 + (((nl >> 2) ^ (mlq & 15)) << 3)) = pk;
+              if (q == 0 && (rg & 1) && issue_now) {               // the next tile's K-tile 0: one half-tile after every second group
+                if (j == 0 && rg == 1) ISSUE_H(ap, 0, 0, 0);
+                if (j == 0 && rg == 3) ISSUE_H(bp, 0, 2, 0);
+                if (j == 1 && rg == 1) ISSUE_H(bp, b_dh, 3, 0);
+                if (j == 1 && rg == 3) ISSUE_H(ap, a_dh, 1, 0);
+              }
+            }
+          }
+        }
+        if (q == 1 && has_pre) {
+#pragma unroll
+          for (int x = 0; x < 8; ++x) pre1[x] = load_once16<NT_IN>(pre_base + (long)(128 + 16 * x) * pre_ld * 2 + pre_off);
+        }
+        wait_lgkm0();
+        V4_BARRIER();                          // quarter q staged / buffer (q - 1) & 1 free again (q = 4: the staging tile is free)
+        if (q <= 3) TRACE();
+      }
+      pend = is_gelu ? 32 : 16;
+    } else {
       constexpr int RSTEP = ROLES ? 8 : 16, NIT = ROLES ? 16 : 8;   // ROLES: only waves 0-3 read back and store
       const bool storer = !ROLES || wm == 0;
       const int cc = te & 31;                 // 16-byte chunk of the row (8 columns)

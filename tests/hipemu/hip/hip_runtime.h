@@ -31,12 +31,14 @@ extern dim3 blockDim, gridDim;
 #define warpSize 64
 
 struct uint4 { uint32_t x, y, z, w; };
+struct int4 { int32_t x, y, z, w; };
 struct uint2 { uint32_t x, y; };
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return uint4{a, b, c, d}; }
+static inline int4 make_int4(int32_t a, int32_t b, int32_t c, int32_t d) { return int4{a, b, c, d}; }
 static inline uint2 make_uint2(uint32_t a, uint32_t b) { return uint2{a, b}; }
 
 static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }

@@ -191,7 +191,7 @@ def test_text_embed(dtype):
 
 
 @pytest.mark.parametrize("rows,d,V,dtype", [(5000, 512, 3000, torch.bfloat16), (700, 520, 90, torch.float32), (33, 768, 49408, torch.bfloat16),
-                                            (22016, 512, 49408, torch.bfloat16)])
+                                            (22016, 512, 49408, torch.bfloat16), (900, 64, 70001, torch.float32)])
 def test_embed_table_grad_sorted_segments(rows, d, V, dtype):
     """dh_embed_table_grad: counting sort by id + one wave per 16 sorted rows.  Zipf-like ids (runs far longer than a wave's chunk next
     to ids that occur once), a table that already holds gradient, ids outside the vocabulary (skipped), d not a multiple of 512
@@ -301,7 +301,7 @@ def test_infonce(b, B, D, label0):
     dpairs = [(q.to(cuda), k.to(cuda)) for q, k in pairs]
     _poison_lds(ops)
     row_loss, row_lse, c1, c5, logits = ops.infonce_fwd(dpairs, scale.to(cuda), label0, want_logits=True)
-    assert rel_err(row_loss, torch.stack(losses).detach()) < 5e-5   # fp32 FMA chains over D, fast exp
+    assert rel_err(row_loss, torch.stack(losses).detach()) < (5e-5 if D <= 1024 else 1e-4)   # fp32 FMA chains over D, fast exp
     assert rel_err(logits, torch.stack(logits_r)) < 1e-5
     assert torch.equal(c1.cpu().double(), torch.stack(c1r)) and torch.equal(c5.cpu().double(), torch.stack(c5r))
     _poison_lds(ops)

@@ -33,6 +33,7 @@ CASES = [
     ("test_vision_embed", (F32,)),
     ("test_embed_table_grad_sorted_segments", (700, 520, 90, F32)),
     ("test_embed_table_grad_sorted_segments", (1500, 512, 3000, BF16)),
+    ("test_embed_table_grad_sorted_segments", (300, 64, 70001, F32)),
     ("test_pool_and_l2norm", (BF16,)),
     ("test_infonce", (8, 8, 64, 0)),
     ("test_infonce", (40, 120, 512, 40)),
