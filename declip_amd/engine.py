@@ -9,6 +9,8 @@ slices of the flat buffer (declip_amd/dist.py) without any packing copies.
 Every arithmetic step goes through declip_amd.ops (= the C-ABI); torch is used for memory,
 streams and the autograd graph plumbing only.
 """
+import os
+
 import torch
 
 from . import ops
@@ -116,7 +118,9 @@ class FlatParams:
             # the shared anchor leaf is consumed by towers on different streams on purpose; its gradient is never used
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         while len(self.side_streams) <= i:
-            self.side_streams.append(torch.cuda.Stream(device=self.flat_p.device))
+            # DH_SIDE_PRIORITY=-1: the side stream (CLIP: the longer image tower) gets its workgroups dispatched first when both
+            # streams have work pending (A/B switch; default: equal priority)
+            self.side_streams.append(torch.cuda.Stream(device=self.flat_p.device, priority=int(os.environ.get("DH_SIDE_PRIORITY", "0"))))
         return self.side_streams[i]
 
     def join_streams(self):
