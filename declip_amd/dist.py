@@ -328,6 +328,7 @@ class DistModule(torch.nn.Module):
         if not is_dist():
             return
         tdist.broadcast(self._flat.flat_p, 0)          # one flattened broadcast instead of ~300
+        self._flat.params_changed()
         for b in self.module.buffers():
             tdist.broadcast(b, 0)
 

@@ -44,6 +44,26 @@ class FlatParams:
         self._zero_event = None
         self._pending_uses = {}      # id(tower) -> forwards of this step whose backward has not run yet (see tower_forward)
         self._early_ok = True        # may grads_ready() hand ranges to the reducer in the backward that is running now?
+        # The fused AdamW writes the bf16 mirror in the pass that updates the master weights (optim.FlatAdamW.step), so the next
+        # step needs no cast (0.23 ms / 0.9 GB per CLIP step).  Everything ELSE that writes weights says so: params_changed() --
+        # called by the load_state_dict hooks below, DistModule.broadcast_params and a re-attach; code that edits weight matrices
+        # through p.data must call it too (the solver's own in-place edits are the temperature scalars, read as fp32).
+        # DH_MIRROR_TRUST=0 restores the unconditional cast of every step.
+        self.trust_mirror = os.environ.get("DH_MIRROR_TRUST", "1") == "1"
+        self._mirror_by_opt = False  # the valid mirror was written by the fused optimizer (any other optimizer: recast every step)
+        for m in module.modules():
+            if hasattr(m, "register_load_state_dict_post_hook"):
+                m.register_load_state_dict_post_hook(lambda mod, incompatible, store=self: store.params_changed())
+
+    def params_changed(self):
+        """Weights were written by something other than the fused optimizer: the bf16 mirror is recast at the next begin_step()."""
+        self.mirror_fresh = False
+        self._mirror_by_opt = False
+
+    def mirror_written_by_optimizer(self):
+        """optim.FlatAdamW.step: the bf16 mirror was written together with the master weights."""
+        self.mirror_fresh = self.flat_b is not None
+        self._mirror_by_opt = self.mirror_fresh
 
     # ------------------------------------------------------------------ construction
     def attach(self):
@@ -76,6 +96,7 @@ class FlatParams:
             self.flat_b = torch.zeros(off + SLACK, device=dev, dtype=torch.bfloat16)[:off]
         self.anchor = torch.zeros(1, device=dev, dtype=torch.float32, requires_grad=True)
         self.mirror_fresh = False
+        self._mirror_by_opt = False
         return self
 
     def attached(self):
@@ -135,6 +156,7 @@ class FlatParams:
         if self.flat_b is not None and not self.mirror_fresh:
             ops.cast(self.flat_p, self.flat_b)
             self.mirror_fresh = True
+            self._mirror_by_opt = False
 
     def begin_step(self):
         """Call at the start of every forward in training: parameters may have changed."""
@@ -144,7 +166,8 @@ class FlatParams:
             self._zero_event = None
             self._pending_uses = {}
         self.join_streams()
-        self.mirror_fresh = False
+        if not (self.trust_mirror and self._mirror_by_opt):
+            self.mirror_fresh = False
         self.refresh_mirror()
 
     # ------------------------------------------------------------------ backward protocol
@@ -155,6 +178,9 @@ class FlatParams:
                 torch.cuda.current_stream(self.flat_p.device).wait_event(self._zero_event)
             return
         self._in_backward = True
+        # gradients are being produced, so an optimizer is about to write the weights: only the fused AdamW re-asserts that it left
+        # a valid mirror behind (mirror_written_by_optimizer); after any other optimizer the next begin_step() recasts
+        self._mirror_by_opt = False
         base, end = self.flat_g.data_ptr(), self.flat_g.data_ptr() + 4 * self.total
         live = [p for p in self.params if p.grad is not None and base <= p.grad.data_ptr() < end]
         if live and self.reducer is not None and self.reducer.distributed():

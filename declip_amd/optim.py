@@ -115,7 +115,7 @@ class FlatAdamW(torch.optim.Optimizer):
         b1, b2 = g0["betas"]
         ops.adamw_segmented(flat.flat_p, flat.flat_g, self.m, self.v, flat.flat_b, self._seg_start, self._seg_lr,
                             self._seg_wd, b1, b2, g0["eps"], self.step_count, grad_scale)
-        flat.mirror_fresh = flat.flat_b is not None
+        flat.mirror_written_by_optimizer()
         return loss
 
 

@@ -176,6 +176,57 @@ def test_flat_adamw_tables_match_torch_adamw(mocked_engine):
     assert torch.equal(got["visual.conv1.weight"].detach(), synth.synth_state(synth.clip_shapes(cfg), seed=seed)["visual.conv1.weight"])
 
 
+def test_bf16_mirror_is_recast_only_when_something_else_wrote_the_weights(mocked_engine, monkeypatch):
+    """The fused AdamW writes the bf16 mirror with the master weights, so begin_step() casts the 151 M parameters again only when
+    something else touched them: a foreign optimizer (every step), load_state_dict, params_changed(), DH_MIRROR_TRUST=0.  At every
+    forward the mirror must equal bf16(master) for every weight the GEMMs read."""
+    from declip_amd import ops, synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.optim import build_adamw
+    from declip_amd.testing import build_clip
+    cfg, b = synth.TINY, 4
+    casts = []
+    real_cast = ops.cast
+
+    def counting_cast(src, dst, *a, **k):
+        casts.append(src.numel())
+        return real_cast(src, dst, *a, **k)
+    monkeypatch.setattr(ops, "cast", counting_cast)
+    crit = ClipInfoCELoss()
+
+    def steps(model, opt, n, flat):
+        full = []
+        for step in range(n):
+            before = len([c for c in casts if c == flat.total])
+            images = synth.synth_images(b, res=cfg["res"], seed=step)
+            ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=step, vocab=cfg["vocab"])
+            opt.zero_grad()
+            li, lt = model({"images": images, "captions": ids})
+            for p in flat.params:                                  # the invariant the trust rests on
+                if p.dim() >= 2:
+                    assert torch.equal(flat.wview(p), p.data.to(torch.bfloat16)), flat.names[id(p)]
+            loss, _ = crit(li, lt)
+            loss.backward()
+            opt.step()
+            full.append(len([c for c in casts if c == flat.total]) - before)
+        return full
+
+    model = build_clip(cfg, dtype="bf16", seed=3, device="cpu")
+    flat = model.__dict__["_flat_store"].ensure()
+    opt = build_adamw(model, lr=1e-3, betas=(0.9, 0.98), weight_decay=0.1)
+    assert steps(model, opt, 3, flat) == [1, 0, 0]                  # first step casts, the optimizer keeps the mirror afterwards
+    model.load_state_dict(synth.synth_state(synth.clip_shapes(cfg), seed=4), strict=True)
+    assert steps(model, opt, 2, flat) == [1, 0]                     # load_state_dict hook
+    with torch.no_grad():
+        model.visual.proj.data.mul_(0.5)
+    flat.params_changed()
+    assert steps(model, opt, 1, flat) == [1]
+    sgd = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    assert steps(model, sgd, 3, flat) == [0, 1, 1]                  # a foreign optimizer never hands over a mirror: cast every step
+    flat.trust_mirror = False
+    assert steps(model, opt, 2, flat) == [1, 1]
+
+
 def test_resnet_fc_head_matches_golden(mocked_engine):
     """64 px input: the final map is 2x2, ModifiedResNet.forward takes the adaptive-pool + fc head (modified_resnet.py:209-211);
     the attention pool is off the path (grad None, untouched by the optimiser), fc trains."""

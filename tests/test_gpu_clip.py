@@ -287,3 +287,37 @@ def test_clip_two_tower_streams_match_one_stream(monkeypatch):
         assert abs(a - c) <= 3e-3 * abs(c)
     for n, g in g0.items():
         assert float((g1[n] - g).abs().max()) <= 1e-2 * float(g.abs().max()) + 1e-12, n
+
+
+def test_bf16_mirror_written_by_the_fused_adamw_equals_a_cast_of_the_master_weights(monkeypatch):
+    """begin_step() trusts the bf16 mirror that adamw_seg_kernel writes next to the master weights (no 0.9 GB cast per step): after every
+    optimizer step the mirror must be bit-identical to a round-to-nearest-even cast of the fp32 parameters, and no full-size cast
+    may run after the first step."""
+    from declip_amd import ops, synth
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.optim import build_adamw
+    from declip_amd.testing import build_clip
+    cfg, b = synth.TINY, 8
+    model = build_clip(cfg, dtype="bf16", seed=5)
+    flat = model.__dict__["_flat_store"].ensure()
+    opt = build_adamw(model, lr=1e-3, betas=(0.9, 0.98), weight_decay=0.1)
+    crit = ClipInfoCELoss()
+    full_casts = []
+    real_cast = ops.cast
+
+    def counting_cast(src, dst, *a, **k):
+        if src.numel() == flat.total:
+            full_casts.append(1)
+        return real_cast(src, dst, *a, **k)
+    monkeypatch.setattr(ops, "cast", counting_cast)
+    for step in range(3):
+        images = synth.synth_images(b, res=cfg["res"], seed=step).cuda()
+        ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=step, vocab=cfg["vocab"]).cuda()
+        opt.zero_grad()
+        li, lt = model({"images": images, "captions": ids})
+        loss, _ = crit(li, lt)
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        assert torch.equal(flat.flat_b, flat.flat_p.to(torch.bfloat16)), step
+    assert len(full_casts) == 1
