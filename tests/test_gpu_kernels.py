@@ -350,9 +350,10 @@ def test_adamw_matches_torch():
 # ----------------------------------------------------------------------------- DeCLIP heads
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("relu", [True, False])
-def test_bn1d_groups(dtype, relu):
+@pytest.mark.parametrize("G,R,C", [(2, 24, 200), (2, 24, 203), (2, 512, 1024), (3, 70, 72)])
+def test_bn1d_groups(dtype, relu, G, R, C):
+    """C % 8 == 0: the 16-byte kernels (8 column chunks x 32 row lanes per block); otherwise the column-per-lane ones."""
     ops = _ops()
-    G, R, C = 2, 24, 200
     x = rnd(G * R, C, seed=80).to(dtype)
     w, b = 1 + 0.1 * rnd(C, seed=81), 0.1 * rnd(C, seed=82)
     dy = rnd(G * R, C, seed=83).to(dtype)

@@ -41,8 +41,10 @@ CASES = [
     ("test_infonce", (40, 140, 1280, 100)),
     ("test_ce_rows", ()),
     ("test_adamw_matches_torch", ()),
-    ("test_bn1d_groups", (BF16, True)),
-    ("test_bn1d_groups", (F32, False)),
+    ("test_bn1d_groups", (BF16, True, 2, 24, 200)),
+    ("test_bn1d_groups", (F32, False, 2, 24, 203)),
+    ("test_bn1d_groups", (F32, True, 3, 70, 72)),
+    ("test_bn1d_groups", (BF16, False, 2, 128, 256)),
     ("test_cos_rows", (F32,)),
     ("test_nn_bank_query_ties_and_ragged_sizes", ()),
     ("test_nn_bank_query_exact", (40, 5000, 512)),
