@@ -46,6 +46,30 @@ def main(path):
         print("first-to-last dispatch span %.3f ms; >=1 kernel resident %.3f ms (%.1f %%); sum of durations / resident time = %.3f" % (
             span / 1e6, busy / 1e6, 100.0 * busy / span, total / busy))
 
+    # per optimizer step (between consecutive launches of the step's last kernel, the fused AdamW): wall span, time with at least
+    # one kernel resident, sum of kernel durations -- idle = span - resident is launch latency / dependency stalls, sum / resident
+    # > 1 is what the two tower streams overlap
+    q = "select s.%s, d.start, d.end from %s d join %s s on d.kernel_id = s.id order by d.start" % (name_col, kd, ks)
+    rows = list(c.execute(q))
+    marks = [i for i, r in enumerate(rows) if "adamw_seg_kernel" in r[0]]
+    if len(marks) >= 3:
+        print("per step (AdamW to AdamW): span_ms resident_ms idle_ms sum_ms dispatches")
+        for a, b in zip(marks[:-1], marks[1:]):
+            seg = rows[a + 1:b + 1]
+            t0, t1 = rows[a][2], rows[b][2]
+            busy, cs, ce, tot = 0, None, None, 0
+            for _, st, en in seg:
+                tot += en - st
+                if cs is None:
+                    cs, ce = st, en
+                elif st > ce:
+                    busy += ce - cs
+                    cs, ce = st, en
+                else:
+                    ce = max(ce, en)
+            busy += ce - cs
+            print("   %.3f %.3f %.3f %.3f %d" % ((t1 - t0) / 1e6, busy / 1e6, (t1 - t0 - busy) / 1e6, tot / 1e6, len(seg)))
+
 
 if __name__ == "__main__":
     main(sys.argv[1])
