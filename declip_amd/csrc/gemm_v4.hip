@@ -263,14 +263,24 @@ __device__ __forceinline__ const bf16_t* piece_src(const bf16_t* P, long ld, int
 // inside a group hands the same 8 A panels to two (ntx = 3) or three (ntx = 12: 8 x 4 tiles per XCD) XCDs -- the PMC counters
 // showed 2.7x the algorithmic read traffic on the N = 3072 forward GEMM.  group_m = 1 is row-major: all ntx tiles of a row
 // (one A panel) sit on one XCD; only the small weight operand is fetched by every XCD.
+// a / b for 0 <= a < 2^21, b > 0 through the fp32 reciprocal (exact after one correction step).  The work-item decode runs once per
+// tile on every wave between the main loop and the epilogue; the compiler's 32-bit integer division is a ~35-instruction dependent
+// chain, and five of them were most of the ~900 cycles the in-kernel trace shows for "next tile requested".
+__device__ __forceinline__ int fdiv(int a, int b) {
+  int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+  const int r = a - q * b;
+  q += r >= b ? 1 : 0;
+  q -= r < 0 ? 1 : 0;
+  return __builtin_amdgcn_readfirstlane(q);      // every caller passes wave-uniform values: keep the quotient in a scalar register
+}
 __device__ __forceinline__ void tile_from_logical(int b, int ntx, int nty, int& tile_x, int& tile_y, int GROUP_M = 8) {
   const int in_group = GROUP_M * ntx;
-  const int gid = b / in_group;
+  const int gid = fdiv(b, in_group);
   const int first_m = gid * GROUP_M;
   const int gsz = min(nty - first_m, GROUP_M);
   const int rem = b - gid * in_group;
-  tile_y = first_m + rem % gsz;
-  tile_x = rem / gsz;
+  tile_x = fdiv(rem, gsz);
+  tile_y = first_m + (rem - tile_x * gsz);
 }
 // Work items of a launch.  Plain launches: n_fullitems = tiles x splits whole items.  TAIL-SLICED launches (bf16 outputs
 // whose tile count leaves the last round mostly empty, e.g. 300 tiles on 256 CUs): n_fullitems = n_full whole tiles (a
@@ -296,7 +306,7 @@ __device__ __forceinline__ bool decode_pos(int x, int l, int ntx, int nty, int n
   chunk_of(n_fullitems, x, sf, lf);
   if (l < lf) {
     const int logical = sf + l, nb = ntx * nty;
-    it.z = logical / nb;
+    it.z = fdiv(logical, nb);
     tile_from_logical(logical - it.z * nb, ntx, nty, it.tile_x, it.tile_y, gm);
     it.kbeg = it.z * k_per_split;
     it.nk = (min(K, it.kbeg + k_per_split) - it.kbeg) / BK;
@@ -310,9 +320,9 @@ __device__ __forceinline__ bool decode_pos(int x, int l, int ntx, int nty, int n
   chunk_of(rem * S, x, ss, ls);
   const int j0 = l - lf;
   if (j0 >= ls) return false;
-  const int j = ss + j0, lt = j / S, sl = j - lt * S, nkt = K / BK;
+  const int j = ss + j0, lt = fdiv(j, S), sl = j - lt * S, nkt = K / BK;
   tile_from_logical(n_full + lt, ntx, nty, it.tile_x, it.tile_y, gm);
-  const int k0 = sl * nkt / S, k1 = (sl + 1) * nkt / S;
+  const int k0 = fdiv(sl * nkt, S), k1 = fdiv((sl + 1) * nkt, S);
   it.z = 0; it.kbeg = k0 * BK; it.nk = k1 - k0; it.slice = j; it.p = 0;
   return true;
 }
@@ -324,7 +334,7 @@ __device__ __forceinline__ bool decode_group(kargp_t kp, int x, int l, int nitem
   chunk_of(nitems, x, sf, lf);
   if (l >= lf) return false;
   const int logical = sf + l;
-  it.z = logical / T;
+  it.z = fdiv(logical, T);
   const int t = logical - it.z * T;
   int p = 0;
 #pragma unroll
@@ -1037,25 +1047,29 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
           V4_BARRIER();
           {
             const int c = te & 63;            // 16-byte unit of the row (4 columns)
-            f32x4_t rb[8];                     // all eight LDS reads first: read -> wait -> store per row was a dependent round trip each
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-              const int rl2 = wave + 8 * it;
-              rb[it] = *reinterpret_cast<const f32x4_t*>(Cs + rl2 * 1024 + ((c ^ (rl2 & 7)) << 4));
+            for (int half = 0; half < 2; ++half) {
+            f32x4_t rb[4];                     // four LDS reads first: read -> wait -> store per row was a dependent round trip each
+#pragma unroll
+            for (int it4 = 0; it4 < 4; ++it4) {
+              const int rl2 = wave + 8 * (half * 4 + it4);
+              rb[it4] = *reinterpret_cast<const f32x4_t*>(Cs + rl2 * 1024 + ((c ^ (rl2 & 7)) << 4));
             }
             wait_lgkm0();
 #pragma unroll
-            for (int it = 0; it < 8; ++it) asm volatile("" : "+v"(rb[it]));
+            for (int it4 = 0; it4 < 4; ++it4) asm volatile("" : "+v"(rb[it4]));
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
+            for (int it4 = 0; it4 < 4; ++it4) {
+              const int it = half * 4 + it4;
               const int rl2 = wave + 8 * it;                                       // staging row 0..63 (wave-uniform)
               const long mr = i * 128 + (rl2 >> 5) * 64 + ii * 32 + (rl2 & 31);    // row inside the tile
-              const f32x4_t v = rb[it];
+              const f32x4_t v = rb[it4];
 #if V4_NT_STORE >= 4
               __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(reinterpret_cast<unsigned char*>(Wp + mr * wld) + (uint32_t)(c * 16)));
 #else
               *reinterpret_cast<f32x4_t*>(reinterpret_cast<unsigned char*>(Wp + mr * wld) + (uint32_t)(c * 16)) = v;
 #endif
+            }
             }
           }
           wait_lgkm0();

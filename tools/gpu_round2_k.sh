@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU session K: pipelined bf16 epilogue of the persistent GEMM (four quarter passes, store issue of quarter q-1 next to the
+# GPU session K: A/B of a change in gemm_v4.hip (build/old = the previous commit): tests, in-kernel trace, same-box bench
 # conversions of quarter q, next tile's K-tile 0 requested between the conversions): tests, in-kernel trace, same-box A/B
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
