@@ -4,6 +4,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/final
 timeout 1800 python -m pytest tests -m gpu -q > gpurun_out/final/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/final/pytest_gpu.txt
 tail -6 gpurun_out/final/pytest_gpu.txt
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.txt 2>&1; echo "smoke rc=$?" >> gpurun_out/final/smoke.txt; tail -2 gpurun_out/final/smoke.txt
 DH_BENCH_GEMM_TABLE=gpurun_out/final/gemm_table_clip.txt timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/final/bench_clip.txt 2>gpurun_out/final/bench_clip.err
 for m in declip slip filip defilip; do
   timeout 300 python bench.py --model $m --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/final/bench_$m.txt 2>&1
