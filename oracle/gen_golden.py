@@ -279,13 +279,20 @@ def gen_declip(name, cfg, b, seed=0, nn_size=256, world=1):
     print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
 
 
-def gen_slip(name, cfg, b, seed=0):
-    """Reference SLIP (model/slip.py) + slip_solver.py loss composition, one rank."""
+def run_slip_rank(rank, world, cfg, b, seed, ret):
+    """One reference SLIP rank (model/slip.py) + slip_solver.py loss composition: local rows [rank*b, (rank+1)*b) of the global
+    batch; world > 1 exercises the gathered SimCLR features (NT_Xent_gather with positives at rank*b + i, nt_xent.py:64-83) and
+    the / world_size of slip_solver.py:457,490."""
     import contextlib
     import io
-    os.environ["SLURM_PROCID"], os.environ["SLURM_NTASKS"] = "0", "1"
+    os.environ["SLURM_PROCID"], os.environ["SLURM_NTASKS"] = str(rank), str(world)
     ref = ref_harness.load_reference()
-    ref_harness.ensure_gloo_group()
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world, init_method="tcp://127.0.0.1:29544")
+        torch.set_num_threads(max(1, (os.cpu_count() or 2) // world))
+    else:
+        ref_harness.ensure_gloo_group()
     rs = ref.modules["prototype.model.slip"]
     vt = ref.modules["prototype.model.image_encoder.visual_transformer"]
     tt = ref.modules["prototype.model.text_encoder.text_transformer"]
@@ -300,10 +307,12 @@ def gen_slip(name, cfg, b, seed=0):
         sd = synth.synth_state(synth.slip_shapes(cfg), seed=seed)
         model.load_state_dict(sd, strict=True)
         model.train()
-    images = synth.synth_images(b, views=3, res=cfg["res"], seed=seed)
-    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
-    patch_tokenize(model.text_encoder, {i: ids[i] for i in range(b)})
-    out = model({"images": images, "captions": [[i] for i in range(b)]}, return_dict=True)
+    B = b * world
+    images = synth.synth_images(B, views=3, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
+    sl = slice(rank * b, (rank + 1) * b)
+    patch_tokenize(model.text_encoder, {i: ids[i] for i in range(B)})
+    out = model({"images": images[sl], "captions": [[i] for i in range(rank * b, (rank + 1) * b)]}, return_dict=True)
     crit = ref.modules["prototype.loss_functions.loss"].ClipInfoCELoss()
     nx = ref.modules["prototype.loss_functions.nt_xent"]
     simclr_crit, mon_crit = nx.NT_Xent_gather(b), nx.NT_Xent(b)
@@ -313,12 +322,48 @@ def gen_slip(name, cfg, b, seed=0):
     simclr = simclr_crit(s1, g1, s2, g2)
     tf, imf = out["features"]
     monitor = mon_crit(imf, tf)
-    total = clip_loss + simclr                                           # yfcc15m_vit_slip/config.yaml:28-30
+    total = (clip_loss + simclr) / world                                 # yfcc15m_vit_slip/config.yaml:28-30; slip_solver.py:457,490
     total.backward()
-    ret = dict(kind="slip", cfg=cfg, b=b, seed=seed, loss=float(total),
-               parts=dict(clip=float(clip_loss), simclr=float(simclr), nt_xent=float(monitor)),
-               logits_i=li.detach().clone(), sim1=s1.detach().clone(),
-               grads=grad_digest([(n, p.grad) for n, p in model.named_parameters()]), torch_version=torch.__version__)
+    grads = []
+    for name, p in model.named_parameters():
+        g = p.grad
+        if g is not None and world > 1:
+            dist.all_reduce(g)                                           # utils/dist.py:71-74 (SUM)
+        grads.append((name, g))
+    tot = total.detach().clone()
+    parts = torch.tensor([float(clip_loss), float(simclr), float(monitor)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tot)
+        dist.all_reduce(parts)
+        parts /= world
+    if rank == 0:
+        ret.update(loss=float(tot), parts=dict(clip=float(parts[0]), simclr=float(parts[1]), nt_xent=float(parts[2])),
+                   grads=grad_digest(grads))
+        ret.update(logits_i=li.detach().clone(), sim1=s1.detach().clone())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _spawn_slip(rank, world, cfg, b, seed, path):
+    ret = {}
+    run_slip_rank(rank, world, cfg, b, seed, ret)
+    if rank == 0:
+        torch.save(ret, path)
+
+
+def gen_slip(name, cfg, b, seed=0, world=1):
+    """Reference SLIP (model/slip.py) + slip_solver.py loss composition, one or two ranks."""
+    if world == 1:
+        ret = {}
+        run_slip_rank(0, 1, cfg, b, seed, ret)
+    else:
+        import torch.multiprocessing as mp
+        tmp = "/tmp/_golden_%s.pt" % name
+        mp.spawn(_spawn_slip, args=(world, cfg, b, seed, tmp), nprocs=world, join=True)
+        ret = torch.load(tmp, weights_only=False)
+        os.remove(tmp)
+    ret.update(kind="slip", cfg=cfg, b=b, seed=seed, world=world, torch_version=torch.__version__)
     path = os.path.join(GOLDEN_DIR, name + ".pt")
     torch.save(ret, path)
     print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
@@ -422,13 +467,20 @@ def gen_filip(name, cfg, b, seed=0, world=1):
     print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
 
 
-def gen_defilip(name, cfg, b, seed=0, nn_size=256):
-    """Reference DEFILIP (model/defilip.py) + defilip_solver.py loss composition (declip weights + filip 0.2)."""
+def run_defilip_rank(rank, world, cfg, b, seed, nn_size, ret):
+    """One reference DEFILIP rank (model/defilip.py) + defilip_solver.py loss composition (declip weights + filip 0.2, every term
+    divided by world_size): local rows [rank*b, (rank+1)*b) of the global batch; world > 1: the DeCLIP feature gathers AND the gathered
+    top-16 token sets of the dense loss span B = world*b captions (label0 = rank*b); per-rank NN bank as in run_declip_rank."""
     import contextlib
     import io
-    os.environ["SLURM_PROCID"], os.environ["SLURM_NTASKS"] = "0", "1"
+    os.environ["SLURM_PROCID"], os.environ["SLURM_NTASKS"] = str(rank), str(world)
     ref = ref_harness.load_reference()
-    ref_harness.ensure_gloo_group()
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world, init_method="tcp://127.0.0.1:29546")
+        torch.set_num_threads(max(1, (os.cpu_count() or 2) // world))
+    else:
+        ref_harness.ensure_gloo_group()
     rd = ref.modules["prototype.model.defilip"]
     vt = ref.modules["prototype.model.image_encoder.visual_transformer"]
     tt = ref.modules["prototype.model.text_encoder.text_transformer"]
@@ -445,13 +497,15 @@ def gen_defilip(name, cfg, b, seed=0, nn_size=256):
         sd = synth.synth_state(synth.defilip_shapes(cfg), seed=seed)
         model.load_state_dict(sd, strict=True)
         model.train()
-    images = synth.synth_images(b, views=2, res=cfg["res"], seed=seed)
-    ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
-    ids_aug = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+    B = b * world
+    images = synth.synth_images(B, views=2, res=cfg["res"], seed=seed)
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+    ids_aug = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
     ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
-    model.nn_replacer_text.bank = synth.synth_bank(nn_size, cfg["embed_dim"], seed=seed).t().clone()
+    model.nn_replacer_text.bank = synth.synth_bank(nn_size, cfg["embed_dim"], seed=seed + rank).t().clone()   # per-rank bank
     model.nn_replacer_text.bank_ptr = torch.LongTensor([0])
     off = ref_harness.AUG_KEY_OFFSET
+    sl = slice(rank * b, (rank + 1) * b)
 
     def tokenize(texts, context_length=77, return_length=False, mask_type=None):
         keys = [int(t) for t in texts]
@@ -459,7 +513,7 @@ def gen_defilip(name, cfg, b, seed=0, nn_size=256):
             return torch.stack([ids_masked[k] for k in keys]), torch.stack([labels[k] for k in keys])
         return torch.stack([ids_aug[k - off] if k >= off else ids[k] for k in keys])
     model.encode_text.tokenize = tokenize
-    out = model({"images": images, "captions": [[i] for i in range(b)]}, return_dict=True)
+    out = model({"images": images[sl], "captions": [[i] for i in range(rank * b, (rank + 1) * b)]}, return_dict=True)
     L = ref.modules["prototype.loss_functions.loss"]
     crit, sim_crit = L.ClipInfoCELoss(), L.SimsiamLoss()
     li1, li2, lt1, lt2 = out["logits"]
@@ -472,12 +526,48 @@ def gen_defilip(name, cfg, b, seed=0, nn_size=256):
     mlm = out["text_self_supervised"]
     fi, ft = out["filip"]
     filip_loss = crit(fi, ft)[0]
-    total = 0.4 * clip_loss + 0.2 * sim_loss + 0.2 * mlm + 0.2 * nn_loss + 0.2 * filip_loss
+    total = (0.4 * clip_loss + 0.2 * sim_loss + 0.2 * mlm + 0.2 * nn_loss + 0.2 * filip_loss) / world
     total.backward()
-    ret = dict(kind="defilip", cfg=cfg, b=b, seed=seed, nn_size=nn_size, loss=float(total),
-               parts=dict(clip=float(clip_loss), nn=float(nn_loss), simsiam=float(sim_loss), mlm=float(mlm), filip=float(filip_loss)),
-               filip_i=fi.detach().clone(), grads=grad_digest([(n, p.grad) for n, p in model.named_parameters()]),
-               torch_version=torch.__version__)
+    grads = []
+    for name, p in model.named_parameters():
+        g = p.grad
+        if g is not None and world > 1:
+            dist.all_reduce(g)                                           # utils/dist.py:71-74 (SUM)
+        grads.append((name, g))
+    tot = total.detach().clone()
+    parts = torch.tensor([float(clip_loss), float(nn_loss), float(sim_loss), float(mlm), float(filip_loss)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tot)
+        dist.all_reduce(parts)
+        parts /= world
+    if rank == 0:
+        ret.update(loss=float(tot), parts=dict(clip=float(parts[0]), nn=float(parts[1]), simsiam=float(parts[2]), mlm=float(parts[3]),
+                                                filip=float(parts[4])),
+                   filip_i=fi.detach().clone(), grads=grad_digest(grads))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _spawn_defilip(rank, world, cfg, b, seed, nn_size, path):
+    ret = {}
+    run_defilip_rank(rank, world, cfg, b, seed, nn_size, ret)
+    if rank == 0:
+        torch.save(ret, path)
+
+
+def gen_defilip(name, cfg, b, seed=0, nn_size=256, world=1):
+    """Reference DEFILIP (model/defilip.py) + defilip_solver.py loss composition, one or two ranks."""
+    if world == 1:
+        ret = {}
+        run_defilip_rank(0, 1, cfg, b, seed, nn_size, ret)
+    else:
+        import torch.multiprocessing as mp
+        tmp = "/tmp/_golden_%s.pt" % name
+        mp.spawn(_spawn_defilip, args=(world, cfg, b, seed, nn_size, tmp), nprocs=world, join=True)
+        ret = torch.load(tmp, weights_only=False)
+        os.remove(tmp)
+    ret.update(kind="defilip", cfg=cfg, b=b, seed=seed, nn_size=nn_size, world=world, torch_version=torch.__version__)
     path = os.path.join(GOLDEN_DIR, name + ".pt")
     torch.save(ret, path)
     print("wrote %s  loss=%.6f parts=%s (%d KB)" % (path, ret["loss"], ret["parts"], os.path.getsize(path) // 1024))
@@ -561,9 +651,11 @@ FIXTURES = {
     "declip_tiny_w2": lambda: gen_declip("declip_tiny_w2", synth.TINY, b=4, seed=31, world=2),
     "filip_small_w2": lambda: gen_filip("filip_small_w2", synth.FILIP_SMALL, b=4, seed=32, world=2),
     "slip_tiny": lambda: gen_slip("slip_tiny", synth.TINY, b=5, seed=4),
+    "slip_tiny_w2": lambda: gen_slip("slip_tiny_w2", synth.TINY, b=3, seed=33, world=2),
     "filip_small": lambda: gen_filip("filip_small", synth.FILIP_SMALL, b=5, seed=6),
     "filip_r50_tiny": lambda: gen_filip("filip_r50_tiny", synth.R50_TINY_FILIP, b=4, seed=13),
     "defilip_small": lambda: gen_defilip("defilip_small", synth.FILIP_SMALL, b=4, seed=7),
+    "defilip_small_w2": lambda: gen_defilip("defilip_small_w2", synth.FILIP_SMALL, b=4, seed=34, world=2),
     # full-width fixtures at the smallest batches whose GEMMs are whole 256-row tiles, i.e. that run on the benchmarked
     # gemm_v4 kernel in bf16; minutes of CPU and up to ~40 GB each, logits kept as digests
     "clip_vitb32_b256": lambda: gen_clip("clip_vitb32_b256", synth.VITB32, b=256, seed=21),

@@ -427,6 +427,88 @@ def _w_filip(rank, world, port, out):
         out.put("ok")
 
 
+def _w_slip(rank, world, port, out):
+    """SLIP data-parallel step: the SimCLR features of both views are gathered (NT-Xent over 2B candidates with the positives at
+    rank*b + i, nt_xent.py:64-83), the CLIP logits span B captions; against TWO reference ranks (tests/golden/slip_tiny_w2.pt)."""
+    _init(rank, world, port)
+    _mock_ops()
+    from declip_amd import dist as dd
+    from declip_amd import synth
+    from declip_amd.loss import ClipInfoCELoss, NT_Xent, NT_Xent_gather
+    from declip_amd.steps import slip_loss
+    from declip_amd.testing import build_slip
+    from oracle_util import check_grad_digests, load_golden
+    g = load_golden("slip_tiny_w2")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_slip(cfg, dtype="fp32", seed=seed, device="cpu")
+    wrapped = dd.DistModule(model, sync=False, bucket_bytes=1 << 14)
+    B = b * world
+    sl = slice(rank * b, (rank + 1) * b)
+    images = synth.synth_images(B, views=3, res=cfg["res"], seed=seed)[sl]
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])[sl]
+    o = slip_loss(wrapped, {"images": images, "captions": ids}, ClipInfoCELoss(), NT_Xent_gather(b), NT_Xent(b), world_size=world)
+    o["loss"].backward()
+    total = o["loss"].detach().clone()
+    parts = torch.stack([o["parts"][k].detach().reshape(()) for k in ("clip", "simclr", "nt_xent")]).double()
+    torch.distributed.all_reduce(total)
+    torch.distributed.all_reduce(parts)                       # each part is already divided by world (slip_solver.py:457,490): the sum is the rank mean
+    li, _ = o["outputs"]["logits"]
+    assert li.shape == (b, B)
+    if rank == 0:
+        assert abs(float(total) - g["loss"]) <= 1e-4 * abs(g["loss"]), (float(total), g["loss"])
+        for i, k in enumerate(("clip", "simclr", "nt_xent")):
+            assert abs(float(parts[i]) - g["parts"][k]) <= 2e-4 * max(1.0, abs(g["parts"][k])), (k, float(parts[i]), g["parts"][k])
+        assert float((li.materialize().detach() - g["logits_i"]).abs().max()) <= 1e-4 * float(g["logits_i"].abs().max())
+        assert float((o["outputs"]["sim_features"][0].detach() - g["sim1"]).abs().max()) <= 1e-4 * float(g["sim1"].abs().max())
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+        check_grad_digests(g["grads"], grads, rtol=1e-3)
+        out.put("ok")
+
+
+def _w_defilip(rank, world, port, out):
+    """DeFILIP data-parallel step: DeCLIP's six-tensor gather + per-rank NN bank + masked-LM head AND FILIP's gathered top-16 token
+    sets (dense logits over B = 2b captions, labels from rank*b) in one step; against TWO reference ranks
+    (tests/golden/defilip_small_w2.pt)."""
+    _init(rank, world, port)
+    _mock_ops()
+    from declip_amd import dist as dd
+    from declip_amd import synth
+    from declip_amd.heads import SimsiamLoss
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.steps import DEFILIP_WEIGHTS, declip_loss
+    from declip_amd.testing import build_defilip
+    from oracle_util import check_grad_digests, load_golden
+    g = load_golden("defilip_small_w2")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_defilip(cfg, dtype="fp32", seed=seed, nn_size=g["nn_size"], device="cpu")
+    model.nn_replacer_text.bank = synth.synth_bank(g["nn_size"], cfg["embed_dim"], seed=seed + rank)     # per-rank bank, as the golden
+    wrapped = dd.DistModule(model, sync=False, bucket_bytes=1 << 14)
+    B = b * world
+    sl = slice(rank * b, (rank + 1) * b)
+    images = synth.synth_images(B, views=2, res=cfg["res"], seed=seed)[sl]
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+    ids_aug = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+    ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+    batch = {"images": images, "captions": torch.stack([ids_masked[sl], ids_aug[sl]], dim=1), "mlm_labels": labels[sl]}
+    o = declip_loss(wrapped, batch, ClipInfoCELoss(), SimsiamLoss(), None, weights=DEFILIP_WEIGHTS, world_size=world)
+    o["loss"].backward()
+    total = o["loss"].detach().clone()
+    names = ("clip", "nn", "simsiam", "mlm", "filip")
+    parts = torch.stack([o["parts"][k].detach().reshape(()) for k in names])
+    torch.distributed.all_reduce(total)
+    torch.distributed.all_reduce(parts)                  # every term is already divided by world_size: the sum is the mean over ranks
+    fi = o["outputs"]["filip"][0].detach()
+    assert fi.shape == (b, B)
+    if rank == 0:
+        assert abs(float(total) - g["loss"]) <= 1e-4 * abs(g["loss"]), (float(total), g["loss"])
+        for v, k in zip(parts.tolist(), names):
+            assert abs(v - g["parts"][k]) <= 2e-4 * max(1.0, abs(g["parts"][k])), (k, v, g["parts"][k])
+        assert float((fi - g["filip_i"]).abs().max()) <= 1e-4 * float(g["filip_i"].abs().max())
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+        check_grad_digests(g["grads"], grads, rtol=1e-3)
+        out.put("ok")
+
+
 def _w_clip_bf16_buckets(rank, world, port, out):
     """gradient buckets cross the wire as bf16 (DistModule(grad_dtype=torch.bfloat16) / DH_GRAD_BF16=1): the two-rank reference
     golden at the bf16 tolerance -- every gradient norm within 1 % (one rounding of each rank's addend and of the sum), and the
@@ -502,7 +584,7 @@ def _w_zero_shot(rank, world, port, out):
         out.put("ok")
 
 
-@pytest.mark.parametrize("fn", [_w_gather, _w_reducer, _w_reducer_gap, _w_clip, _w_clip_tower_twice, _w_clip_packed_pooled, _w_clip_r50, _w_clip_r50_syncbn, _w_zero_shot, _w_declip, _w_declip_global_bank, _w_filip,
+@pytest.mark.parametrize("fn", [_w_gather, _w_reducer, _w_reducer_gap, _w_clip, _w_clip_tower_twice, _w_clip_packed_pooled, _w_clip_r50, _w_clip_r50_syncbn, _w_zero_shot, _w_declip, _w_declip_global_bank, _w_filip, _w_slip, _w_defilip,
                                 _w_clip_bf16_buckets])
 def test_world2(fn):
     port = _free_port()
