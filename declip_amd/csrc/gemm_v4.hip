@@ -1144,19 +1144,42 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
         for (int rg = 0; rg < 4; ++rg) asm volatile("" : "+v"(bq[j][rg].x), "+v"(bq[j][rg].y), "+v"(bq[j][rg].z), "+v"(bq[j][rg].w));
 #pragma unroll
       for (int q = 0; q <= 4; ++q) {
-        if (q >= 1) {                          // read back + store quarter q - 1: the four LDS reads first, then the stores
-          const int qs = q - 1, i = qs >> 1, ii = qs & 1;
-          const unsigned char* Cq = Cs + (qs & 1) * (64 * 512);
-          uint4 raws[4];
+        // order inside a phase: (1) the four LDS reads of quarter q-1 are ISSUED, (2) quarter q is converted and staged while they
+        // are in flight (the staging writes go to the other half of the buffer; LDS operations retire in order, so the wait the
+        // compiler places before the first use of the read data leaves the eight younger writes outstanding), (3) the global stores
+        // of quarter q-1.  With the reads waited for before the conversions, every phase exposed one LDS round trip.
+        uint4 raws[4];
+        if (q >= 1) {
+          const unsigned char* Cq = Cs + ((q - 1) & 1) * (64 * 512);
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             const int row = r0 + 16 * it;                                        // staging row 0..63
             const int pc = cc ^ ((row & 15) >> 1);
             raws[it] = *reinterpret_cast<const uint4*>(Cq + row * 512 + pc * 16);
           }
-          wait_lgkm0();
+        }
+        if (q <= 3) {                          // convert + stage quarter q
+          unsigned char* Cq = Cs + (q & 1) * (64 * 512);
 #pragma unroll
-          for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(raws[it].x), "+v"(raws[it].y), "+v"(raws[it].z), "+v"(raws[it].w));
+          for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int nl = j * 128 + br + 8 * rg + 4 * (le >> 5);
+              uint2 pk;
+              pk.x = pack2bf_hw(acc[q][j][rg * 4 + 0] * e.alpha + bq[j][rg].x, acc[q][j][rg * 4 + 1] * e.alpha + bq[j][rg].y);
+              pk.y = pack2bf_hw(acc[q][j][rg * 4 + 2] * e.alpha + bq[j][rg].z, acc[q][j][rg * 4 + 3] * e.alpha + bq[j][rg].w);
+              *reinterpret_cast<uint2*>(Cq + mlq * 512 + (((nl >> 2) ^ (mlq & 15)) << 3)) = pk;
+              if (q == 0 && (rg & 1) && issue_now) {               // the next tile's K-tile 0: one half-tile after every second group
+                if (j == 0 && rg == 1) ISSUE_H(ap, 0, 0, 0);
+                if (j == 0 && rg == 3) ISSUE_H(bp, 0, 2, 0);
+                if (j == 1 && rg == 1) ISSUE_H(bp, BDHQ, 3, 0);
+                if (j == 1 && rg == 3) ISSUE_H(ap, a_dh, 1, 0);
+              }
+            }
+          }
+        }
+        if (q >= 1) {                          // store quarter q - 1
+          const int qs = q - 1, i = qs >> 1, ii = qs & 1;
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             const int row = r0 + 16 * it;
@@ -1195,26 +1218,6 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
               store_c16<NT_OUT>(Cb + mu * e.ldc * 2 + c_off, pk);
             }
             if (it & 1) __builtin_amdgcn_sched_barrier(0);      // keep the unrolled iterations from being interleaved (register pressure)
-          }
-        }
-        if (q <= 3) {                          // convert + stage quarter q
-          unsigned char* Cq = Cs + (q & 1) * (64 * 512);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-              const int nl = j * 128 + br + 8 * rg + 4 * (le >> 5);
-              uint2 pk;
-              pk.x = pack2bf_hw(acc[q][j][rg * 4 + 0] * e.alpha + bq[j][rg].x, acc[q][j][rg * 4 + 1] * e.alpha + bq[j][rg].y);
-              pk.y = pack2bf_hw(acc[q][j][rg * 4 + 2] * e.alpha + bq[j][rg].z, acc[q][j][rg * 4 + 3] * e.alpha + bq[j][rg].w);
-              *reinterpret_cast<uint2*>(Cq + mlq * 512 + (((nl >> 2) ^ (mlq & 15)) << 3)) = pk;
-              if (q == 0 && (rg & 1) && issue_now) {               // the next tile's K-tile 0: one half-tile after every second group
-                if (j == 0 && rg == 1) ISSUE_H(ap, 0, 0, 0);
-                if (j == 0 && rg == 3) ISSUE_H(bp, 0, 2, 0);
-                if (j == 1 && rg == 1) ISSUE_H(bp, BDHQ, 3, 0);
-                if (j == 1 && rg == 3) ISSUE_H(ap, a_dh, 1, 0);
-              }
-            }
           }
         }
         if (q == 1 && has_pre) {
