@@ -24,7 +24,16 @@ def r8(lo, hi):
 
 
 def draw():
-    kind = random.choice(["gemm", "gemm", "ln", "attn", "nce", "nn", "conv", "bn", "pool"])
+    kind = random.choice(["gemm", "gemm", "ln", "attn", "nce", "nn", "conv", "bn", "pool", "embgrad", "bn1d", "nce_wide"])
+    if kind == "embgrad":       # sort-by-id segmented reduction: few / many distinct ids, d with masked lanes, vocabularies above one scan round
+        return "K", "test_embed_table_grad_sorted_segments", (random.randint(20, 3000), 8 * random.randint(1, 100), random.choice([17, 90, 1000, 3000, 49408, 70001]),
+                                                               random.choice([F32, BF16]))
+    if kind == "bn1d":          # C % 8 == 0: the 16-byte kernels, otherwise the column-per-lane ones; groups with few or many rows
+        return "K", "test_bn1d_groups", (random.choice([F32, BF16]), random.random() < 0.5, random.randint(1, 3), random.randint(3, 200),
+                                         random.choice([8, 64, 72, 100, 200, 203, 256, 520, 1024]))
+    if kind == "nce_wide":      # X staged per pass, dX in 512-column chunks
+        b, W = random.randint(16, 50), random.randint(2, 3)     # (W = 1 at these batch sizes: the known tiny-loss relative-bound misses)
+        return "K", "test_infonce", (b, b * W, random.choice([544, 640, 768, 1024, 1280, 1536]), random.randint(0, W - 1) * b)
     if kind == "gemm":
         dtype = random.choice([F32, BF16])
         generic = dtype == BF16 and random.random() < 0.3
