@@ -72,3 +72,27 @@ def test_cpu_tensors_are_rejected():
     from declip_amd import lib, ops
     with pytest.raises(lib.DeclipHipError):
         ops.layernorm_fwd(torch.zeros(4, 8), torch.ones(8), torch.zeros(8))
+
+
+def test_communicator_context_fails_loudly_without_a_device():
+    """The comm entry points (csrc/comm.hip) bind RCCL at run time and never fall back: on a box without a GPU dh_init returns
+    NULL with the reason in dh_last_error(), bad arguments are refused, and nothing crashes.  (dh_comm_unique_id needs no device:
+    it proves that RCCL was found and bound.)"""
+    import ctypes
+    from declip_amd import lib as L
+    lib = L.load()
+    buf = ctypes.create_string_buffer(128)
+    assert lib.dh_comm_unique_id(buf, 16) == -1 and b"128" in lib.dh_last_error()
+    rc = lib.dh_comm_unique_id(buf, 128)
+    if rc != 0:                                   # no RCCL on this machine: that, too, must be a clean error
+        assert b"RCCL" in lib.dh_last_error()
+        return
+    assert buf.raw != b"\x00" * 128
+    assert lib.dh_init(3, 2, 0, buf) is None and b"rank 3 of 2" in lib.dh_last_error()
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.dh_init(0, 1, 0, buf) is None and b"visible devices" in lib.dh_last_error()
+    assert lib.dh_allgather_packed(None, None, None, 1, 1, 2, None, None) == -1
+    assert lib.dh_reducescatter_packed(None, None, None, None, 1, 1, 2, None, None) == -1
+    assert lib.dh_allreduce_bucket(None, None, 0, None, None) == -1
+    assert lib.dh_comm_wait(None, None) == -1 and lib.dh_finalize(None) == -1
