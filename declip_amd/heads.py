@@ -280,13 +280,25 @@ class MlmHeadFn(torch.autograd.Function):
         return dwords.view(wshape), None, None, None, None
 
 
+def _mlm_selection(labels, dev):
+    """(positions, labels) of the masked tokens on the device.  The selection is index arithmetic on the labels' own device (the host,
+    normally) plus two small uploads; it is kept WITH the labels tensor object (version-checked), so a batch that is stepped on
+    repeatedly -- a resident synthetic batch, gradient accumulation over the same micro-batch, a captured step -- uploads once and
+    forward() contains no host-to-device copy."""
+    tag = getattr(labels, "_dh_mlm", None)
+    if tag is not None and tag[0] == labels._version and tag[1] == str(dev):
+        return tag[2], tag[3]
+    lab = labels.reshape(-1)
+    sel = (lab != -100).nonzero(as_tuple=False).reshape(-1)
+    sel_d = engine.to_device_async(sel, dev)
+    labels_sel = engine.to_device_async(lab[sel.to(lab.device)], dev)
+    labels._dh_mlm = (labels._version, str(dev), sel_d, labels_sel)
+    return sel_d, labels_sel
+
+
 def mlm_loss(words, labels, lin, flat):
     """mean CE over positions with labels != -100 (declip.py:331-334)."""
-    lab = labels.reshape(-1)
-    sel = (lab != -100).nonzero(as_tuple=False).reshape(-1)        # index arithmetic (host sync only if labels live on the GPU)
-    dev = words.device
-    idx = engine.to_device_async(sel, dev)
-    labels_sel = engine.to_device_async(lab[sel.to(lab.device)], dev)
+    idx, labels_sel = _mlm_selection(labels, words.device)
     return MlmHeadFn.apply(words, idx, labels_sel, lin, flat).mean()
 
 
@@ -294,10 +306,6 @@ def mlm_loss_packed(words_p, pk, n_captions, labels, lin, flat):
     """mlm_loss on the PACKED word features [rows_pad, width] of engine.TextTowerPackedFn: the masked positions (bi, l) of the first
     `n_captions` captions are rows cu[bi] + l (a masked token lies inside its caption)."""
     L = labels.shape[-1]
-    lab = labels.reshape(-1)
-    sel = (lab != -100).nonzero(as_tuple=False).reshape(-1)        # index arithmetic on the labels' own device (the host, normally)
-    dev = words_p.device
-    sel_d = engine.to_device_async(sel, dev)
+    sel_d, labels_sel = _mlm_selection(labels, words_p.device)
     idx = pk.cu[:n_captions].long()[sel_d // L] + sel_d % L
-    labels_sel = engine.to_device_async(lab[sel.to(lab.device)], dev)
     return MlmHeadFn.apply(words_p.unsqueeze(0), idx, labels_sel, lin, flat).mean()

@@ -61,6 +61,15 @@ def build_declip(cfg, dtype="bf16", seed=0, nn_size=256, fused_loss=True, device
     return model
 
 
+def _captions_to(caps, device):
+    """captions to the device WITH the packed row count taken on the host copy (what declip_amd.prefetch does for a real loader):
+    the step then never reads a count back from the device (no host stall in forward(), and the step stays capturable)."""
+    rows = int((caps.reshape(-1, caps.shape[-1]).argmax(dim=-1) + 1).sum())
+    out = caps.to(device)
+    out._dh_rows = (out._version, rows)
+    return out
+
+
 def declip_batch(cfg, b, seed=0, device="cuda"):
     """seeded DeCLIP batch: two channel-stacked views, masked ids + labels, augmented ids."""
     images = synth.synth_images(b, views=2, res=cfg["res"], seed=seed)
@@ -68,7 +77,7 @@ def declip_batch(cfg, b, seed=0, device="cuda"):
     ids_aug = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"])
     ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
     caps = torch.stack([ids_masked, ids_aug], dim=1)
-    return {"images": images.to(device), "captions": caps.to(device), "mlm_labels": labels}
+    return {"images": images.to(device), "captions": _captions_to(caps, device), "mlm_labels": labels}
 
 
 def build_slip(cfg, dtype="bf16", seed=0, fused_loss=True, device="cuda", load_synth=True):
@@ -91,7 +100,7 @@ def build_slip(cfg, dtype="bf16", seed=0, fused_loss=True, device="cuda", load_s
 def slip_batch(cfg, b, seed=0, device="cuda"):
     images = synth.synth_images(b, views=3, res=cfg["res"], seed=seed)
     ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
-    return {"images": images.to(device), "captions": ids.to(device)}
+    return {"images": images.to(device), "captions": _captions_to(ids, device)}
 
 
 def build_filip(cfg, dtype="bf16", seed=0, fused_loss=True, device="cuda", load_synth=True):
@@ -121,7 +130,7 @@ def filip_batch(cfg, b, seed=0, device="cuda"):
     images = synth.synth_images(b, views=2, res=cfg["res"], seed=seed)
     ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
     ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
-    return {"images": images.to(device), "captions": ids_masked.to(device), "mlm_labels": labels}
+    return {"images": images.to(device), "captions": _captions_to(ids_masked, device), "mlm_labels": labels}
 
 
 def build_defilip(cfg, dtype="bf16", seed=0, nn_size=256, device="cuda", load_synth=True, dense_aug=False):
@@ -151,4 +160,4 @@ def defilip_batch(cfg, b, seed=0, device="cuda"):
     ids = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
     ids_aug = synth.synth_tokens(b, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
     ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
-    return {"images": images.to(device), "captions": torch.stack([ids_masked, ids_aug], dim=1).to(device), "mlm_labels": labels}
+    return {"images": images.to(device), "captions": _captions_to(torch.stack([ids_masked, ids_aug], dim=1), device), "mlm_labels": labels}

@@ -598,3 +598,23 @@ def test_zero_shot_from_prompt_strings(mocked_engine, tmp_path):
     emb_ids = zeroshot.class_embeddings(model, ids, 3)
     assert float((emb - emb_ids).abs().max()) <= 1e-6
     assert float((emb.norm(dim=-1) - 1).abs().max()) < 1e-5
+
+
+def test_batches_carry_host_row_counts_and_mlm_selection_is_uploaded_once(mocked_engine):
+    """The batch helpers take the packed row count on the HOST copy of the captions (as declip_amd.prefetch does for a loader) and the
+    masked-LM selection is cached with its labels tensor: a step on a resident batch has no device read-back and no upload in forward()."""
+    from declip_amd import heads, synth
+    from declip_amd.testing import declip_batch, defilip_batch, filip_batch, slip_batch
+    cfg = synth.TINY
+    for make in (declip_batch, defilip_batch, filip_batch, slip_batch):
+        caps = make(synth.FILIP_SMALL if make in (defilip_batch, filip_batch) else cfg, 5, seed=2, device="cpu")["captions"]
+        want = int((caps.reshape(-1, caps.shape[-1]).argmax(dim=-1) + 1).sum())
+        assert caps._dh_rows == (caps._version, want), make.__name__
+    labels = declip_batch(cfg, 5, seed=2, device="cpu")["mlm_labels"]
+    a = heads._mlm_selection(labels, torch.device("cpu"))
+    b = heads._mlm_selection(labels, torch.device("cpu"))
+    assert a[0] is b[0] and a[1] is b[1]                           # second call: the cached tensors
+    assert torch.equal(a[0], (labels.reshape(-1) != -100).nonzero().reshape(-1)) and torch.equal(a[1], labels.reshape(-1)[a[0]])
+    labels[0, 1] = 7                                               # an in-place edit bumps the version: selected again
+    c = heads._mlm_selection(labels, torch.device("cpu"))
+    assert c[0] is not a[0] and int(c[1][(c[0] == 1).nonzero()[0, 0]]) == 7
