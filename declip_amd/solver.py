@@ -205,10 +205,21 @@ def optim_entry(model, opt_cfg, base_lr=None):
     kw = dict(opt_cfg.get("kwargs", {}))
     if base_lr is not None:
         kw["lr"] = base_lr
-    if opt_cfg["type"] in ("AdamW", "FusedFP16AdamW"):
+    typ = opt_cfg["type"]
+    # the reference's own aliases when linklink.optim is absent (optimizer/__init__.py:8-15): FusedFP16SGD = SGD, FusedFP16AdamW = AdamW;
+    # the FP16* wrappers of fp16_optim.py keep fp32 master weights around a half model -- the engine's masters are fp32 already
+    typ = {"FusedFP16SGD": "SGD", "FP16SGD": "SGD", "FusedFP16AdamW": "AdamW", "FP16AdamW": "AdamW", "FP16RMSprop": "RMSprop"}.get(typ, typ)
+    if typ == "AdamW" and not kw.get("amsgrad", False):
+        kw.pop("amsgrad", None)
         kw["betas"] = tuple(kw.get("betas", (0.9, 0.999)))
         return FlatAdamW(groups, model.__dict__["_flat_store"], **kw)
-    return getattr(torch.optim, opt_cfg["type"])(groups, **kw)
+    if typ in ("LARS", "AdamW_SGD", "FP16AdamW_SGD"):
+        raise NotImplementedError("optimizer.type %s (optimizer/lars.py, AdamW_SGD.py) is not rebuilt: no shipped CLIP-family config uses it" % typ)
+    if not hasattr(torch.optim, typ):
+        raise ValueError("unknown optimizer.type %r" % (opt_cfg["type"],))
+    # any torch optimizer steps the fp32 master weights (views into the flat buffer); the bf16 mirror is recast at the next step
+    # because only the fused AdamW hands one over (engine.FlatParams.begin_step) -- AdamW with amsgrad: True lands here as well
+    return getattr(torch.optim, typ)(groups, **kw)
 
 
 # --------------------------------------------------------------------------------------- synthetic data

@@ -272,3 +272,26 @@ def test_exhausted_loader_is_reported(mocked):
     s = ClsSolver(cfg, train_loader=[one], device="cpu")
     with pytest.raises(RuntimeError, match="exhausted"):
         s.train(max_steps=3)
+
+
+@pytest.mark.parametrize("typ,kwargs,expect", [("FusedFP16AdamW", dict(lr=1e-4, betas=[0.9, 0.98], eps=1e-8, weight_decay=0.1), "FlatAdamW"),
+                                               ("FusedFP16SGD", dict(lr=1e-3, momentum=0.9, weight_decay=1e-4, nesterov=True), "SGD"),
+                                               ("AdamW", dict(lr=1e-4, amsgrad=True), "AdamW"), ("LARS", dict(lr=1.0), None)])
+def test_reference_optimizer_names(mocked, typ, kwargs, expect):
+    """optimizer/__init__.py:3-26: the reference's registry names.  FusedFP16SGD / FusedFP16AdamW are SGD / AdamW there when
+    linklink.optim is absent; a torch optimizer (anything but the fused AdamW) steps the fp32 masters and the mirror is recast the
+    step after (two training steps run, the loss moves); LARS / AdamW_SGD are refused by name."""
+    from declip_amd.solver import ClsSolver
+    cfg = _config("clip")
+    cfg["saver"] = dict(print_freq=100, save_freq=0, pretrain=dict(auto_resume=False))
+    cfg["optimizer"] = dict(type=typ, kwargs=dict(kwargs))
+    if expect is None:
+        with pytest.raises(NotImplementedError, match="LARS"):
+            ClsSolver(cfg, device="cpu")
+        return
+    s = ClsSolver(cfg, device="cpu")
+    assert type(s.optimizer).__name__ == expect
+    before = [p.detach().clone() for p in s.model.module.parameters() if p.requires_grad][:4]
+    s.train(max_steps=2)
+    after = [p.detach() for p in s.model.module.parameters() if p.requires_grad][:4]
+    assert any(not torch.equal(a, b) for a, b in zip(after, before))
