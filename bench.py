@@ -259,6 +259,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    while use_graph and graphed.graph is None:
+        step()             # fewer warm-up steps than the capture needs (2 eager + 1 captured): the capture must not land in the timed region
     # long-lived objects (model, optimizer tables, cached workspaces) out of the collector's way: a generation-2 pass over
     # them in the middle of a step costs the host up to ~200 ms (seen on the DeCLIP step, tools/declip_steps.py)
     import gc
