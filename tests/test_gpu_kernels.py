@@ -301,7 +301,10 @@ def test_infonce(b, B, D, label0):
     dpairs = [(q.to(cuda), k.to(cuda)) for q, k in pairs]
     _poison_lds(ops)
     row_loss, row_lse, c1, c5, logits = ops.infonce_fwd(dpairs, scale.to(cuda), label0, want_logits=True)
-    assert rel_err(row_loss, torch.stack(losses).detach()) < (5e-5 if D <= 1024 else 1e-4)   # fp32 FMA chains over D, fast exp
+    ref_loss = torch.stack(losses).detach()
+    # fp32 FMA chains over D, fast exp: relative to the largest row loss, with an absolute floor for batches whose losses are all
+    # ~0.05 (few candidates: the fp32 rounding of logits ~7 is 6e-6 absolute whatever the loss)
+    assert rel_err(row_loss, ref_loss) < (5e-5 if D <= 1024 else 1e-4) or float((row_loss.cpu().double() - ref_loss).abs().max()) < 1e-5
     assert rel_err(logits, torch.stack(logits_r)) < 1e-5
     assert torch.equal(c1.cpu().double(), torch.stack(c1r)) and torch.equal(c5.cpu().double(), torch.stack(c5r))
     _poison_lds(ops)
