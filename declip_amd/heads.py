@@ -198,6 +198,10 @@ class NNMemoryBankModule(nn.Module):
 
     @torch.no_grad()
     def _enqueue(self, batch):
+        if batch.is_cuda and torch.cuda.is_current_stream_capturing():
+            # the write pointer is host state: a replayed graph would enqueue into the slots of the captured step for ever
+            raise DeclipHipError("NNMemoryBankModule: the queue cannot be updated from inside a captured graph (its write pointer lives "
+                                 "on the host); run DeCLIP / DeFILIP steps eagerly")
         b, ptr = batch.shape[0], self.bank_ptr
         if ptr + b >= self.size:
             self.bank[ptr:] = batch[:self.size - ptr]
