@@ -224,7 +224,7 @@ def main():
     wrapped = dh_dist.DistModule(model, sync=False)
     opt = build_adamw(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
 
-    use_graph = (args.graph if args.graph is not None else os.environ.get("DH_STEP_GRAPH", "1" if args.model in ("clip", "clip_r50", "filip") else "0")) == "1" and world == 1
+    use_graph = (args.graph if args.graph is not None else os.environ.get("DH_STEP_GRAPH", "1" if args.model in ("clip", "clip_r50", "filip", "declip", "defilip") else "0")) == "1" and world == 1
 
     def fwd_bwd():
         if args.model in ("clip", "clip_r50"):

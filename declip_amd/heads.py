@@ -187,8 +187,24 @@ class NNMemoryBankModule(nn.Module):
         if topk != 1:
             raise NotImplementedError("topk > 1 (all shipped configs use nn_topk=1)")
         self.size, self.topk = size, topk
-        self.bank = None
-        self.bank_ptr = 0
+        self.bank = None             # [size, D] fp32: the first `size` rows of _store (a caller may also assign a tensor directly)
+        self._store = None           # [size + spill, D]: rows past `size` take the batch tail that a wrapping enqueue drops
+        self._ptr = None             # [1] int64 on the bank's device: the write pointer
+        self._ptr_init = 0
+        self._ar = None
+
+    # The write pointer lives on the DEVICE: enqueue is index arithmetic + index_copy_ on the stream, with no host value baked into a
+    # launch -- a step captured as a hipGraph (declip_amd/graph.py) advances the queue on every replay.  `bank_ptr` (the reference's
+    # attribute, memory_bank.py:66) reads it back; only tests and checkpoints do.
+    @property
+    def bank_ptr(self):
+        return int(self._ptr.item()) if self._ptr is not None else self._ptr_init
+
+    @bank_ptr.setter
+    def bank_ptr(self, v):
+        self._ptr_init = int(v)
+        if self._ptr is not None:
+            self._ptr.fill_(int(v))
 
     @torch.no_grad()
     def init_bank(self, dim, device, generator=None):
@@ -198,17 +214,20 @@ class NNMemoryBankModule(nn.Module):
 
     @torch.no_grad()
     def _enqueue(self, batch):
-        if batch.is_cuda and torch.cuda.is_current_stream_capturing():
-            # the write pointer is host state: a replayed graph would enqueue into the slots of the captured step for ever
-            raise DeclipHipError("NNMemoryBankModule: the queue cannot be updated from inside a captured graph (its write pointer lives "
-                                 "on the host); run DeCLIP / DeFILIP steps eagerly")
-        b, ptr = batch.shape[0], self.bank_ptr
-        if ptr + b >= self.size:
-            self.bank[ptr:] = batch[:self.size - ptr]
-            self.bank_ptr = 0
-        else:
-            self.bank[ptr:ptr + b] = batch
-            self.bank_ptr = ptr + b
+        """FIFO enqueue that drops the batch tail on wrap and resets the pointer (memory_bank.py:82-87): rows ptr .. ptr+b-1 are
+        written, those >= size land in the spill rows behind the bank (never searched); ptr = 0 if ptr + b >= size else ptr + b."""
+        b, dev = batch.shape[0], batch.device
+        if self._store is None or self.bank.data_ptr() != self._store.data_ptr() or self._store.shape[0] < self.size + b:
+            store = torch.empty(self.size + max(b, 1024), self.bank.shape[1], device=dev, dtype=self.bank.dtype)
+            store[:self.size].copy_(self.bank)
+            self._store, self.bank = store, store[:self.size]
+        if self._ptr is None or self._ptr.device != dev:
+            self._ptr = torch.full((1,), self._ptr_init, device=dev, dtype=torch.int64)
+        if self._ar is None or self._ar.numel() < b or self._ar.device != dev:
+            self._ar = torch.arange(max(b, 1024), device=dev, dtype=torch.int64)
+        self._store.index_copy_(0, self._ptr + self._ar[:b], batch)
+        nxt = self._ptr + b
+        self._ptr.copy_(torch.where(nxt >= self.size, torch.zeros_like(nxt), nxt))
 
     @torch.no_grad()
     def forward(self, output, update=False, query=True, enqueue=None):

@@ -618,3 +618,31 @@ def test_batches_carry_host_row_counts_and_mlm_selection_is_uploaded_once(mocked
     labels[0, 1] = 7                                               # an in-place edit bumps the version: selected again
     c = heads._mlm_selection(labels, torch.device("cpu"))
     assert c[0] is not a[0] and int(c[1][(c[0] == 1).nonzero()[0, 0]]) == 7
+
+
+def test_nn_queue_enqueue_semantics_with_the_pointer_on_the_device(mocked_engine):
+    """memory_bank.py:82-87: FIFO enqueue; a batch that reaches the end of the queue is written up to the last slot, its tail is
+    DROPPED and the pointer returns to 0 (also when it ends exactly on the last slot).  The pointer is a device tensor (graph-safe);
+    `bank_ptr` reads it back, assigning `bank` / `bank_ptr` from outside (tests, checkpoints) keeps working."""
+    from declip_amd.heads import NNMemoryBankModule
+    m = NNMemoryBankModule(size=10)
+    m.bank = torch.zeros(10, 3)
+    m.bank_ptr = 0
+    ref, ptr = torch.zeros(10, 3), 0
+    g = torch.Generator().manual_seed(0)
+    for step, b in enumerate([4, 4, 4, 3, 7, 5, 5, 1, 9, 2]):
+        batch = torch.randn(b, 3, generator=g)
+        if ptr + b >= 10:
+            ref[ptr:] = batch[:10 - ptr]
+            ptr = 0
+        else:
+            ref[ptr:ptr + b] = batch
+            ptr += b
+        m(batch, update=True, query=False)
+        assert m.bank_ptr == ptr, (step, m.bank_ptr, ptr)
+        assert torch.equal(m.bank, ref), step
+        assert m.bank.shape == (10, 3) and m.bank.is_contiguous()
+    m.bank = torch.ones(10, 3)                                        # replaced from outside: the next enqueue adopts it
+    m.bank_ptr = 8
+    m(torch.full((3, 3), 5.0), update=True, query=False)
+    assert m.bank_ptr == 0 and float(m.bank[8:].sum()) == 30.0 and float(m.bank[:8].sum()) == 24.0
