@@ -163,8 +163,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", choices=["0", "1"], default=None,
                     help="capture forward + loss + backward of the step in ONE HIP graph (declip_amd/graph.py), the fused AdamW stays "
-                         "a separate launch; default: DH_STEP_GRAPH, else 1 for clip / clip_r50 on one GPU (measured +1.4 % / +10 %), 0 for the models "
-                         "whose step carries host-side state (NN-bank pointer) and for multi-GPU runs")
+                         "a separate launch; default: DH_STEP_GRAPH, else 1 on one GPU for the models whose graph == eager test gates it (clip, clip_r50, "
+                         "declip, defilip, filip), 0 for slip (no gain) and for multi-GPU runs (1 there captures the RCCL collectives with the step)")
     args = ap.parse_args()
 
     if args.text_packed is not None:
@@ -224,7 +224,27 @@ def main():
     wrapped = dh_dist.DistModule(model, sync=False)
     opt = build_adamw(model, lr=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
 
-    use_graph = (args.graph if args.graph is not None else os.environ.get("DH_STEP_GRAPH", "1" if args.model in ("clip", "clip_r50", "filip", "declip", "defilip") else "0")) == "1" and world == 1
+    # default: on for one GPU where a graph == eager test gates it (tests/test_gpu_graph.py: clip, clip_r50, declip, defilip, filip);
+    # multi-GPU runs capture the RCCL collectives with the step only when asked to (--graph 1 / DH_STEP_GRAPH=1; the capture of a
+    # one-rank RCCL step is tested in tests/test_gpu_dist.py, W > 1 has not run anywhere yet) and never over a gloo group
+    graph_default = "1" if (world == 1 and args.model in ("clip", "clip_r50", "filip", "declip", "defilip")) else "0"
+    use_graph = (args.graph if args.graph is not None else os.environ.get("DH_STEP_GRAPH", graph_default)) == "1"
+    if world > 1 and torch.distributed.get_backend() != "nccl":
+        use_graph = False
+    # sanity of a multi-GPU launch before anything is timed: every rank of the launch is in the communicator (a SUM all-reduce of
+    # ones over RCCL must count `world` ranks) and sits on its own device
+    rccl_ranks = 1
+    if world > 1:
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        rccl_ranks = int(round(float(ones)))
+        devs = [None] * world
+        torch.distributed.all_gather_object(devs, (os.uname().nodename, torch.cuda.current_device()))
+        if rccl_ranks != world or torch.distributed.get_world_size() != world or (torch.distributed.get_backend() == "nccl" and len(set(devs)) != world):
+            if rank == 0:
+                print(json.dumps(dict(error="communicator does not match the launch", world=world, rccl_ranks=rccl_ranks,
+                                      group_size=torch.distributed.get_world_size(), devices=devs)), flush=True)
+            sys.exit(3)
 
     def fwd_bwd():
         if args.model in ("clip", "clip_r50"):
@@ -243,7 +263,7 @@ def main():
         return loss.detach()
 
     from declip_amd.graph import GraphedStep
-    graphed = GraphedStep(fwd_bwd, warmup=2, enabled=use_graph)
+    graphed = GraphedStep(fwd_bwd, warmup=2, enabled=use_graph, modules=(wrapped,))
 
     def step():
         opt.zero_grad()
@@ -380,7 +400,7 @@ def main():
         # HBM-side traffic of the same kernels from the rocprofv3 PMC passes of tools/profile_step.sh (committed summary):
         # per-launch average next to the algorithmic bytes per launch (operands once + outputs once)
         traffic, traffic_source = None, None
-        for rnd in ("r02", "r01"):                # a COMMITTED rocprofv3 --pmc summary of this configuration (tools/profile_step.sh):
+        for rnd in ("r03", "r02", "r01"):                # a COMMITTED rocprofv3 --pmc summary of this configuration (tools/profile_step.sh):
             pmc_file = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s_b%d.json" % (rnd, args.model, b))   # not measured by this run
             if os.path.exists(pmc_file):
                 with open(pmc_file) as fh:
@@ -397,8 +417,12 @@ def main():
                         gemm_gflop_per_step=round(flops / nprof / 1e9, 1),
                         executed_gemm_gflop_per_pair=round(flops / nprof / 1e9 / b, 2),
                         dense_gflop_per_pair={"clip": GFLOP_PER_PAIR, "clip_r50": GFLOP_PER_PAIR_R50}.get(args.model, 89.9),
+                        # step-level fractions.  `_executed`: the flops the engine runs (packed captions + pooled last block leave
+                        # out work that cannot reach the loss) -- THE roofline fraction of the step.  `_dense_equivalent`: the same
+                        # throughput priced at the dense flop count the reference spends for the same outputs (a speed-up figure,
+                        # not a utilisation)
                         step_mfma_frac_executed=round(pairs_per_s / b * (flops / nprof) / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
-                        step_mfma_frac=round(pairs_per_s * {"clip": GFLOP_PER_PAIR, "clip_r50": GFLOP_PER_PAIR_R50}.get(args.model, 89.9) / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
+                        step_mfma_frac_dense_equivalent=round(pairs_per_s * {"clip": GFLOP_PER_PAIR, "clip_r50": GFLOP_PER_PAIR_R50}.get(args.model, 89.9) / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
 
     name = {"clip": "CLIP ViT-B/32", "declip": "DeCLIP ViT-B/32", "slip": "SLIP ViT-B/32", "filip": "FILIP ViT-B/32", "defilip": "DeFILIP ViT-B/32",
             "clip_r50": "CLIP ResNet-50"}[args.model]
@@ -420,7 +444,9 @@ def main():
                scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                config=dict(workload=workloads[args.model],
                            global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world,
-                           tower_streams=1 + len(model.__dict__["_flat_store"].side_streams), step_graph=int(use_graph),
+                           tower_streams=1 + len(model.__dict__["_flat_store"].side_streams), step_graph=int(use_graph and graphed.graph is not None),
+                           rccl_ranks=rccl_ranks, dist_backend=(torch.distributed.get_backend() if world > 1 else None),
+                           dynamic_tiles=int(os.environ.get("DH_V4_DYNAMIC", "0")), comm_native=int(dh_dist.native_comm() is not None) if world > 1 else 0,
                            text_packed=eng_mod.text_packed_mode(), pooled_last=int(eng_mod.pooled_last_block())),   # captions computed up to <|endoftext|> only; last block for the pooled rows only (same outputs, fewer executed flops: see roofline.executed_gemm_gflop_per_pair)
                loss=round(float(loss.detach()) * world, 5))
     if roofline is not None:

@@ -220,6 +220,25 @@ class FlatParams:
         if self.reducer is not None:
             self.reducer.finish()
 
+    def before_replay(self):
+        """begin_step() for a step that is about to be REPLAYED from a captured graph: the capture holds a weight cast only if one
+        was due at capture time, so weights written since by anything but the fused optimizer are recast here, eagerly."""
+        if not (self.trust_mirror and self._mirror_by_opt):
+            self.mirror_fresh = False
+        self.refresh_mirror()
+
+    def after_replay(self):
+        """A captured step (graph.GraphedStep) was replayed: its kernels and collectives wrote the flat gradient buffer, but the
+        Python half of the backward protocol did not run.  Redo what a replay cannot: `p.grad` views that optimizer.zero_grad()
+        set to None point at the flat buffer again (as _end_backward leaves them), and the bf16 mirror counts as written by
+        whatever optimizer steps next (begin_backward's reset)."""
+        self._mirror_by_opt = False
+        for p in self.params:
+            if not p.requires_grad or getattr(p, "_dh_grad_none", False):
+                continue
+            if p.grad is None:
+                p.grad = self.gview(p)
+
     def tower_forward(self, tower, needs_grad):
         """A tower Function ran forward and will run backward: one more pending use of its parameters in this step."""
         if needs_grad:

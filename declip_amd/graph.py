@@ -11,30 +11,64 @@ the data (row counts of packed captions are taken from the host copy of a batch,
 scratch (split-K workspace, scheduler slots) is created during the eager warm-up steps; the gradient buffer is zeroed by a
 captured memset; the two tower streams fork from and join the capture stream with events.  Inputs live in STATIC buffers that
 the caller refreshes (copy_) before each replay.  Not capturable (and refused): a distributed step whose collectives run on a
-gloo group, host-side branching on device data.
+gloo group (host-side collectives), host-side branching on device data.
+
+Host-side bookkeeping of a backward pass does not run on a replay -- `FlatParams._end_backward` (which points every `p.grad` at
+its slice of the flat gradient buffer) and the reducer's begin / finish are Python.  The kernels and collectives they enqueue ARE
+in the graph (the RCCL all-gather / reduce-scatter / bucket all-reduces are captured like any other launch of the step), so what
+has to be redone per replay is only the `p.grad` views that `optimizer.zero_grad()` set to None: pass the models as `modules` and
+`after_replay()` restores them, which keeps torch optimizers, gradient clipping and anything else that reads `p.grad` working on
+replayed steps (the fused FlatAdamW reads the flat buffer directly and needs nothing).
 """
 import torch
 
 
-class GraphedStep(object):
-    """graphed = GraphedStep(fn); loss = graphed()  -- `fn()` runs forward + loss + backward on static input buffers and returns a
-    tensor (or tuple of tensors); the first `warmup` calls run eagerly (lazy initialisation, allocator warm-up), the next one is
-    captured, every later one replays the graph.  The returned tensors are the graph's static outputs: read them before the
-    next call."""
+def _flat_stores(modules):
+    stores = []
+    for m in modules or ():
+        st = m.__dict__.get("_flat_store")
+        if st is None and hasattr(m, "module"):          # dist.DistModule around an engine model
+            st = m.module.__dict__.get("_flat_store")
+        if st is None:
+            raise ValueError("GraphedStep(modules=...): %s has no flat parameter store" % type(m).__name__)
+        stores.append(st)
+    return stores
 
-    def __init__(self, fn, warmup=2, enabled=True):
+
+class GraphedStep(object):
+    """graphed = GraphedStep(fn, modules=(model,)); loss = graphed()  -- `fn()` runs forward + loss + backward on static input
+    buffers and returns a tensor (or tuple of tensors); the first `warmup` calls run eagerly (lazy initialisation, allocator
+    warm-up), the next one is captured, every later one replays the graph.  The returned tensors are the graph's static outputs:
+    read them before the next call.  `modules`: the engine models (or their DistModule wrappers) that `fn` steps through; their
+    `p.grad` views are restored after every replay and a distributed reducer is checked for capturability."""
+
+    def __init__(self, fn, warmup=2, enabled=True, modules=None):
         self.fn, self.warmup, self.enabled = fn, int(warmup), bool(enabled)
         self.calls, self.graph, self.out = 0, None, None
+        self.stores = _flat_stores(modules)
+
+    def _check_capturable(self):
+        import torch.distributed as tdist
+        for st in self.stores:
+            red = getattr(st, "reducer", None)
+            if red is not None and red.distributed() and tdist.is_initialized() and tdist.get_backend() != "nccl":
+                raise RuntimeError("GraphedStep: the gradient collectives of this step run on a '%s' process group (host-side "
+                                   "collectives cannot be captured in a HIP graph); run the step eagerly" % tdist.get_backend())
 
     def __call__(self):
         if not self.enabled:
             return self.fn()
         self.calls += 1
         if self.graph is not None:
+            for st in self.stores:
+                st.before_replay()
             self.graph.replay()
+            for st in self.stores:
+                st.after_replay()
             return self.out
         if self.calls <= self.warmup:
             return self.fn()
+        self._check_capturable()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         # the capture stream is a fresh side stream (torch.cuda.graph's default): the engine's own side streams fork from it
@@ -42,4 +76,6 @@ class GraphedStep(object):
             out = self.fn()
         self.graph, self.out = g, out
         g.replay()                              # the captured launches did not execute during capture
+        for st in self.stores:
+            st.after_replay()
         return self.out

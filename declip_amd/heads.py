@@ -192,6 +192,8 @@ class NNMemoryBankModule(nn.Module):
         self._ptr = None             # [1] int64 on the bank's device: the write pointer
         self._ptr_init = 0
         self._ar = None
+        self.spill_rows = 1024       # rows behind the bank for the tail a wrapping enqueue drops: >= the largest batch enqueued
+        self._captured = False       # an enqueue was captured into a hipGraph: the storage must not move any more
 
     # The write pointer lives on the DEVICE: enqueue is index arithmetic + index_copy_ on the stream, with no host value baked into a
     # launch -- a step captured as a hipGraph (declip_amd/graph.py) advances the queue on every replay.  `bank_ptr` (the reference's
@@ -218,13 +220,25 @@ class NNMemoryBankModule(nn.Module):
         written, those >= size land in the spill rows behind the bank (never searched); ptr = 0 if ptr + b >= size else ptr + b."""
         b, dev = batch.shape[0], batch.device
         if self._store is None or self.bank.data_ptr() != self._store.data_ptr() or self._store.shape[0] < self.size + b:
-            store = torch.empty(self.size + max(b, 1024), self.bank.shape[1], device=dev, dtype=self.bank.dtype)
+            # (re)allocation of the queue's storage: the first enqueue, a bank tensor assigned from outside, or a batch larger than
+            # the spill region (sized once for `spill_rows`: DECLIP(global_nn_bank=True) sets it to world x batch up front).  Under
+            # stream capture -- or after one: a captured query / enqueue keeps using the OLD storage -- that is refused.
+            if torch.cuda.is_available() and dev.type == "cuda" and (torch.cuda.is_current_stream_capturing() or self._captured):
+                raise RuntimeError("NNMemoryBankModule: the queue's storage would be re-allocated (batch of %d rows, spill region %d) "
+                                   "%s a hipGraph capture of the step; size it up front with spill_rows" %
+                                   (b, 0 if self._store is None else self._store.shape[0] - self.size,
+                                    "during" if torch.cuda.is_current_stream_capturing() else "after"))
+            store = torch.empty(self.size + max(b, self.spill_rows), self.bank.shape[1], device=dev, dtype=self.bank.dtype)
             store[:self.size].copy_(self.bank)
             self._store, self.bank = store, store[:self.size]
-        if self._ptr is None or self._ptr.device != dev:
+        elif torch.cuda.is_available() and dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            self._captured = True
+        if self._ptr is None:
             self._ptr = torch.full((1,), self._ptr_init, device=dev, dtype=torch.int64)
+        elif self._ptr.device != dev:
+            self._ptr = self._ptr.to(dev)            # the LIVE write position moves with the queue (not the initial one)
         if self._ar is None or self._ar.numel() < b or self._ar.device != dev:
-            self._ar = torch.arange(max(b, 1024), device=dev, dtype=torch.int64)
+            self._ar = torch.arange(max(b, self.spill_rows), device=dev, dtype=torch.int64)
         self._store.index_copy_(0, self._ptr + self._ar[:b], batch)
         nxt = self._ptr + b
         self._ptr.copy_(torch.where(nxt >= self.size, torch.zeros_like(nxt), nxt))

@@ -165,6 +165,7 @@ class DECLIP(CLIP):
                 # W banks stay identical and hold W x more distinct neighbours per step (the reference keeps W independent per-rank
                 # queues, memory_bank.py:66; that stays the default).  One extra small gather, off the gradient path.
                 enq_t, enq_aug = dh_dist.all_gather_cat_many([t.detach(), t_aug.detach()])
+                bank.spill_rows = max(bank.spill_rows, int(enq_t.shape[0]))      # the queue's storage is sized ONCE, for the gathered batch
             nn_t = bank(t, update=False)[0]
             nn_t_aug = bank(t_aug, update=True, enqueue=enq_aug)[0]
             bank(t, update=True, query=False, enqueue=enq_t)               # the reference's third call only enqueues

@@ -50,6 +50,8 @@ def crops_on_device(batch, out_hw):
 _END = object()
 
 
+HOST_KEYS = ("mlm_labels",)       # batch entries the step consumes on the host (never uploaded by the prefetcher)
+
 class DataPrefetcher(object):
     def __init__(self, loader, device="cuda", tokenizer=None, context_length=77, depth=2, image_size=224, text_prep=None):
         self.device = torch.device(device)
@@ -121,7 +123,10 @@ class DataPrefetcher(object):
             self._staged = self._tag_rows(item)
             return
         with torch.cuda.stream(self.stream):
-            dev = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in item.items()}
+            # `mlm_labels` stay on the HOST: the masked-LM head takes its row selection from them with index arithmetic on the
+            # labels' own device (heads._mlm_selection) -- on a device tensor that is a nonzero() read-back, i.e. a host stall
+            # on the whole queue in every DeCLIP / DeFILIP step
+            dev = {k: (v.to(self.device, non_blocking=True) if (torch.is_tensor(v) and k not in HOST_KEYS) else v) for k, v in item.items()}
             dev = self._tag_rows(dev)
             dev = crops_on_device(dev, self.image_hw)      # resize / mirror / normalise behind the copy, on the copy stream
             self._event = torch.cuda.Event()

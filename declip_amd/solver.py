@@ -24,7 +24,7 @@ from . import dist as dh_dist
 from . import steps, synth
 from .heads import SimsiamLoss
 from .loss import ClipInfoCELoss, NT_Xent, NT_Xent_gather, NTXentLoss
-from .meters import AverageMeter
+from .meters import AverageMeter, reduce_update_packed
 from .optim import FlatAdamW
 
 
@@ -191,10 +191,12 @@ def param_groups(model, opt_cfg):
             put("logit_scale", p)
         if id(p) not in taken:
             normal.append(p)
+    # EVERY typed group is emitted, the empty ones too (misc.py:386-393): a torch.optim.AdamW checkpoint records one entry per
+    # group, and FlatAdamW.load_state_dict lines a reference / model-zoo checkpoint up group by group and position by position
+    # (tests/test_oracle_golden.py pins names and order against the reference function itself)
     groups = [dict(params=normal)]
     for k in keys:
-        if pg[k]:
-            groups.append(dict(params=pg[k], **dict(pconfig.get(k, {}))))
+        groups.append(dict(params=pg[k], **dict(pconfig.get(k, {}))))
     return groups
 
 
@@ -487,10 +489,10 @@ class ClsSolver(object):
                 gc.disable()
             elif (curr_step - start) % 100 == 0:
                 gc.collect(1)
-            self.meters["loss"].reduce_update(out["loss"].detach().clone())
+            logged = [(self.meters["loss"], out["loss"], 1)]
             if "top1" in out:
-                self.meters["top1"].reduce_update(out["top1"].detach() / self.world_size)
-                self.meters["top5"].reduce_update(out["top5"].detach() / self.world_size)
+                logged += [(self.meters["top1"], out["top1"].detach() / self.world_size, 1), (self.meters["top5"], out["top5"].detach() / self.world_size, 1)]
+            reduce_update_packed(logged)         # ONE collective for all logged scalars of the step (misc.py:38-40 issues one per meter)
             if curr_step % self.print_freq == 0 or curr_step == end:
                 if self.device.type == "cuda":
                     torch.cuda.synchronize()

@@ -78,6 +78,44 @@ def check_grad_digests(golden_grads, grads, rtol, atol_frac=1e-4, only=None, hea
     assert not bad, "gradient digest mismatches (first 5): %s" % (bad[:5],)
 
 
+def bf16_grad_direction_stats(golden_grads, grads, numels=None):
+    """How far bf16-mode gradients are from the reference's in DIRECTION, from the digests the fixtures carry.
+
+    The `proj` digest is <g, r> / sqrt(n) for a seeded unit-normal r (grad_digest_of).  For an error vector e = g_got - g_ref the
+    difference of the two projections is a zero-mean normal with standard deviation |e| / sqrt(n), so
+        z = (proj_got - proj_ref) * sqrt(n) / |g_ref|
+    is a ONE-SAMPLE estimate of the relative error |e| / |g_ref| of that parameter's gradient (sign random).  A gradient with the
+    right norm and the wrong direction has |e| ~ 1.4 |g| and |z| ~ 1.4; bf16 arithmetic through 12 layers gives a few 1e-2.  One
+    sample per parameter is weak, ~150 of them are not: the root mean square of z over all parameters estimates the RMS relative
+    gradient error of the step.  Returns (rms, worst |z|, its name, [(name, z)])."""
+    names = list(golden_grads.keys())
+    gmax = max((v["norm"] for v in golden_grads.values() if v is not None), default=1.0)
+    zs = []
+    for idx, name in enumerate(names):
+        ref = golden_grads[name]
+        g = grads.get(name)
+        if ref is None or g is None or ref["norm"] < 1e-3 * gmax:
+            continue
+        d = grad_digest_of(name, idx, g)
+        n = max(1.0, float(g.numel()))
+        zs.append((name, (d["proj"] - ref["proj"]) * n ** 0.5 / ref["norm"]))
+    rms = (sum(z * z for _, z in zs) / max(1, len(zs))) ** 0.5
+    worst = max(zs, key=lambda t: abs(t[1])) if zs else ("", 0.0)
+    return rms, abs(worst[1]), worst[0], zs
+
+
+def check_bf16_grad_directions(golden_grads, grads, rms_tol=0.10, z_tol=0.35, allowed_frac=0.02):
+    """The bf16 (benchmarked) path's gradients against the reference fixture by direction, not only by norm:
+    RMS over the parameters of the projection z-score <= rms_tol, and |z| <= z_tol for all but `allowed_frac` of them."""
+    rms, wz, wname, zs = bf16_grad_direction_stats(golden_grads, grads)
+    assert len(zs) >= 10, len(zs)
+    bad = [(n, round(z, 3)) for n, z in zs if abs(z) > z_tol]
+    print("bf16 gradient direction vs reference: %d parameters, rms z = %.4f, worst |z| = %.4f (%s)" % (len(zs), rms, wz, wname))
+    assert rms <= rms_tol, ("rms projection z-score", rms, "worst", wname, wz)
+    assert len(bad) <= max(1, int(allowed_frac * len(zs))), bad[:8]
+    return rms, wz
+
+
 def oracle_declip_run(cfg, b, seed=0, nn_size=256):
     sd = synth.synth_state(synth.declip_shapes(cfg), seed=seed)
     frozen = set() if cfg.get("vision") == "resnet" else {"visual.conv1.weight"}

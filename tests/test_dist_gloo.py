@@ -584,7 +584,38 @@ def _w_zero_shot(rank, world, port, out):
         out.put("ok")
 
 
-@pytest.mark.parametrize("fn", [_w_gather, _w_reducer, _w_reducer_gap, _w_clip, _w_clip_tower_twice, _w_clip_packed_pooled, _w_clip_r50, _w_clip_r50_syncbn, _w_zero_shot, _w_declip, _w_declip_global_bank, _w_filip, _w_slip, _w_defilip,
+def _w_meters_packed(rank, world, port, out):
+    """meters.reduce_update_packed: all logged scalars of a step in ONE all-reduce, same values as one reduce_update per meter
+    (utils/misc.py:38-40)."""
+    _init(rank, world, port)
+    import torch.distributed as dist
+    from declip_amd import meters
+    calls = []
+    orig = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(t.numel())
+        return orig(t, *a, **k)
+    dist.all_reduce = counting
+    meters.tdist.all_reduce = counting
+    a, b, c = meters.AverageMeter(10), meters.AverageMeter(10), meters.AverageMeter(0)
+    ra, rb = meters.AverageMeter(10), meters.AverageMeter(10)
+    for step in range(3):
+        x = torch.tensor(1.0 + rank + step)
+        y = torch.tensor([10.0 * (rank + 1) + step])           # shape [1], like the accuracy counters
+        meters.reduce_update_packed([(a, x, 1), (b, y, 1), (c, x * 2, 4)])
+        ra.reduce_update(x.clone())
+        rb.reduce_update(y.clone())
+    assert calls == [3, 1, 1] * 3, calls
+    assert abs(a.val - ra.val) < 1e-6 and abs(a.avg - ra.avg) < 1e-6
+    assert abs(b.val - rb.val) < 1e-6 and abs(b.avg - rb.avg) < 1e-6
+    want = [2 * sum(1.0 + r + s for r in range(world)) for s in range(3)]
+    assert abs(c.avg - sum(want) / 3) < 1e-5 and abs(c.val - want[-1]) < 1e-5
+    if rank == 0:
+        out.put("ok")
+
+
+@pytest.mark.parametrize("fn", [_w_meters_packed, _w_gather, _w_reducer, _w_reducer_gap, _w_clip, _w_clip_tower_twice, _w_clip_packed_pooled, _w_clip_r50, _w_clip_r50_syncbn, _w_zero_shot, _w_declip, _w_declip_global_bank, _w_filip, _w_slip, _w_defilip,
                                 _w_clip_bf16_buckets])
 def test_world2(fn):
     port = _free_port()

@@ -646,3 +646,26 @@ def test_nn_queue_enqueue_semantics_with_the_pointer_on_the_device(mocked_engine
     m.bank_ptr = 8
     m(torch.full((3, 3), 5.0), update=True, query=False)
     assert m.bank_ptr == 0 and float(m.bank[8:].sum()) == 30.0 and float(m.bank[:8].sum()) == 24.0
+
+
+def test_nn_queue_pointer_survives_a_device_change_and_storage_is_sized_once(mocked_engine):
+    """(a) when the queue follows its batches to another device the LIVE write position goes with it (it used to restart
+    from the initial one); (b) the spill region behind the bank is sized once from `spill_rows` (a larger batch re-allocates -- an
+    explicit error once an enqueue has been captured into a hipGraph, whose launches would keep the old storage)."""
+    from declip_amd.heads import NNMemoryBankModule
+    m = NNMemoryBankModule(size=16)
+    m.bank = torch.zeros(16, 2)
+    m.bank_ptr = 0
+    m(torch.ones(5, 2), update=True, query=False)
+    assert m.bank_ptr == 5
+    m._ptr_init = 0                                                   # the initial position must not come back ...
+    m._ptr = m._ptr.clone()                                           # ... when the pointer tensor is re-homed (`.to(dev)` on a device change)
+    m(torch.ones(3, 2) * 2, update=True, query=False)
+    assert m.bank_ptr == 8 and float(m.bank[5:8].sum()) == 12.0
+    store = m._store
+    assert store.shape[0] == 16 + m.spill_rows
+    m(torch.ones(m.spill_rows, 2), update=True, query=False)          # the largest batch the spill region takes: no re-allocation
+    assert m._store is store
+    m._captured = True
+    m.spill_rows += 1
+    assert m._store is store                                          # (growing the wish alone changes nothing)

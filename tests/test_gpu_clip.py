@@ -4,7 +4,7 @@ bf16 mode: documented looser bounds."""
 import pytest
 import torch
 
-from oracle_util import check_grad_digests, load_golden, oracle_clip_run
+from oracle_util import check_bf16_grad_directions, check_grad_digests, load_golden, oracle_clip_run
 
 pytestmark = pytest.mark.gpu
 
@@ -68,6 +68,8 @@ def test_clip_bf16_close_to_reference(name, loss_tol, gnorm_tol):
         if abs(got - ref["norm"]) > gnorm_tol * ref["norm"]:
             bad.append((n, got, ref["norm"]))
     assert len(bad) <= max(1, len(g["grads"]) // 50), bad[:8]
+    # direction, not only size: the fixture's seeded projection of every gradient as a z-score of its relative error
+    check_bf16_grad_directions(g["grads"], out["grads"])
 
 
 def test_clip_accuracy_matches_oracle():
@@ -230,7 +232,7 @@ def test_clip_bf16_vitb32_b256_v4_gemm_matches_v2_gemm():
     assert abs(a["loss"] - ref["loss"]) <= 2e-3 * abs(ref["loss"])
     scale = float(ref["logits_i"].abs().max())
     assert float((a["logits_i"] - ref["logits_i"]).abs().max()) <= 3e-2 * scale      # the documented bf16 bound
-    worst = 0.0
+    worst, min_cos = 0.0, (2.0, "")
     for n, g in ref["grads"].items():
         if g is None:
             continue
@@ -239,10 +241,52 @@ def test_clip_bf16_vitb32_b256_v4_gemm_matches_v2_gemm():
         if nr == 0.0:
             continue
         worst = max(worst, abs(float(ga.norm()) - nr) / nr)
-        # direction as well as size: cosine of the two gradients
+        # direction as well as size: cosine of the two gradients (0.999 = at most 4.5 % of the gradient off-direction; two bf16
+        # GEMM families differ by the rounding of single outputs whose fp32 sums were accumulated in a different order)
         cos = float((ga.double().flatten() @ g.double().flatten()) / (ga.double().norm() * g.double().norm() + 1e-30))
-        assert cos > 0.98, (n, cos)
+        if cos < min_cos[0]:
+            min_cos = (cos, n)
+    print("v4 vs v2 GEMM family, bf16 step: smallest gradient cosine %.6f (%s), worst norm deviation %.4f" % (min_cos + (worst,)))
+    assert min_cos[0] >= 0.999, min_cos
     assert worst < 5e-2, worst
+
+
+def test_clip_bf16_v4_step_gradients_match_fp32_step_in_direction():
+    """The TIMED path (bf16, every tower GEMM on gemm_v4) against the validation path (fp32: the arithmetic that meets the
+    reference at 1e-3 in test_gpu_golden_fullwidth.py) on the reference fixture's inputs at b = 256: loss, and for EVERY parameter
+    the full gradient tensor -- cosine and relative error, not a digest.  Stated bound for the benchmarked kernel: cosine >= 0.995
+    per parameter (<= 10 % of a gradient off-direction), relative error <= 0.12, loss within 1e-3 relative (VERDICT r2 next #2)."""
+    from declip_amd import ops
+    g = load_golden("clip_vitb32_b256")
+    ops.gemm_stats(reset=True)
+    lo = run_engine(g["cfg"], g["b"], g["seed"], g["logit_scale"], "bf16")
+    stats = ops.gemm_stats()
+    assert stats["v4"] >= 200 and stats["v4"] >= 0.8 * sum(stats.values()), stats
+    hi = run_engine(g["cfg"], g["b"], g["seed"], g["logit_scale"], "fp32")
+    assert abs(hi["loss"] - g["loss"]) <= 1e-3 * abs(g["loss"])
+    assert abs(lo["loss"] - hi["loss"]) <= 1e-3 * abs(hi["loss"]), (lo["loss"], hi["loss"])
+    gmax = max(float(v.norm()) for v in hi["grads"].values() if v is not None)
+    worst_cos, worst_rel, named = (2.0, ""), (0.0, ""), {}
+    for n, gh in hi["grads"].items():
+        if gh is None or float(gh.norm()) < 1e-3 * gmax:
+            continue
+        gl = lo["grads"][n].double().flatten()
+        gh = gh.double().flatten()
+        cos = float(gl @ gh / (gl.norm() * gh.norm() + 1e-30))
+        rel = float((gl - gh).norm() / gh.norm())
+        named[n] = (cos, rel)
+        if cos < worst_cos[0]:
+            worst_cos = (cos, n)
+        if rel > worst_rel[0]:
+            worst_rel = (rel, n)
+    print("bf16 (gemm_v4) vs fp32 step, %d parameters: smallest cosine %.6f (%s), largest relative error %.4f (%s)"
+          % (len(named), worst_cos[0], worst_cos[1], worst_rel[0], worst_rel[1]))
+    for n in ("visual.proj", "visual.transformer.resblocks.0.attn.in_proj_weight", "visual.transformer.resblocks.11.mlp.c_fc.weight",
+              "encode_text.transformer.resblocks.0.mlp.c_proj.weight", "encode_text.token_embedding.weight", "logit_scale"):
+        assert n in named, n
+        print("   %-60s cos %.6f rel %.4f" % ((n,) + named[n]))
+    assert worst_cos[0] >= 0.995, worst_cos
+    assert worst_rel[0] <= 0.12, worst_rel
 
 
 def test_clip_two_tower_streams_match_one_stream(monkeypatch):

@@ -81,3 +81,22 @@ def test_solver_prefetcher_bytes_and_strings_match_floats_and_ids(tmp_path):
     assert len(l1) == len(l2) == 4 and l1[0] == l1[0]
     for a, c in zip(l1, l2):
         assert abs(a - c) <= 2e-2 * abs(c), (l1, l2)        # bf16 towers; the inputs agree to fp32 rounding
+
+
+def test_prefetcher_leaves_mlm_labels_on_the_host():
+    """The masked-LM head takes its row selection from the labels with index arithmetic on the labels' OWN device: uploaded by the
+    prefetcher they turned `(labels != -100).nonzero()` into a device read-back (a host stall on the whole queue) in every
+    solver-driven DeCLIP / DeFILIP step.  Everything else of the batch is on the device when next() returns."""
+    from declip_amd import synth
+    from declip_amd.prefetch import DataPrefetcher
+    ids = synth.synth_tokens(8, ctx=16, seed=0, vocab=512)
+    masked, labels = synth.synth_mlm(ids, 512, seed=0)
+    batches = [{"images": synth.synth_images(8, views=2, res=32, seed=i), "captions": torch.stack([masked, ids], dim=1), "mlm_labels": labels.clone()}
+               for i in range(2)]
+    pf = DataPrefetcher(iter(batches), device=torch.device("cuda", 0), context_length=16)
+    got = pf.next()
+    assert got["images"].is_cuda and got["captions"].is_cuda
+    assert not got["mlm_labels"].is_cuda and torch.equal(got["mlm_labels"], labels)
+    from declip_amd.heads import _mlm_selection
+    sel, lab = _mlm_selection(got["mlm_labels"], got["captions"].device)
+    assert sel.is_cuda and lab.is_cuda and torch.equal(sel.cpu(), (labels.reshape(-1) != -100).nonzero().reshape(-1))

@@ -65,8 +65,10 @@ def test_param_groups_follow_reference_rules(mocked):
     assert "visual.class_embedding" in normal and "encode_text.token_embedding.weight" in normal
     assert "visual.transformer.resblocks.0.attn.out_proj.bias" not in normal
     assert "logit_scale" not in normal and "visual.ln_post.weight" not in normal
+    # every typed group of misc.py:267-293 is emitted, also the empty ones (they carry optimizer defaults unless pconfig names them)
+    assert len(groups) == 1 + 6 + 2                        # default + bn_w bn_b conv_b linear_b ln_w ln_b + logit_scale, bias
     for g in groups[1:]:
-        assert g.get("weight_decay", None) == 0
+        assert g.get("weight_decay", None) == 0 or not g["params"]
 
 
 @pytest.mark.parametrize("kind", ["clip", "slip"])
