@@ -55,9 +55,6 @@
 #ifndef V4_NT_STORE
 #define V4_NT_STORE 3
 #endif
-#ifndef V4_TWO_PHASE
-#define V4_TWO_PHASE 1   // K-tile schedule: 1 = two phases of 16 MFMAs (4 barriers per K-tile), 0 = four phases of 8 (8 barriers)
-#endif
 #if V4_TRACE
 // tuning aid (-DV4_TRACE=1): s_memtime stamps of workgroups 0 / 100 / 200, waves 0 and 4, read back with dh_v4_trace_read
 __device__ long v4_trace_buf[6 * 256];
@@ -595,11 +592,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     // ---- rest of the prologue: A0, B0 of K-tile 1 go to ring buffer 1 (free: every wave is past the epilogue)
     ADVANCE_SRC();
     ISSUE_H(ap, 0, 0, 1); ISSUE_H(bp, 0, 2, 1);
-#if V4_TWO_PHASE
-    if (ROLES) WAITV(6); else wait_vmcnt_plus<6>(pend);    // A0, B0, B1 of K-tile 0 have landed (A1 and K-tile 1's A0, B0 may fly)
-#else
-    if (ROLES) WAITV(8); else wait_vmcnt_8_plus(pend);     // A0, B0 of K-tile 0 have landed
-#endif
+    wait_vmcnt_plus<6>(pend);                // A0, B0, B1 of K-tile 0 have landed (A1 and K-tile 1's A0, B0 may fly)
     V4_BARRIER();
     TRACE();                                 // [0] prologue done
     if (wm == 1) V4_BARRIER();               // waves 4-7 run one barrier behind waves 0-3 from here on
@@ -623,7 +616,6 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       const bool cs_now = want_cs && cs_ctr == txcur;
       cs_ctr = cs_ctr + 1 == ntx_cs ? 0 : cs_ctr + 1;
 
-#if V4_TWO_PHASE
       // Two phases per K-tile.  Phase A: fragments of A0, B0, B1 (16 reads), 16 MFMAs (quadrants A0B0, A0B1); phase B:
       // fragments of A1 (8 reads), 16 MFMAs (A1B1, A1B0).  Every load segment ends with lgkmcnt(0) BEFORE its barrier, so a
       // half-tile can be refilled in the very next phase: phase B requests A0, B0 of K-tile kt+2 (read in phase A), phase A
@@ -684,93 +676,6 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       __builtin_amdgcn_s_setprio(0);
       V4_BARRIER();
     }
-#else
-      // ---- phase 1: quadrant (A0, B0)
-      const uint32_t boff = buf * STAGE_BYTES;
-      if (do_frag) {
-        frag4<TB, 2>(fb0, bkm + boff, sB0, br, lm);
-        frag4<TA, 0>(fa0[0], akm0 + boff, sA0, ar, lm);
-        frag4<TA, 0>(fa0[1], akm1 + boff, sA0, ar + 32, lm);
-      }
-      if (has1) { ISSUE_H(bp, BDHQ, 3, nbuf); if (ROLES) WAITV(8); else wait_vmcnt_8_plus(pk); } else { WAITV(2); }      // B1(kt) has landed
-      V4_BARRIER();
-      wait_lgkm0();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) MFMA(acc[ii][0], fa0[ii][s], fb0[s]);
-      __builtin_amdgcn_s_setprio(0);
-      V4_BARRIER();
-
-      // ---- phase 2: quadrant (A0, B1)
-      if (do_frag) frag4<TB, 3>(fb1, bkm + boff, sB1, br, lm);
-      if (has1) { ISSUE_H(ap, a_dh, 1, nbuf); if (ROLES) WAITV(8); else wait_vmcnt_8_plus(pk); } else { WAITV(0); }      // A1(kt) has landed
-      V4_BARRIER();
-      wait_lgkm0();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) MFMA(acc[ii][1], fa0[ii][s], fb1[s]);
-      if (TA && cs_now) {
-        // column sums of A rows (bias gradient): wave wn takes k16-step wn; indicator fragment = ones in column c
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          const uint32_t one = ((lane & 31) == ii) ? 0x3f803f80u : 0u;
-          union { uint32_t u[4]; bf16x8_t v; } ind;
-          ind.u[0] = ind.u[1] = ind.u[2] = ind.u[3] = one;
-          const bf16x8_t af = wn == 0 ? fa0[ii][0] : wn == 1 ? fa0[ii][1] : wn == 2 ? fa0[ii][2] : fa0[ii][3];
-          cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ind.v, cs, 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-      V4_BARRIER();
-
-      // ---- phase 3: quadrant (A1, B1)
-      if (do_frag) {
-        frag4<TA, 1>(fa1[0], akm0 + boff, sA1, ar, lm);
-        frag4<TA, 1>(fa1[1], akm1 + boff, sA1, ar + 32, lm);
-      }
-      if (has2) ISSUE_H(ap, astep, 0, buf);                                   // A0(kt+2): A0(kt) was read in phase 1
-      V4_BARRIER();
-      wait_lgkm0();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) MFMA(acc[2 + ii][1], fa1[ii][s], fb1[s]);
-      __builtin_amdgcn_s_setprio(0);
-      V4_BARRIER();
-
-      // ---- phase 4: quadrant (A1, B0); no fragment reads
-      if (has2) { ISSUE_H(bp, bstep, 2, buf); WAITV(8); } else if (has1) { WAITV(4); }   // A0, B0 of tile kt+1 have landed
-      ADVANCE_SRC();
-      V4_BARRIER();
-      wait_lgkm0();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) MFMA(acc[2 + ii][0], fa1[ii][s], fb0[s]);
-      if (TA && cs_now) {
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          const uint32_t one = ((lane & 31) == 2 + ii) ? 0x3f803f80u : 0u;
-          union { uint32_t u[4]; bf16x8_t v; } ind;
-          ind.u[0] = ind.u[1] = ind.u[2] = ind.u[3] = one;
-          const bf16x8_t af = wn == 0 ? fa1[ii][0] : wn == 1 ? fa1[ii][1] : wn == 2 ? fa1[ii][2] : fa1[ii][3];
-          cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ind.v, cs, 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-      V4_BARRIER();
-    }
-#endif
     if (wm == 0) V4_BARRIER();               // re-align the two wave groups; the whole ring is free from here
     TRACE();                                 // [1] main loop done
 

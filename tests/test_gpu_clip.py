@@ -69,7 +69,8 @@ def test_clip_bf16_close_to_reference(name, loss_tol, gnorm_tol):
             bad.append((n, got, ref["norm"]))
     assert len(bad) <= max(1, len(g["grads"]) // 50), bad[:8]
     # direction, not only size: the fixture's seeded projection of every gradient as a z-score of its relative error
-    check_bf16_grad_directions(g["grads"], out["grads"])
+    # (measured on the MI355X, round 3: rms z 0.022 / 0.029, worst |z| 0.058 / 0.085 for clip_tiny / clip_vitb32_b8)
+    check_bf16_grad_directions(g["grads"], out["grads"], rms_tol=0.06, z_tol=0.25)
 
 
 def test_clip_accuracy_matches_oracle():
@@ -247,15 +248,15 @@ def test_clip_bf16_vitb32_b256_v4_gemm_matches_v2_gemm():
         if cos < min_cos[0]:
             min_cos = (cos, n)
     print("v4 vs v2 GEMM family, bf16 step: smallest gradient cosine %.6f (%s), worst norm deviation %.4f" % (min_cos + (worst,)))
-    assert min_cos[0] >= 0.999, min_cos
+    assert min_cos[0] >= 0.999, min_cos            # measured on the MI355X (round 3): 0.99940
     assert worst < 5e-2, worst
 
 
 def test_clip_bf16_v4_step_gradients_match_fp32_step_in_direction():
     """The TIMED path (bf16, every tower GEMM on gemm_v4) against the validation path (fp32: the arithmetic that meets the
     reference at 1e-3 in test_gpu_golden_fullwidth.py) on the reference fixture's inputs at b = 256: loss, and for EVERY parameter
-    the full gradient tensor -- cosine and relative error, not a digest.  Stated bound for the benchmarked kernel: cosine >= 0.995
-    per parameter (<= 10 % of a gradient off-direction), relative error <= 0.12, loss within 1e-3 relative (VERDICT r2 next #2)."""
+    the full gradient tensor -- cosine and relative error, not a digest.  Stated bound for the benchmarked kernel: cosine >= 0.998
+    per parameter (<= 6.3 % of a gradient off-direction), relative error <= 0.06, loss within 1e-3 relative (VERDICT r2 next #2)."""
     from declip_amd import ops
     g = load_golden("clip_vitb32_b256")
     ops.gemm_stats(reset=True)
@@ -285,8 +286,9 @@ def test_clip_bf16_v4_step_gradients_match_fp32_step_in_direction():
               "encode_text.transformer.resblocks.0.mlp.c_proj.weight", "encode_text.token_embedding.weight", "logit_scale"):
         assert n in named, n
         print("   %-60s cos %.6f rel %.4f" % ((n,) + named[n]))
-    assert worst_cos[0] >= 0.995, worst_cos
-    assert worst_rel[0] <= 0.12, worst_rel
+    # measured on the MI355X (round 3): smallest cosine 0.99956, largest relative error 0.0295 over 302 parameters
+    assert worst_cos[0] >= 0.998, worst_cos
+    assert worst_rel[0] <= 0.06, worst_rel
 
 
 def test_clip_two_tower_streams_match_one_stream(monkeypatch):

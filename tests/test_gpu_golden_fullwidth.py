@@ -99,7 +99,8 @@ def test_clip_vitb32_b256_matches_reference_golden(dtype):
         check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
     else:
         assert_ran_on_v4(stats, 200)
-        check_bf16_grad_norms(g["grads"], named_grads(model))
+        # measured on the MI355X (round 3): rms z 0.027, worst |z| 0.086 over 302 parameters
+        check_bf16_grad_norms(g["grads"], named_grads(model), rms_tol=0.06, z_tol=0.25)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -133,7 +134,9 @@ def test_declip_vitb32_b128_matches_reference_golden(dtype):
         assert abs(float(model.nn_replacer_text.bank.double().sum()) - g["bank_sum"]) <= 1e-3 * max(1.0, abs(g["bank_sum"]))
     else:
         assert_ran_on_v4(stats, 200)
-        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04)
+        # measured (round 3): rms z 0.081, worst |z| 0.46 on projector.bn1.weight -- the affine gradients of the SimSiam head's
+        # BatchNorm1d layers are sums of cancelling terms over 128 rows, the towers sit at 0.03-0.05 like CLIP's
+        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.15, z_tol=0.35)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -158,7 +161,9 @@ def test_slip_vitb32_b128_matches_reference_golden(dtype):
         check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
     else:
         assert_ran_on_v4(stats, 200)
-        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04)
+        # measured (round 3): rms z 0.137, worst |z| 0.50 on predictor_sim.bn1.bias: the SimCLR head (768-4096-4096-256 with two
+        # BatchNorm1d over 2 x 128 rows, NT-Xent at temperature 0.1) is the most ill-conditioned gradient path of the five families
+        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.22, z_tol=0.40)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -186,4 +191,5 @@ def test_filip_vitb32_e768_b256_matches_reference_golden(dtype):
         check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
     else:
         assert_ran_on_v4(stats, 200)
-        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04)
+        # measured (round 3): rms z 0.052, worst |z| 0.17
+        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.10, z_tol=0.35)
