@@ -16,10 +16,14 @@
 //   * each half-tile (A0/A1/B0/B1 of a K-tile) is consumed in exactly one phase, so it is re-filled two phases
 //     later for K-tile t+2: 4 half-tiles (64 KiB) are always in flight and the waits are COUNTED
 //     (s_waitcnt vmcnt(8): "everything but the 4 youngest half-tiles"), never a drain;
-//   * PERSISTENT: one workgroup per CU walks a list of tiles.  The first four half-tiles of the NEXT tile are
-//     requested before the epilogue of the current one (into ring buffer 0, the epilogue stages through buffer 1),
-//     and the epilogue's global stores are never waited for: they drain while the next main loop runs (the
-//     counted waits of that tile's first K-tile are widened by the number of stores in flight);
+//   * PERSISTENT: one workgroup per CU walks a list of tiles as ONE continuous stream of K-tiles (round 3).  The four
+//     half-tiles of the NEXT tile's K-tile 0 are requested from inside the last two K-tiles of the current one -- in the slots and
+//     with the counted waits a longer tile would use for its own K-tiles nk, nk+1 -- and the next work item is decoded (tile
+//     coordinates, DMA source addresses) in the load segments of the second-to-last K-tile, which request nothing of their own;
+//     so the operands of the next tile land under the last MFMAs and the epilogue, and nothing is decoded, requested or waited
+//     for between the main loops.  The epilogue stages through the ring buffer of the last K-tile (the buffer parity of a tile
+//     flips when nk is odd); its global stores are never waited for: they drain while the next main loop runs (the counted
+//     waits of that tile's first K-tile are widened by the number of stores in flight);
 //   * bf16 outputs (MODE_STORE): MFMAs are issued with swapped operands (acc = C^T fragments: a lane owns 4
 //     consecutive columns of a row), packed with v_cvt_pk_bf16_f32 and staged in LDS with conflict-free
 //     ds_write_b64, then written as 16-byte vectors on full 512-byte row segments; alpha/bias in fp32 before the
@@ -35,6 +39,7 @@
 //   K-contiguous  [128 rows][64 k]   128-B rows, 16-B chunk c of row r at slot c ^ ((r>>1)&7)
 //   contraction-major [64 k][128 out] 256-B rows, 16-B chunk c of row k at slot c ^ ((k&3)<<2)
 #include "dh_common.h"
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -42,11 +47,18 @@
 #define V4_ABL 0
 #endif
 
-#ifndef V4_PIPE_EPI
-#define V4_PIPE_EPI 1     // bf16 epilogue in four pipelined quarter passes (0: the two staged passes of round 1)
-#endif
 #ifndef V4_TRACE
 #define V4_TRACE 0
+#endif
+// Where a wave requests its LDS-DMA pieces inside a K-tile.  0 (rounds 1-2): two half-tiles in each LOAD segment (B1, A1 of the next
+// K-tile in phase A, A0, B0 of the one after in phase B), none in the MFMA segments.  1 (round 3): ONE half-tile per segment, the
+// MFMA segments included -- phase A load B1, phase A MFMA A1, phase B load A0, phase B MFMA B0.  The in-kernel trace shows why: a
+// load segment of phase A (16 fragment reads + 4 LDS-DMA issues at 100+ cycles each inside a segment that also reads fragments)
+// takes ~750 cycles against the 512 of the 16 MFMAs it is paired with, phase B's ~560 -- a K-tile costs 2 x 750 + 2 x 560, the
+// matrix pipe idles a fifth of the main loop.  An LDS-DMA issued BETWEEN two MFMAs costs the wave ~60 cycles of which 32 are the
+// MFMA it follows.
+#ifndef V4_SCHED
+#define V4_SCHED 1
 #endif
 // Cache policy of the epilogue traffic (measured in-step, CLIP b=512): 0 none; 1 output tiles stored non-temporal (+1.2 %: a
 // 128 KB tile per CU per epilogue otherwise displaces the A/B panels the XCD's 4 MB L2 is holding for the next tiles; the 4d-wide
@@ -63,6 +75,30 @@ extern "C" int dh_v4_trace_clear() { static long z[6 * 256]; return (int)hipMemc
 #endif
 
 namespace v4 {
+
+// The pieces of this file that are inline ISA or address-space tricks, behind macros -- so that the SAME kernel body also
+// compiles as plain C++ for the host emulation of tests/hipemu (-DDH_HOST_EMU, test infrastructure: HIP threads as fibers, an
+// LDS-DMA is a synchronous 16-byte copy per lane, waits are no-ops, the transpose read is the emulation's wave collective).  The
+// emulation checks indexing, ring-buffer parity, barrier counts and the epilogues; it cannot see what the counted waits protect.
+#ifdef DH_HOST_EMU
+#define V4_EMU 1
+#define V4_KARGP(ka) ((kargp_t)(&(ka)))
+#define V4_OPAQUE_S(x) do { } while (0)
+#define V4_OPAQUE_V(x) do { } while (0)
+#define V4_KEEP_V2(a, b) do { (void)(a); (void)(b); } while (0)
+#define V4_RFL(x) (x)
+#define V4_LDS_ADDR(p) 0u
+#define V4_RCP(x) (1.f / (x))
+#else
+#define V4_EMU 0
+#define V4_KARGP(ka) ((kargp_t)__builtin_amdgcn_kernarg_segment_ptr())
+#define V4_OPAQUE_S(x) asm volatile("" : "+s"(x))
+#define V4_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#define V4_KEEP_V2(a, b) asm volatile("" ::"v"(a), "v"(b))
+#define V4_RFL(x) __builtin_amdgcn_readfirstlane(x)
+#define V4_LDS_ADDR(p) ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)(p))
+#define V4_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 // 16-byte store of an output tile row piece; V4_NT_STORE: non-temporal (the tile is not read again by this kernel: keep it
@@ -141,11 +177,16 @@ struct KArgs {
   long zs, cs_zs;                         // floats per K-slice slab: partial tiles (sum M*N), bias-gradient partials (sum ntx*M)
   GProb gp[MAX_GROUP];
 };
+#if V4_EMU
+typedef const unsigned char* kargp_t;
+template <typename T> __device__ __forceinline__ T karg_load(kargp_t kp, int off) { T v; memcpy(&v, kp + off, sizeof(T)); return v; }
+#else
 typedef const __attribute__((address_space(4))) unsigned char* kargp_t;
 template <typename T> __device__ __forceinline__ T karg_load(kargp_t kp, int off) {
   typedef const __attribute__((address_space(4))) T* P;
   return *(P)(kp + off);
 }
+#endif
 #define KARG(kp, T, field) karg_load<T>((kp), (int)offsetof(KArgs, field))
 #define GPARG(kp, p, T, field) karg_load<T>((kp), (int)(offsetof(KArgs, gp) + offsetof(GProb, field)) + (p) * (int)sizeof(GProb))
 
@@ -166,11 +207,16 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // LDS-DMA in flight it puts s_waitcnt vmcnt(0) in front of the next LDS access it cannot prove disjoint (every ds_read /
 // ds_write of the epilogue, every transpose read), i.e. it drains the pipeline.  With the DMA (and the transpose reads)
 // issued from asm the compiler sees no VMEM traffic in the main loop at all and every wait there is one of ours.
+#if V4_EMU
+__device__ __forceinline__ void dma16(const bf16_t* src, unsigned char* lds_dst_uniform) { memcpy(lds_dst_uniform + 16 * emu_lane(), src, 16); }
+template <int N> __device__ __forceinline__ void wait_vmcnt() { }
+#else
 __device__ __forceinline__ void dma16(const bf16_t* src, unsigned char* lds_dst_uniform) {
   const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_dst_uniform;
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(src) : "memory", "m0");
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#endif
 // "all but the 4 youngest half-tiles and the `s` epilogue stores issued between them" (s is wave-uniform)
 template <int N> __device__ __forceinline__ void wait_vmcnt_plus(int s) {   // "all but the N youngest loads and the s stores between them"
   if (s == 0) wait_vmcnt<N>();
@@ -178,13 +224,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_plus(int s) {   // "
   else if (s == 32) wait_vmcnt<N + 32>();
   else wait_vmcnt<N>();                            // unknown count: conservative
 }
-__device__ __forceinline__ void wait_vmcnt_8_plus(int s) {
-  if (s == 0) wait_vmcnt<8>();
-  else if (s == 16) wait_vmcnt<24>();
-  else if (s == 32) wait_vmcnt<40>();
-  else wait_vmcnt<8>();                            // unknown count: conservative
+// end of an epilogue: "everything but the s youngest operations" (= the epilogue's own stores)
+__device__ __forceinline__ void wait_vmcnt_tail(int s) {
+  if (s == 16) wait_vmcnt<16>();
+  else if (s == 32) wait_vmcnt<32>();
+  else wait_vmcnt<0>();                            // no stores / unknown count: drain
 }
+#if V4_EMU
+__device__ __forceinline__ void wait_lgkm0() { }
+#else
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
 
 // fragment of a K-contiguous half-tile: rows r0 + (lane&31), k = 16*s + 8*(lane>>5) .. +7
 __device__ __forceinline__ bf16x8_t frag_kcontig(const unsigned char* tile, int r0, int s, int lane) {
@@ -207,8 +257,14 @@ __device__ __forceinline__ uint32_t kmajor_lane_off(int o0, int lane) {
 }
 template <int OFF> __device__ __forceinline__ bf16x8_t frag_km(uint32_t addr) {
   s16x4 lo, hi;
+#if V4_EMU
+  const unsigned char* base = (const unsigned char*)emu_dyn_lds() + addr;
+  lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(base + OFF);
+  hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(base + OFF + 1024);
+#else
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF));
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 1024));
+#endif
   union { struct { s16x4 a, b; } s; bf16x8_t v; } u;
   u.s.a = lo; u.s.b = hi;
   return u.v;
@@ -264,11 +320,11 @@ __device__ __forceinline__ const bf16_t* piece_src(const bf16_t* P, long ld, int
 // tile on every wave between the main loop and the epilogue; the compiler's 32-bit integer division is a ~35-instruction dependent
 // chain, and five of them were most of the ~900 cycles the in-kernel trace shows for "next tile requested".
 __device__ __forceinline__ int fdiv(int a, int b) {
-  int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+  int q = (int)((float)a * V4_RCP((float)b));
   const int r = a - q * b;
   q += r >= b ? 1 : 0;
   q -= r < 0 ? 1 : 0;
-  return __builtin_amdgcn_readfirstlane(q);      // every caller passes wave-uniform values: keep the quotient in a scalar register
+  return V4_RFL(q);      // every caller passes wave-uniform values: keep the quotient in a scalar register
 }
 __device__ __forceinline__ void tile_from_logical(int b, int ntx, int nty, int& tile_x, int& tile_y, int GROUP_M = 8) {
   const int in_group = GROUP_M * ntx;
@@ -345,11 +401,11 @@ __device__ __forceinline__ bool decode_group(kargp_t kp, int x, int l, int nitem
 }
 __device__ __forceinline__ int wgs_on_xcd(int x, int grid) { return x < grid ? ((grid - 1 - x) >> 3) + 1 : 0; }
 
-template <bool TA, bool TB, int MODE, bool ROLES>
+template <bool TA, bool TB, int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) {
   // launch-time view of the arguments (prologue); the epilogues re-read what they need (see KArgs)
-  kargp_t kp = (kargp_t)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(kp));
+  kargp_t kp = V4_KARGP(ka_unused);
+  V4_OPAQUE_S(kp);
   const bf16_t* A = KARG(kp, const bf16_t*, A);
   const bf16_t* B = KARG(kp, const bf16_t*, B);
   long lda = KARG(kp, long, lda), ldb = KARG(kp, long, ldb);
@@ -360,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
   int ntx = KARG(kp, int, ntx), nty = KARG(kp, int, nty), nitems = KARG(kp, int, nitems), n_full = KARG(kp, int, n_full), S = KARG(kp, int, S);
   int* sched = KARG(kp, int*, sched);
   const int dyn = sched ? KARG(kp, int, dyn) : 0;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  DH_DYN_LDS_A16(unsigned char, smem);
   constexpr bool SWAP = MODE != MODE_ATOMIC;
   constexpr bool STORE = MODE <= MODE_STORE_RES;
   constexpr bool GROUP = MODE == MODE_GROUP;
@@ -376,29 +432,23 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       astep = (long)BK * lda; bstep = (long)BK * ldb;                                           \
     }                                                                                           \
   } while (0)
-  // ROLES: waves 4-7 issue ALL LDS-DMA and never store; waves 0-3 do all global stores of the epilogue and never wait on
-  // vmcnt in the main loop.  A wave's vmcnt retires in order, so a wave with epilogue stores in flight cannot wait for a
-  // younger load without also waiting for those stores to reach HBM; with the roles split the stores of tile i drain during
-  // the whole main loop of tile i+1.
-  constexpr int NP = ROLES ? 4 : 2;              // 1-KiB pieces of a half-tile per issuing wave
-  constexpr int WF = ROLES ? 2 : 1;              // vmcnt ops per half-tile relative to the 2-piece scheme   // acc holds C^T fragments (lane = row, 4 consecutive columns per register group)
+  constexpr int NP = 2;                          // 1-KiB pieces of a half-tile per wave
   // compile-time ablation (tuning aid: -DV4_ABL=mask; 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no epilogue)
   constexpr bool do_dma = !(V4_ABL & 1), do_mfma = !(V4_ABL & 2), do_frag = !(V4_ABL & 4), do_epi = !(V4_ABL & 8);
   const int t = threadIdx.x;
   const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wave = V4_RFL(t >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int ar = wm * 64, br = wn * 32;             // this wave's rows inside an A half / columns inside a B half
-  const bool issuer = !ROLES || wm == 1;
-  unsigned char* const wdst = smem + (ROLES ? (wave & 3) * 4096 : wave * 2048);   // this wave's slice of a half-tile
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+  unsigned char* const wdst = smem + wave * 2048;   // this wave's slice of a half-tile
+  const uint32_t lds0 = V4_LDS_ADDR(smem);
   long astep = TA ? (long)BK * lda : BK;             // (MODE_GROUP: per problem, LOAD_PROBLEM)
   long bstep = TB ? (long)BK * ldb : BK;
 
   // DMA sources.  Shapes are whole tiles (host-checked).  Each wave stages pieces 2w, 2w+1 of every half-tile: two per-lane
   // pointers per operand (the source swizzle of a K-contiguous piece depends on the piece), half +1 = a wave-uniform offset
   // (128 rows / 128 columns).  ap* / bp* point at K-tile kt+1 while K-tile kt is multiplied (A1, B1 of kt+1 and A0, B0 of kt+2
-  // are issued there).
+  // are issued there); from the second-to-last K-tile of an item on they point at K-tile 0 of the NEXT item (see the main loop).
   const long a_dh = TA ? 128 : 128 * lda;
   const long b_dh = TB ? 128 : 128 * ldb;
   const bf16_t *ap[NP], *bp[NP];
@@ -412,10 +462,10 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
 #define SETUP_SRC(m0_, n0_, kbeg_)                                                            \
   do {                                                                                        \
     _Pragma("unroll") for (int q = 0; q < NP; ++q) {                                          \
-      ap[q] = piece_src<TA>(A, lda, (ROLES ? (wave & 3) * 4 : wave * 2) + q, lane, (m0_), M, (kbeg_)); \
-      bp[q] = piece_src<TB>(B, ldb, (ROLES ? (wave & 3) * 4 : wave * 2) + q, lane, (n0_), N, (kbeg_)); \
+      ap[q] = piece_src<TA>(A, lda, wave * 2 + q, lane, (m0_), M, (kbeg_));                   \
+      bp[q] = piece_src<TB>(B, ldb, wave * 2 + q, lane, (n0_), N, (kbeg_));                   \
       if (RAGGED_B) {                                                                         \
-        const int rl_ = ((ROLES ? (wave & 3) * 4 : wave * 2) + q) * 8 + (lane >> 3);          \
+        const int rl_ = (wave * 2 + q) * 8 + (lane >> 3);                                     \
         const int r0_ = min((n0_) + rl_, N - 1), r1_ = min((n0_) + rl_ + 128, N - 1);         \
         bdh[q] = (long)(r1_ - r0_) * ldb;                                                     \
       }                                                                                       \
@@ -423,17 +473,22 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
   } while (0)
 #define ISSUE_H(P, OFF, REGION, buf)                                                          \
   do {                                                                                        \
-    if (!do_dma || !issuer) break;                                                            \
+    if (!do_dma) break;                                                                       \
     _Pragma("unroll") for (int q = 0; q < NP; ++q)                                            \
       dma16((P)[q] + (OFF), wdst + (buf) * STAGE_BYTES + (REGION) * HALF_BYTES + q * 1024);   \
+  } while (0)
+#define ISSUE_PIECE(P, OFF, REGION, buf, q)                                                   \
+  do {                                                                                        \
+    if (!do_dma) break;                                                                       \
+    dma16((P)[q] + (OFF), wdst + (buf) * STAGE_BYTES + (REGION) * HALF_BYTES + (q) * 1024);   \
   } while (0)
 #define ADVANCE_SRC()                                                                         \
   do {                                                                                        \
     _Pragma("unroll") for (int q = 0; q < NP; ++q) { ap[q] += astep; bp[q] += bstep; }        \
   } while (0)
-#define WAITV(N) do { if (issuer) wait_vmcnt<(N) * WF>(); } while (0)
+#define WAITV(N) wait_vmcnt<(N)>()
 #define MFMA(ACCV, AF, BF) \
-  if (!do_mfma) { asm volatile("" ::"v"(AF), "v"(BF)); } else ACCV = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF, AF, ACCV, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, BF, ACCV, 0, 0, 0)
+  if (!do_mfma) { V4_KEEP_V2(AF, BF); } else ACCV = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF, AF, ACCV, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, BF, ACCV, 0, 0, 0)
 
 #if V4_TRACE
   const int trace_slot = (blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : blockIdx.x == 200 ? 2 : -1);
@@ -441,118 +496,111 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
   long* trace_p = v4_trace_buf + (trace_slot * 2 + (t >> 8)) * 256;
   int trace_n = 0;
 #define TRACE() do { if (tracing && trace_n < 255) trace_p[1 + trace_n++] = __builtin_readcyclecounter(); } while (0)
+#if V4_TRACE >= 2          // 2: + four stamps inside each of the last two K-tiles of an item; 3: + four stamps inside K-tile 2 of every item (a steady-state K-tile)
+#define TRACE_FINE() TRACE()
+#else
+#define TRACE_FINE() do { } while (0)
+#endif
 #else
 #define TRACE() do { } while (0)
+#define TRACE_FINE() do { } while (0)
 #endif
   // ---- work distribution state (see decode_pos)
   const int xcd = blockIdx.x & 7, grid = gridDim.x;
   int n_fullitems = S ? n_full : nitems;
   int* const sched_lds = reinterpret_cast<int*>(smem + SCHED_OFF);      // [0] = packed (x << 24 | l) of the item after next, or -1
-  // first_of(x): positions of XCD x's list that are handed out statically (one per workgroup; none when fully dynamic)
-  auto first_of = [&](int x) { return dyn == 2 ? 0 : wgs_on_xcd(x, grid); };
   auto list_len = [&](int x) {
     int sf, lf, ss = 0, ls = 0;
     chunk_of(n_fullitems, x, sf, lf);
     if (S) chunk_of((ntx * nty - n_full) * S, x, ss, ls);
     return lf + ls;
   };
-  // thread 0 only.  fetch_raw: the non-blocking part -- one returning atomic on the own XCD's counter (plus, when stealing
-  // is enabled, a snapshot of all eight counters), results read much later.  INLINE ASM: inside the exec-masked
-  // `if (t == 0)` hipcc would wait for a visible returning atomic right at the end of the branch (vmcnt(0): the next
-  // tile's loads were just requested).  The result registers are read only after wait_vmcnt_plus<8>() at the end of the
-  // epilogue (these requests are older than everything issued after them: in-order vmcnt).
-  // The asynchronous results live in PLAIN variables written by the issuing asm and "re-defined" by the asm that waits for
-  // them (FETCH_WAIT ties them to the s_waitcnt as in/out operands): the compiler must not copy them in between, because a
-  // copy made before the wait would carry the stale register contents (checked in the ISA: no moves, no spills).
-#define FETCH_ISSUE(RAW, SN)                                                                                   \
+  // thread 0 only (dyn == 1: every workgroup's first position is static, the further ones come from its XCD's counter).
+  // FETCH_ISSUE: the non-blocking part -- one returning atomic on the own XCD's counter, result read much later.  INLINE ASM:
+  // inside the exec-masked `if (t == 0)` hipcc would wait for a visible returning atomic right at the end of the branch.  The
+  // result register is read only after the wait at the end of the epilogue (the request is older than everything issued after
+  // it: in-order vmcnt).  It lives in a PLAIN variable written by the issuing asm and "re-defined" by the asm that waits for
+  // it (FETCH_WAIT ties it to the s_waitcnt as an in/out operand): the compiler must not copy it in between, because a copy
+  // made before the wait would carry the stale register contents (checked in the ISA: no moves, no spills).
+#if V4_EMU
+#define FETCH_ISSUE(RAW) do { RAW = 1 << 22; if (wgs_on_xcd(xcd, grid) < list_len(xcd)) RAW = atomicAdd(sched + xcd, 1); } while (0)
+#define FETCH_WAIT(N, RAW) do { } while (0)
+#else
+#define FETCH_ISSUE(RAW)                                                                                       \
   do {                                                                                                        \
     RAW = 1 << 22;                                                                                            \
-    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) SN[q_] = 1 << 22;                                        \
-    if (first_of(xcd) < list_len(xcd)) {                                                                      \
+    if (wgs_on_xcd(xcd, grid) < list_len(xcd)) {                                                              \
       const int one_ = 1;                                                                                     \
       int* p_ = sched + xcd;                                                                                  \
       asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(RAW) : "v"(p_), "v"(one_) : "memory");      \
     }                                                                                                         \
-    if (dyn == 2) {                                                                                           \
-      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(SN[0]) : "v"(sched) : "memory");                \
-      asm volatile("global_load_dword %0, %1, off offset:4 sc1" : "=v"(SN[1]) : "v"(sched) : "memory");       \
-      asm volatile("global_load_dword %0, %1, off offset:8 sc1" : "=v"(SN[2]) : "v"(sched) : "memory");       \
-      asm volatile("global_load_dword %0, %1, off offset:12 sc1" : "=v"(SN[3]) : "v"(sched) : "memory");      \
-      asm volatile("global_load_dword %0, %1, off offset:16 sc1" : "=v"(SN[4]) : "v"(sched) : "memory");      \
-      asm volatile("global_load_dword %0, %1, off offset:20 sc1" : "=v"(SN[5]) : "v"(sched) : "memory");      \
-      asm volatile("global_load_dword %0, %1, off offset:24 sc1" : "=v"(SN[6]) : "v"(sched) : "memory");      \
-      asm volatile("global_load_dword %0, %1, off offset:28 sc1" : "=v"(SN[7]) : "v"(sched) : "memory");      \
-    }                                                                                                         \
   } while (0)
-#define FETCH_WAIT(N, RAW, SN)                                                                                                    \
-  asm volatile("s_waitcnt vmcnt(%9)" : "+v"(RAW), "+v"(SN[0]), "+v"(SN[1]), "+v"(SN[2]), "+v"(SN[3]), "+v"(SN[4]), "+v"(SN[5]), \
-               "+v"(SN[6]), "+v"(SN[7]) : "n"(N) : "memory")
-  // fetch_finish: packed position of the next item, or -1.  Stealing (dyn == 2): only lists whose counter snapshot says
-  // something is left are tried (a blocking atomic each: this is the end of the kernel)
-  auto fetch_finish = [&](int raw, const int* snap) -> int {
-    const int l0 = first_of(xcd) + raw;
-    if (l0 < list_len(xcd)) return (xcd << 24) | l0;
-    if (dyn != 2) return -1;
-    for (int k = 1; k < 8; ++k) {
-      const int x = (xcd + k) & 7;
-      const int total = list_len(x);
-      int sn = 0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) sn = q == x ? snap[q] : sn;
-      if (sn >= total) continue;
-      const int l = atomicAdd(sched + x, 1);
-      if (l < total) return (x << 24) | l;
-    }
-    return -1;
+#define FETCH_WAIT(N, RAW) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(RAW) : "n"(N) : "memory")
+#endif
+  // packed position of the next item, or -1
+  auto fetch_finish = [&](int raw) -> int {
+    const int l0 = wgs_on_xcd(xcd, grid) + raw;
+    return l0 < list_len(xcd) ? ((xcd << 24) | l0) : -1;
   };
   Item nxt;
   bool have;
-  if (dyn == 2) {
-    // fully dynamic: the first TWO positions come from the counters (a late-starting workgroup owns nothing)
-    if (t == 0) {
-      int r0, r1, sa[8], sb[8];
-      FETCH_ISSUE(r0, sa);
-      FETCH_ISSUE(r1, sb);
-      FETCH_WAIT(0, r0, sa);
-      FETCH_WAIT(0, r1, sb);
-      sched_lds[1] = fetch_finish(r0, sa);
-      sched_lds[0] = fetch_finish(r1, sb);
-    }
-    __syncthreads();
-    const int p0 = __builtin_amdgcn_readfirstlane(sched_lds[1]);
-    have = p0 >= 0 && DECODE(p0 >> 24, p0 & 0xffffff, nxt);
-  } else {
+  {
     const int my_l = blockIdx.x >> 3;                                    // position in XCD `xcd`'s list
     have = DECODE(xcd, my_l, nxt);                                       // grid <= items: always true
     if (t == 0) {
       int v;
-      if (dyn) { int r0, sa[8]; FETCH_ISSUE(r0, sa); FETCH_WAIT(0, r0, sa); v = fetch_finish(r0, sa); }
+      if (dyn) { int r0; FETCH_ISSUE(r0); FETCH_WAIT(0, r0); v = fetch_finish(r0); }
       else { const int l = my_l + wgs_on_xcd(xcd, grid); v = (xcd << 24) | l; }     // static partition (validity checked at decode)
       sched_lds[0] = v;
     }
   }
-  if (have) {   // first tile: the four half-tiles of its K-tile 0, in steady-state FIFO order
-    LOAD_PROBLEM(kp, nxt.p);
-    SETUP_SRC(nxt.tile_y * BM, nxt.tile_x * BN, nxt.kbeg);
-    ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, BDHQ, 3, 0); ISSUE_H(ap, a_dh, 1, 0);
+  // FAST hand-over to the next item (the forward / dX launches: one K-slice, row-major tile order, static partition, no tail
+  // slices, whole tiles).  A workgroup's items are positions l, l + s, l + 2s ... of its XCD's chunk, so the next tile is the
+  // current one plus a constant (s mod ntx, s / ntx) with a carry, and its DMA sources are the current ones plus a wave-uniform
+  // 64-bit offset (the per-lane part of a source address does not depend on the tile): ~15 scalar + 8 vector instructions.  The
+  // general decode (kernel arguments re-read, five integer divisions, four per-lane 64-bit address computations) measured
+  // ~1.8 k cycles per wave group in the in-kernel trace -- three MFMA segments, which nothing can hide.  It stays for the
+  // launches that need it (grouped / split-K weight gradients, tail slices, dynamic scheduling, the ragged vocabulary of the
+  // cross-entropy modes): their items are 50+ K-tiles long.
+  const bool fast = !GROUP && !RAGGED_B && dyn == 0 && S == 0 && nitems == ntx * nty && KARG(kp, int, group_m) == 1;
+  int left = 0, sx_f = 0, sy_f = 0, d_m = 0, d_n = 0;
+  const int ntx_f = ntx;
+  if (fast) {
+    int sf, lf;
+    chunk_of(nitems, xcd, sf, lf);
+    const int st = wgs_on_xcd(xcd, grid), my_l = blockIdx.x >> 3;
+    left = fdiv(lf - my_l + st - 1, st);               // items of this workgroup, the current one included
+    sy_f = fdiv(st, ntx);
+    sx_f = st - sy_f * ntx;
   }
   if (STORE) {   // bias -> LDS once (no global load may sit between the epilogue stores of the persistent loop)
     for (int q = t; q < N / 4; q += 512)
       *reinterpret_cast<float4*>(smem + BIAS_OFF + 16 * q) = e.bias ? *reinterpret_cast<const float4*>(e.bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // ---- ONE continuous stream of K-tiles across the items of this workgroup.  K-tile kt of an item sits in ring buffer
+  // (kt ^ tp) & 1; the four half-tiles of the NEXT item's K-tile 0 are requested from inside the last two K-tiles of the current
+  // one, exactly where a longer item would request its own K-tiles nk and nk+1 (same slots, same counted waits), so they land
+  // under the last MFMAs and the whole epilogue instead of being requested -- and waited for -- after the main loop; the next
+  // item is decoded (tile coordinates, source addresses) in the load segments of the second-to-last K-tile, which have no
+  // requests of their own to make.  The epilogue stages through the buffer of the last K-tile; the buffer of the next item's
+  // K-tile 0 is the other one, so the tile parity `tp` flips when nk is odd.
+  int tp = 0;
+  if (have) {   // first item: the four half-tiles of its K-tile 0, in steady-state FIFO order
+    LOAD_PROBLEM(kp, nxt.p);
+    SETUP_SRC(nxt.tile_y * BM, nxt.tile_x * BN, nxt.kbeg);
+    ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, BDHQ, 3, 0); ISSUE_H(ap, a_dh, 1, 0);
+    wait_vmcnt<0>();                   // (once per launch; later items find their K-tile 0 landed at the end of the previous epilogue)
+  }
+  wait_lgkm0();
+  V4_BARRIER();
   int pend = 0;                      // epilogue stores of the previous tile that may still be in flight (per wave-instruction stream)
 
-  // everything the epilogue / the choice of the next item needs, re-read from the kernarg segment (see KArgs)
+  // everything the epilogue needs, re-read from the kernarg segment (see KArgs)
 #define RELOAD_ARGS()                                                                                   \
   do {                                                                                                  \
-    kargp_t kq = (kargp_t)__builtin_amdgcn_kernarg_segment_ptr();                     \
-    asm volatile("" : "+s"(kq));                                                                        \
-    A = KARG(kq, const bf16_t*, A); B = KARG(kq, const bf16_t*, B);                                     \
-    lda = KARG(kq, long, lda); ldb = KARG(kq, long, ldb);                                               \
-    M = KARG(kq, int, M); N = KARG(kq, int, N); K = KARG(kq, int, K); k_per_split = KARG(kq, int, k_per_split); \
-    ntx = KARG(kq, int, ntx); nty = KARG(kq, int, nty); nitems = KARG(kq, int, nitems);                 \
-    n_full = KARG(kq, int, n_full); S = KARG(kq, int, S); sched = KARG(kq, int*, sched);                \
-    e.M = M; e.N = N; e.C = KARG(kq, void*, e.C); e.ldc = KARG(kq, long, e.ldc);                        \
+    kargp_t kq = V4_KARGP(ka_unused);                                                                   \
+    V4_OPAQUE_S(kq);                                                                                    \
+    e.M = KARG(kq, int, M); e.N = KARG(kq, int, N); e.C = KARG(kq, void*, e.C); e.ldc = KARG(kq, long, e.ldc); \
     e.bias = KARG(kq, const float*, e.bias); e.epilogue = KARG(kq, int, e.epilogue);                    \
     e.residual = KARG(kq, const void*, e.residual); e.ldr = KARG(kq, long, e.ldr);                      \
     e.aux = KARG(kq, void*, e.aux); e.ldaux = KARG(kq, long, e.ldaux); e.alpha = KARG(kq, float, e.alpha); \
@@ -562,6 +610,149 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     e.ce_g = KARG(kq, const float*, e.ce_g); e.ce_part = KARG(kq, float*, e.ce_part); e.ce_lab = KARG(kq, float*, e.ce_lab); \
     e.ce_n = KARG(kq, int, e.ce_n); e.ce_V = KARG(kq, int, e.ce_V); e.ce_ldd = KARG(kq, int, e.ce_ldd);            \
   } while (0)
+  // what the choice and the source addresses of the next item need (read in the second-to-last K-tile of every item)
+#define RELOAD_SCHED_ARGS()                                                                             \
+  do {                                                                                                  \
+    kargp_t kq = V4_KARGP(ka_unused);                                                                   \
+    V4_OPAQUE_S(kq);                                                                                    \
+    A = KARG(kq, const bf16_t*, A); B = KARG(kq, const bf16_t*, B);                                     \
+    lda = KARG(kq, long, lda); ldb = KARG(kq, long, ldb);                                               \
+    M = KARG(kq, int, M); N = KARG(kq, int, N); K = KARG(kq, int, K); k_per_split = KARG(kq, int, k_per_split); \
+    ntx = KARG(kq, int, ntx); nty = KARG(kq, int, nty); nitems = KARG(kq, int, nitems);                 \
+    n_full = KARG(kq, int, n_full); S = KARG(kq, int, S); sched = KARG(kq, int*, sched);                \
+    n_fullitems = S ? n_full : nitems;                                                                  \
+  } while (0)
+
+  // One K-tile in ring buffer `buf_`: two phases.  Phase A: fragments of A0, B0, B1 (16 reads), 16 MFMAs (quadrants A0B0, A0B1);
+  // phase B: fragments of A1 (8 reads), 16 MFMAs (A1B1, A1B0).  Every load segment ends with lgkmcnt(0) BEFORE its barrier, so a
+  // half-tile can be refilled in the very next phase: phase B requests A0, B0 of the K-tile after next (read in phase A), phase A
+  // of the next K-tile requests its B1, A1.  Waits: phase A for A1 of this K-tile = all but the 4 youngest half-tiles; phase B
+  // for A0, B0, B1 of the next K-tile = all but the 3 youngest.
+  // KIND 0: a K-tile with at least two more of the same item behind it.  KIND 1: the second-to-last K-tile -- its phase A decodes
+  // the next item, its phase B points the sources at that item's K-tile 0 and requests A0, B0 of it.  KIND 2: the last K-tile --
+  // phase A requests B1, A1 of the next item's K-tile 0, phase B requests nothing.
+#define KTILE(KIND, bufx_, pk_, tr_)                                                                                                   \
+  do {                                                                                                                           \
+    const int buf_ = V4_RFL(bufx_);     /* wave-uniform by construction; said explicitly (it ends up in M0 of the LDS-DMA) */   \
+    const int nbuf_ = buf_ ^ 1;                                                                                                  \
+    const unsigned char* sA0 = smem + (buf_) * STAGE_BYTES;                                                                      \
+    const unsigned char* sA1 = sA0 + HALF_BYTES;                                                                                 \
+    const unsigned char* sB0 = sA0 + 2 * HALF_BYTES;                                                                             \
+    const unsigned char* sB1 = sA0 + 3 * HALF_BYTES;                                                                             \
+    bf16x8_t fa0[2][4], fa1[2][4], fb0[4], fb1[4];                                                                               \
+    if (!do_frag) {                                                                                                              \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                            \
+        fb0[s] = bf16x8_t{}; fb1[s] = bf16x8_t{}; fa0[0][s] = bf16x8_t{}; fa0[1][s] = bf16x8_t{}; fa1[0][s] = bf16x8_t{}; fa1[1][s] = bf16x8_t{}; \
+        V4_OPAQUE_V(fb0[s]); V4_OPAQUE_V(fb1[s]); V4_OPAQUE_V(fa0[0][s]); V4_OPAQUE_V(fa0[1][s]); V4_OPAQUE_V(fa1[0][s]); V4_OPAQUE_V(fa1[1][s]); \
+      }                                                                                                                          \
+    }                                                                                                                            \
+    const bool cs_now = want_cs && cs_ctr == txcur;                                                                              \
+    cs_ctr = cs_ctr + 1 == ntx_cs ? 0 : cs_ctr + 1;                                                                              \
+    const uint32_t boff = (buf_) * STAGE_BYTES;                                                                                  \
+    if (do_frag) {                                                                                                               \
+      frag4<TB, 2>(fb0, bkm + boff, sB0, br, lm);                                                                                \
+      frag4<TB, 3>(fb1, bkm + boff, sB1, br, lm);                                                                                \
+      frag4<TA, 0>(fa0[0], akm0 + boff, sA0, ar, lm);                                                                            \
+      frag4<TA, 0>(fa0[1], akm1 + boff, sA0, ar + 32, lm);                                                                       \
+    }                                                                                                                            \
+    const bool more_ = (KIND) != 2 || have;   /* a K-tile follows (KIND 2: the next item's K-tile 0) */                           \
+    if (more_) {                        /* B1 (V4_SCHED 0: and A1) of that K-tile -> the other buffer; then: A1 of THIS K-tile has landed */ \
+      if (V4_SCHED) { ISSUE_H(bp, BDHQ, 3, nbuf_); wait_vmcnt_plus<6>(pk_); }                                                     \
+      else { ISSUE_H(bp, BDHQ, 3, nbuf_); ISSUE_H(ap, a_dh, 1, nbuf_); wait_vmcnt_plus<8>(pk_); }                                 \
+    } else { WAITV(0); }                                                                                                         \
+    if ((KIND) == 1) {                  /* the next item: which one, and its tile coordinates (scalar work in a load segment that requests little) */ \
+      if (fast) {                                                                                                                \
+        left -= 1;                                                                                                               \
+        have = left > 0;                                                                                                         \
+        if (have) {                                                                                                              \
+          int tx_ = nxt.tile_x + sx_f;                                                                                           \
+          const int cy_ = tx_ >= ntx_f ? 1 : 0;                                                                                  \
+          tx_ -= cy_ ? ntx_f : 0;                                                                                                \
+          const int ty_ = nxt.tile_y + sy_f + cy_;                                                                               \
+          d_m = (ty_ - nxt.tile_y) * BM; d_n = (tx_ - nxt.tile_x) * BN;                                                          \
+          nxt.tile_x = tx_; nxt.tile_y = ty_;                                                                                    \
+        }                                                                                                                        \
+      } else {                                                                                                                   \
+        RELOAD_SCHED_ARGS();                                                                                                     \
+        const int packed_ = V4_RFL(sched_lds[0]);   /* published before the previous epilogue's last barrier */                  \
+        nxt_packed = packed_;                                                                                                    \
+        have = packed_ >= 0 && DECODE(packed_ >> 24, packed_ & 0xffffff, nxt);                                                   \
+      }                                                                                                                          \
+    }                                                                                                                            \
+    wait_lgkm0();                                                                                                                \
+    if (tr_) TRACE_FINE();      /* load segment A done (before its barrier) */                                           \
+    V4_BARRIER();                                                                                                                \
+    if (tr_) TRACE_FINE();      /* barrier passed */                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                                               \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                              \
+      _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) { MFMA(acc[ii][0], fa0[ii][s], fb0[s]); MFMA(acc[ii][1], fa0[ii][s], fb1[s]); } \
+      if (V4_SCHED && more_ && (s == 0 || s == 2)) {   /* A1 of the next K-tile: one piece behind the 4th, one behind the 12th MFMA */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        if (s == 0) ISSUE_PIECE(ap, a_dh, 1, nbuf_, 0); else ISSUE_PIECE(ap, a_dh, 1, nbuf_, 1);                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+      }                                                                                                                          \
+    }                                                                                                                            \
+    if (TA && cs_now) {                                                                                                          \
+      /* column sums of A rows (bias gradient): wave wn takes k16-step wn; indicator fragment = ones in column c */              \
+      _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) {                                                                         \
+        const uint32_t one = ((lane & 31) == ii) ? 0x3f803f80u : 0u;                                                             \
+        union { uint32_t u[4]; bf16x8_t v; } ind;                                                                                \
+        ind.u[0] = ind.u[1] = ind.u[2] = ind.u[3] = one;                                                                         \
+        const bf16x8_t af = wn == 0 ? fa0[ii][0] : wn == 1 ? fa0[ii][1] : wn == 2 ? fa0[ii][2] : fa0[ii][3];                     \
+        cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ind.v, cs, 0, 0, 0);                                                    \
+      }                                                                                                                          \
+    }                                                                                                                            \
+    __builtin_amdgcn_s_setprio(0);                                                                                               \
+    V4_BARRIER();                                                                                                                \
+    if (tr_) TRACE_FINE();      /* MFMA segment A done, barrier passed */                                                \
+                                                                                                                                 \
+    if (do_frag) {                                                                                                               \
+      frag4<TA, 1>(fa1[0], akm0 + boff, sA1, ar, lm);                                                                            \
+      frag4<TA, 1>(fa1[1], akm1 + boff, sA1, ar + 32, lm);                                                                       \
+    }                                                                                                                            \
+    if ((KIND) == 0) {                  /* A0 (V4_SCHED 0: and B0) of the K-tile after next -> this buffer (read in phase A); then: A0, B0, B1 of the next K-tile have landed */ \
+      if (V4_SCHED) { ADVANCE_SRC(); ISSUE_H(ap, 0, 0, (buf_)); WAITV(4); }                                                      \
+      else { ISSUE_H(ap, astep, 0, (buf_)); ISSUE_H(bp, bstep, 2, (buf_)); WAITV(6); ADVANCE_SRC(); }                            \
+    } else if ((KIND) == 1) {                                                                                                    \
+      if (have) {                       /* sources -> K-tile 0 of the next item; its A0, B0 take the slots a K-tile nk would take */ \
+        if (fast) {                     /* the sources point at K-tile nk - 1 of this item: step back to k = 0, over to the next tile */ \
+          const long back_ = (long)(nk - 1) * BK;                                                                                \
+          const long dA_ = TA ? ((long)d_m - back_ * lda) : ((long)d_m * lda - back_);                                           \
+          const long dB_ = TB ? ((long)d_n - back_ * ldb) : ((long)d_n * ldb - back_);                                           \
+          _Pragma("unroll") for (int q = 0; q < NP; ++q) { ap[q] += dA_; bp[q] += dB_; }                                         \
+        } else {                                                                                                                 \
+          LOAD_PROBLEM(kp, nxt.p);                                                                                               \
+          SETUP_SRC(nxt.tile_y * BM, nxt.tile_x * BN, nxt.kbeg);                                                                 \
+        }                                                                                                                        \
+        if (V4_SCHED) { ISSUE_H(ap, 0, 0, (buf_)); WAITV(4); }                                                                   \
+        else { ISSUE_H(ap, 0, 0, (buf_)); ISSUE_H(bp, 0, 2, (buf_)); WAITV(6); }                                                 \
+      } else { WAITV(2); }              /* A0, B0, B1 of the last K-tile have landed */                                          \
+    }                                                                                                                            \
+    wait_lgkm0();                                                                                                                \
+    if (tr_) TRACE_FINE();      /* load segment B done */                                                                \
+    V4_BARRIER();                                                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                                               \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                              \
+      _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) { MFMA(acc[2 + ii][1], fa1[ii][s], fb1[s]); MFMA(acc[2 + ii][0], fa1[ii][s], fb0[s]); } \
+      if (V4_SCHED && ((KIND) == 0 || ((KIND) == 1 && have)) && (s == 0 || s == 2)) {   /* B0 of the K-tile after next (KIND 1: of the next item's K-tile 0) */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        if (s == 0) ISSUE_PIECE(bp, 0, 2, (buf_), 0); else ISSUE_PIECE(bp, 0, 2, (buf_), 1);                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+      }                                                                                                                          \
+    }                                                                                                                            \
+    if (TA && cs_now) {                                                                                                          \
+      _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) {                                                                         \
+        const uint32_t one = ((lane & 31) == 2 + ii) ? 0x3f803f80u : 0u;                                                         \
+        union { uint32_t u[4]; bf16x8_t v; } ind;                                                                                \
+        ind.u[0] = ind.u[1] = ind.u[2] = ind.u[3] = one;                                                                         \
+        const bf16x8_t af = wn == 0 ? fa1[ii][0] : wn == 1 ? fa1[ii][1] : wn == 2 ? fa1[ii][2] : fa1[ii][3];                     \
+        cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ind.v, cs, 0, 0, 0);                                                    \
+      }                                                                                                                          \
+    }                                                                                                                            \
+    __builtin_amdgcn_s_setprio(0);                                                                                               \
+    V4_BARRIER();                                                                                                                \
+  } while (0)
+
   while (have) {
     const int m0 = nxt.tile_y * BM, n0 = nxt.tile_x * BN;
     const int nk = nxt.nk;                                         // host guarantees nk >= 2
@@ -570,11 +761,12 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     const int cur_slice = nxt.slice;
     const int pcur = nxt.p;
     const int ntx_cs = GROUP ? GPARG(kp, pcur, int, ntx) : ntx;
+    int nxt_packed = -1;
 
     // fragment addressing restarts from an opaque lane id per tile, so its ~12 address registers are not kept live across
     // the epilogue of the previous tile (same trick as `te` below)
     int lm = lane;
-    asm volatile("" : "+v"(lm));
+    V4_OPAQUE_V(lm);
     const uint32_t akm0 = lds0 + kmajor_lane_off(ar, lm), akm1 = lds0 + kmajor_lane_off(ar + 32, lm), bkm = lds0 + kmajor_lane_off(br, lm);
     f32x16_t acc[4][2];
 #pragma unroll
@@ -589,124 +781,38 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     const bool want_cs = TA && (GROUP ? GPARG(kp, pcur, float*, a_colsum) != nullptr : e.a_colsum != nullptr);
     int cs_ctr = 0;                  // K-tiles with cs_ctr == tile_x contribute (spreads the extra MFMAs over the tile columns)
 
-    // ---- rest of the prologue: A0, B0 of K-tile 1 go to ring buffer 1 (free: every wave is past the epilogue)
+    // ---- K-tile 0 of this item is in LDS (requested by the previous item, or before the loop); A0, B0 of K-tile 1 go to the
+    // other buffer: it was the previous epilogue's staging area, and every wave is past that epilogue's last barrier
     ADVANCE_SRC();
-    ISSUE_H(ap, 0, 0, 1); ISSUE_H(bp, 0, 2, 1);
-    wait_vmcnt_plus<6>(pend);                // A0, B0, B1 of K-tile 0 have landed (A1 and K-tile 1's A0, B0 may fly)
-    V4_BARRIER();
-    TRACE();                                 // [0] prologue done
+    { const int b1_ = V4_RFL(tp ^ 1); ISSUE_H(ap, 0, 0, b1_); ISSUE_H(bp, 0, 2, b1_); }
+    TRACE();                                 // [0] tile started
     if (wm == 1) V4_BARRIER();               // waves 4-7 run one barrier behind waves 0-3 from here on
 
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1, nbuf = buf ^ 1;
-      const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
-      const int pk = kt == 0 ? pend : 0;     // K-tile 0 of a tile: the previous epilogue's stores sit between its loads
-      const unsigned char* sA0 = smem + buf * STAGE_BYTES;
-      const unsigned char* sA1 = sA0 + HALF_BYTES;
-      const unsigned char* sB0 = sA0 + 2 * HALF_BYTES;
-      const unsigned char* sB1 = sA0 + 3 * HALF_BYTES;
-      bf16x8_t fa0[2][4], fa1[2][4], fb0[4], fb1[4];
-      if (!do_frag) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          fb0[s] = bf16x8_t{}; fb1[s] = bf16x8_t{}; fa0[0][s] = bf16x8_t{}; fa0[1][s] = bf16x8_t{}; fa1[0][s] = bf16x8_t{}; fa1[1][s] = bf16x8_t{};
-          asm volatile("" : "+v"(fb0[s]), "+v"(fb1[s]), "+v"(fa0[0][s]), "+v"(fa0[1][s]), "+v"(fa1[0][s]), "+v"(fa1[1][s]));
-        }
-      }
-      const bool cs_now = want_cs && cs_ctr == txcur;
-      cs_ctr = cs_ctr + 1 == ntx_cs ? 0 : cs_ctr + 1;
+    for (int kt = 0; kt < nk - 2; ++kt) KTILE(0, (kt ^ tp) & 1, (kt == 0 ? pend : 0), (V4_TRACE >= 3 && kt == 2));
+    TRACE();                                 // [1] K-tiles 0 .. nk-3 done
+    KTILE(1, (nk ^ tp) & 1, (nk == 2 ? pend : 0), (V4_TRACE == 2));   // K-tile nk - 2
+    TRACE();                                 // [2] K-tile nk-2 done (next item decoded, its A0 / B0 requested)
+    KTILE(2, (nk ^ tp ^ 1) & 1, 0, (V4_TRACE == 2));                    // K-tile nk - 1
+    if (wm == 0) V4_BARRIER();               // re-align the two wave groups; the buffer of the last K-tile is free from here
+    TRACE();                                 // [3] main loop done
+    const int sbuf = V4_RFL((nk ^ tp ^ 1) & 1);      // ring buffer of the last K-tile = the epilogue's staging area (the other one holds / receives the next item's K-tile 0)
+    tp = sbuf ^ 1;
 
-      // Two phases per K-tile.  Phase A: fragments of A0, B0, B1 (16 reads), 16 MFMAs (quadrants A0B0, A0B1); phase B:
-      // fragments of A1 (8 reads), 16 MFMAs (A1B1, A1B0).  Every load segment ends with lgkmcnt(0) BEFORE its barrier, so a
-      // half-tile can be refilled in the very next phase: phase B requests A0, B0 of K-tile kt+2 (read in phase A), phase A
-      // of the next K-tile requests B1, A1 of kt+2.  Waits: phase A for A1(kt) = all but the 4 youngest half-tiles; phase B
-      // for A0, B0, B1 of kt+1 = all but the 3 youngest.
-      const uint32_t boff = buf * STAGE_BYTES;
-      if (do_frag) {
-        frag4<TB, 2>(fb0, bkm + boff, sB0, br, lm);
-        frag4<TB, 3>(fb1, bkm + boff, sB1, br, lm);
-        frag4<TA, 0>(fa0[0], akm0 + boff, sA0, ar, lm);
-        frag4<TA, 0>(fa0[1], akm1 + boff, sA0, ar + 32, lm);
-      }
-      if (has1) { ISSUE_H(bp, BDHQ, 3, nbuf); ISSUE_H(ap, a_dh, 1, nbuf); if (ROLES) WAITV(8); else wait_vmcnt_plus<8>(pk); } else { WAITV(0); }   // A1(kt) has landed
-      wait_lgkm0();
-      V4_BARRIER();
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) { MFMA(acc[ii][0], fa0[ii][s], fb0[s]); MFMA(acc[ii][1], fa0[ii][s], fb1[s]); }
-      if (TA && cs_now) {
-        // column sums of A rows (bias gradient): wave wn takes k16-step wn; indicator fragment = ones in column c
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          const uint32_t one = ((lane & 31) == ii) ? 0x3f803f80u : 0u;
-          union { uint32_t u[4]; bf16x8_t v; } ind;
-          ind.u[0] = ind.u[1] = ind.u[2] = ind.u[3] = one;
-          const bf16x8_t af = wn == 0 ? fa0[ii][0] : wn == 1 ? fa0[ii][1] : wn == 2 ? fa0[ii][2] : fa0[ii][3];
-          cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ind.v, cs, 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-      V4_BARRIER();
-
-      if (do_frag) {
-        frag4<TA, 1>(fa1[0], akm0 + boff, sA1, ar, lm);
-        frag4<TA, 1>(fa1[1], akm1 + boff, sA1, ar + 32, lm);
-      }
-      if (has2) { ISSUE_H(ap, astep, 0, buf); ISSUE_H(bp, bstep, 2, buf); WAITV(6); } else if (has1) { WAITV(2); }   // A0, B0, B1 of kt+1 have landed
-      ADVANCE_SRC();
-      wait_lgkm0();
-      V4_BARRIER();
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) { MFMA(acc[2 + ii][1], fa1[ii][s], fb1[s]); MFMA(acc[2 + ii][0], fa1[ii][s], fb0[s]); }
-      if (TA && cs_now) {
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          const uint32_t one = ((lane & 31) == 2 + ii) ? 0x3f803f80u : 0u;
-          union { uint32_t u[4]; bf16x8_t v; } ind;
-          ind.u[0] = ind.u[1] = ind.u[2] = ind.u[3] = one;
-          const bf16x8_t af = wn == 0 ? fa1[ii][0] : wn == 1 ? fa1[ii][1] : wn == 2 ? fa1[ii][2] : fa1[ii][3];
-          cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ind.v, cs, 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-      V4_BARRIER();
-    }
-    if (wm == 0) V4_BARRIER();               // re-align the two wave groups; the whole ring is free from here
-    TRACE();                                 // [1] main loop done
-
-    // ---- next work item: request the four half-tiles of its K-tile 0 into ring buffer 0 BEFORE the epilogue
-    constexpr bool STORE_MODE = MODE == MODE_STORE || MODE == MODE_STORE_RES || MODE == MODE_STORE_GELU || MODE == MODE_STORE_DGELU;
-    constexpr bool PIPE = V4_PIPE_EPI && !ROLES && STORE_MODE && !GROUP && do_epi;
-    const bool defer_issue = PIPE && !((MODE == MODE_STORE || MODE == MODE_STORE_RES) && cur_slice >= 0);
+    // ---- the item after next (thread 0): requested now, published at the end of this epilogue
     RELOAD_ARGS();
-    n_fullitems = S ? n_full : nitems;
-    const int packed = __builtin_amdgcn_readfirstlane(sched_lds[0]);       // published before this tile's prologue barrier
-    have = packed >= 0 && DECODE(packed >> 24, packed & 0xffffff, nxt);
-    int fut = -1;                                // thread 0: the item after that (published at the end of this epilogue)
-    int fut_raw = 1 << 22, fut_sn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (have) {
-      if (t == 0) {
-        if (dyn) FETCH_ISSUE(fut_raw, fut_sn);   // no control flow depends on it until the end of the epilogue
-        else { const int x = packed >> 24, l = (packed & 0xffffff) + wgs_on_xcd(x, grid); fut = (x << 24) | l; }
-      }
-      LOAD_PROBLEM(kp, nxt.p);
-      SETUP_SRC(nxt.tile_y * BM, nxt.tile_x * BN, nxt.kbeg);
-      // the pipelined bf16 epilogue issues these 8 LDS-DMA pieces between the conversions of its first quarter pass (an LDS-DMA
-      // issue costs the wave ~100 cycles of the shared address path; the conversions are VALU work: ~1000 cycles per tile hidden)
-      if (!defer_issue) { ISSUE_H(ap, 0, 0, 0); ISSUE_H(bp, 0, 2, 0); ISSUE_H(bp, BDHQ, 3, 0); ISSUE_H(ap, a_dh, 1, 0); }
+    int fut = -1;
+    int fut_raw = 1 << 22;
+    if (have && t == 0 && !fast) {
+      if (dyn) FETCH_ISSUE(fut_raw);           // no control flow depends on it until the end of the epilogue
+      else { const int x = nxt_packed >> 24, l = (nxt_packed & 0xffffff) + wgs_on_xcd(x, grid); fut = (x << 24) | l; }
     }
-    TRACE();                                 // [2] next tile requested
+    TRACE();                                 // [4] epilogue arguments loaded
     pend = 0;
     do {   // the epilogue flavours leave with `break`
     // the epilogue's per-lane indexing starts from an OPAQUE copy of the thread id: otherwise the compiler hoists ~30 loop-
     // invariant address registers out of the persistent tile loop and keeps them live across the main loop (spills)
     int te = t;
-    asm volatile("" : "+v"(te));
+    V4_OPAQUE_V(te);
     const int le = te & 63;
     if (!do_epi) {
       if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(e.C)[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7] + cs[2];
@@ -765,8 +871,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       // 1.6 + 2.6 GB per step at the FILIP batch) never exists.
       // acc[i*2+ii][j]: lane -> row (lane&31), registers 4*rg .. +3 -> columns 8*rg + 4*(lane>>5) + {0..3} of a 32-column group,
       // i.e. l-group g = rg>>1 of the fragment, m = 8*(rg&1) + 4*(lane>>5) + x.
-      float* mv = reinterpret_cast<float*>(smem + STAGE_BYTES);                    // [256 rows][16 l] max values
-      unsigned char* ma = smem + STAGE_BYTES + 256 * 16 * 4;                         // [256 rows][16 l] arg-max
+      float* mv = reinterpret_cast<float*>(smem + sbuf * STAGE_BYTES);             // [256 rows][16 l] max values
+      unsigned char* ma = smem + sbuf * STAGE_BYTES + 256 * 16 * 4;                  // [256 rows][16 l] arg-max
       const int hh = le >> 5;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -825,11 +931,12 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       // positions, columns = 49409 vocabulary entries).  Forward: per-row (max, sum exp) of the tile's 256 columns + the label
       // logit leave the chip (8 bytes per row and tile instead of 1 KB of fp32 logits); a finalize kernel merges the 194 tiles
       // of a row.  Backward: the tile is recomputed and dl = g (softmax - onehot) is stored as bf16 for the two gradient GEMMs.
-      float* cb = reinterpret_cast<float*>(smem + STAGE_BYTES);                 // [256] bias of the tile's columns
-      int* lb = reinterpret_cast<int*>(smem + STAGE_BYTES + 1024);              // [256] label of the tile's rows (-1: padding row)
-      float* rl = reinterpret_cast<float*>(smem + STAGE_BYTES + 2048);          // BWD: [256] lse, FWD: unused
-      float* rg = reinterpret_cast<float*>(smem + STAGE_BYTES + 3072);          // BWD: [256] upstream gradient
-      float* red = reinterpret_cast<float*>(smem + STAGE_BYTES + 4096);         // FWD: [256 rows][4 wn][2]
+      unsigned char* const ce_base = smem + sbuf * STAGE_BYTES;                 // the staging buffer (ring buffer of the last K-tile)
+      float* cb = reinterpret_cast<float*>(ce_base);                            // [256] bias of the tile's columns
+      int* lb = reinterpret_cast<int*>(ce_base + 1024);                         // [256] label of the tile's rows (-1: padding row)
+      float* rl = reinterpret_cast<float*>(ce_base + 2048);                     // BWD: [256] lse, FWD: unused
+      float* rg = reinterpret_cast<float*>(ce_base + 3072);                     // BWD: [256] upstream gradient
+      float* red = reinterpret_cast<float*>(ce_base + 4096);                    // FWD: [256 rows][4 wn][2]
       const int V = e.ce_V, nrows = e.ce_n;
       if (te < 256) {
         const int c = n0 + te, r = m0 + te;
@@ -883,7 +990,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       } else {
         // dl tile, bf16, staged through LDS like the plain bf16 epilogue (two passes of 128 rows, 512-byte staging rows,
         // 8-byte unit u of row r at unit u ^ (r & 15)); columns >= ce_ldd (beyond the dl buffer's row) are not stored
-        unsigned char* Cd = smem + STAGE_BYTES + 8192;
+        unsigned char* Cd = ce_base + 8192;
         unsigned char* Db = reinterpret_cast<unsigned char*>(e.C) + ((long)m0 * e.ce_ldd + n0) * 2;
         const int cc = te & 31, r0 = te >> 5;
 #pragma unroll
@@ -931,7 +1038,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       break;
     }
 
-    unsigned char* Cs = smem + STAGE_BYTES;  // ring buffer 1 (buffer 0 is receiving the next tile)
+    unsigned char* Cs = smem + sbuf * STAGE_BYTES;  // the ring buffer of the last K-tile (the other one holds the next item's K-tile 0)
     constexpr bool SLICEABLE = MODE == MODE_STORE || MODE == MODE_STORE_RES;   // the N = d GEMMs (few tiles) use these flavours
     if (MODE == MODE_PARTIAL || GROUP || (SLICEABLE && cur_slice >= 0)) {
       // fp32 partial tile: MODE_PARTIAL -> ws[z][m][n]; tail slice -> its private [256][256] tile of the workspace.
@@ -974,7 +1081,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
             }
             wait_lgkm0();
 #pragma unroll
-            for (int it4 = 0; it4 < 4; ++it4) asm volatile("" : "+v"(rb[it4]));
+            for (int it4 = 0; it4 < 4; ++it4) V4_OPAQUE_V(rb[it4]);
 #pragma unroll
             for (int it4 = 0; it4 < 4; ++it4) {
               const int it = half * 4 + it4;
@@ -1001,7 +1108,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     // -> 4 consecutive columns 8*rg + 4*(lane>>5) + {0..3}.  Two passes (A-half i = rows i*128 ..): staging tile
     // [128 rows][512 B] in ring buffer 1, 8-byte unit u of row r at unit u ^ (r & 15)  (conflict-free ds_write_b64;
     // ds_read_b128 sees whole 16-byte chunks, halves swapped on odd rows).
-    if constexpr (PIPE) {
+    {
       // Four quarter passes q = (i, ii): rows i*128 + wm*64 + ii*32 + 0..31 of both wave groups -> staging rows wm*32 + (lane&31)
       // of buffer q & 1 (two [64 rows][512 B] halves of ring buffer 1).  Phase q converts and stages quarter q (VALU + LDS
       // writes) right after ISSUING the read-back + global stores of quarter q-1 (LDS reads + the vector-memory path): the two
@@ -1032,7 +1139,6 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
         for (int x = 0; x < 8; ++x) pre0[x] = load_once16<NT_IN>(pre_base + (long)(16 * x) * pre_ld * 2 + pre_off);
       }
       const int mlq = wm * 32 + (le & 31);
-      const bool issue_now = defer_issue && have;
       // the lane's 8 bias quads (columns j*128 + br + 8*rg + 4*(lane>>5) ..+3) are the same for all four quarters: ONE batch of
       // LDS reads.  (Read next to their use, every conversion group was a dependent LDS round trip -- the compiler cannot move a
       // read of the bias area across the staging writes -- and 16 of them per half were most of the epilogue's 9.5 k cycles.)
@@ -1046,7 +1152,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) asm volatile("" : "+v"(bq[j][rg].x), "+v"(bq[j][rg].y), "+v"(bq[j][rg].z), "+v"(bq[j][rg].w));
+        for (int rg = 0; rg < 4; ++rg) { V4_OPAQUE_V(bq[j][rg].x); V4_OPAQUE_V(bq[j][rg].y); V4_OPAQUE_V(bq[j][rg].z); V4_OPAQUE_V(bq[j][rg].w); }
 #pragma unroll
       for (int q = 0; q <= 4; ++q) {
         // order inside a phase: (1) the four LDS reads of quarter q-1 are ISSUED, (2) quarter q is converted and staged while they
@@ -1074,12 +1180,6 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
               pk.x = pack2bf_hw(acc[q][j][rg * 4 + 0] * e.alpha + bq[j][rg].x, acc[q][j][rg * 4 + 1] * e.alpha + bq[j][rg].y);
               pk.y = pack2bf_hw(acc[q][j][rg * 4 + 2] * e.alpha + bq[j][rg].z, acc[q][j][rg * 4 + 3] * e.alpha + bq[j][rg].w);
               *reinterpret_cast<uint2*>(Cq + mlq * 512 + (((nl >> 2) ^ (mlq & 15)) << 3)) = pk;
-              if (q == 0 && (rg & 1) && issue_now) {               // the next tile's K-tile 0: one half-tile after every second group
-                if (j == 0 && rg == 1) ISSUE_H(ap, 0, 0, 0);
-                if (j == 0 && rg == 3) ISSUE_H(bp, 0, 2, 0);
-                if (j == 1 && rg == 1) ISSUE_H(bp, BDHQ, 3, 0);
-                if (j == 1 && rg == 3) ISSUE_H(ap, a_dh, 1, 0);
-              }
             }
           }
         }
@@ -1129,125 +1229,26 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
 #pragma unroll
           for (int x = 0; x < 8; ++x) pre1[x] = load_once16<NT_IN>(pre_base + (long)(128 + 16 * x) * pre_ld * 2 + pre_off);
         }
-        wait_lgkm0();
-        V4_BARRIER();                          // quarter q staged / buffer (q - 1) & 1 free again (q = 4: the staging tile is free)
-        if (q <= 3) TRACE();
+        if (q <= 3) {                          // (q = 4: the end-of-item barrier below)
+          wait_lgkm0();
+          V4_BARRIER();                        // quarter q staged / buffer (q - 1) & 1 free again
+          TRACE();
+        }
       }
       pend = is_gelu ? 32 : 16;
-    } else {
-      constexpr int RSTEP = ROLES ? 8 : 16, NIT = ROLES ? 16 : 8;   // ROLES: only waves 0-3 read back and store
-      const bool storer = !ROLES || wm == 0;
-      const int cc = te & 31;                 // 16-byte chunk of the row (8 columns)
-      const int r0 = ROLES ? ((te >> 5) & 7) : (te >> 5);
-      // every global access of the epilogue = wave-uniform row base (SGPRs) + one 32-bit per-lane byte offset: no
-      // per-row 64-bit address VGPRs (they would not fit beside the accumulators)
-      unsigned char* Cb = reinterpret_cast<unsigned char*>(e.C) + ((long)m0 * e.ldc + n0) * 2;
-      const uint32_t c_off = ((uint32_t)r0 * (uint32_t)e.ldc + cc * 8) * 2;
-      unsigned char* Xb = reinterpret_cast<unsigned char*>(e.aux) + ((long)m0 * e.ldaux + n0) * 2;
-      const uint32_t x_off = ((uint32_t)r0 * (uint32_t)e.ldaux + cc * 8) * 2;
-      const unsigned char* Rb = reinterpret_cast<const unsigned char*>(e.residual) + ((long)m0 * e.ldr + n0) * 2;
-      const uint32_t r_off = ((uint32_t)r0 * (uint32_t)e.ldr + cc * 8) * 2;
-      constexpr bool is_gelu = MODE == MODE_STORE_GELU, is_dgelu = MODE == MODE_STORE_DGELU;
-      // output stores: V4_NT_STORE 1 = all non-temporal, 2 = only the 4d-wide GELU / dGELU outputs, 0 = none
-      constexpr bool NT_OUT = V4_NT_STORE == 1 || V4_NT_STORE >= 3 || (V4_NT_STORE == 2 && (is_gelu || is_dgelu));
-      constexpr bool NT_IN = V4_NT_STORE >= 3;          // 3: also the read-once epilogue operands
-      // operands of the fused epilogue (dGELU pre-activation, or else the residual) are requested BEFORE any store of
-      // the tile: pass 0's before its staging, pass 1's right after pass 0's staging (its accumulators are dead by then)
-      constexpr bool has_pre = MODE == MODE_STORE_DGELU || MODE == MODE_STORE_RES;
-      const unsigned char* pre_base = is_dgelu ? Xb : Rb;
-      const uint32_t pre_off = is_dgelu ? x_off : r_off;
-      const long pre_ld = is_dgelu ? e.ldaux : e.ldr;
-      static_assert(!(ROLES && (MODE == MODE_STORE_DGELU || MODE == MODE_STORE_RES)), "ROLES: plain / GELU epilogues only");
-      uint4 pre0[8], pre1[8];
-      if (has_pre) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) pre0[q] = load_once16<NT_IN>(pre_base + (long)(16 * q) * pre_ld * 2 + pre_off);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          const int ml = ar + ii * 32 + (le & 31);
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-              const int nl = j * 128 + br + 8 * rg + 4 * (le >> 5);
-              const float4 bq = *reinterpret_cast<const float4*>(smem + BIAS_OFF + 4 * (n0 + nl));
-              uint2 pk;
-              pk.x = pack2bf_hw(acc[i * 2 + ii][j][rg * 4 + 0] * e.alpha + bq.x, acc[i * 2 + ii][j][rg * 4 + 1] * e.alpha + bq.y);
-              pk.y = pack2bf_hw(acc[i * 2 + ii][j][rg * 4 + 2] * e.alpha + bq.z, acc[i * 2 + ii][j][rg * 4 + 3] * e.alpha + bq.w);
-              *reinterpret_cast<uint2*>(Cs + ml * 512 + (((nl >> 2) ^ (ml & 15)) << 3)) = pk;
-            }
-        }
-        if (i == 0 && has_pre) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) pre1[q] = load_once16<NT_IN>(pre_base + (long)(128 + 16 * q) * pre_ld * 2 + pre_off);
-        }
-        wait_lgkm0();
-        V4_BARRIER();
-        TRACE();                             // [3],[5] pass staged
-        if (storer) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const int row = r0 + RSTEP * it;
-          const long mu = i * 128 + RSTEP * it;         // wave-uniform part of the row index (relative to m0)
-          const int pc = cc ^ ((row & 15) >> 1);
-          uint4 raw = *reinterpret_cast<const uint4*>(Cs + row * 512 + pc * 16);
-          if (row & 1) { uint32_t tx = raw.x, ty = raw.y; raw.x = raw.z; raw.y = raw.w; raw.z = tx; raw.w = ty; }
-          if (MODE == MODE_STORE) {
-            store_c16<NT_OUT>(Cb + mu * e.ldc * 2 + c_off, raw);
-          } else {
-            const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
-            float v[8];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) { v[2 * x] = __uint_as_float(wv[x] << 16); v[2 * x + 1] = __uint_as_float(wv[x] & 0xffff0000u); }
-            if (is_gelu) {
-              store_c16<NT_OUT>(Xb + mu * e.ldaux * 2 + x_off, raw);
-#pragma unroll
-              for (int x = 0; x < 8; ++x) v[x] = quick_gelu_f(v[x]);
-            }
-            if (has_pre) {
-              const uint4 pr = i == 0 ? pre0[it] : pre1[it];
-              const uint32_t pw[4] = {pr.x, pr.y, pr.z, pr.w};
-              float pf[8];
-#pragma unroll
-              for (int x = 0; x < 4; ++x) { pf[2 * x] = __uint_as_float(pw[x] << 16); pf[2 * x + 1] = __uint_as_float(pw[x] & 0xffff0000u); }
-              if (is_dgelu) {
-#pragma unroll
-                for (int x = 0; x < 8; ++x) v[x] *= quick_gelu_grad_f(pf[x]);
-              } else {
-#pragma unroll
-                for (int x = 0; x < 8; ++x) v[x] += pf[x];
-              }
-            }
-            {
-              uint4 pk;
-              pk.x = pack2bf_hw(v[0], v[1]); pk.y = pack2bf_hw(v[2], v[3]); pk.z = pack2bf_hw(v[4], v[5]); pk.w = pack2bf_hw(v[6], v[7]);
-              store_c16<NT_OUT>(Cb + mu * e.ldc * 2 + c_off, pk);
-            }
-          }
-          if (it & 1) __builtin_amdgcn_sched_barrier(0);      // keep the unrolled iterations from being interleaved (register pressure)
-        }
-        }
-        wait_lgkm0();
-        V4_BARRIER();                        // staging tile free again (next pass / the next tile's K-tile 1)
-        TRACE();                             // [4],[6] pass stored
-      }
-      pend = ROLES ? 0 : (is_gelu ? 32 : 16);
     }
       } while (0);
+    // ---- end of the item.  The next item's K-tile 0 (requested during the last two K-tiles) has landed: everything this wave
+    // requested before the epilogue's `pend` stores is older than they are (in-order vmcnt).  The scheduler word is published.
+    // Both BEFORE the barrier that every wave passes on its way into the next item.
+    wait_vmcnt_tail(pend);
     if (t == 0) {
-      if (dyn && have) {
-        // the raw counter value was requested before this epilogue's P4 loads (8), prefetch loads and stores: it is older
-        // than the `8 + pend` operations that may still be in flight, so this wait does not touch the stores
-        if (pend == 32) FETCH_WAIT(40, fut_raw, fut_sn);
-        else if (pend == 16) FETCH_WAIT(24, fut_raw, fut_sn);
-        else FETCH_WAIT(8, fut_raw, fut_sn);
-        fut = fetch_finish(fut_raw, fut_sn);
-      }
-      sched_lds[0] = fut;                        // read by every wave at the start of the NEXT epilogue (barriers in between)
+      if (dyn && have) { FETCH_WAIT(63, fut_raw); fut = fetch_finish(fut_raw); }
+      sched_lds[0] = fut;                        // read by every wave in the second-to-last K-tile of the NEXT item
     }
+    wait_lgkm0();
+    V4_BARRIER();
+    TRACE();                                 // [n] epilogue done
   }
   if (dyn && t == 0) {
     // self-resetting scheduler state: the last workgroup to leave zeroes the counters for the next launch on this stream
@@ -1262,15 +1263,20 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
 #endif
 #undef MFMA
 #undef TRACE
+#undef TRACE_FINE
 #undef ISSUE_H
 #undef SETUP_SRC
 #undef RELOAD_ARGS
 #undef FETCH_ISSUE
 #undef FETCH_WAIT
 #undef ADVANCE_SRC
+#undef ISSUE_PIECE
 #undef WAITV
 #undef DECODE
 #undef LOAD_PROBLEM
+#undef KTILE
+#undef RELOAD_SCHED_ARGS
+#undef BDHQ
 }
 
 // out[m][n] (+)= sum_z ws[z][m][n]   (the split-K partial tiles of MODE_PARTIAL)
@@ -1368,6 +1374,9 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict
 }
 
 static int num_cus() {
+#if V4_EMU
+  return 8;      // the work distribution deals items to 8 XCD lists: the emulated "chip" has one workgroup per list
+#endif
   static int n = 0;
   if (!n) {
     int dev = 0;
@@ -1415,11 +1424,11 @@ static int v4_group_m(bool ta) {
   return ta ? 8 : 1;
 }
 
-template <bool TA, bool TB, int MODE, bool ROLES>
+template <bool TA, bool TB, int MODE>
 void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, int n_full, int S, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_v4_kernel<TA, TB, MODE, ROLES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_v4_kernel<TA, TB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   const int ntx = dh_cdiv(a->N, BN), nty = dh_cdiv(a->M, BM);
@@ -1431,7 +1440,7 @@ void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, int n
   ka.M = a->M; ka.N = a->N; ka.K = a->K; ka.k_per_split = kps; ka.ntx = ntx; ka.nty = nty; ka.nitems = nitems; ka.n_full = n_full; ka.S = S;
   ka.sched = sched_slot(st, &ka.dyn); ka.e = e;
   ka.group_m = v4_group_m(TA);
-  hipLaunchKernelGGL((gemm_v4_kernel<TA, TB, MODE, ROLES>), dim3(grid), dim3(512), LDS_BYTES, st, ka);
+  hipLaunchKernelGGL((gemm_v4_kernel<TA, TB, MODE>), dim3(grid), dim3(512), LDS_BYTES, st, ka);
 }
 
 }  // namespace v4
@@ -1522,25 +1531,15 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
       if (s_ >= 2 && a->ws_bytes >= (int64_t)rem * s_ * BM * BN * 4) { S = s_; n_full = T - rem; }
     }
   }
-  static int roles = -1;                         // DH_V4_ROLES=1: loader / storer wave groups (measured: no gain over the widened waits)
-  if (roles < 0) { const char* ev = getenv("DH_V4_ROLES"); roles = ev ? atoi(ev) : 0; }
   switch (md) {
-    case MODE_ATOMIC: launch<true, true, MODE_ATOMIC, false>(a, e, split, kps, n_full, S, st); break;
-    case MODE_PARTIAL: launch<true, true, MODE_PARTIAL, false>(a, e, split, kps, n_full, S, st); break;
-    case MODE_STORE_GELU:
-      if (roles) launch<false, false, MODE_STORE_GELU, true>(a, e, split, kps, n_full, S, st);
-      else launch<false, false, MODE_STORE_GELU, false>(a, e, split, kps, n_full, S, st);
-      break;
-    case MODE_STORE_RES: launch<false, false, MODE_STORE_RES, false>(a, e, split, kps, n_full, S, st); break;
-    case MODE_STORE_DGELU: launch<false, true, MODE_STORE_DGELU, false>(a, e, split, kps, n_full, S, st); break;
+    case MODE_ATOMIC: launch<true, true, MODE_ATOMIC>(a, e, split, kps, n_full, S, st); break;
+    case MODE_PARTIAL: launch<true, true, MODE_PARTIAL>(a, e, split, kps, n_full, S, st); break;
+    case MODE_STORE_GELU: launch<false, false, MODE_STORE_GELU>(a, e, split, kps, n_full, S, st); break;
+    case MODE_STORE_RES: launch<false, false, MODE_STORE_RES>(a, e, split, kps, n_full, S, st); break;
+    case MODE_STORE_DGELU: launch<false, true, MODE_STORE_DGELU>(a, e, split, kps, n_full, S, st); break;
     default:
-      if (a->b_kmajor) {
-        if (roles) launch<false, true, MODE_STORE, true>(a, e, split, kps, n_full, S, st);
-        else launch<false, true, MODE_STORE, false>(a, e, split, kps, n_full, S, st);
-      } else {
-        if (roles) launch<false, false, MODE_STORE, true>(a, e, split, kps, n_full, S, st);
-        else launch<false, false, MODE_STORE, false>(a, e, split, kps, n_full, S, st);
-      }
+      if (a->b_kmajor) launch<false, true, MODE_STORE>(a, e, split, kps, n_full, S, st);
+      else launch<false, false, MODE_STORE>(a, e, split, kps, n_full, S, st);
   }
   if (S) hipLaunchKernelGGL(tail_fixup_kernel, dim3((dh_cdiv(a->N, BN) * dh_cdiv(a->M, BM) - n_full) * 32), dim3(256), 0, st,
                             (const float*)a->ws, S, n_full, dh_cdiv(a->N, BN), dh_cdiv(a->M, BM), e, v4_group_m(false));
@@ -1667,7 +1666,7 @@ bool dh_gemm_try_v4_group(const dh_gemm_args* a, int n, hipStream_t st) {
   if (a[0].ws_bytes < (int64_t)split * (zs + cs_zs) * 4) return false;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_v4_kernel<true, true, MODE_GROUP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_v4_kernel<true, true, MODE_GROUP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   ka.K = K; ka.k_per_split = kps; ka.nitems = T * split; ka.T = T; ka.ngrp = n; ka.zs = zs; ka.cs_zs = cs_zs;
@@ -1681,7 +1680,7 @@ bool dh_gemm_try_v4_group(const dh_gemm_args* a, int n, hipStream_t st) {
   ka.e.a_colsum = any_cs ? ka.gp[0].a_colsum : nullptr;
   int grid = G;
   if (grid > ka.nitems) grid = ka.nitems;
-  hipLaunchKernelGGL((gemm_v4_kernel<true, true, MODE_GROUP, false>), dim3(grid), dim3(512), LDS_BYTES, st, ka);
+  hipLaunchKernelGGL((gemm_v4_kernel<true, true, MODE_GROUP>), dim3(grid), dim3(512), LDS_BYTES, st, ka);
   int blocks = (int)((zs / 4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a[0].ws, (const float*)ka.e.ws_cs, zs, cs_zs, split, gr);
@@ -1705,7 +1704,7 @@ bool dh_maxsim_try_v4(const void* Q, const void* Ksel, int rows_pad, int b, int 
   EpiParams e;
   memset(&e, 0, sizeof(e));
   e.M = rows_pad; e.N = N; e.C = raw; e.ldc = B; e.aux = arg; e.ldaux = B; e.alpha = 1.f; e.ms_J = J; e.ms_b = b; e.ms_B = B;
-  launch<false, false, MODE_MAXSIM, false>(&a, e, 1, D, 0, 0, st);
+  launch<false, false, MODE_MAXSIM>(&a, e, 1, D, 0, 0, st);
   return true;
 }
 
@@ -1755,7 +1754,7 @@ bool dh_ce_try_v4_fwd(const void* X, const void* W, const float* bias, const lon
   e.M = n_pad; e.N = V; e.bias = bias; e.alpha = 1.f; e.ce_labels = labels; e.ce_part = ws; e.ce_lab = ws + (int64_t)n_pad * ntx * 2;
   e.ce_n = n; e.ce_V = V;
   g_group_m_override = dh_cdiv(n_pad, BM);      // column-major: the 50 MB vocabulary matrix is fetched once, the 6 MB of rows stay in L2
-  launch<false, false, MODE_CE_FWD, false>(&a, e, 1, K, 0, 0, st);
+  launch<false, false, MODE_CE_FWD>(&a, e, 1, K, 0, 0, st);
   g_group_m_override = 0;
   int blocks = dh_cdiv(n, 4);
   if (blocks > 2048) blocks = 2048;
@@ -1775,7 +1774,7 @@ bool dh_ce_try_v4_bwd(const void* X, const void* W, const float* bias, const lon
   e.M = n_pad; e.N = V; e.C = dl; e.ldc = ldd; e.bias = bias; e.alpha = 1.f; e.ce_labels = labels; e.ce_lse = row_lse; e.ce_g = g_row;
   e.ce_n = n; e.ce_V = V; e.ce_ldd = (int)ldd;
   g_group_m_override = dh_cdiv(n_pad, BM);
-  launch<false, false, MODE_CE_BWD, false>(&a, e, 1, K, 0, 0, st);
+  launch<false, false, MODE_CE_BWD>(&a, e, 1, K, 0, 0, st);
   g_group_m_override = 0;
   return true;
 }

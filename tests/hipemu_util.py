@@ -76,7 +76,9 @@ def emu_ops(sources, symbols):
 # Everything of declip_amd/csrc that is plain HIP C++ (MFMA builtins, shuffles, LDS): all kernels except the three GEMM families
 # written with inline ISA, whose place in the dispatcher is taken by stubs that decline (tests/hipemu/emu_stubs.cpp).
 ALL_SOURCES = ["embed.hip", "layernorm.hip", "declip_ops.hip", "filip.hip", "infonce.hip", "attention.hip", "gemm.hip", "resnet_ops.hip",
-               "emu_stubs.cpp"]
+               "emu_stubs.cpp", "emu_stubs_v4.cpp"]
+# ... and the same with the benchmarked persistent GEMM itself (gemm_v4.hip keeps its inline ISA behind macros): kernel-level tests only
+V4_SOURCES = [s for s in ALL_SOURCES if s != "emu_stubs_v4.cpp"] + ["gemm_v4.hip"]
 _NOT_EMULATED = {"dh_bpe_create", "dh_bpe_destroy", "dh_bpe_vocab_size", "dh_bpe_encode", "dh_version", "dh_device_info", "dh_gemm_v4_enable",
                  "dh_last_error",
                  # the communicator context is RCCL + HIP streams / events: nothing of it exists on the host
@@ -90,7 +92,7 @@ def all_symbols():
 
 
 @contextlib.contextmanager
-def emulated_gpu():
+def emulated_gpu(sources=None):
     """Run GPU-side test code on the host: declip_amd.ops bound to the emulated library, `.cuda()` / `.to("cuda")` are identities,
     the model builders of declip_amd.testing place models on the CPU.  Inside the block the `-m gpu` test functions of
     tests/test_gpu_*.py can be called as they are (those that do not name the device literally)."""
@@ -101,7 +103,7 @@ def emulated_gpu():
     from declip_amd import engine, testing
     saved = dict(t_cuda=torch.Tensor.cuda, m_cuda=torch.nn.Module.cuda, sync=torch.cuda.synchronize, req=engine._require_gpu)
     builders = {n: getattr(testing, n) for n in dir(testing) if n.startswith("build_") or n.endswith("_batch")}
-    with emu_ops(ALL_SOURCES, all_symbols()) as ops:
+    with emu_ops(ALL_SOURCES if sources is None else sources, all_symbols()) as ops:
         torch.Tensor.cuda = lambda self, *a, **k: self
         torch.nn.Module.cuda = lambda self, *a, **k: self
         torch.cuda.synchronize = lambda *a, **k: None

@@ -35,15 +35,23 @@ int main(int argc, char** argv) {
   printf("M=%d N=%d K=%d epi=%d dw=%d: %.1f us (incl. the reduce pass for dw)\n", M, N, K, epi, dw, ms * 1e3);
   std::vector<long> tb(6 * 256);
   rd(tb.data(), 6 * 256);
-  const char* names[7] = {"prologue->", "mainloop", "req-next", "stage0", "store0", "stage1", "store1"};
-  if (dw) { names[3] = "pass0"; names[4] = "pass1"; names[5] = "pass2"; names[6] = "pass3"; }
+  // stamps per tile: 10 since the continuous K-tile stream of round 3 (tile started, K-tiles 0..nk-3 done, K-tile nk-2 done, main
+  // loop done, epilogue arguments loaded, quarter passes 0-3 staged, end of item); 7 for a trace build of the round-2 kernel
+  const int spt = argc > 6 ? atoi(argv[6]) : 10;
+  const char* names10[10] = {"", "steady", "kt(nk-2)", "kt(nk-1)", "args", "q0", "q1", "q2", "q3", "q4+tail"};
+  const char* names7[7] = {"", "mainloop", "req-next", "stage0", "store0", "stage1", "store1"};
+  // -DV4_TRACE=2: + load A done, barrier, MFMA A done, load B done inside K-tiles nk-2 and nk-1
+  const char* names18[18] = {"", "steady", "LA", "bar", "MA+bar", "LB", "MB(kt nk-2)", "LA", "bar", "MA+bar", "LB", "MB+realign(kt nk-1)", "args", "q0", "q1", "q2", "q3", "q4+tail"};
+  // -DV4_TRACE=3: load A done, barrier, MFMA A done, load B done inside K-tile 2 (steady state), then the 10 coarse stamps
+  const char* names14[14] = {"", "kt0-1+LA(2)", "bar", "MA+bar", "LB", "MB(2)+rest of steady", "kt(nk-2)", "kt(nk-1)", "args", "q0", "q1", "q2", "q3", "q4+tail"};
+  const char** names = spt == 10 ? names10 : spt == 18 ? names18 : spt == 14 ? names14 : names7;
   for (int slot = 0; slot < 6; ++slot) {
     long* p = tb.data() + slot * 256; int n = (int)p[0];
     printf("WG %d wave %d: %d stamps; per tile [cycles]: ", slot / 2 == 0 ? 0 : slot / 2 == 1 ? 100 : 200, (slot & 1) * 4, n);
-    for (int i = 0; i + 6 < n; i += 7) {
-      printf("\n   tile %d: t0=%ld |", i / 7, p[1 + i] - p[1]);
-      for (int j = 1; j < 7; ++j) printf(" %s %ld", names[j], p[1 + i + j] - p[1 + i + j - 1]);
-      if (i + 7 < n) printf(" | next prologue %ld", p[1 + i + 7] - p[1 + i + 6]);
+    for (int i = 0; i + spt - 1 < n; i += spt) {
+      printf("\n   tile %d: t0=%ld |", i / spt, p[1 + i] - p[1]);
+      for (int j = 1; j < spt; ++j) printf(" %s %ld", names[j], p[1 + i + j] - p[1 + i + j - 1]);
+      if (i + spt < n) printf(" | -> next tile %ld", p[1 + i + spt] - p[1 + i + spt - 1]);
     }
     printf("\n");
   }
