@@ -57,8 +57,12 @@
 // takes ~750 cycles against the 512 of the 16 MFMAs it is paired with, phase B's ~560 -- a K-tile costs 2 x 750 + 2 x 560, the
 // matrix pipe idles a fifth of the main loop.  An LDS-DMA issued BETWEEN two MFMAs costs the wave ~60 cycles of which 32 are the
 // MFMA it follows.
+// 2: the same idea at PIECE granularity (a wave requests two 1-KiB pieces per half-tile), balanced against what the ablation
+// builds measured (profiles/r03_gemm_trace_stream_sched.txt: fragment reads are free, a piece costs a load segment ~100 cycles and
+// an MFMA segment ~60): load A (16 fragment reads) 2 pieces, MFMA A 1, load B (8 reads) 4, MFMA B 1 --
+//   load A: B1.1, A1.0 of K-tile kt+1 | MFMA A: A1.1 of kt+1 | load B: A0.0, A0.1, B0.0, B0.1 of kt+2 | MFMA B: B1.0 of kt+2.
 #ifndef V4_SCHED
-#define V4_SCHED 1
+#define V4_SCHED 2
 #endif
 // Cache policy of the epilogue traffic (measured in-step, CLIP b=512): 0 none; 1 output tiles stored non-temporal (+1.2 %: a
 // 128 KB tile per CU per epilogue otherwise displaces the A/B panels the XCD's 4 MB L2 is holding for the next tiles; the 4d-wide
@@ -223,6 +227,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_plus(int s) {   // "
   else if (s == 16) wait_vmcnt<N + 16>();
   else if (s == 32) wait_vmcnt<N + 32>();
   else wait_vmcnt<N>();                            // unknown count: conservative
+}
+__device__ __forceinline__ void wait_vmcnt_7_plus(int s) {   // V4_SCHED 2: "all but the 7 youngest pieces and the s stores between them"
+  if (s == 0) wait_vmcnt<7>();
+  else if (s == 16) wait_vmcnt<23>();
+  else if (s == 32) wait_vmcnt<39>();
+  else wait_vmcnt<7>();
 }
 // end of an epilogue: "everything but the s youngest operations" (= the epilogue's own stores)
 __device__ __forceinline__ void wait_vmcnt_tail(int s) {
@@ -459,6 +469,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
   constexpr bool RAGGED_B = (MODE == MODE_CE_FWD || MODE == MODE_CE_BWD) && !TB;
   long bdh[NP];
 #define BDHQ (RAGGED_B ? bdh[q] : b_dh)
+#define BDH_(qq) (RAGGED_B ? bdh[qq] : b_dh)
 #define SETUP_SRC(m0_, n0_, kbeg_)                                                            \
   do {                                                                                        \
     _Pragma("unroll") for (int q = 0; q < NP; ++q) {                                          \
@@ -657,7 +668,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     }                                                                                                                            \
     const bool more_ = (KIND) != 2 || have;   /* a K-tile follows (KIND 2: the next item's K-tile 0) */                           \
     if (more_) {                        /* B1 (V4_SCHED 0: and A1) of that K-tile -> the other buffer; then: A1 of THIS K-tile has landed */ \
-      if (V4_SCHED) { ISSUE_H(bp, BDHQ, 3, nbuf_); wait_vmcnt_plus<6>(pk_); }                                                     \
+      if (V4_SCHED == 2) { ISSUE_PIECE(bp, BDH_(1), 3, nbuf_, 1); ISSUE_PIECE(ap, a_dh, 1, nbuf_, 0); wait_vmcnt_7_plus(pk_); }     \
+      else if (V4_SCHED) { ISSUE_H(bp, BDHQ, 3, nbuf_); wait_vmcnt_plus<6>(pk_); }                                                \
       else { ISSUE_H(bp, BDHQ, 3, nbuf_); ISSUE_H(ap, a_dh, 1, nbuf_); wait_vmcnt_plus<8>(pk_); }                                 \
     } else { WAITV(0); }                                                                                                         \
     if ((KIND) == 1) {                  /* the next item: which one, and its tile coordinates (scalar work in a load segment that requests little) */ \
@@ -686,9 +698,14 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     __builtin_amdgcn_s_setprio(1);                                                                                               \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                              \
       _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) { MFMA(acc[ii][0], fa0[ii][s], fb0[s]); MFMA(acc[ii][1], fa0[ii][s], fb1[s]); } \
-      if (V4_SCHED && more_ && (s == 0 || s == 2)) {   /* A1 of the next K-tile: one piece behind the 4th, one behind the 12th MFMA */ \
+      if (V4_SCHED == 1 && more_ && (s == 0 || s == 2)) {   /* A1 of the next K-tile: one piece behind the 4th, one behind the 12th MFMA */ \
         __builtin_amdgcn_sched_barrier(0);                                                                                       \
         if (s == 0) ISSUE_PIECE(ap, a_dh, 1, nbuf_, 0); else ISSUE_PIECE(ap, a_dh, 1, nbuf_, 1);                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+      }                                                                                                                          \
+      if (V4_SCHED == 2 && more_ && s == 1) {          /* A1.1 of the next K-tile behind the 8th MFMA */                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        ISSUE_PIECE(ap, a_dh, 1, nbuf_, 1);                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                                       \
       }                                                                                                                          \
     }                                                                                                                            \
@@ -711,7 +728,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       frag4<TA, 1>(fa1[1], akm1 + boff, sA1, ar + 32, lm);                                                                       \
     }                                                                                                                            \
     if ((KIND) == 0) {                  /* A0 (V4_SCHED 0: and B0) of the K-tile after next -> this buffer (read in phase A); then: A0, B0, B1 of the next K-tile have landed */ \
-      if (V4_SCHED) { ADVANCE_SRC(); ISSUE_H(ap, 0, 0, (buf_)); WAITV(4); }                                                      \
+      if (V4_SCHED == 2) { ADVANCE_SRC(); ISSUE_H(ap, 0, 0, (buf_)); ISSUE_H(bp, 0, 2, (buf_)); WAITV(6); }                      \
+      else if (V4_SCHED) { ADVANCE_SRC(); ISSUE_H(ap, 0, 0, (buf_)); WAITV(4); }                                                 \
       else { ISSUE_H(ap, astep, 0, (buf_)); ISSUE_H(bp, bstep, 2, (buf_)); WAITV(6); ADVANCE_SRC(); }                            \
     } else if ((KIND) == 1) {                                                                                                    \
       if (have) {                       /* sources -> K-tile 0 of the next item; its A0, B0 take the slots a K-tile nk would take */ \
@@ -724,7 +742,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
           LOAD_PROBLEM(kp, nxt.p);                                                                                               \
           SETUP_SRC(nxt.tile_y * BM, nxt.tile_x * BN, nxt.kbeg);                                                                 \
         }                                                                                                                        \
-        if (V4_SCHED) { ISSUE_H(ap, 0, 0, (buf_)); WAITV(4); }                                                                   \
+        if (V4_SCHED == 2) { ISSUE_H(ap, 0, 0, (buf_)); ISSUE_H(bp, 0, 2, (buf_)); WAITV(6); }                                   \
+        else if (V4_SCHED) { ISSUE_H(ap, 0, 0, (buf_)); WAITV(4); }                                                              \
         else { ISSUE_H(ap, 0, 0, (buf_)); ISSUE_H(bp, 0, 2, (buf_)); WAITV(6); }                                                 \
       } else { WAITV(2); }              /* A0, B0, B1 of the last K-tile have landed */                                          \
     }                                                                                                                            \
@@ -734,7 +753,12 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     __builtin_amdgcn_s_setprio(1);                                                                                               \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                              \
       _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) { MFMA(acc[2 + ii][1], fa1[ii][s], fb1[s]); MFMA(acc[2 + ii][0], fa1[ii][s], fb0[s]); } \
-      if (V4_SCHED && ((KIND) == 0 || ((KIND) == 1 && have)) && (s == 0 || s == 2)) {   /* B0 of the K-tile after next (KIND 1: of the next item's K-tile 0) */ \
+      if (V4_SCHED == 2 && ((KIND) == 0 || ((KIND) == 1 && have)) && s == 1) {   /* B1.0 of the K-tile after next (KIND 1: of the next item's K-tile 0) behind the 8th MFMA */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        ISSUE_PIECE(bp, BDH_(0), 3, (buf_), 0);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+      }                                                                                                                          \
+      if (V4_SCHED == 1 && ((KIND) == 0 || ((KIND) == 1 && have)) && (s == 0 || s == 2)) {   /* B0 of the K-tile after next (KIND 1: of the next item's K-tile 0) */ \
         __builtin_amdgcn_sched_barrier(0);                                                                                       \
         if (s == 0) ISSUE_PIECE(bp, 0, 2, (buf_), 0); else ISSUE_PIECE(bp, 0, 2, (buf_), 1);                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                       \
@@ -784,7 +808,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     // ---- K-tile 0 of this item is in LDS (requested by the previous item, or before the loop); A0, B0 of K-tile 1 go to the
     // other buffer: it was the previous epilogue's staging area, and every wave is past that epilogue's last barrier
     ADVANCE_SRC();
-    { const int b1_ = V4_RFL(tp ^ 1); ISSUE_H(ap, 0, 0, b1_); ISSUE_H(bp, 0, 2, b1_); }
+    { const int b1_ = V4_RFL(tp ^ 1); ISSUE_H(ap, 0, 0, b1_); ISSUE_H(bp, 0, 2, b1_); if (V4_SCHED == 2) ISSUE_PIECE(bp, BDH_(0), 3, b1_, 0); }   // (V4_SCHED 2: + the piece B1.0 that MFMA segment B of a K-tile "-1" would have requested)
     TRACE();                                 // [0] tile started
     if (wm == 1) V4_BARRIER();               // waves 4-7 run one barrier behind waves 0-3 from here on
 
@@ -1277,6 +1301,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
 #undef KTILE
 #undef RELOAD_SCHED_ARGS
 #undef BDHQ
+#undef BDH_
 }
 
 // out[m][n] (+)= sum_z ws[z][m][n]   (the split-K partial tiles of MODE_PARTIAL)
