@@ -95,7 +95,8 @@ __device__ __forceinline__ bf16x8_t kmask(bf16x8_t f, bool dead) {
 // (lse stays [b][heads][L]); the dense instantiation is the code it was before the template parameter existed.
 template <int NKB, bool VL>  // NKB: number of 16-key blocks (L16/16), compile-time so scores stay in registers
 __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
-                                     int L, int heads, int causal, float scale, int nbh, const int* __restrict__ cu) {
+                                     int L, int heads, int causal, float scale, int nbh, const int* __restrict__ cu,
+                                     int tail0, int tail1) {
   constexpr int L16 = NKB * 16;
   constexpr int NKS = (L16 + 31) / 32;          // 32-wide k-steps over the keys
   constexpr bool KTAIL = (L16 % 32) != 0;
@@ -207,6 +208,13 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
   }
   __syncthreads();                         // every wave is done with the tiles before the next pair overwrites them
   }
+  if (VL && tail1 > tail0) {
+    // packed layout: the rows between the last caption and the whole-tile row count are ZERO (they meet the weight-gradient GEMMs as
+    // contraction rows); written here instead of by a separate fill launch per attention call (24 launches per CLIP step)
+    uint4* tp_ = reinterpret_cast<uint4*>(out + (long)tail0 * (d_model));
+    const long n16 = (long)(tail1 - tail0) * (d_model) / 8;
+    for (long i = (long)blockIdx.x * nthr + tid; i < n16; i += (long)gridDim.x * nthr) tp_[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -216,7 +224,7 @@ template <int NKB, bool VL>
 __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                      const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                      bf16_t* __restrict__ dqkv, int L, int heads, int causal, float scale, int nbh,
-                                     const int* __restrict__ cu) {
+                                     const int* __restrict__ cu, int tail0, int tail1) {
   constexpr int L16 = NKB * 16;
   constexpr int NKS = (L16 + 31) / 32;
   constexpr bool KTAIL = (L16 % 32) != 0;
@@ -387,6 +395,13 @@ __global__ void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_
   }
   __syncthreads();                         // every wave is done with the tiles before the next pair overwrites them
   }
+  if (VL && tail1 > tail0) {
+    // packed layout: the rows between the last caption and the whole-tile row count are ZERO (they meet the weight-gradient GEMMs as
+    // contraction rows); written here instead of by a separate fill launch per attention call (24 launches per CLIP step)
+    uint4* tp_ = reinterpret_cast<uint4*>(dqkv + (long)tail0 * (3 * d_model));
+    const long n16 = (long)(tail1 - tail0) * (3 * d_model) / 8;
+    for (long i = (long)blockIdx.x * nthr + tid; i < n16; i += (long)gridDim.x * nthr) tp_[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -510,7 +525,7 @@ static int attn_cus() {
 
 template <int NKB>
 int launch_fwd_mfma(const bf16_t* qkv, bf16_t* out, float* lse, int b, int L, int heads, int causal, float scale,
-                    hipStream_t st, const int* cu = nullptr) {
+                    hipStream_t st, const int* cu = nullptr, int tail0 = 0, int tail1 = 0) {
   constexpr int L16 = NKB * 16, TS = L16 + 8;
   size_t lds = (size_t)(3 * L16 * RS + L16 * TS + 64) * sizeof(bf16_t);
   if (cu) hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -518,13 +533,13 @@ int launch_fwd_mfma(const bf16_t* qkv, bf16_t* out, float* lse, int b, int L, in
   const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
   int grid = attn_cus() * (per_cu < 1 ? 1 : per_cu);
   if (grid > b * heads) grid = b * heads;
-  if (cu) hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKB, true>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads, cu);
-  else hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKB, false>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads, cu);
+  if (cu) hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKB, true>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads, cu, tail0, tail1);
+  else hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKB, false>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads, cu, 0, 0);
   return 0;
 }
 template <int NKB>
 int launch_bwd_mfma(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int b,
-                    int L, int heads, int causal, float scale, hipStream_t st, const int* cu = nullptr) {
+                    int L, int heads, int causal, float scale, hipStream_t st, const int* cu = nullptr, int tail0 = 0, int tail1 = 0) {
   constexpr int L16 = NKB * 16, TS = L16 + 8;
   size_t lds = (size_t)(4 * L16 * RS + 2 * L16 * TS + 64) * sizeof(bf16_t) + L16 * sizeof(float);
   if (cu) hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -532,8 +547,8 @@ int launch_bwd_mfma(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
   const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
   int grid = attn_cus() * (per_cu < 1 ? 1 : per_cu);
   if (grid > b * heads) grid = b * heads;
-  if (cu) hipLaunchKernelGGL((attn_bwd_mfma_kernel<NKB, true>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads, cu);
-  else hipLaunchKernelGGL((attn_bwd_mfma_kernel<NKB, false>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads, cu);
+  if (cu) hipLaunchKernelGGL((attn_bwd_mfma_kernel<NKB, true>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads, cu, tail0, tail1);
+  else hipLaunchKernelGGL((attn_bwd_mfma_kernel<NKB, false>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads, cu, 0, 0);
   return 0;
 }
 
@@ -547,14 +562,14 @@ int launch_bwd_mfma(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
   }
 
 static int attn_fwd_impl(int dtype, const void* qkv, void* out, float* lse, int b, int L, int heads, int hd, int causal,
-                         const int* cu, dh_stream_t stream) {
+                         const int* cu, dh_stream_t stream, int tail0 = 0, int tail1 = 0) {
   hipStream_t st = (hipStream_t)stream;
   DH_REQUIRE(qkv && out && lse && b > 0 && L > 0 && heads > 0, "dh_attn_fwd: bad args");
   DH_REQUIRE(L <= 128 && hd <= 64, "dh_attn_fwd: L<=128 and hd<=64 required (got %d, %d)", L, hd);
   const float scale = 1.0f / sqrtf((float)hd);
   if (dtype == DH_BF16 && hd == 64) {
     const int nkb = (L + 15) / 16;
-#define CALL(N) launch_fwd_mfma<N>((const bf16_t*)qkv, (bf16_t*)out, lse, b, L, heads, causal, scale, st, cu)
+#define CALL(N) launch_fwd_mfma<N>((const bf16_t*)qkv, (bf16_t*)out, lse, b, L, heads, causal, scale, st, cu, tail0, tail1)
     DISPATCH_NKB(nkb, CALL)
 #undef CALL
   } else {
@@ -576,21 +591,30 @@ extern "C" int dh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, in
                            int causal, dh_stream_t stream) {
   return attn_fwd_impl(dtype, qkv, out, lse, b, L, heads, hd, causal, nullptr, stream);
 }
+// rows / rows_pad: valid rows (= cu_seqlens[b]) and allocated rows of the packed layout; rows [rows, rows_pad) of `out` are
+// written as zeros (inside the attention kernel on the bf16 path, by a memset otherwise)
 extern "C" int dh_attn_varlen_fwd(int dtype, const void* qkv, void* out, float* lse, const int* cu_seqlens, int b, int Lmax, int heads,
-                                  int hd, int causal, dh_stream_t stream) {
+                                  int hd, int causal, int rows, int rows_pad, dh_stream_t stream) {
   DH_REQUIRE(cu_seqlens, "dh_attn_varlen_fwd: cu_seqlens is NULL");
-  return attn_fwd_impl(dtype, qkv, out, lse, b, Lmax, heads, hd, causal, cu_seqlens, stream);
+  DH_REQUIRE(rows >= 0 && rows_pad >= rows, "dh_attn_varlen_fwd: rows %d, rows_pad %d", rows, rows_pad);
+  const bool in_kernel = dtype == DH_BF16 && hd == 64;
+  if (!in_kernel && rows_pad > rows) {
+    const size_t esz = dtype == DH_BF16 ? 2 : 4, w = (size_t)heads * hd;
+    if (hipMemsetAsync((char*)out + (size_t)rows * w * esz, 0, (size_t)(rows_pad - rows) * w * esz, (hipStream_t)stream) != hipSuccess)
+      DH_FAIL(DH_ERR_LAUNCH, "dh_attn_varlen_fwd: memset failed");
+  }
+  return attn_fwd_impl(dtype, qkv, out, lse, b, Lmax, heads, hd, causal, cu_seqlens, stream, rows, in_kernel ? rows_pad : rows);
 }
 
 static int attn_bwd_impl(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int b, int L,
-                         int heads, int hd, int causal, const int* cu, dh_stream_t stream) {
+                         int heads, int hd, int causal, const int* cu, dh_stream_t stream, int tail0 = 0, int tail1 = 0) {
   hipStream_t st = (hipStream_t)stream;
   DH_REQUIRE(qkv && out && dout && lse && dqkv && b > 0 && L > 0 && heads > 0, "dh_attn_bwd: bad args");
   DH_REQUIRE(L <= 128 && hd <= 64, "dh_attn_bwd: L<=128 and hd<=64 required (got %d, %d)", L, hd);
   const float scale = 1.0f / sqrtf((float)hd);
   if (dtype == DH_BF16 && hd == 64) {
     const int nkb = (L + 15) / 16;
-#define CALL(N) launch_bwd_mfma<N>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, b, L, heads, causal, scale, st, cu)
+#define CALL(N) launch_bwd_mfma<N>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, b, L, heads, causal, scale, st, cu, tail0, tail1)
     DISPATCH_NKB(nkb, CALL)
 #undef CALL
   } else {
@@ -613,9 +637,17 @@ extern "C" int dh_attn_bwd(int dtype, const void* qkv, const void* out, const vo
   return attn_bwd_impl(dtype, qkv, out, dout, lse, dqkv, b, L, heads, hd, causal, nullptr, stream);
 }
 extern "C" int dh_attn_varlen_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
-                                  const int* cu_seqlens, int b, int Lmax, int heads, int hd, int causal, dh_stream_t stream) {
+                                  const int* cu_seqlens, int b, int Lmax, int heads, int hd, int causal, int rows, int rows_pad,
+                                  dh_stream_t stream) {
   DH_REQUIRE(cu_seqlens, "dh_attn_varlen_bwd: cu_seqlens is NULL");
-  return attn_bwd_impl(dtype, qkv, out, dout, lse, dqkv, b, Lmax, heads, hd, causal, cu_seqlens, stream);
+  DH_REQUIRE(rows >= 0 && rows_pad >= rows, "dh_attn_varlen_bwd: rows %d, rows_pad %d", rows, rows_pad);
+  const bool in_kernel = dtype == DH_BF16 && hd == 64;
+  if (!in_kernel && rows_pad > rows) {
+    const size_t esz = dtype == DH_BF16 ? 2 : 4, w = (size_t)3 * heads * hd;
+    if (hipMemsetAsync((char*)dqkv + (size_t)rows * w * esz, 0, (size_t)(rows_pad - rows) * w * esz, (hipStream_t)stream) != hipSuccess)
+      DH_FAIL(DH_ERR_LAUNCH, "dh_attn_varlen_bwd: memset failed");
+  }
+  return attn_bwd_impl(dtype, qkv, out, dout, lse, dqkv, b, Lmax, heads, hd, causal, cu_seqlens, stream, rows, in_kernel ? rows_pad : rows);
 }
 
 // ------------------------------------------------------------------------------------------

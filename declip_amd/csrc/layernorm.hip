@@ -3,6 +3,7 @@
 // Backward fuses the residual-branch gradient add (dx = LN'(dy) + dres) and produces
 // dgamma/dbeta through per-block partials + a second tiny reduce kernel (no atomics storm).
 #include "dh_common.h"
+#include <string.h>
 
 namespace {
 
@@ -353,6 +354,37 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
   }
 }
 
+// The same for up to LN_MANY LayerNorms in ONE launch (blockIdx.z = which): a tower's backward leaves the per-block partials of
+// every LayerNorm in place and reduces them together at its end -- 51 reduce launches per CLIP step become 2.
+constexpr int LN_MANY = 32;
+struct LnMany {
+  const float* part[LN_MANY];
+  float* dw[LN_MANY];
+  float* db[LN_MANY];
+  int nb[LN_MANY];
+  int d[LN_MANY];
+};
+__global__ __launch_bounds__(256) void ln_reduce_many_kernel(LnMany m) {
+  __shared__ float red[4][64];
+  const int z = blockIdx.z;
+  const int d = m.d[z], nblocks = m.nb[z];
+  const float* __restrict__ part = m.part[z];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);  // over 2*d
+  if (blockIdx.x * 64 >= 2 * d) return;                // (block-uniform: grid.x is sized for the widest item)
+  const int rl = threadIdx.x >> 6;
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+  float s = 0.f;
+  if (i < 2 * d)
+    for (int b = b0 + rl; b < b1; b += 4) s += part[(long)b * 2 * d + i];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && i < 2 * d) {
+    s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(i < d ? m.dw[z] + i : m.db[z] + (i - d), s);
+  }
+}
+
 }  // namespace
 
 static int ln_grid(int rows) {
@@ -404,9 +436,12 @@ extern "C" int64_t dh_layernorm_bwd_ws_bytes(int rows, int d) {
   return (int64_t)nb * 2 * d * sizeof(float);
 }
 
-extern "C" int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const float* w, const float* mean,
-                                const float* rstd, const void* dres, void* dx, float* dw, float* db, int rows, int d,
-                                void* ws, int64_t ws_bytes, dh_stream_t stream) {
+// nb_out == nullptr: the whole backward (partials + reduce into dw / db).  Otherwise the reduce is left to the caller
+// (dh_ln_reduce_many on the partials kept in `ws`): *nb_out = partial rows written, 0 if this shape took the scalar kernel
+// (which accumulates into dw / db directly).
+static int ln_bwd_impl(int dtype, const void* dy, const void* x, const float* w, const float* mean,
+                       const float* rstd, const void* dres, void* dx, float* dw, float* db, int rows, int d,
+                       void* ws, int64_t ws_bytes, dh_stream_t stream, int* nb_out) {
   hipStream_t st = (hipStream_t)stream;
   DH_REQUIRE(dy && x && w && mean && rstd && dx && dw && db && rows > 0 && d > 0, "dh_layernorm_bwd: bad args");
   const bool vec = (d % 8 == 0) && d <= 8 * 64 * LN_MAXC && (size_t)(8 * d * sizeof(float)) <= 64 * 1024;
@@ -439,13 +474,52 @@ extern "C" int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const 
 #undef LN_BWD32
     }
     DH_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3(dh_cdiv(2 * d, 64), nb >= 64 ? 16 : 1), dim3(256), 0, st, (const float*)ws, nb, d, dw, db);
+    if (nb_out) *nb_out = nb;
+    else hipLaunchKernelGGL(ln_reduce_kernel, dim3(dh_cdiv(2 * d, 64), nb >= 64 ? 16 : 1), dim3(256), 0, st, (const float*)ws, nb, d, dw, db);
   } else {
+    if (nb_out) *nb_out = 0;
     dim3 grid(ln_grid(rows) > 256 ? 256 : ln_grid(rows));
     if (dtype == DH_BF16)
       hipLaunchKernelGGL(ln_bwd_scalar_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw, db, rows, d);
     else
       hipLaunchKernelGGL(ln_bwd_scalar_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)x, w, mean, rstd, (const float*)dres, (float*)dx, dw, db, rows, d);
+  }
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+
+extern "C" int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const float* w, const float* mean,
+                                const float* rstd, const void* dres, void* dx, float* dw, float* db, int rows, int d,
+                                void* ws, int64_t ws_bytes, dh_stream_t stream) {
+  return ln_bwd_impl(dtype, dy, x, w, mean, rstd, dres, dx, dw, db, rows, d, ws, ws_bytes, stream, nullptr);
+}
+
+// LayerNorm backward WITHOUT the reduction of the weight / bias gradient partials: they stay in `part` ([*nb_out][2 d] fp32, the
+// size dh_layernorm_bwd_ws_bytes reports) until dh_ln_reduce_many adds them into dw / db.
+extern "C" int dh_layernorm_bwd_part(int dtype, const void* dy, const void* x, const float* w, const float* mean,
+                                     const float* rstd, const void* dres, void* dx, float* dw, float* db, int rows, int d,
+                                     void* part, int64_t part_bytes, int* nb_out, dh_stream_t stream) {
+  DH_REQUIRE(nb_out, "dh_layernorm_bwd_part: nb_out is NULL");
+  return ln_bwd_impl(dtype, dy, x, w, mean, rstd, dres, dx, dw, db, rows, d, part, part_bytes, stream, nb_out);
+}
+
+// dw[i] += column sums of part[i][nb[i]][0 .. d[i]), db[i] += those of columns d[i] .. 2 d[i]; ONE launch per 32 items.
+extern "C" int dh_ln_reduce_many(const dh_ln_part* items, int n, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(items && n >= 0, "dh_ln_reduce_many: bad args");
+  for (int i0 = 0; i0 < n; i0 += LN_MANY) {
+    LnMany m;
+    memset(&m, 0, sizeof(m));
+    int cnt = 0, dmax = 0;
+    for (int i = i0; i < n && cnt < LN_MANY; ++i) {
+      const dh_ln_part& it = items[i];
+      if (it.nb <= 0) continue;                      // (the scalar kernel accumulated directly)
+      DH_REQUIRE(it.part && it.dw && it.db && it.d > 0, "dh_ln_reduce_many: item %d: bad pointers / width", i);
+      m.part[cnt] = it.part; m.dw[cnt] = it.dw; m.db[cnt] = it.db; m.nb[cnt] = it.nb; m.d[cnt] = it.d;
+      dmax = it.d > dmax ? it.d : dmax;
+      ++cnt;
+    }
+    if (cnt) hipLaunchKernelGGL(ln_reduce_many_kernel, dim3(dh_cdiv(2 * dmax, 64), 16, cnt), dim3(256), 0, st, m);
   }
   DH_CHECK_LAUNCH();
   return DH_OK;

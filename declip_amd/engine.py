@@ -340,6 +340,74 @@ class DwGroup:
                     ops.gemm_dw_group(chunk, ws=ws)
 
 
+class LnGradBatch:
+    """The LayerNorm weight / bias gradients of ONE tower backward, reduced together.
+
+    Every LayerNorm backward leaves its per-block partials in a slice of a persistent arena (ops.layernorm_bwd_part) and the
+    reduction into the gradient buffer is ONE launch for all of them at the end of the tower's backward (ops.ln_reduce_many) --
+    the CLIP step had 51 reduce launches of ~5 us each plus their dispatch gaps.  Under data parallelism the gradients of a
+    block may only be handed to the bucketed all-reduce once its LayerNorm gradients are final, so there the batch is flushed
+    every `DIST_BLOCKS` blocks and `ready()` releases the parameters collected since (FlatParams.grads_ready)."""
+    DIST_BLOCKS = 2
+
+    def __init__(self, flat, tower):
+        self.flat, self.key = flat, id(tower)
+        self.items, self.off, self.pending, self.nblocks = [], 0, [], 0
+        self.dist = flat.reducer is not None and flat.reducer.distributed()
+        self.enabled = os.environ.get("DH_LN_BATCH", "1") == "1"
+
+    def _slice(self, n, device):
+        arenas = self.flat.__dict__.setdefault("_ln_arenas", {})
+        key = (self.key, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+        ar = arenas.get(key)
+        if ar is None or self.off + n > ar.numel():
+            # (a grown arena replaces the old one; slices already handed out keep the old storage alive until the flush)
+            ar = torch.empty(max(2 * (self.off + n), 1 << 22), device=device, dtype=torch.float32)
+            arenas[key] = ar
+            self.off = 0
+        part = ar[self.off:self.off + n]
+        self.off += (n + 63) // 64 * 64
+        return part
+
+    def bwd(self, dy, x, w, mean, rstd, dw, db, dres=None):
+        if not self.enabled:
+            return ops.layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=dres)
+        part = self._slice(ops.layernorm_bwd_ws_elems(x.shape[0], x.shape[1]), x.device)
+        dx, nb = ops.layernorm_bwd_part(dy, x, w, mean, rstd, dw, db, part, dres=dres)
+        self.items.append((part, nb, x.shape[1], dw, db))
+        return dx
+
+    def flush(self):
+        if self.items:
+            ops.ln_reduce_many(self.items)
+        self.items, self.off = [], 0
+
+    def ready(self, params, block=True):
+        """FlatParams.grads_ready for `params`, once their LayerNorm gradients are reduced."""
+        if not self.dist:
+            self.flat.grads_ready(params)            # (no collective is waiting for them: the batch is flushed at the end)
+            return
+        self.pending += list(params)
+        self.nblocks += 1 if block else 0
+        if self.nblocks >= self.DIST_BLOCKS:
+            self.release()
+
+    def release(self):
+        self.flush()
+        if self.pending:
+            self.flat.grads_ready(self.pending)
+        self.pending, self.nblocks = [], 0
+
+
+_LNB = None        # the batch of the tower backward that is running (autograd runs the towers' backward functions one after the other)
+
+
+def _ln_bwd(dy, x, w, mean, rstd, dw, db, dres=None):
+    if _LNB is not None:
+        return _LNB.bwd(dy, x, w, mean, rstd, dw, db, dres=dres)
+    return ops.layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=dres)
+
+
 def block_fwd(x, r, b, L, heads, causal, save):
     """x: [b*L, d].  Returns x_out; if `save`, also the tuple needed by block_bwd."""
     h1, mean1, rstd1 = ops.layernorm_fwd(x, r.ln1_w, r.ln1_b, r.eps1)
@@ -364,14 +432,14 @@ def block_bwd(dx_out, r, saved, b, L, heads, causal):
     dw.add(du, h2, r.g_w_fc, r.g_b_fc)
     ws = gemm_workspace(du.device) if du.is_cuda and du.dtype == torch.bfloat16 else None
     dh2 = ops.gemm(du, r.w_fc, b_kmajor=True, ws=ws)
-    dx_mid = ops.layernorm_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)
+    dx_mid = _ln_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)
     # attention: x_mid = x + attn(h1) Wout^T + bout
     dw.add(dx_mid, a, r.g_w_out, r.g_b_out)
     da = ops.gemm(dx_mid, r.w_out, b_kmajor=True, ws=ws)
     dqkv = ops.attn_bwd(qkv, a, da, lse, b, L, heads, causal)
     dw.add(dqkv, h1, r.g_w_in, r.g_b_in)
     dh1 = ops.gemm(dqkv, r.w_in, b_kmajor=True, ws=ws)
-    dx = ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
+    dx = _ln_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
     dw.flush()                         # the block's four weight gradients: one grouped launch (all inputs are final here)
     return dx
 
@@ -430,7 +498,7 @@ def block_bwd_pooled(dx_out, r, saved, sel, row0, nkeys, Lmax, heads):
     dw.add(du, h2, r.g_w_fc, r.g_b_fc)
     ws = gemm_workspace(x.device) if x.is_cuda and x.dtype == torch.bfloat16 else None
     dh2 = ops.gemm(du, r.w_fc, b_kmajor=True, ws=ws)
-    dx_mid = ops.layernorm_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)       # [b, d]
+    dx_mid = _ln_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)       # [b, d]
     dw.add(dx_mid, a, r.g_w_out, r.g_b_out)
     da = ops.gemm(dx_mid, r.w_out, b_kmajor=True, ws=ws)
     dq, dkv = ops.attn_pooled_bwd(q, kv, da, lse, row0, nkeys, heads, Lmax)
@@ -438,7 +506,7 @@ def block_bwd_pooled(dx_out, r, saved, sel, row0, nkeys, Lmax, heads):
     dw.add(dkv, h1, r.g_w_in[d:], r.g_b_in[d:])
     dh1 = ops.gemm(dkv, r.w_in[d:], b_kmajor=True, ws=ws)                 # [R, d]
     ops.scatter_rows_add(ops.gemm(dq, r.w_in[:d], b_kmajor=True, ws=ws), sel, dh1)
-    dx = ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b)
+    dx = _ln_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b)
     ops.scatter_rows_add(dx_mid, sel, dx)                                 # the residual path of the pooled rows (x_mid = x[sel] + ...)
     dw.flush()
     return dx
@@ -520,6 +588,19 @@ class VisionTowerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        global _LNB
+        flat = ctx.tower._flat()
+        lnb = LnGradBatch(flat, ctx.tower)
+        prev, _LNB = _LNB, lnb
+        try:
+            out = VisionTowerFn._backward_impl(ctx, lnb, *grads)
+            lnb.release()                    # ONE reduce launch for the tower's LayerNorm gradients; the rest of its parameters released
+            return out
+        finally:
+            _LNB = prev
+
+    @staticmethod
+    def _backward_impl(ctx, lnb, *grads):
         tower = ctx.tower
         flat = tower._flat()
         flat.begin_backward()
@@ -548,24 +629,24 @@ class VisionTowerFn(torch.autograd.Function):
         pool = ctx.pool
         blocks = list(zip(ctx.refs, ctx.saved_blocks))
         if dfeat is not None:
-            dpooled = ops.layernorm_bwd(dfeat, pooled, tower.ln_post.weight.data, mean_p, rstd_p, g(tower.ln_post.weight), g(tower.ln_post.bias))
+            dpooled = _ln_bwd(dfeat, pooled, tower.ln_post.weight.data, mean_p, rstd_p, g(tower.ln_post.weight), g(tower.ln_post.bias))
             dx = ops.pool_rows_bwd(dpooled, None, b, L) if pool is None else None
         else:
             dpooled = None
             dx = torch.zeros(b * L, width, device=x_final.device, dtype=dtype)
         if ddense is not None:
             dx.view(b, L, width)[:, 1:, :].add_(ddense.to(dtype))
-        flat.grads_ready([tower.proj, tower.ln_post.weight, tower.ln_post.bias])
+        lnb.ready([tower.proj, tower.ln_post.weight, tower.ln_post.bias], block=False)
         if pool is not None:
             r, s = blocks.pop()
             if dpooled is None:
                 dpooled = torch.zeros(b, width, device=x_final.device, dtype=dtype)
             dx = block_bwd_pooled(dpooled, r, s, pool[0], pool[1], pool[2], L, heads)
-            flat.grads_ready(r.params)
+            lnb.ready(r.params)
         for r, s in reversed(blocks):
             dx = block_bwd(dx, r, s, b, L, heads, False)
-            flat.grads_ready(r.params)
-        dx0 = ops.layernorm_bwd(dx, x0, tower.ln_pre.weight.data, mean0, rstd0, g(tower.ln_pre.weight), g(tower.ln_pre.bias))
+            lnb.ready(r.params)
+        dx0 = _ln_bwd(dx, x0, tower.ln_pre.weight.data, mean0, rstd0, g(tower.ln_pre.weight), g(tower.ln_pre.bias))
         ops.vit_assemble_bwd(dx0, g(tower.class_embedding), g(tower.positional_embedding), b, npatch)
         if tower.conv1.weight.requires_grad:
             dpatch = dx0.view(b, L, width)[:, 1:, :].contiguous().view(b * npatch, width)
@@ -624,6 +705,19 @@ class TextTowerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        global _LNB
+        flat = ctx.tower._flat()
+        lnb = LnGradBatch(flat, ctx.tower)
+        prev, _LNB = _LNB, lnb
+        try:
+            out = TextTowerFn._backward_impl(ctx, lnb, *grads)
+            lnb.release()                    # ONE reduce launch for the tower's LayerNorm gradients; the rest of its parameters released
+            return out
+        finally:
+            _LNB = prev
+
+    @staticmethod
+    def _backward_impl(ctx, lnb, *grads):
         tower = ctx.tower
         flat = tower._flat()
         flat.begin_backward()
@@ -645,19 +739,19 @@ class TextTowerFn(torch.autograd.Function):
             dw_total = ops.pool_rows_bwd(dfeat, eot, b, L) if dfeat is not None else torch.zeros(b * L, width, device=ids.device, dtype=dtype)
             if dwords is not None:
                 dw_total.add_(dwords.reshape(b * L, width).to(dtype))
-            dx = ops.layernorm_bwd(dw_total, x_final, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
+            dx = _ln_bwd(dw_total, x_final, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
         else:
-            dpooled = ops.layernorm_bwd(dfeat, pooled, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
+            dpooled = _ln_bwd(dfeat, pooled, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
             dx = ops.pool_rows_bwd(dpooled, eot, b, L) if ctx.pool is None else None
-        flat.grads_ready([tp.weight, tp.bias, tower.ln_final.weight, tower.ln_final.bias])
+        lnb.ready([tp.weight, tp.bias, tower.ln_final.weight, tower.ln_final.bias], block=False)
         blocks = list(zip(ctx.refs, ctx.saved_blocks))
         if ctx.pool is not None:
             r, s = blocks.pop()
             dx = block_bwd_pooled(dpooled, r, s, ctx.pool[0], ctx.pool[1], ctx.pool[2], L, heads)
-            flat.grads_ready(r.params)
+            lnb.ready(r.params)
         for r, s in reversed(blocks):
             dx = block_bwd(dx, r, s, b, L, heads, True)
-            flat.grads_ready(r.params)
+            lnb.ready(r.params)
         te, pe = tower.token_embedding.weight, tower.positional_embedding
         V = te.shape[0]
         ops.text_embed_bwd(ids, dx, g(te) if te.requires_grad else None, g(pe) if pe.requires_grad else None,
@@ -741,7 +835,7 @@ def block_bwd_packed(dx_out, r, saved, pk, heads):
     dw.add(du, h2, r.g_w_fc, r.g_b_fc)
     ws = gemm_workspace(du.device) if du.is_cuda and du.dtype == torch.bfloat16 else None
     dh2 = ops.gemm(du, r.w_fc, b_kmajor=True, ws=ws)
-    dx_mid = ops.layernorm_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)
+    dx_mid = _ln_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)
     dw.add(dx_mid, a, r.g_w_out, r.g_b_out)
     da = ops.gemm(dx_mid, r.w_out, b_kmajor=True, ws=ws)
     if pk.varlen:
@@ -756,7 +850,7 @@ def block_bwd_packed(dx_out, r, saved, pk, heads):
         dqkv = ops.gather_rows(dqkv_d, pk.pack_idx, pk.rows_pad)
     dw.add(dqkv, h1, r.g_w_in, r.g_b_in)
     dh1 = ops.gemm(dqkv, r.w_in, b_kmajor=True, ws=ws)
-    dx = ops.layernorm_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
+    dx = _ln_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
     dw.flush()
     return dx
 
@@ -817,6 +911,19 @@ class TextTowerPackedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        global _LNB
+        flat = ctx.tower._flat()
+        lnb = LnGradBatch(flat, ctx.tower)
+        prev, _LNB = _LNB, lnb
+        try:
+            out = TextTowerPackedFn._backward_impl(ctx, lnb, *grads)
+            lnb.release()                    # ONE reduce launch for the tower's LayerNorm gradients; the rest of its parameters released
+            return out
+        finally:
+            _LNB = prev
+
+    @staticmethod
+    def _backward_impl(ctx, lnb, *grads):
         tower, pk = ctx.tower, ctx.pk
         flat = tower._flat()
         flat.begin_backward()
@@ -839,22 +946,22 @@ class TextTowerPackedFn(torch.autograd.Function):
                 ops.scatter_rows_add(dfeat, pk.eot_rows, dw_total)
             if dwords is not None:
                 dw_total.add_(dwords.reshape(dw_total.shape).to(dtype))
-            dx = ops.layernorm_bwd(dw_total, x_final, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
+            dx = _ln_bwd(dw_total, x_final, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
         else:
-            dpooled = ops.layernorm_bwd(dfeat, pooled, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
+            dpooled = _ln_bwd(dfeat, pooled, lnw, mean_f, rstd_f, g(tower.ln_final.weight), g(tower.ln_final.bias))
             dx = None
             if ctx.pool is None:
                 dx = torch.zeros(x_final.shape, device=dpooled.device, dtype=dtype)
                 ops.scatter_rows_add(dpooled, pk.eot_rows, dx)
-        flat.grads_ready([tp.weight, tp.bias, tower.ln_final.weight, tower.ln_final.bias])
+        lnb.ready([tp.weight, tp.bias, tower.ln_final.weight, tower.ln_final.bias], block=False)
         blocks = list(zip(ctx.refs, ctx.saved_blocks))
         if ctx.pool is not None:
             r, s = blocks.pop()
             dx = block_bwd_pooled(dpooled, r, s, ctx.pool[0], ctx.pool[1], ctx.pool[2], pk.L, tower.heads)
-            flat.grads_ready(r.params)
+            lnb.ready(r.params)
         for r, s in reversed(blocks):
             dx = block_bwd_packed(dx, r, s, pk, tower.heads)
-            flat.grads_ready(r.params)
+            lnb.ready(r.params)
         te, pe = tower.token_embedding.weight, tower.positional_embedding
         V = te.shape[0]
         ops.text_embed_packed_bwd(pk.ids_p, pk.cu, dx, g(te) if te.requires_grad else None, g(pe) if pe.requires_grad else None,

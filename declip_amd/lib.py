@@ -37,6 +37,11 @@ class NcePair(Structure):
     _fields_ = [("Q", c_void_p), ("K", c_void_p), ("dQ", c_void_p), ("dK", c_void_p)]
 
 
+class LnPart(Structure):
+    """dh_ln_part (include/declip_hip.h): the partials of one LayerNorm backward waiting for dh_ln_reduce_many."""
+    _fields_ = [("part", c_void_p), ("dw", c_void_p), ("db", c_void_p), ("nb", ctypes.c_int32), ("d", ctypes.c_int32)]
+
+
 _P = c_void_p
 _PROTOS = {
     "dh_bpe_create": (c_void_p, [c_char_p, c_int64, c_int]),
@@ -54,10 +59,12 @@ _PROTOS = {
     "dh_layernorm_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
     "dh_layernorm_bwd_ws_bytes": (c_int64, [c_int, c_int]),
     "dh_layernorm_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int64, _P]),
+    "dh_layernorm_bwd_part": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int64, _P, _P]),
+    "dh_ln_reduce_many": (c_int, [_P, c_int, _P]),
     "dh_attn_fwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "dh_attn_varlen_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "dh_attn_varlen_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dh_attn_varlen_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dh_attn_varlen_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_pooled_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_pooled_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "dh_text_embed_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),

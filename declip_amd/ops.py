@@ -128,6 +128,38 @@ def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None):
     return dx
 
 
+def layernorm_bwd_part(dy, x, w, mean, rstd, dw, db, part, dres=None):
+    """layernorm_bwd with the weight / bias gradient reduction deferred: the per-block partials stay in `part` (fp32, at least
+    layernorm_bwd_ws_elems(rows, d) elements, alive until ln_reduce_many ran).  Returns (dx, nb): nb partial rows, 0 = accumulated
+    into dw / db directly."""
+    _contig(dy, "dy"), _contig(x, "x")
+    rows, d = x.shape
+    lib = L.load()
+    dx = torch.empty_like(x)
+    nb = ctypes.c_int(0)
+    _req(part.dtype == torch.float32 and part.is_contiguous(), "part: contiguous fp32")
+    check(lib.dh_layernorm_bwd_part(dt(x), ptr(dy), ptr(x), ptr(w), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dw), ptr(db),
+                                    rows, d, ptr(part), part.numel() * 4, ctypes.byref(nb), stream()), "dh_layernorm_bwd_part")
+    return dx, int(nb.value)
+
+
+def layernorm_bwd_ws_elems(rows, d):
+    return max(int(L.load().dh_layernorm_bwd_ws_bytes(rows, d)), 4) // 4
+
+
+def ln_reduce_many(items):
+    """items: [(part, nb, d, dw, db)] from layernorm_bwd_part: dw += column sums of part[:nb, :d], db += those of part[:nb, d:2d], for
+    all items in ONE launch per 32 (dh_ln_reduce_many)."""
+    items = [it for it in items if it[1] > 0]
+    if not items:
+        return
+    arr = (L.LnPart * len(items))()
+    for a, (part, nb, d, dw, db) in zip(arr, items):
+        _req(dw.dtype == torch.float32 and db.dtype == torch.float32 and dw.numel() == d and db.numel() == d, "ln_reduce_many: dw / db fp32 [d]")
+        a.part, a.dw, a.db, a.nb, a.d = ptr(part), ptr(dw), ptr(db), nb, d
+    check(L.load().dh_ln_reduce_many(arr, len(items), stream()), "dh_ln_reduce_many")
+
+
 def attn_fwd(qkv, b, Lq, heads, causal):
     _contig(qkv, "qkv")
     d3 = qkv.shape[-1]
@@ -154,23 +186,19 @@ def attn_varlen_fwd(qkv, cu, rows, b, Lmax, heads, causal):
     _contig(qkv, "qkv")
     _req(cu.dtype == torch.int32 and cu.numel() == b + 1, 'cu.dtype == torch.int32 and cu.numel() == b + 1')
     d = qkv.shape[-1] // 3
-    out = torch.empty(qkv.shape[0], d, device=qkv.device, dtype=qkv.dtype)
-    if qkv.shape[0] > rows:
-        out[rows:].zero_()
+    out = torch.empty(qkv.shape[0], d, device=qkv.device, dtype=qkv.dtype)      # the tail rows [rows, rows_pad) are zeroed by the call
     lse = torch.empty(b, heads, Lmax, device=qkv.device, dtype=torch.float32)
     check(L.load().dh_attn_varlen_fwd(dt(qkv), ptr(qkv), ptr(out), ptr(lse), ptr(_contig(cu, "cu")), b, Lmax, heads, d // heads, int(causal),
-                                      stream()), "dh_attn_varlen_fwd")
+                                      int(rows), int(qkv.shape[0]), stream()), "dh_attn_varlen_fwd")
     return out, lse
 
 
 def attn_varlen_bwd(qkv, out, dout, lse, cu, rows, b, Lmax, heads, causal):
     _contig(qkv, "qkv"), _contig(out, "out"), _contig(dout, "dout")
     d = qkv.shape[-1] // 3
-    dqkv = torch.empty_like(qkv)
-    if qkv.shape[0] > rows:
-        dqkv[rows:].zero_()
+    dqkv = torch.empty_like(qkv)                                                 # (tail rows zeroed by the call)
     check(L.load().dh_attn_varlen_bwd(dt(qkv), ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(_contig(cu, "cu")), b, Lmax, heads,
-                                      d // heads, int(causal), stream()), "dh_attn_varlen_bwd")
+                                      d // heads, int(causal), int(rows), int(qkv.shape[0]), stream()), "dh_attn_varlen_bwd")
     return dqkv
 
 

@@ -115,6 +115,21 @@ int64_t dh_layernorm_bwd_ws_bytes(int rows, int d);
 int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
                      const void* dres, void* dx, float* dw, float* db, int rows, int d, void* ws, int64_t ws_bytes,
                      dh_stream_t stream);
+/* The same with the reduction of the weight / bias gradient DEFERRED: the per-block partials stay in `part` ([*nb_out][2 d] fp32,
+ * at least dh_layernorm_bwd_ws_bytes(rows, d) bytes, owned by the caller until the reduce ran) and dh_ln_reduce_many adds the
+ * partials of up to 32 LayerNorms per launch into their dw / db.  A tower's backward (24 LayerNorms + ln_pre / ln_post of
+ * base_transformer.py:29-53, visual_transformer.py:55-82) then issues ONE reduce instead of one per LayerNorm.  *nb_out = 0: this
+ * shape was accumulated into dw / db directly (nothing to reduce). */
+typedef struct dh_ln_part {
+  const float* part; /* [nb][2 d] partials written by dh_layernorm_bwd_part */
+  float* dw;         /* [d] accumulated into */
+  float* db;         /* [d] accumulated into */
+  int32_t nb, d;
+} dh_ln_part;
+int dh_layernorm_bwd_part(int dtype, const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                          const void* dres, void* dx, float* dw, float* db, int rows, int d, void* part, int64_t part_bytes,
+                          int* nb_out, dh_stream_t stream);
+int dh_ln_reduce_many(const dh_ln_part* items, int n, dh_stream_t stream);
 
 /* ---------------------------------------------------------------- attention -------------
  * nn.MultiheadAttention(x,x,x, attn_mask) core (base_transformer.py:33,45-48; causal mask
@@ -131,12 +146,14 @@ int dh_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, c
                 int L, int heads, int hd, int causal, dh_stream_t stream);
 /* The same on PACKED (variable-length) sequences: pair (bi, h) owns rows cu_seqlens[bi] .. cu_seqlens[bi+1] of qkv / out / dout /
  * dqkv ([rows][3*d] / [rows][d]; cu_seqlens int32 [b + 1] in device memory, every length <= Lmax); lse stays [b][heads][Lmax].
- * Rows outside the sequences are neither read nor written.  Used by the packed text tower (captions computed up to
+ * rows = cu_seqlens[b] (the caller knows it on the host), rows_pad >= rows = the allocated row count (whole GEMM tiles): rows
+ * [rows, rows_pad) of out / dqkv are written as ZEROS -- they are contraction rows of the weight-gradient GEMMs -- by the
+ * attention kernel itself on the bf16 path (no separate fill launch).  Used by the packed text tower (captions computed up to
  * <|endoftext|> only). */
 int dh_attn_varlen_fwd(int dtype, const void* qkv, void* out, float* lse, const int* cu_seqlens, int b, int Lmax, int heads, int hd,
-                       int causal, dh_stream_t stream);
+                       int causal, int rows, int rows_pad, dh_stream_t stream);
 int dh_attn_varlen_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
-                       const int* cu_seqlens, int b, int Lmax, int heads, int hd, int causal, dh_stream_t stream);
+                       const int* cu_seqlens, int b, int Lmax, int heads, int hd, int causal, int rows, int rows_pad, dh_stream_t stream);
 /* Pooled-query attention for the LAST block of a tower: only the pooled row's output is used downstream (CLS,
  * image_encoder/visual_transformer.py:70-72; <|endoftext|>, text_encoder/text_transformer.py:203), so that block's query projection,
  * attention, out_proj and MLP are needed for b rows, not b*L (K, V still come from every row).  q [b][d] (the pooled rows'

@@ -85,6 +85,28 @@ def layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=None):
     return dx.to(x.dtype)
 
 
+def layernorm_bwd_ws_elems(rows, d):
+    return 2 * d
+
+
+def layernorm_bwd_part(dy, x, w, mean, rstd, dw, db, part, dres=None):
+    """the deferred form (engine.LnGradBatch): the gradient of weight / bias is left in `part` as ONE partial row, added by
+    ln_reduce_many -- so the mock exercises the host-side batching (arena slices, flush points) like the kernels do."""
+    d = x.shape[1]
+    zw, zb = torch.zeros(d), torch.zeros(d)
+    dx = layernorm_bwd(dy, x, w, mean, rstd, zw, zb, dres=dres)
+    part[:d].copy_(zw)
+    part[d:2 * d].copy_(zb)
+    return dx, 1
+
+
+def ln_reduce_many(items):
+    for part, nb, d, dw, db in items:
+        if nb > 0:
+            dw += part[:nb * 2 * d].view(nb, 2 * d)[:, :d].sum(0)
+            db += part[:nb * 2 * d].view(nb, 2 * d)[:, d:].sum(0)
+
+
 def _attn(qkv, b, L, heads, causal):
     d = qkv.shape[-1] // 3
     hd = d // heads

@@ -140,7 +140,9 @@ def test_graphed_multiview_step_equals_eager_step(family, cfg_name, b):
             _refresh_mlm_selection(batch["mlm_labels"], labels0[perm], dev)
 
     results = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "eager2", "graph"):        # eager twice: the run-to-run noise floor of this model (see the end of the test)
+        if mode == "eager2" and family != "filip":
+            continue                                    # (only FILIP needs the measured floor: see below)
         caps0 = labels0 = None
         model, opt, batch, fwd_bwd = make()
         stepper = GraphedStep(fwd_bwd, warmup=2, enabled=(mode == "graph"), modules=(model,))
@@ -178,4 +180,16 @@ def test_graphed_multiview_step_equals_eager_step(family, cfg_name, b):
     # steps and the discrete choices of these models (nearest neighbour, top-16 tokens) amplify a little
     for a, c in zip(g["losses"], e["losses"]):
         assert abs(a - c) <= 1e-2 * abs(c), (g["losses"], e["losses"])
-    assert float((g["grad"] - e["grad"]).norm()) <= 6e-2 * float(e["grad"].norm()), float((g["grad"] - e["grad"]).norm()) / float(e["grad"].norm())
+    gdiff = float((g["grad"] - e["grad"]).norm()) / float(e["grad"].norm())
+    gtol = 6e-2
+    if family == "filip":
+        # FILIP's whole gradient passes through arg-max choices (filip.py:96-105: max over the 16 selected tokens, top-16 selection
+        # itself): after six optimiser steps two EAGER runs that differ by atomic ordering alone sit tens of per cent apart (measured
+        # 0.31 on the MI355X) although their losses agree to 1e-2 -- so the bound is this model's own measured run-to-run floor; what
+        # a capture bug produces (a stale input buffer, a dropped node) is an unrelated gradient at ~1.4
+        e2 = results["eager2"]
+        floor = float((e2["grad"] - e["grad"]).norm()) / float(e["grad"].norm())
+        print("FILIP gradient after %d steps: graph vs eager %.4f, eager vs eager %.4f" % (steps, gdiff, floor))
+        gtol = max(gtol, 2.5 * floor)
+        assert gtol < 1.0, floor
+    assert gdiff <= gtol, (gdiff, gtol)

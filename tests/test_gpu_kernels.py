@@ -126,6 +126,37 @@ def test_layernorm(dtype, rows, d):
     assert rel_err(db, br.grad) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_deferred_reduce_of_many(dtype):
+    """dh_layernorm_bwd_part + dh_ln_reduce_many: the weight / bias gradient partials of several LayerNorms (different widths and
+    row counts, one of them through the scalar kernel that accumulates directly) reduced by ONE launch into gradients that
+    already hold values == one dh_layernorm_bwd each."""
+    ops = _ops()
+    cases = [(200, 768), (77, 512), (9, 100), (300, 768), (64, 128)]
+    items, want, got_dx, want_dx = [], [], [], []
+    for i, (rows, d) in enumerate(cases):
+        x = rnd(rows, d, seed=40 + i).to(dtype).to(cuda)
+        w, b = (1 + 0.1 * rnd(d, seed=50 + i)).to(cuda), (0.1 * rnd(d, seed=60 + i)).to(cuda)
+        dy = rnd(rows, d, seed=70 + i).to(dtype).to(cuda)
+        _, mean, rstd = ops.layernorm_fwd(x, w, b)
+        dw0, db0 = rnd(d, seed=80 + i).to(cuda), rnd(d, seed=90 + i).to(cuda)
+        dw_a, db_a = dw0.clone(), db0.clone()
+        want_dx.append(ops.layernorm_bwd(dy, x, w, mean, rstd, dw_a, db_a))
+        want.append((dw_a, db_a))
+        dw_b, db_b = dw0.clone(), db0.clone()
+        part = torch.full((ops.layernorm_bwd_ws_elems(rows, d) + 64,), float("nan"), device=cuda)
+        dx, nb = ops.layernorm_bwd_part(dy, x, w, mean, rstd, dw_b, db_b, part)
+        got_dx.append(dx)
+        if nb > 0:
+            assert torch.equal(dw_b, dw0) and torch.equal(db_b, db0)          # nothing reduced yet
+        items.append((part, nb, d, dw_b, db_b))
+    assert any(it[1] == 0 for it in items) and sum(it[1] > 0 for it in items) >= 3
+    ops.ln_reduce_many(items)
+    for (part, nb, d, dw_b, db_b), (dw_a, db_a), dx, dxw in zip(items, want, got_dx, want_dx):
+        assert torch.equal(dx, dxw)
+        assert rel_err(dw_b, dw_a) < 1e-5 and rel_err(db_b, db_a) < 1e-5
+
+
 # ----------------------------------------------------------------------------- attention
 def attn_ref(qkv, heads, causal):
     b, L, d3 = qkv.shape

@@ -24,6 +24,8 @@ CASES = [
     ("test_layernorm", (BF16, 50, 768)),
     ("test_layernorm", (F32, 77, 512)),
     ("test_layernorm", (BF16, 9, 100)),
+    ("test_layernorm_deferred_reduce_of_many", (BF16,)),
+    ("test_layernorm_deferred_reduce_of_many", (F32,)),
     ("test_attention", (BF16, 3, 50, 12, False)),
     ("test_attention", (BF16, 2, 77, 8, True)),
     ("test_attention", (BF16, 2, 33, 1, True)),
