@@ -25,7 +25,8 @@ PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
 def _host_cpu():
-    """(model string, physical cores) of the host this runs on."""
+    """(model string, cores this process may use: physical cores of the affinity mask, capped by the container's CPU quota)."""
+    from declip_amd import hostinfo
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as fh:
@@ -35,12 +36,7 @@ def _host_cpu():
                     break
     except OSError:
         pass
-    try:
-        import psutil
-        cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
-    except Exception:
-        cores = os.cpu_count() or 1
-    return model, int(cores)
+    return model, hostinfo.usable_cores()
 
 
 def _cpu_sample(cfg, label, batch, steps, use_reference):
@@ -95,7 +91,7 @@ def _cpu_sample(cfg, label, batch, steps, use_reference):
 def cpu_baseline(batch=32, steps=3, r50=True):
     """the reference's CPU path beside the GPU number -- CLIP ViT-B/32 (the metric's model) and CLIP ResNet-50
     (BASELINE.json configs[0], the reference's own CPU-runnable case), batch 32, fp32, 1 warm-up + 3 timed steps (median), torch
-    threads = physical cores.  Bounded: ~10-30 s of CPU work on the GPU box's host."""
+    threads = the cores this process may use (physical cores, capped by the container's CPU quota: hostinfo.usable_cores).  Bounded: ~10-30 s of CPU work on the GPU box's host."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from declip_amd import synth
     from oracle import ref_harness
@@ -109,7 +105,7 @@ def cpu_baseline(batch=32, steps=3, r50=True):
     finally:
         torch.set_num_threads(prev)
     return dict(value=main_s["value"], unit="pairs/s", cores=cores, cpu=model, kind="reference" if use_ref else "port",
-                sample="%s fp32 fwd+bwd+AdamW, batch %d, 1 warm-up + %d timed steps (median), torch CPU, %d threads (= physical cores); "
+                sample="%s fp32 fwd+bwd+AdamW, batch %d, 1 warm-up + %d timed steps (median), torch CPU, %d threads (= usable cores: physical, capped by the cgroup CPU quota); "
                        "%s" % (main_s["config"], batch, steps, cores,
                                "the unmodified reference's modules (oracle/ref_harness.py)" if use_ref else
                                "oracle/restated.py, the CPU restatement of the reference (the reference tree is not on this box)"),
@@ -165,6 +161,11 @@ def main():
                     help="capture forward + loss + backward of the step in ONE HIP graph (declip_amd/graph.py), the fused AdamW stays "
                          "a separate launch; default: DH_STEP_GRAPH, else 1 on one GPU for the models whose graph == eager test gates it (clip, clip_r50, "
                          "declip, defilip, filip), 0 for slip (no gain) and for multi-GPU runs (1 there captures the RCCL collectives with the step)")
+    ap.add_argument("--pipeline", choices=["0", "1"], default="0",
+                    help="1: the timed steps take their batches from the input pipeline instead of one resident batch -- decoded uint8 images at "
+                         "their source size + crop boxes + caption STRINGS through declip_amd.prefetch.DataPrefetcher (BPE on its worker "
+                         "thread, pinned upload on a copy stream, resize / mirror / normalise on the GPU; clip_solver.py:30-63, "
+                         "imagenet_dataloader.py:36-47).  Eager steps (every batch has its own packed row count).  clip only.")
     args = ap.parse_args()
 
     if args.text_packed is not None:
@@ -173,7 +174,8 @@ def main():
         os.environ["DH_POOLED_LAST"] = args.pooled_last
     from declip_amd import dist as dh_dist
     from declip_amd import engine as eng_mod
-    from declip_amd import ops, synth
+    from declip_amd import hostinfo, ops, synth
+    host_threads = hostinfo.limit_host_threads()      # the container's CPU quota, not the node's visible cores (hostinfo.py)
     from declip_amd.loss import ClipInfoCELoss
     from declip_amd.optim import build_adamw
     from declip_amd.testing import build_clip, build_declip, declip_batch
@@ -262,10 +264,25 @@ def main():
         loss.backward()                          # gradient all-reduce overlaps inside (dist.FlatReducer)
         return loss.detach()
 
+    pipeline = None
+    if args.pipeline == "1":
+        assert args.model == "clip", "--pipeline: the CLIP intake (one view, one caption per pair)"
+        import itertools
+        import tempfile
+        from declip_amd.bpe import NativeTokenizer
+        from declip_amd.prefetch import DataPrefetcher
+        use_graph = False                        # captions of varying length: a packed row count per batch
+        pool = synth.synth_decoded_batches(b, n_batches=6, seed=rank)
+        tok = NativeTokenizer(synth.synthetic_bpe_file(os.path.join(tempfile.gettempdir(), "dh_synthetic_bpe.txt.gz")))
+        pipeline = DataPrefetcher(itertools.cycle(pool), dev, tokenizer=tok, context_length=77, image_size=224)
+
     from declip_amd.graph import GraphedStep
     graphed = GraphedStep(fwd_bwd, warmup=2, enabled=use_graph, modules=(wrapped,))
 
     def step():
+        if pipeline is not None:
+            nxt = pipeline.next()                # the caller's stream waits for the copy stream's event: no host synchronisation
+            batch["images"], batch["captions"] = nxt["images"], nxt["captions"]
         opt.zero_grad()
         loss = graphed()
         wrapped.sync_gradients()
@@ -298,6 +315,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_elapsed = time.perf_counter() - t0      # the host's share: everything enqueued, nothing waited for yet
     sync()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -306,6 +324,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
     ms_per_step = elapsed / args.steps * 1e3
+    host_ms_per_step = host_elapsed / args.steps * 1e3
     pairs_per_s = b * world * args.steps / elapsed
 
     roofline = None
@@ -440,11 +459,16 @@ def main():
                     "fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d (BASELINE.json configs[0]), 224x224 images, 77-token captions" % b,
     }
     out = dict(metric="image-text pairs/sec %s" % name, value=round(pairs_per_s, 2), unit="pairs/s", n_gpus=world,
-               steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
+               steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), host_ms_per_step=round(host_ms_per_step, 3), higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic" if pipeline is None else "synthetic, through the input pipeline",
                config=dict(workload=workloads[args.model],
                            global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world,
                            tower_streams=1 + len(model.__dict__["_flat_store"].side_streams), step_graph=int(use_graph and graphed.graph is not None),
+                           input_pipeline=(None if pipeline is None else
+                                           "DataPrefetcher: uint8 canvases 256x320 (source sizes 192-256 x 256-320) + RandomResizedCrop boxes + mirror "
+                                           "flags + caption strings; BPE (dh_bpe_encode) and box bookkeeping on 1 worker thread (%d host cores usable), "
+                                           "pinned H2D on a copy stream, dh_image_resized_crop_u8 on the GPU" % hostinfo.usable_cores()),
+                           host_threads=host_threads,
                            rccl_ranks=rccl_ranks, dist_backend=(torch.distributed.get_backend() if world > 1 else None),
                            dynamic_tiles=int(os.environ.get("DH_V4_DYNAMIC", "0")), comm_native=int(dh_dist.native_comm() is not None) if world > 1 else 0,
                            text_packed=eng_mod.text_packed_mode(), pooled_last=int(eng_mod.pooled_last_block())),   # captions computed up to <|endoftext|> only; last block for the pooled rows only (same outputs, fewer executed flops: see roofline.executed_gemm_gflop_per_pair)
@@ -455,6 +479,8 @@ def main():
         out["loss_delta_vs_cpu_ref"] = loss_delta_vs_cpu_ref(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+    if pipeline is not None:
+        pipeline.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1,0 +1,64 @@
+"""How many host cores this process may really use.
+
+A training process sees every core of the node (`os.cpu_count()`, the affinity mask), but a container's CPU quota (cgroup
+`cpu.max` / `cpu.cfs_quota_us`) can be far smaller -- the MI355X boxes of this project: 256 hardware threads visible, a quota of
+16.  torch sizes its OpenMP teams by the visible cores; a 128-thread team that spin-waits after every small CPU operation burns
+the quota in a few milliseconds and the kernel THROTTLES the whole process, the thread that enqueues GPU work included
+(measured: the bf16 CLIP step 23.5 -> 44-63 ms as soon as one [512, 77] argmax per step ran on the host; 49 of 362 scheduler
+periods throttled; profiles/r03_pipeline_host_threads.txt).  `limit_host_threads()` clamps torch's intra-op threads to what the
+quota grants; the training entry points (bench.py, solver.ClipSolver) call it before anything else.
+"""
+import os
+
+__all__ = ["usable_cores", "limit_host_threads"]
+
+
+def _cgroup_quota():
+    """cores granted by the CPU controller of this process' cgroup (v2, then v1), or None when unlimited / unreadable."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                       # v2: "<quota|max> <period>"
+            quota, period = fh.read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            return int(quota) / int(period)
+        return None
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+            quota = int(fh.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+            period = int(fh.read())
+        if quota > 0 and period > 0:
+            return quota / period
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def usable_cores(physical=True):
+    """min(cores of the affinity mask [physical ones: hyper-thread siblings counted once], the cgroup CPU quota), at least 1."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    if physical:
+        try:
+            import psutil
+            phys = psutil.cpu_count(logical=False)
+            if phys:
+                n = min(n, int(phys))
+        except Exception:
+            pass
+    quota = _cgroup_quota()
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
+def limit_host_threads(reserve=0):
+    """Clamp torch's intra-op CPU threads to usable_cores() - reserve (never raises them); returns the count now in force."""
+    import torch
+    n = max(1, usable_cores() - reserve)
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return torch.get_num_threads()

@@ -66,6 +66,7 @@ class DataPrefetcher(object):
         self._cuda = self.device.type == "cuda"
         self.stream = torch.cuda.Stream(device=self.device) if self._cuda else None
         self._staged, self._event = None, None
+        self._stop = False
         self._thread = threading.Thread(target=self._work, name="declip-prefetch", daemon=True)
         self._thread.start()
         self._stage()
@@ -85,7 +86,9 @@ class DataPrefetcher(object):
         if torch.is_tensor(caps) and caps.dtype == torch.int64 and not caps.is_cuda:
             # packed captions (DH_TEXT_PACKED, engine.PackedCaptions) size their buffers by the number of caption rows up to
             # <|endoftext|>: counted HERE, on the host copy, so that the step never reads it back from the device
-            out["_caption_rows"] = int((caps.argmax(dim=-1) + 1).sum())
+            # (numpy, NOT torch: a torch CPU reduction wakes an OpenMP team sized by the node's visible cores, whose spin-waiting
+            # burns a container's CPU quota and gets the enqueueing thread throttled -- hostinfo.py)
+            out["_caption_rows"] = int((caps.numpy().argmax(axis=-1) + 1).sum())
         if self._cuda:
             for k, v in out.items():
                 if torch.is_tensor(v) and not v.is_cuda and not v.is_pinned():
@@ -103,10 +106,29 @@ class DataPrefetcher(object):
     def _work(self):
         try:
             for batch in self._it:
-                self._q.put(self._prepare(batch))
+                item = self._prepare(batch)
+                while not self._stop:                # (a bounded put: close() must be able to end a worker that is ahead of the step)
+                    try:
+                        self._q.put(item, timeout=0.1)
+                        break
+                    except queue.Full:
+                        pass
+                if self._stop:
+                    return
             self._q.put(_END)
         except BaseException as e:       # surfaces in the training thread at the next next()
             self._q.put(e)
+
+    def close(self):
+        """Stop the worker thread (an endless loader never ends it) and drop what it prepared; the prefetcher yields nothing afterwards."""
+        self._stop = True
+        try:
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
+        self._thread.join(timeout=5.0)
+        self._staged = None
 
     # ---- training thread ---------------------------------------------------------------------------------------------
     def _stage(self):

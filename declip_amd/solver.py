@@ -278,6 +278,8 @@ class ClsSolver(object):
 
     # ---- clip_solver.py:104-165
     def setup_env(self):
+        from . import hostinfo
+        self.host_threads = hostinfo.limit_host_threads()      # a container's CPU quota, not the node's visible cores (hostinfo.py)
         self.rank, self.world_size = dh_dist.get_rank(), dh_dist.get_world_size()
         self.device = torch.device("cuda", torch.cuda.current_device()) if self._device_kind == "cuda" else torch.device(self._device_kind)
         saver = self.config.get("saver", AttrDict())

@@ -265,3 +265,51 @@ FILIP_VITB32 = dict(VITB32, embed_dim=768)
 # FILIP needs >= 16 image tokens and >= 16 text tokens: 160 px / 32 = 25 patches, 24-token context
 FILIP_SMALL = dict(v_width=128, v_layers=2, v_heads=2, patch=32, res=160,
                    t_width=128, t_layers=2, t_heads=2, ctx=24, embed_dim=64, vocab=VOCAB)
+
+
+def synthetic_bpe_file(path):
+    """A BPE merges file with the layout of the one the reference downloads (bpe_simple_vocab_16e6.txt.gz, dataset_prepare.md:36-37:
+    header line + 48 894 merges -> vocabulary 49 409 with <|mask|>, simple_tokenizer.py:66-75) whose merges never apply to ordinary
+    text: captions tokenise into their characters, so a caption's token count is its character count -- enough to drive the
+    tokeniser at a realistic load when no real vocabulary is on the box (bench.py --pipeline)."""
+    import gzip
+    import os
+    if not os.path.exists(path):
+        n_merges = 49152 - 256 - 2
+        lines = ["#version: synthetic"] + ["q%d z" % i for i in range(n_merges)] + [""]
+        tmp = path + ".%d.tmp" % os.getpid()
+        with gzip.open(tmp, "wb") as f:
+            f.write("\n".join(lines).encode("utf-8"))
+        os.replace(tmp, path)
+    return path
+
+
+def synth_decoded_batches(b, n_batches=6, src_hw=(256, 320), out_hw=(224, 224), seed=0, pinned=True):
+    """`n_batches` host batches as a decoder + the reference's data pipeline would hand them over (imagenet_dataloader.py:36-47,
+    clip_dataloader.py:47-53): decoded uint8 HWC images of varying SOURCE sizes on one (pinned) canvas, RandomResizedCrop boxes drawn on
+    the host (declip_amd.augment), a mirror flag, and caption STRINGS (lengths ~ U{6..75} tokens with synthetic_bpe_file's vocabulary)."""
+    import numpy as np
+    import torch
+    from . import augment
+    g = np.random.default_rng(seed)
+    alphabet = np.array(list("abcdefghijklmnopqrstuvwxyz"))
+    out = []
+    for _ in range(n_batches):
+        hs = g.integers(src_hw[0] - 64, src_hw[0] + 1, size=b)
+        ws = g.integers(src_hw[1] - 64, src_hw[1] + 1, size=b)
+        canvas = torch.zeros(b, src_hw[0], src_hw[1], 3, dtype=torch.uint8, pin_memory=bool(pinned))
+        canvas.copy_(torch.from_numpy(g.integers(0, 256, size=(b, src_hw[0], src_hw[1], 3), dtype=np.uint8)))
+        sizes = [(int(h), int(w)) for h, w in zip(hs, ws)]
+        boxes = torch.from_numpy(augment.random_resized_crop_params(sizes, out_hw, generator=g))
+        flip = torch.from_numpy(g.integers(0, 2, size=b).astype(np.int32))
+        caps = []
+        for n in g.integers(4, 74, size=b):              # + SOT / EOT: 6 .. 75 tokens
+            chars = alphabet[g.integers(0, 26, size=int(n))]
+            words, i = [], 0
+            while i < len(chars):                         # words of 2-8 letters (a space does not cost a token)
+                k = int(g.integers(2, 9))
+                words.append("".join(chars[i:i + k]))
+                i += k
+            caps.append([" ".join(words)])                # the reference's batches carry a LIST of captions per sample (clip.py:110-111)
+        out.append({"images": canvas, "image_boxes": boxes, "image_flip": flip, "captions": caps})
+    return out

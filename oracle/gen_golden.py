@@ -662,6 +662,7 @@ FIXTURES = {
     "declip_vitb32_b128": lambda: gen_declip("declip_vitb32_b128", synth.VITB32, b=128, seed=22, nn_size=4096),
     "slip_vitb32_b128": lambda: gen_slip("slip_vitb32_b128", synth.VITB32, b=128, seed=23),
     "filip_vitb32_e768_b256": lambda: gen_filip("filip_vitb32_e768_b256", synth.FILIP_VITB32, b=256, seed=24),
+    "declip_vitb32_b128_w2": lambda: gen_declip("declip_vitb32_b128_w2", synth.VITB32, b=128, seed=26, nn_size=4096, world=2),
     "filip_vitb32_e768_b256_w2": lambda: gen_filip("filip_vitb32_e768_b256_w2", synth.FILIP_VITB32, b=256, seed=25, world=2),
     "zeroshot_tiny": lambda: gen_zeroshot("zeroshot_tiny", synth.TINY, label_num=7, prompts_num=3, b=5, batches=2, seed=8),
 }
