@@ -291,10 +291,91 @@ def test_filip_two_ranks_on_one_gpu_match_two_reference_ranks(dtype):
     assert q.get() == "ok"
 
 
-def _declip_w2_worker(rank, world, port, out):
-    """DeCLIP, two ranks on the one GPU, fp32: the six-tensor packed gather in flight on the engine's communication stream while
-    the masked-LM head runs on the compute stream (dist.all_gather_cat_many_async), its reduce-scatter backward replayed there by
-    autograd -- against TWO reference ranks (tests/golden/declip_tiny_w2.pt, 1e-3)."""
+def _declip_w2_worker(rank, world, port, fixture, dtype, out):
+    """DeCLIP, two ranks on the one GPU: the six-tensor packed gather in flight on the engine's communication stream while the
+    masked-LM head runs on the compute stream (dist.all_gather_cat_many_async), its reduce-scatter backward replayed there by
+    autograd -- against TWO reference ranks: tests/golden/declip_tiny_w2.pt (fp32, 1e-3, two steps) and, at ViT-B/32 width with
+    b = 128 per rank (every tower GEMM on the persistent 256 x 256 kernel in bf16), tests/golden/declip_vitb32_b128_w2.pt."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from declip_amd import dist as dd
+    from declip_amd import ops, synth
+    from declip_amd.heads import SimsiamLoss
+    from declip_amd.loss import ClipInfoCELoss, NTXentLoss
+    from declip_amd.steps import declip_loss
+    from declip_amd.testing import build_declip
+    from oracle_util import check_grad_digests, load_golden
+    from test_gpu_golden_fullwidth import assert_ran_on_v4, check_bf16_grad_norms, named_grads
+    g = load_golden(fixture)
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    full = fixture != "declip_tiny_w2"
+    model = build_declip(cfg, dtype=dtype, seed=seed, nn_size=g["nn_size"])
+    wrapped = dd.DistModule(model, sync=False, bucket_bytes=(48 << 20) if full else (1 << 16))
+    B = b * world
+    sl = slice(rank * b, (rank + 1) * b)
+    images = synth.synth_images(B, views=2, res=cfg["res"], seed=seed)[sl].cuda()
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
+    ids_aug = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"])
+    ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+    batch = {"images": images, "captions": torch.stack([ids_masked[sl], ids_aug[sl]], dim=1).cuda(), "mlm_labels": labels[sl]}
+    tol = 1e-3 if dtype == "fp32" else 3e-2
+    for it in range(1 if full else 2):        # twice: stream / event state of the first step must not leak into the second
+        for p in model.parameters():
+            p.grad = None
+        model.nn_replacer_text.bank = synth.synth_bank(g["nn_size"], cfg["embed_dim"], seed=seed + rank).cuda()
+        model.nn_replacer_text.bank_ptr = 0
+        ops.gemm_stats(reset=True)
+        o = declip_loss(wrapped, batch, ClipInfoCELoss(), SimsiamLoss(), NTXentLoss(b), world_size=world)
+        o["loss"].backward()
+        wrapped.sync_gradients()
+        torch.cuda.synchronize()
+        stats = ops.gemm_stats()
+        assert len(dd._COMM_STREAMS) == 1     # the gather really went through the communication stream
+        total = o["loss"].detach().clone()
+        dist.all_reduce(total)
+        if rank == 0:
+            assert abs(float(total) - g["loss"]) <= tol * abs(g["loss"]), (float(total), g["loss"])
+            li1 = o["outputs"]["logits"][0].materialize().detach().float().cpu()
+            assert float((li1 - g["logits_i1"]).abs().max()) <= tol * float(g["logits_i1"].abs().max())
+            if dtype == "fp32":
+                check_grad_digests(g["grads"], named_grads(model), rtol=1e-3)
+            else:
+                assert_ran_on_v4(stats, 200)
+                check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.15, z_tol=0.35)
+    dist.barrier()
+    if rank == 0:
+        out.put("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fixture,dtype", [("declip_tiny_w2", "fp32"), ("declip_vitb32_b128_w2", "fp32"), ("declip_vitb32_b128_w2", "bf16")])
+def test_declip_two_ranks_on_one_gpu_match_two_reference_ranks(fixture, dtype):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_declip_w2_worker, args=(r, 2, port, fixture, dtype, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        if p.is_alive():
+            p.terminate()
+            p.join(10)
+            pytest.fail("rank timed out")
+        assert p.exitcode == 0
+    assert q.get() == "ok"
+
+
+def _small_w2_worker(rank, world, port, kind, out):
+    """The remaining two-rank data-parallel steps on the one GPU (gloo between two processes that share it), fp32, against TWO reference
+    ranks: CLIP ResNet-50 (ModifiedResNet tower, per-rank BatchNorm statistics, buckets launched from inside the tower's backward;
+    clip_r50_tiny_w2), SLIP (SimCLR features of both views gathered, NT-Xent positives at rank*b + i; slip_tiny_w2) and DeFILIP
+    (DeCLIP's six-tensor gather + per-rank NN bank + FILIP's gathered token sets; defilip_small_w2) -- the CPU-mocked versions of
+    these steps are tests/test_dist_gloo.py, here the HIP kernels compute them."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
@@ -304,50 +385,77 @@ def _declip_w2_worker(rank, world, port, out):
     from declip_amd import dist as dd
     from declip_amd import synth
     from declip_amd.heads import SimsiamLoss
-    from declip_amd.loss import ClipInfoCELoss, NTXentLoss
-    from declip_amd.steps import declip_loss
-    from declip_amd.testing import build_declip
+    from declip_amd.loss import ClipInfoCELoss, NT_Xent, NT_Xent_gather
+    from declip_amd.steps import DEFILIP_WEIGHTS, declip_loss, slip_loss
+    from declip_amd.testing import build_clip, build_defilip, build_slip
     from oracle_util import check_grad_digests, load_golden
-    g = load_golden("declip_tiny_w2")
+    from test_gpu_golden_fullwidth import named_grads
+    g = load_golden({"clip_r50": "clip_r50_tiny_w2", "slip": "slip_tiny_w2", "defilip": "defilip_small_w2"}[kind])
     cfg, b, seed = g["cfg"], g["b"], g["seed"]
-    model = build_declip(cfg, dtype="fp32", seed=seed, nn_size=g["nn_size"])
-    model.nn_replacer_text.bank = synth.synth_bank(g["nn_size"], cfg["embed_dim"], seed=seed + rank).cuda()
-    wrapped = dd.DistModule(model, sync=False, bucket_bytes=1 << 16)
     B = b * world
     sl = slice(rank * b, (rank + 1) * b)
-    images = synth.synth_images(B, views=2, res=cfg["res"], seed=seed)[sl].cuda()
-    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])
-    ids_aug = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"])
-    ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
-    batch = {"images": images, "captions": torch.stack([ids_masked[sl], ids_aug[sl]], dim=1).cuda(), "mlm_labels": labels[sl]}
-    for it in range(2):                       # twice: stream / event state of the first step must not leak into the second
-        for p in model.parameters():
-            p.grad = None
+    only = None
+    if kind == "clip_r50":
+        model = build_clip(cfg, dtype="fp32", use_allgather=True, seed=seed)
+        wrapped = dd.DistModule(model, sync=False, bucket_bytes=1 << 18)
+        images = synth.synth_images(B, res=cfg["res"], seed=seed)[sl].cuda()
+        ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])[sl].cuda()
+        li, lt = wrapped({"images": images, "captions": ids})
+        loss, _ = ClipInfoCELoss()(li, lt)
+        loss = loss / world
+        logits, ref_logits = li, g["logits_i"]
+        is_bn = lambda n: ".bn" in n or "downsample.1." in n       # noqa: E731
+        only = lambda n: not is_bn(n)                               # noqa: E731
+    elif kind == "slip":
+        model = build_slip(cfg, dtype="fp32", seed=seed)
+        wrapped = dd.DistModule(model, sync=False, bucket_bytes=1 << 14)
+        images = synth.synth_images(B, views=3, res=cfg["res"], seed=seed)[sl].cuda()
+        ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])[sl].cuda()
+        o = slip_loss(wrapped, {"images": images, "captions": ids}, ClipInfoCELoss(), NT_Xent_gather(b), NT_Xent(b), world_size=world)
+        loss, logits, ref_logits = o["loss"], o["outputs"]["logits"][0], g["logits_i"]
+    else:
+        model = build_defilip(cfg, dtype="fp32", seed=seed, nn_size=g["nn_size"])
         model.nn_replacer_text.bank = synth.synth_bank(g["nn_size"], cfg["embed_dim"], seed=seed + rank).cuda()
-        model.nn_replacer_text.bank_ptr = 0
-        o = declip_loss(wrapped, batch, ClipInfoCELoss(), SimsiamLoss(), NTXentLoss(b), world_size=world)
-        o["loss"].backward()
-        torch.cuda.synchronize()
-        assert len(dd._COMM_STREAMS) == 1     # the gather really went through the communication stream
-        total = o["loss"].detach().clone()
-        dist.all_reduce(total)
-        if rank == 0:
-            assert abs(float(total) - g["loss"]) <= 1e-3 * abs(g["loss"]), (float(total), g["loss"])
-            li1 = o["outputs"]["logits"][0].materialize().detach().cpu()
-            assert float((li1 - g["logits_i1"]).abs().max()) <= 1e-3 * float(g["logits_i1"].abs().max())
-            grads = {n: (p.grad.detach().float().cpu() if p.grad is not None else None) for n, p in model.named_parameters()}
-            check_grad_digests(g["grads"], grads, rtol=1e-3)
+        wrapped = dd.DistModule(model, sync=False, bucket_bytes=1 << 14)
+        images = synth.synth_images(B, views=2, res=cfg["res"], seed=seed)[sl].cuda()
+        ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+        ids_aug = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed + 50, vocab=cfg["vocab"], min_len=cfg["ctx"] - 6)
+        ids_masked, labels = synth.synth_mlm(ids, cfg["vocab"], seed=seed)
+        batch = {"images": images, "captions": torch.stack([ids_masked[sl], ids_aug[sl]], dim=1).cuda(), "mlm_labels": labels[sl]}
+        o = declip_loss(wrapped, batch, ClipInfoCELoss(), SimsiamLoss(), None, weights=DEFILIP_WEIGHTS, world_size=world)
+        loss, logits, ref_logits = o["loss"], o["outputs"]["filip"][0], g["filip_i"]
+    loss.backward()
+    wrapped.sync_gradients()
+    torch.cuda.synchronize()
+    total = loss.detach().clone()
+    dist.all_reduce(total)
+    if rank == 0:
+        assert abs(float(total) - g["loss"]) <= 1e-3 * abs(g["loss"]), (float(total), g["loss"])
+        got = (logits.materialize() if hasattr(logits, "materialize") else logits).detach().float().cpu()
+        assert got.shape == (b, B)
+        assert float((got - ref_logits).abs().max()) <= 1e-3 * float(ref_logits.abs().max())
+        grads = named_grads(model)
+        check_grad_digests(g["grads"], grads, rtol=3e-3 if kind == "clip_r50" else 1e-3, **({"only": only} if only else {}))
+        if kind == "clip_r50":
+            for n, ref in g["grads"].items():
+                if not only(n) and ref is not None and ref["norm"] > 1e-6:
+                    assert abs(float(grads[n].double().norm()) - ref["norm"]) <= 5e-2 * ref["norm"], n
+            bufs = dict(model.named_buffers())
+            for k, v in g["bn_buffers"].items():                   # BatchNorm statistics stay per rank: rank 0's against the reference's rank 0
+                if not k.endswith("num_batches_tracked"):
+                    assert float((bufs[k].cpu() - v).abs().max()) <= 1e-3 * max(1.0, float(v.abs().max())), k
     dist.barrier()
     if rank == 0:
         out.put("ok")
     dist.destroy_process_group()
 
 
-def test_declip_two_ranks_on_one_gpu_match_two_reference_ranks():
+@pytest.mark.parametrize("kind", ["clip_r50", "slip", "defilip"])
+def test_small_two_rank_steps_on_one_gpu_match_two_reference_ranks(kind):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_declip_w2_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_small_w2_worker, args=(r, 2, port, kind, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
