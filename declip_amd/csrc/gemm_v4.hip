@@ -1538,8 +1538,8 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
   // tail slicing (bf16 outputs): when the last round of whole tiles would use at most half of the CUs, cut those tiles in K
   int n_full = 0, S = 0;
   if ((md == MODE_STORE || md == MODE_STORE_RES) && a->ws && (((uintptr_t)a->ws & 15) == 0)) {
-    static int tail = -1;
-    if (tail < 0) { const char* ev = getenv("DH_V4_TAIL"); tail = ev ? atoi(ev) : 1; }
+    int tail = 1;      // (read per call: the tests switch it between calls)
+    { const char* ev = getenv("DH_V4_TAIL"); if (ev) tail = atoi(ev); }
     const int T = dh_cdiv(a->N, BN) * dh_cdiv(a->M, BM), G = num_cus(), rem = T % G, nkt = a->K / BK;
     if (tail && T <= G / 2 && nkt >= 8) {
       // FEW tiles (the M = b GEMMs of the pooled last block: 6-24 tiles of 12-48 K-tiles ran on 6-24 CUs, 20-68 us each at 12-90
@@ -1549,7 +1549,10 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
       if (s_ > nkt / 2) s_ = nkt / 2;
       if (s_ >= 2 && a->ws_bytes >= (int64_t)T * s_ * BM * BN * 4) { S = s_; n_full = 0; }
     } else
-    if (tail && T > G && rem > 0 && rem <= G / 2 && nkt >= 24) {   // short-K tiles: the slice overheads eat the gain (measured)
+    // LONG tile lists (300 tiles of the N = d tower GEMMs on 256 CUs): only with DH_V4_TAIL=2.  Since the K-tile stream runs
+    // across work items the whole tail round costs the step exactly what its 34 fix-up launches cost (CLIP b = 512, same box:
+    // 23.52 ms with, 23.53-23.56 ms without; profiles/r03_ab_tail_slicing.txt), so the default keeps the launches out
+    if (tail >= 2 && T > G && rem > 0 && rem <= G / 2 && nkt >= 24) {   // short-K tiles: the slice overheads eat the gain (measured)
       int s_ = G / rem;
       if (s_ > 8) s_ = 8;
       if (s_ > nkt / 2) s_ = nkt / 2;

@@ -220,6 +220,30 @@ def test_attention_varlen_matches_per_sequence_reference(dtype, causal):
         assert float((lse[i, :, :n] - ref_lse).abs().max()) <= (1e-4 if dtype == F32 else 3e-2)
 
 
+@pytest.mark.parametrize("L,causal", [(50, False), (64, True), (33, True)])
+def test_attention_dense_mfma_matches_reference(L, causal):
+    """dh_attn_fwd / _bwd, bf16 (the MFMA kernels; L = 50 / 64: four 16-key blocks, the image tower's instantiation; L = 33: three, with
+    a half-empty last contraction step) against fp32 attention; six (batch, head) pairs on the emulated chip's workgroups."""
+    torch.manual_seed(1)
+    b, heads, hd = 3, 2, 64
+    d = heads * hd
+    qkv = (torch.randn(b * L, 3 * d) * 0.7).to(BF16)
+    dout = torch.randn(b * L, d).to(BF16)
+    with emulated_gpu() as ops:
+        out, lse = ops.attn_fwd(qkv, b, L, heads, causal)
+        dqkv = ops.attn_bwd(qkv, out, dout, lse, b, L, heads, causal)
+    x = qkv.float().requires_grad_()
+    q, k, v = [t.reshape(b, L, heads, hd).transpose(1, 2) for t in x.split(d, dim=1)]
+    s = (q @ k.transpose(2, 3)) * hd ** -0.5
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    ref = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(b * L, d)
+    ref.backward(dout.float())
+    assert float((out.float() - ref.detach()).abs().max()) <= 2e-2 * max(1.0, float(ref.abs().max()))
+    assert float((dqkv.float() - x.grad).abs().max()) <= 6e-2 * max(1.0, float(x.grad.abs().max()))
+    assert float((lse - torch.logsumexp(s.detach(), dim=-1)).abs().max()) <= 3e-2
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_attention_pooled_query_matches_reference(dtype):
     """dh_attn_pooled_fwd / _bwd: one query per sequence against its keys (kv rows row0 .. row0 + nkeys - 1): outputs, lse, dq and
