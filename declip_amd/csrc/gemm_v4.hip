@@ -1419,8 +1419,9 @@ static int* sched_slot(hipStream_t st, int* dyn) {
   // DH_V4_DYNAMIC: 0 (default) static partition; 1 dynamic after each workgroup's first item -- declip_amd.dist sets it for
   // multi-GPU jobs, where RCCL kernels hold CUs during the overlapped gradient all-reduce (measured with a 16-CU hog:
   // static 83 -> 119 us, dynamic 83 -> 101 us; costs ~1.5 % when nothing else runs); 2 fully dynamic + stealing (experimental)
-  static int mode = -1;
-  if (mode < 0) { const char* ev = getenv("DH_V4_DYNAMIC"); mode = ev ? atoi(ev) : 0; }
+  int mode = 0;        // (read per call: the tests switch it between calls; declip_amd.dist sets it before the first launch)
+  { const char* ev = getenv("DH_V4_DYNAMIC"); if (ev) mode = atoi(ev); }
+  if (mode != 0 && mode != 1) mode = 0;
   *dyn = mode;
   if (!mode) return nullptr;
   constexpr int NSLOT = 16;

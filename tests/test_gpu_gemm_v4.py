@@ -215,3 +215,81 @@ def test_v5_experimental_kernel_matches_v4(M, N, K, tb, res):
     o5 = ops.gemm(A, B, b_kmajor=tb, bias=bias, residual=r, force_generic=5)
     assert rel_err(o5, o4.float()) < 8e-3                    # one bf16 ulp where the accumulation order differs
     assert torch.equal(ops.gemm(A, B, b_kmajor=tb, bias=bias, residual=r, force_generic=5), o5)
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv, self.prev = kv, {}
+
+    def __enter__(self):
+        import os
+        for k, v in self.kv.items():
+            self.prev[k] = os.environ.get(k)
+            os.environ[k] = v
+
+    def __exit__(self, *a):
+        import os
+        for k, v in self.prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_v4_dynamic_tile_distribution_is_bit_identical_to_the_static_one():
+    """DH_V4_DYNAMIC=1 -- what every multi-GPU job runs with (declip_amd.dist.initialize: RCCL's kernels hold CUs during the overlapped
+    gradient all-reduce) -- on the tower shapes: which workgroup computes a tile must not change a bit of it.  Forward + bias,
+    residual, GELU + pre-activation, dX + dGELU, the sliced few-tile schedule, split-K and grouped weight gradients; twice, because
+    the per-XCD counters must be back at zero after every launch."""
+    from declip_amd.lib import EPI_DGELU, EPI_GELU
+    ops = _ops()
+    M = 25600
+    A, B, bias = rnd(M, 768, seed=1).to(bf).to(cuda), rnd(3072, 768, seed=2, scale=0.2).to(bf).to(cuda), rnd(3072, seed=3).to(cuda)
+    B2, bias2 = rnd(768, 768, seed=4, scale=0.2).to(bf).to(cuda), rnd(768, seed=5).to(cuda)
+    R = rnd(M, 768, seed=6).to(bf).to(cuda)
+    dY, U = rnd(M, 768, seed=7).to(bf).to(cuda), rnd(M, 3072, seed=8).to(bf).to(cuda)
+    Wp = rnd(768, 3072, seed=11, scale=0.1).to(bf).to(cuda)                     # c_proj weight as stored [out = 768][in = 3072]: contraction-major B of its dX
+    As, Bs = rnd(512, 3072, seed=9).to(bf).to(cuda), rnd(768, 3072, seed=10, scale=0.1).to(bf).to(cuda)          # 6 tiles: K-sliced over the chip
+    probs_src = [(rnd(M, 768, seed=20).to(bf).to(cuda), rnd(M, 768, seed=21).to(bf).to(cuda)),
+                 (rnd(M, 2304, seed=22).to(bf).to(cuda), rnd(M, 768, seed=23).to(bf).to(cuda))]
+
+    def run():
+        outs = []
+        outs.append(ops.gemm(A, B, bias=bias, force_generic=4))
+        outs.append(ops.gemm(A, B2, bias=bias2, residual=R, ws=_ws(), force_generic=4))
+        aux = torch.empty(M, 3072, device=cuda, dtype=bf)
+        outs.append(ops.gemm(A, B, bias=bias, epilogue=EPI_GELU, aux=aux, force_generic=4))
+        outs.append(aux)
+        outs.append(ops.gemm(dY, Wp, b_kmajor=True, epilogue=EPI_DGELU, aux=U, force_generic=4))
+        outs.append(ops.gemm(As, Bs, ws=_ws(), force_generic=4))
+        gw = torch.zeros(768, 768, device=cuda)
+        gb = torch.zeros(768, device=cuda)
+        ops.gemm(probs_src[0][0], probs_src[0][1], a_kmajor=True, b_kmajor=True, out=gw, accumulate=True, split_k=8, a_colsum=gb, ws=_ws(), force_generic=4)
+        outs += [gw, gb]
+        probs = [(dy, x, torch.zeros(dy.shape[1], x.shape[1], device=cuda), torch.zeros(dy.shape[1], device=cuda)) for dy, x in probs_src]
+        ops.gemm_dw_group(probs, ws=_ws(512 << 20))
+        outs += [p[2] for p in probs] + [p[3] for p in probs]
+        torch.cuda.synchronize()
+        return outs
+
+    static = run()
+    with _env(DH_V4_DYNAMIC="1"):
+        ops.gemm_stats(reset=True)
+        dyn1 = run()
+        dyn2 = run()
+        st = ops.gemm_stats()
+    assert st["v4"] >= 2 * 8, st
+    for i, (a, b, c) in enumerate(zip(static, dyn1, dyn2)):
+        assert torch.isfinite(a.float()).all(), i
+        assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+        assert torch.equal(a, c), (i, float((a.float() - c.float()).abs().max()))
+    ref = A.double().cpu() @ B.double().cpu().t() + bias.double().cpu()
+    assert rel_err(static[0], ref) < TOL
+
+
+def test_clip_bf16_step_under_the_dynamic_tile_distribution_matches_the_reference():
+    """the full-width CLIP step (tests/golden/clip_vitb32_b256.pt, bf16 bounds) with DH_V4_DYNAMIC=1 and both tower streams: the
+    configuration of every rank of a multi-GPU run"""
+    import test_gpu_golden_fullwidth as T
+    with _env(DH_V4_DYNAMIC="1"):
+        T.test_clip_vitb32_b256_matches_reference_golden("bf16")
