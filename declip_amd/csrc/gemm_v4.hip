@@ -527,26 +527,27 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     return lf + ls;
   };
   // thread 0 only (dyn == 1: every workgroup's first position is static, the further ones come from its XCD's counter).
-  // FETCH_ISSUE: the non-blocking part -- one returning atomic on the own XCD's counter, result read much later.  INLINE ASM:
-  // inside the exec-masked `if (t == 0)` hipcc would wait for a visible returning atomic right at the end of the branch.  The
-  // result register is read only after the wait at the end of the epilogue (the request is older than everything issued after
-  // it: in-order vmcnt).  It lives in a PLAIN variable written by the issuing asm and "re-defined" by the asm that waits for
-  // it (FETCH_WAIT ties it to the s_waitcnt as an in/out operand): the compiler must not copy it in between, because a copy
-  // made before the wait would carry the stale register contents (checked in the ISA: no moves, no spills).
+  // FETCH: one returning atomic on the own XCD's counter AND the wait for it in ONE asm statement.  Rounds 1-2 issued the atomic
+  // at the start of the epilogue and read its result register at the end, relying on the compiler neither copying, spilling nor
+  // re-using that register in between ("checked in the ISA") -- an invariant nothing enforces: after round 3 re-shaped the
+  // hand-over the residual flavour re-used the register inside the epilogue, the late-arriving counter value overwrote a bias
+  // operand of lane 0 and a handful of outputs per launch lost their bias under DH_V4_DYNAMIC=1
+  // (test_v4_dynamic_tile_distribution_is_bit_identical_to_the_static_one found it).  No register reservation mechanism exists
+  // in this toolchain (amdgpu_num_vgpr is ignored under __launch_bounds__), so the fetch is synchronous now: it sits at the very
+  // end of the epilogue, behind the wait that already covers everything older than the epilogue's stores, and costs the store
+  // drain + one L2 atomic round trip per item (measured: see DESIGN.md s4).
 #if V4_EMU
-#define FETCH_ISSUE(RAW) do { RAW = 1 << 22; if (wgs_on_xcd(xcd, grid) < list_len(xcd)) RAW = atomicAdd(sched + xcd, 1); } while (0)
-#define FETCH_WAIT(N, RAW) do { } while (0)
+#define FETCH(RAW) do { RAW = 1 << 22; if (wgs_on_xcd(xcd, grid) < list_len(xcd)) RAW = atomicAdd(sched + xcd, 1); } while (0)
 #else
-#define FETCH_ISSUE(RAW)                                                                                       \
+#define FETCH(RAW)                                                                                             \
   do {                                                                                                        \
     RAW = 1 << 22;                                                                                            \
     if (wgs_on_xcd(xcd, grid) < list_len(xcd)) {                                                              \
       const int one_ = 1;                                                                                     \
       int* p_ = sched + xcd;                                                                                  \
-      asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(RAW) : "v"(p_), "v"(one_) : "memory");      \
+      asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(RAW) : "v"(p_), "v"(one_) : "memory"); \
     }                                                                                                         \
   } while (0)
-#define FETCH_WAIT(N, RAW) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(RAW) : "n"(N) : "memory")
 #endif
   // packed position of the next item, or -1
   auto fetch_finish = [&](int raw) -> int {
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     have = DECODE(xcd, my_l, nxt);                                       // grid <= items: always true
     if (t == 0) {
       int v;
-      if (dyn) { int r0; FETCH_ISSUE(r0); FETCH_WAIT(0, r0); v = fetch_finish(r0); }
+      if (dyn) { int r0; FETCH(r0); v = fetch_finish(r0); }
       else { const int l = my_l + wgs_on_xcd(xcd, grid); v = (xcd << 24) | l; }     // static partition (validity checked at decode)
       sched_lds[0] = v;
     }
@@ -825,11 +826,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     // ---- the item after next (thread 0): requested now, published at the end of this epilogue
     RELOAD_ARGS();
     int fut = -1;
-    int fut_raw = 1 << 22;
-    if (have && t == 0 && !fast) {
-      if (dyn) FETCH_ISSUE(fut_raw);           // no control flow depends on it until the end of the epilogue
-      else { const int x = nxt_packed >> 24, l = (nxt_packed & 0xffffff) + wgs_on_xcd(x, grid); fut = (x << 24) | l; }
-    }
+    if (have && t == 0 && !fast && !dyn) { const int x = nxt_packed >> 24, l = (nxt_packed & 0xffffff) + wgs_on_xcd(x, grid); fut = (x << 24) | l; }
     TRACE();                                 // [4] epilogue arguments loaded
     pend = 0;
     do {   // the epilogue flavours leave with `break`
@@ -1267,7 +1264,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     // Both BEFORE the barrier that every wave passes on its way into the next item.
     wait_vmcnt_tail(pend);
     if (t == 0) {
-      if (dyn && have) { FETCH_WAIT(63, fut_raw); fut = fetch_finish(fut_raw); }
+      if (dyn && have) { int raw_; FETCH(raw_); fut = fetch_finish(raw_); }
       sched_lds[0] = fut;                        // read by every wave in the second-to-last K-tile of the NEXT item
     }
     wait_lgkm0();
@@ -1291,8 +1288,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
 #undef ISSUE_H
 #undef SETUP_SRC
 #undef RELOAD_ARGS
-#undef FETCH_ISSUE
-#undef FETCH_WAIT
+#undef FETCH
 #undef ADVANCE_SRC
 #undef ISSUE_PIECE
 #undef WAITV

@@ -48,6 +48,22 @@ if "attn_txt" in which:
     outs = [ops.attn_varlen_fwd(q, pk.cu, pk.rows, b, L, heads, True) for q in qkv]
     timed(lambda i: ops.attn_varlen_fwd(qkv[i], pk.cu, pk.rows, b, L, heads, True), pk.rows * d * 2 * 4, "attn fwd text (%d rows, 8 heads)" % pk.rows)
     timed(lambda i: ops.attn_varlen_bwd(qkv[i], outs[i][0], dout[i], outs[i][1], pk.cu, pk.rows, b, L, heads, True), pk.rows * d * 2 * 8, "attn bwd text")
+if "attn_txt_short" in which:
+    # what a smaller instantiation would buy for the SHORT captions: 512 captions of 9 .. 48 tokens through the 77-token kernels
+    # (five 16-key blocks, 320 threads, 68 KB of LDS) and through the 48-token ones (three blocks, 192 threads, 38 KB)
+    b, heads, d = 512, 8, 512
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(9, 49, (b,), generator=g)
+    cu = torch.zeros(b + 1, dtype=torch.int32)
+    cu[1:] = lens.cumsum(0).to(torch.int32)
+    rows = int(lens.sum())
+    rows_pad = (rows + 255) // 256 * 256
+    cu = cu.to(dev)
+    qkv, dout = bf(rows_pad, 3 * d), bf(rows_pad, d)
+    for Lmax in (77, 48):
+        outs = [ops.attn_varlen_fwd(q, cu, rows, b, Lmax, heads, True) for q in qkv]
+        timed(lambda i: ops.attn_varlen_fwd(qkv[i], cu, rows, b, Lmax, heads, True), rows * d * 2 * 4, "attn fwd short captions, Lmax %d" % Lmax)
+        timed(lambda i: ops.attn_varlen_bwd(qkv[i], outs[i][0], dout[i], outs[i][1], cu, rows, b, Lmax, heads, True), rows * d * 2 * 8, "attn bwd short captions, Lmax %d" % Lmax)
 if "ln" in which:
     for rows, d in ((25600, 768), (22016, 512)):
         x, dy, dres = bf(rows, d), bf(rows, d), bf(rows, d)
