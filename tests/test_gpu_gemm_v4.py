@@ -279,6 +279,7 @@ def test_v4_dynamic_tile_distribution_is_bit_identical_to_the_static_one():
         dyn2 = run()
         st = ops.gemm_stats()
     assert st["v4"] >= 2 * 8, st
+
     def where(a, b):
         """which 256 x 256 tiles differ, and in how many elements (a scheduling bug shows as whole tiles, rounding as scattered elements)"""
         if a.dim() != 2:
@@ -291,10 +292,9 @@ def test_v4_dynamic_tile_distribution_is_bit_identical_to_the_static_one():
     ref1 = (A.double() @ B2.double().t() + bias2.double() + R.double())
     for name, o in (("static", static[1]), ("dyn1", dyn1[1]), ("dyn2", dyn2[1])):
         bad = ((o.double() - ref1).abs() > ref1.abs() * 2 ** -7 + 0.02)
-        if int(bad.sum()):
-            r, c = bad.nonzero(as_tuple=True)
-            print("RES output of run %s: %d elements beyond bf16 rounding; (row, col, got, fp64, R, bias):" % (name, int(bad.sum())),
-                  [(int(x), int(y), float(o[x, y]), round(float(ref1[x, y]), 4), float(R[x, y]), round(float(bias2[y]), 3)) for x, y in list(zip(r, c))[:10]])
+        r, c = bad.nonzero(as_tuple=True)          # (round 3: the dynamic run lost the bias of lane 0's outputs in a few tiles -- a clobbered register)
+        assert int(bad.sum()) == 0, ("residual flavour, run %s: %d elements beyond bf16 rounding; (row, col, got, fp64, R, bias):" % (name, int(bad.sum())),
+                                     [(int(x), int(y), float(o[x, y]), round(float(ref1[x, y]), 4), float(R[x, y]), round(float(bias2[y]), 3)) for x, y in list(zip(r, c))[:10]])
     for i, (a, b, c) in enumerate(zip(static, dyn1, dyn2)):
         assert torch.isfinite(a.float()).all(), i
         assert torch.equal(a, b), (i, where(a, b))
