@@ -1,6 +1,7 @@
 """Throughput of the CLIP ViT-B/32 training step (BASELINE.json metric: image-text pairs/sec).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          # starts its own N ranks (one process per GPU over RCCL), or under a launcher:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -139,6 +140,94 @@ def loss_delta_vs_cpu_ref(dev):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: start one process per GPU ourselves -- the reference starts its
+    ranks the same way, one process per device with the rank in the environment (prototype/utils/dist.py:18-24,
+    solver/clip_solver.py:740-764).  Rank r gets RANK = LOCAL_RANK = r, WORLD_SIZE = N, MASTER_ADDR = 127.0.0.1 and a free port;
+    rank 0's stdout (the ONE JSON line) is passed through, the other ranks print nothing.  Fewer devices than ranks (RCCL wants
+    one device per rank; DH_DIST_BACKEND=gloo lets ranks share a device for tests): a JSON `error` line and exit code 3 -- never an
+    assertion.  Returns the exit code."""
+    import subprocess
+    backend = os.environ.get("DH_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    dry = "--dry-run-launch" in sys.argv
+    if backend == "nccl" and ndev < n and not dry:
+        print(json.dumps(dict(error="--gpus %d needs %d devices, this box has %d" % (n, n, ndev), n_gpus=n, devices_visible=ndev,
+                              hint="DH_DIST_BACKEND=gloo lets several ranks share one device (functional check only)")), flush=True)
+        return 3
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DH_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL across processes)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = dict(enumerate(procs))
+        while pending:
+            for r, p in list(pending.items()):
+                code = p.poll()
+                if code is None:
+                    continue
+                del pending[r]
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending.values():      # a rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if rc not in (0, 3):
+        print(json.dumps(dict(error="a rank of the self-launched job exited with code %d" % rc, n_gpus=n)), flush=True)
+    return rc
+
+
+def dry_run_launch(args):
+    """--dry-run-launch: everything `bench.py --gpus N` does around the timed steps -- process group from the environment, the
+    SUM-of-ones check of the communicator, (host, device) of every rank, ONE JSON line from rank 0 -- without a model.  Works on a
+    box without a GPU (gloo)."""
+    from declip_amd import dist as dh_dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(json.dumps(dict(error="--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))), flush=True)
+        return 3
+    dh_dist.initialize("nccl")
+    import torch.distributed as tdist
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    ones = torch.ones(1, device=dev)
+    if world > 1:
+        tdist.all_reduce(ones)
+    ranks = [None] * world
+    me = (os.uname().nodename, torch.cuda.current_device() if torch.cuda.is_available() else -1)
+    if world > 1:
+        tdist.all_gather_object(ranks, me)
+    else:
+        ranks = [me]
+    ok = int(round(float(ones))) == world
+    if rank == 0:
+        print(json.dumps(dict(metric="image-text pairs/sec CLIP ViT-B/32", value=0.0, unit="pairs/s", n_gpus=world, steps=0, warmup=0,
+                              dry_run=True, scaling="weak", higher_is_better=True,
+                              config=dict(rccl_ranks=int(round(float(ones))), dist_backend=(tdist.get_backend() if world > 1 else None),
+                                          ranks=[list(x) for x in ranks], self_launched=int(os.environ.get("DH_BENCH_SELF_LAUNCHED", "0")))),
+                         **({} if ok else dict(error="communicator does not match the launch"))), flush=True)
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+    return 0 if ok else 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,7 +255,15 @@ def main():
                          "their source size + crop boxes + caption STRINGS through declip_amd.prefetch.DataPrefetcher (BPE on its worker "
                          "thread, pinned upload on a copy stream, resize / mirror / normalise on the GPU; clip_solver.py:30-63, "
                          "imagenet_dataloader.py:36-47).  Eager steps (every batch has its own packed row count).  clip only.")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="launch check only: rendezvous, communicator sanity check and the JSON line, no model and no timed steps "
+                         "(runs on a box without a GPU over gloo: tests/test_bench_launch.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))         # `python bench.py --gpus N`: this process becomes the launcher of N ranks
+    if args.dry_run_launch:
+        sys.exit(dry_run_launch(args))
 
     if args.text_packed is not None:
         os.environ["DH_TEXT_PACKED"] = args.text_packed
@@ -186,7 +283,10 @@ def main():
         dh_dist.initialize("nccl")
     else:
         torch.cuda.set_device(0)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:                    # (a launcher that set WORLD_SIZE to something else)
+        if rank == 0:
+            print(json.dumps(dict(error="--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))), flush=True)
+        sys.exit(3)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     torch.manual_seed(1234 + rank)            # random-init weights, reproducible from run to run (the loss in the line is then too)
@@ -236,6 +336,7 @@ def main():
     # sanity of a multi-GPU launch before anything is timed: every rank of the launch is in the communicator (a SUM all-reduce of
     # ones over RCCL must count `world` ranks) and sits on its own device
     rccl_ranks = 1
+    devs = [(os.uname().nodename, torch.cuda.current_device())]
     if world > 1:
         ones = torch.ones(1, device=dev)
         torch.distributed.all_reduce(ones)
@@ -489,6 +590,7 @@ def main():
                                            "pinned H2D on a copy stream, dh_image_resized_crop_u8 on the GPU" % hostinfo.usable_cores()),
                            host_threads=host_threads,
                            rccl_ranks=rccl_ranks, dist_backend=(torch.distributed.get_backend() if world > 1 else None),
+                           ranks=[list(x) for x in devs], self_launched=int(os.environ.get("DH_BENCH_SELF_LAUNCHED", "0")),
                            dynamic_tiles=int(os.environ.get("DH_V4_DYNAMIC", "0")), comm_native=int(dh_dist.native_comm() is not None) if world > 1 else 0,
                            text_packed=eng_mod.text_packed_mode(), pooled_last=int(eng_mod.pooled_last_block())),   # captions computed up to <|endoftext|> only; last block for the pooled rows only (same outputs, fewer executed flops: see roofline.executed_gemm_gflop_per_pair)
                loss=round(float(loss.detach()) * world, 5))

@@ -664,6 +664,9 @@ FIXTURES = {
     "filip_vitb32_e768_b256": lambda: gen_filip("filip_vitb32_e768_b256", synth.FILIP_VITB32, b=256, seed=24),
     "declip_vitb32_b128_w2": lambda: gen_declip("declip_vitb32_b128_w2", synth.VITB32, b=128, seed=26, nn_size=4096, world=2),
     "filip_vitb32_e768_b256_w2": lambda: gen_filip("filip_vitb32_e768_b256_w2", synth.FILIP_VITB32, b=256, seed=25, world=2),
+    # round 4: the two families that had no fixture at shapes the benchmarked kernel takes
+    "defilip_vitb32_b128": lambda: gen_defilip("defilip_vitb32_b128", synth.VITB32, b=128, seed=27, nn_size=4096),
+    "slip_vitb32_b128_w2": lambda: gen_slip("slip_vitb32_b128_w2", synth.VITB32, b=128, seed=28, world=2),
     "zeroshot_tiny": lambda: gen_zeroshot("zeroshot_tiny", synth.TINY, label_num=7, prompts_num=3, b=5, batches=2, seed=8),
 }
 
