@@ -316,7 +316,6 @@ int launch_mfma(const dh_gemm_args* a, const EpiParams& e, int split, int kps, h
 bool dh_gemm_try_glds(const dh_gemm_args* a, int split, hipStream_t st);  // gemm_glds.hip
 bool dh_gemm_try_v3(const dh_gemm_args* a, int split, hipStream_t st);    // gemm_v3.hip
 bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st);    // gemm_v4.hip
-bool dh_gemm_try_v5(const dh_gemm_args* a, hipStream_t st);               // gemm_v5.hip (DH_GEMM_V5=1)
 
 // launches per kernel family since the last reset: [0] v4 persistent 256x256, [1] v3, [2] v2 LDS-DMA 128x128, [3] v1 MFMA tiles,
 // [4] generic (VALU).  The parity tests assert with it that a fixture really ran on the benchmarked kernel.
@@ -372,12 +371,6 @@ extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
 
   if (a->a_colsum) DH_REQUIRE(a->a_kmajor, "dh_gemm: a_colsum needs a_kmajor");
   // v2 (LDS-DMA + transpose-read) kernel when shapes/alignments allow it (fuses a_colsum)
-  if ((a->force_generic == 0 || a->force_generic == 5) && dh_gemm_try_v5(a, st)) {
-    ++g_gemm_family_calls[0];
-    DH_CHECK_LAUNCH();
-    return DH_OK;
-  }
-  DH_REQUIRE(a->force_generic != 5, "dh_gemm: the v5 kernel does not support this problem (or DH_GEMM_V5 is not set)");
   if ((a->force_generic == 0 || a->force_generic == 4) && dh_gemm_try_v4(a, split, st)) {
     ++g_gemm_family_calls[0];
     DH_CHECK_LAUNCH();

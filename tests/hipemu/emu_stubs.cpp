@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY -- the GEMM families written entirely in inline ISA (gemm_v3 / gemm_glds / gemm_v5) cannot be emulated:
+// TEST INFRASTRUCTURE ONLY -- the GEMM families written entirely in inline ISA (gemm_v3 / gemm_glds) cannot be emulated:
 // on the host build the dispatcher of gemm.hip sees them decline every problem and falls through to the kernels the emulation
 // covers.  gemm_v4 -- the benchmarked kernel -- keeps its inline ISA behind macros and DOES compile for the emulation (build it
 // instead of emu_stubs_v4.cpp: tests/hipemu_util.py V4_SOURCES).
@@ -8,4 +8,3 @@
 
 bool dh_gemm_try_glds(const dh_gemm_args*, int, hipStream_t) { return false; }
 bool dh_gemm_try_v3(const dh_gemm_args*, int, hipStream_t) { return false; }
-bool dh_gemm_try_v5(const dh_gemm_args*, hipStream_t) { return false; }

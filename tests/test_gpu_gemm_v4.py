@@ -201,22 +201,6 @@ def test_v4_group_falls_back_for_shapes_it_cannot_take():
         assert rel_err(gw, rw) < 2e-5 and rel_err(gb, rb) < 2e-5
 
 
-@pytest.mark.parametrize("M,N,K,tb,res", [(512, 256, 128, False, True), (2816, 1280, 704, False, True), (768, 512, 192, True, False),
-                                           (5120, 768, 768, False, False)])
-def test_v5_experimental_kernel_matches_v4(M, N, K, tb, res):
-    """gemm_v5.hip (256 x 128 tiles, the epilogue of a tile inside the next tile's K loop; opt-in): same results as
-    the production kernel -- several tiles per workgroup (the pipelined epilogue), both operand layouts, bias + residual."""
-    ops = _ops()
-    A = rnd(M, K, seed=1).to(bf).to(cuda)
-    B = (rnd(K, N, seed=2, scale=0.2) if tb else rnd(N, K, seed=2, scale=0.2)).to(bf).to(cuda)
-    bias = rnd(N, seed=3).to(cuda)
-    r = rnd(M, N, seed=4).to(bf).to(cuda) if res else None
-    o4 = ops.gemm(A, B, b_kmajor=tb, bias=bias, residual=r, force_generic=4, ws=_ws())
-    o5 = ops.gemm(A, B, b_kmajor=tb, bias=bias, residual=r, force_generic=5)
-    assert rel_err(o5, o4.float()) < 8e-3                    # one bf16 ulp where the accumulation order differs
-    assert torch.equal(ops.gemm(A, B, b_kmajor=tb, bias=bias, residual=r, force_generic=5), o5)
-
-
 class _env:
     def __init__(self, **kv):
         self.kv, self.prev = kv, {}
