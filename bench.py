@@ -483,6 +483,8 @@ def main():
         # the chip with the other tower's launches and its event-bracketed duration measures the overlap, not the kernel
         streams_env = os.environ.get("DH_TOWER_STREAMS")
         os.environ["DH_TOWER_STREAMS"] = "0"
+        native_env = os.environ.get("DH_BLOCK_NATIVE")
+        os.environ["DH_BLOCK_NATIVE"] = "0"      # per-op composition: the brackets sit around ops.gemm (same kernels as the C-level block calls)
         # one untimed step in this mode first: the text tower now allocates from the main stream's pool, and a hipMalloc
         # between an event pair (ops.gemm allocates its output) would be billed to that GEMM
         ops.gemm = orig
@@ -521,6 +523,10 @@ def main():
             del os.environ["DH_TOWER_STREAMS"]
         else:
             os.environ["DH_TOWER_STREAMS"] = streams_env
+        if native_env is None:
+            del os.environ["DH_BLOCK_NATIVE"]
+        else:
+            os.environ["DH_BLOCK_NATIVE"] = native_env
         flops = sum(r[2] for r in records if r[3] == torch.bfloat16 or args.dtype != "bf16")
         ms_raw = sum(r[0].elapsed_time(r[1]) for r in records if r[3] == torch.bfloat16 or args.dtype != "bf16")
         ms = sum(max(r[0].elapsed_time(r[1]) - pair_ms, 0.0) for r in records if r[3] == torch.bfloat16 or args.dtype != "bf16")
@@ -592,6 +598,7 @@ def main():
                            rccl_ranks=rccl_ranks, dist_backend=(torch.distributed.get_backend() if world > 1 else None),
                            ranks=[list(x) for x in devs], self_launched=int(os.environ.get("DH_BENCH_SELF_LAUNCHED", "0")),
                            dynamic_tiles=int(os.environ.get("DH_V4_DYNAMIC", "0")), comm_native=int(dh_dist.native_comm() is not None) if world > 1 else 0,
+                           native_blocks=int(eng_mod.native_blocks()),
                            text_packed=eng_mod.text_packed_mode(), pooled_last=int(eng_mod.pooled_last_block())),   # captions computed up to <|endoftext|> only; last block for the pooled rows only (same outputs, fewer executed flops: see roofline.executed_gemm_gflop_per_pair)
                loss=round(float(loss.detach()) * world, 5))
     if roofline is not None:

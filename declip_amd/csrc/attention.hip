@@ -208,6 +208,7 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
   }
   __syncthreads();                         // every wave is done with the tiles before the next pair overwrites them
   }
+  if (VL) tail0 = tail0 < 0 ? cu[nbh / heads] : tail0;     // rows = -1: the valid row count is cu_seqlens[b], read here (no host value in the launch: the captured step replays for any batch of this padded size)
   if (VL && tail1 > tail0) {
     // packed layout: the rows between the last caption and the whole-tile row count are ZERO (they meet the weight-gradient GEMMs as
     // contraction rows); written here instead of by a separate fill launch per attention call (24 launches per CLIP step)
@@ -398,6 +399,7 @@ __global__ __launch_bounds__(64 * NKB, 3) void attn_bwd_mfma_kernel(const bf16_t
   }
   __syncthreads();                         // every wave is done with the tiles before the next pair overwrites them
   }
+  if (VL) tail0 = tail0 < 0 ? cu[nbh / heads] : tail0;     // (see the forward kernel)
   if (VL && tail1 > tail0) {
     // packed layout: the rows between the last caption and the whole-tile row count are ZERO (they meet the weight-gradient GEMMs as
     // contraction rows); written here instead of by a separate fill launch per attention call (24 launches per CLIP step)
@@ -602,8 +604,9 @@ extern "C" int dh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, in
 extern "C" int dh_attn_varlen_fwd(int dtype, const void* qkv, void* out, float* lse, const int* cu_seqlens, int b, int Lmax, int heads,
                                   int hd, int causal, int rows, int rows_pad, dh_stream_t stream) {
   DH_REQUIRE(cu_seqlens, "dh_attn_varlen_fwd: cu_seqlens is NULL");
-  DH_REQUIRE(rows >= 0 && rows_pad >= rows, "dh_attn_varlen_fwd: rows %d, rows_pad %d", rows, rows_pad);
   const bool in_kernel = dtype == DH_BF16 && hd == 64;
+  DH_REQUIRE((rows >= 0 && rows_pad >= rows) || (rows == -1 && in_kernel && rows_pad > 0),
+             "dh_attn_varlen_fwd: rows %d, rows_pad %d (rows = -1, 'read cu_seqlens[b] on the device', needs the bf16 / hd = 64 kernels)", rows, rows_pad);
   if (!in_kernel && rows_pad > rows) {
     const size_t esz = dtype == DH_BF16 ? 2 : 4, w = (size_t)heads * hd;
     if (hipMemsetAsync((char*)out + (size_t)rows * w * esz, 0, (size_t)(rows_pad - rows) * w * esz, (hipStream_t)stream) != hipSuccess)
@@ -646,8 +649,9 @@ extern "C" int dh_attn_varlen_bwd(int dtype, const void* qkv, const void* out, c
                                   const int* cu_seqlens, int b, int Lmax, int heads, int hd, int causal, int rows, int rows_pad,
                                   dh_stream_t stream) {
   DH_REQUIRE(cu_seqlens, "dh_attn_varlen_bwd: cu_seqlens is NULL");
-  DH_REQUIRE(rows >= 0 && rows_pad >= rows, "dh_attn_varlen_bwd: rows %d, rows_pad %d", rows, rows_pad);
   const bool in_kernel = dtype == DH_BF16 && hd == 64;
+  DH_REQUIRE((rows >= 0 && rows_pad >= rows) || (rows == -1 && in_kernel && rows_pad > 0),
+             "dh_attn_varlen_bwd: rows %d, rows_pad %d (rows = -1, 'read cu_seqlens[b] on the device', needs the bf16 / hd = 64 kernels)", rows, rows_pad);
   if (!in_kernel && rows_pad > rows) {
     const size_t esz = dtype == DH_BF16 ? 2 : 4, w = (size_t)3 * heads * hd;
     if (hipMemsetAsync((char*)dqkv + (size_t)rows * w * esz, 0, (size_t)(rows_pad - rows) * w * esz, (hipStream_t)stream) != hipSuccess)

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void text_embed_packed_fwd_kernel(const int64_
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)rows_pad * nchunk; i += (long)gridDim.x * 256) {
     const int row = (int)(i / nchunk), ch = (int)(i % nchunk);
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (row < rows) {
+    if (row < rows && pos_idx[row] >= 0) {       // (pos_idx < 0: a padding row of a bookkeeping sized by rows_pad alone)
       float p[8];
       ld8(table + ids_p[row] * d + ch * 8, a);
       ld8(pos + (long)pos_idx[row] * d + ch * 8, p);

@@ -283,6 +283,36 @@ class BlockRefs:
         self.g_w_fc, self.g_b_fc, self.g_w_proj, self.g_b_proj = g(blk.mlp.c_fc.weight), g(blk.mlp.c_fc.bias), g(blk.mlp.c_proj.weight), g(blk.mlp.c_proj.bias)
         self.eps1, self.eps2 = blk.ln_1.eps, blk.ln_2.eps
         self.trainable = all(p.requires_grad for p in self.params)
+        self._cparams = None
+
+    def cparams(self):
+        """lib.BlockParams of this block (dh_block_fwd / dh_block_bwd), filled once: the views above never move while the flat
+        store stays attached (block_refs re-creates the BlockRefs when it does not)."""
+        if self._cparams is None:
+            from .lib import BlockParams
+            ptr = ops.ptr
+            c = BlockParams()
+            for n in ("w_in", "w_out", "w_fc", "w_proj", "b_in", "b_out", "b_fc", "b_proj", "ln1_w", "ln1_b", "ln2_w", "ln2_b",
+                      "g_w_in", "g_w_out", "g_w_fc", "g_w_proj", "g_b_in", "g_b_out", "g_b_fc", "g_b_proj", "g_ln1_w", "g_ln1_b", "g_ln2_w", "g_ln2_b"):
+                setattr(c, n, ptr(getattr(self, n)))
+            c.eps1, c.eps2 = float(self.eps1), float(self.eps2)
+            self._cparams = c
+        return self._cparams
+
+
+def block_refs(flat, blocks):
+    """BlockRefs of a tower's blocks, cached on the block modules: building ~40 tensor views per block on every forward was
+    ~1.5 ms of host time per CLIP step.  The cache key is the identity of the flat buffers (a re-attach replaces them)."""
+    key = (flat.flat_p.data_ptr(), flat.flat_g.data_ptr(), 0 if flat.flat_b is None else flat.flat_b.data_ptr())
+    out = []
+    for blk in blocks:
+        c = blk.__dict__.get("_dh_refs")
+        if c is None or c[0] != key or any(p.data_ptr() != q for p, q in zip(c[1].params, c[2])):
+            r = BlockRefs(flat, blk)
+            c = (key, r, [p.data_ptr() for p in r.params])
+            blk.__dict__["_dh_refs"] = c
+        out.append(c[1])
+    return out
 
 
 def _split_k(mg, ng, kg):
@@ -408,8 +438,110 @@ def _ln_bwd(dy, x, w, mean, rstd, dw, db, dres=None):
     return ops.layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=dres)
 
 
+def native_blocks():
+    """One C-ABI call per transformer block and direction (dh_block_fwd / dh_block_bwd, csrc/block.hip) instead of one per kernel:
+    default.  DH_BLOCK_NATIVE=0 composes the block from the per-op calls in Python (same kernels, same results; bench.py's
+    per-GEMM event brackets need it)."""
+    return os.environ.get("DH_BLOCK_NATIVE", "1") == "1" and ops.block_native_available()
+
+
+_BWD_SCRATCH = {}
+
+
+def _bwd_scratch(device, nbytes):
+    """Temporaries of dh_block_bwd (du, dqkv, dh2, dx_mid, da, dh1), one buffer per device and stream, reused block after block
+    (everything that reads it is enqueued on that stream before the next block overwrites it)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    buf = _BWD_SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        _BWD_SCRATCH[key] = buf
+    return buf
+
+
+class NativeSaved(object):
+    """What dh_block_bwd needs of a block forward that ran through dh_block_fwd: the input, the activation slab, the geometry."""
+    __slots__ = ("x", "act", "b", "L", "heads", "causal", "cu", "rows_valid")
+
+    def views(self):
+        """The slab as the tensors the Python composition saves (block_fwd's tuple; no copies)."""
+        from .lib import dt
+        rows, d = self.x.shape
+        total, off = ops.block_act_layout(dt(self.x), rows, d, self.heads, self.b, self.L)
+        e = self.x.element_size()
+
+        def t(name, shape, dtype):
+            n = 1
+            for v in shape:
+                n *= v
+            nb = n * (4 if dtype == torch.float32 else e)
+            return self.act[off[name]:off[name] + nb].view(dtype).view(shape)
+        dtp = self.x.dtype
+        h1, qkv, a = t("h1", (rows, d), dtp), t("qkv", (rows, 3 * d), dtp), t("a", (rows, d), dtp)
+        x_mid, h2, u, g = t("x_mid", (rows, d), dtp), t("h2", (rows, d), dtp), t("u", (rows, 4 * d), dtp), t("g", (rows, 4 * d), dtp)
+        f = torch.float32
+        mean1, rstd1, mean2, rstd2 = t("mean1", (rows,), f), t("rstd1", (rows,), f), t("mean2", (rows,), f), t("rstd2", (rows,), f)
+        lse = t("lse", (self.b, self.heads, self.L), f)
+        return self.x, mean1, rstd1, h1, qkv, a, lse, x_mid, mean2, rstd2, h2, u, g
+
+
+def _block_cargs(x, r, b, L, heads, causal, cu, rows_valid):
+    from .lib import BlockArgs, dt
+    ptr = ops.ptr
+    a = BlockArgs()
+    rows, d = x.shape
+    a.dtype, a.rows, a.d, a.heads, a.b, a.L, a.causal = dt(x), rows, d, heads, b, L, int(bool(causal))
+    a.cu, a.rows_valid = ptr(cu), int(rows_valid)
+    a.p = r.cparams()
+    if x.is_cuda and x.dtype == torch.bfloat16:
+        ws = gemm_workspace(x.device)
+        a.ws, a.ws_bytes = ptr(ws), ws.numel() * 4
+    return a
+
+
+def _block_fwd_native(x, r, b, L, heads, causal, save, cu=None, rows_valid=0):
+    from .lib import dt
+    ptr = ops.ptr
+    rows, d = x.shape
+    total, _ = ops.block_act_layout(dt(x), rows, d, heads, b, L)
+    act = torch.empty(total, device=x.device, dtype=torch.uint8)
+    x_out = torch.empty_like(x)
+    a = _block_cargs(x, r, b, L, heads, causal, cu, rows_valid)
+    a.save = int(bool(save))
+    a.x, a.x_out, a.act, a.act_bytes = ptr(x), ptr(x_out), ptr(act), total
+    ops.block_fwd(a)
+    if not save:
+        return x_out, None
+    sv = NativeSaved()
+    sv.x, sv.act, sv.b, sv.L, sv.heads, sv.causal, sv.cu, sv.rows_valid = x, act, b, L, heads, causal, cu, rows_valid
+    return x_out, sv
+
+
+def _block_bwd_native(dx_out, r, sv):
+    from .lib import dt
+    ptr = ops.ptr
+    x = sv.x
+    rows, d = x.shape
+    lnb = _LNB
+    n = ops.layernorm_bwd_ws_elems(rows, d)
+    part1, part2 = lnb._slice(n, x.device), lnb._slice(n, x.device)
+    nscr = ops.block_bwd_scratch_bytes(dt(x), rows, d)
+    scratch = _bwd_scratch(x.device, nscr)
+    dx = torch.empty_like(x)
+    a = _block_cargs(x, r, sv.b, sv.L, sv.heads, sv.causal, sv.cu, sv.rows_valid)
+    a.x, a.act, a.act_bytes = ptr(x), ptr(sv.act), sv.act.numel()
+    a.dx_out, a.dx, a.scratch, a.scratch_bytes = ptr(dx_out), ptr(dx), ptr(scratch), nscr
+    a.ln_part1, a.ln_part2, a.ln_part_bytes = ptr(part1), ptr(part2), n * 4
+    ops.block_bwd(a)
+    lnb.items.append((part2, int(a.ln_nb2), d, r.g_ln2_w, r.g_ln2_b))
+    lnb.items.append((part1, int(a.ln_nb1), d, r.g_ln1_w, r.g_ln1_b))
+    return dx
+
+
 def block_fwd(x, r, b, L, heads, causal, save):
-    """x: [b*L, d].  Returns x_out; if `save`, also the tuple needed by block_bwd."""
+    """x: [b*L, d].  Returns x_out; if `save`, also what block_bwd needs."""
+    if native_blocks():
+        return _block_fwd_native(x, r, b, L, heads, causal, save)
     h1, mean1, rstd1 = ops.layernorm_fwd(x, r.ln1_w, r.ln1_b, r.eps1)
     qkv = ops.gemm(h1, r.w_in, bias=r.b_in)
     a, lse = ops.attn_fwd(qkv, b, L, heads, causal)
@@ -424,6 +556,10 @@ def block_fwd(x, r, b, L, heads, causal, save):
 
 
 def block_bwd(dx_out, r, saved, b, L, heads, causal):
+    if isinstance(saved, NativeSaved):
+        if _LNB is not None and _LNB.enabled and native_blocks() and dx_out.is_contiguous():
+            return _block_bwd_native(dx_out, r, saved)
+        saved = saved.views()
     x, mean1, rstd1, h1, qkv, a, lse, x_mid, mean2, rstd2, h2, u, g = saved
     # MLP: x_out = x_mid + gelu(h2 Wfc^T + bfc) Wproj^T + bproj
     dw = DwGroup()
@@ -558,7 +694,7 @@ class VisionTowerFn(torch.autograd.Function):
         patches = ops.gemm(rows, wconv)
         x0 = ops.vit_assemble_fwd(patches, tower.class_embedding.data, tower.positional_embedding.data, b, npatch)
         x, mean0, rstd0 = ops.layernorm_fwd(x0, tower.ln_pre.weight.data, tower.ln_pre.bias.data, tower.ln_pre.eps)
-        refs = [BlockRefs(flat, blk) for blk in tower.transformer.resblocks]
+        refs = block_refs(flat, tower.transformer.resblocks)
         saved_blocks = []
         pool = None
         if pooled_last_block(width, heads, L) and not want_dense and refs:
@@ -668,7 +804,7 @@ class TextTowerFn(torch.autograd.Function):
         b, L = ids.shape
         width, heads = tower.width, tower.heads
         x = ops.text_embed_fwd(ids, tower.token_embedding.weight.data, tower.positional_embedding.data, dtype)
-        refs = [BlockRefs(flat, blk) for blk in tower.transformer.resblocks]
+        refs = block_refs(flat, tower.transformer.resblocks)
         saved_blocks = []
         save = bool(ctx.needs_input_grad[0])
         flat.tower_forward(tower, save)
@@ -788,15 +924,21 @@ class PackedCaptions:
         if tag is not None and tag[0] == ids._version and hasattr(torch, "_assert_async"):
             torch._assert_async(lens.sum() == total)                     # a host-side count that does not match fails loudly (device-side assert, no read-back)
         self.b, self.L, self.rows = b, L, total
-        self.rows_pad = (total + tile - 1) // tile * tile
+        self.rows_pad = rows_pad = (total + tile - 1) // tile * tile
+        # Every index tensor below has a shape that depends on rows_pad only (never on `total`), and no launch argument carries
+        # `total`: the whole bookkeeping is capturable, and a step captured for one batch replays for any batch with the same
+        # rows_pad (graph.GraphedStep keys its graphs by it).  The rows [total, rows_pad) are a dummy run behind the last caption:
+        # sequence index b, pos_idx = -1 (the embedding writes zeros there), id 0 with a zero gradient row.
         cu = torch.zeros(b + 1, device=ids.device, dtype=torch.int64)
         cu[1:] = lens.cumsum(0)
         self.cu = cu.to(torch.int32)
-        seq = torch.repeat_interleave(torch.arange(b, device=ids.device), lens, output_size=total)
-        pos = torch.arange(total, device=ids.device) - cu[seq]
-        self.pos_idx = pos.to(torch.int32).contiguous()
-        self.pack_idx = (seq * L + pos).contiguous()                     # dense row (bi * L + l) of every packed row
-        self.ids_p = ids.reshape(-1)[self.pack_idx].contiguous()
+        lens_ext = torch.cat([lens, rows_pad - cu[b:]])
+        seq = torch.repeat_interleave(torch.arange(b + 1, device=ids.device), lens_ext, output_size=rows_pad)
+        valid = seq < b
+        pos = torch.arange(rows_pad, device=ids.device) - cu[seq]
+        self.pos_idx = torch.where(valid, pos, torch.full_like(pos, -1)).to(torch.int32).contiguous()
+        self.pack_idx = torch.where(valid, seq * L + pos, torch.zeros_like(pos)).contiguous()   # dense row (bi * L + l) of every packed row (padding: row 0)
+        self.ids_p = torch.where(valid, ids.reshape(-1)[self.pack_idx], torch.zeros_like(pos)).contiguous()
         l = torch.arange(L, device=ids.device)[None, :]
         # dense (bi, l) -> a packed row: its own when l < len, else the caption's first row (any finite values do: a padded query
         # is dropped again, a padded key is only seen by padded queries)
@@ -804,18 +946,26 @@ class PackedCaptions:
         self.eot_rows = (cu[1:] - 1).contiguous()
 
 
+def _rows_arg(pk, x, heads):
+    """The valid row count as the attention kernels take it: -1 = "read cu_seqlens[b] on the device" wherever the kernels can
+    (bf16, head dimension 64: nothing of a launch then depends on the batch's caption lengths but rows_pad), the host count else."""
+    return -1 if (x.dtype == torch.bfloat16 and x.shape[1] // heads == 64) else pk.rows
+
+
 def block_fwd_packed(x, r, pk, heads, save):
     """block_fwd on packed rows [rows_pad, d].  Attention: the variable-length kernels on the packed rows (pk.varlen), or -- the
     fallback that touches only long-verified kernels, DH_TEXT_PACKED=2 -- gather to the dense [b, L] layout and back."""
+    if pk.varlen and native_blocks():
+        return _block_fwd_native(x, r, pk.b, pk.L, heads, True, save, cu=pk.cu, rows_valid=_rows_arg(pk, x, heads))
     h1, mean1, rstd1 = ops.layernorm_fwd(x, r.ln1_w, r.ln1_b, r.eps1)
     qkv = ops.gemm(h1, r.w_in, bias=r.b_in)
     if pk.varlen:
-        a, lse = ops.attn_varlen_fwd(qkv, pk.cu, pk.rows, pk.b, pk.L, heads, True)
+        a, lse = ops.attn_varlen_fwd(qkv, pk.cu, _rows_arg(pk, x, heads), pk.b, pk.L, heads, True)
         att_saved = (qkv, a)
     else:
         qkv_d = ops.gather_rows(qkv, pk.unpack_idx)
         a_d, lse = ops.attn_fwd(qkv_d, pk.b, pk.L, heads, True)
-        a = ops.gather_rows(a_d, pk.pack_idx, pk.rows_pad)
+        a = ops.gather_rows(a_d, pk.pack_idx[:pk.rows], pk.rows_pad)
         att_saved = (qkv_d, a_d)
     ws = gemm_workspace(x.device) if x.is_cuda and x.dtype == torch.bfloat16 else None
     x_mid = ops.gemm(a, r.w_out, bias=r.b_out, residual=x, ws=ws)
@@ -828,6 +978,11 @@ def block_fwd_packed(x, r, pk, heads, save):
 
 
 def block_bwd_packed(dx_out, r, saved, pk, heads):
+    if isinstance(saved, NativeSaved):
+        if _LNB is not None and _LNB.enabled and native_blocks() and dx_out.is_contiguous():
+            return _block_bwd_native(dx_out, r, saved)
+        x, mean1, rstd1, h1, qkv, a, lse, x_mid, mean2, rstd2, h2, u, g = saved.views()
+        saved = (x, mean1, rstd1, h1, (qkv, a), a, lse, x_mid, mean2, rstd2, h2, u, g)
     x, mean1, rstd1, h1, att_saved, a, lse, x_mid, mean2, rstd2, h2, u, g = saved
     dw = DwGroup()
     dw.add(dx_out, g, r.g_w_proj, r.g_b_proj)
@@ -840,14 +995,14 @@ def block_bwd_packed(dx_out, r, saved, pk, heads):
     da = ops.gemm(dx_mid, r.w_out, b_kmajor=True, ws=ws)
     if pk.varlen:
         qkv, a_p = att_saved
-        dqkv = ops.attn_varlen_bwd(qkv, a_p, da, lse, pk.cu, pk.rows, pk.b, pk.L, heads, True)
+        dqkv = ops.attn_varlen_bwd(qkv, a_p, da, lse, pk.cu, _rows_arg(pk, x, heads), pk.b, pk.L, heads, True)
     else:
         qkv_d, a_d = att_saved
         # padded queries must carry a ZERO output gradient: a later (padded) query does attend to the valid keys before it
         da_d = torch.zeros(pk.b * pk.L, da.shape[1], device=da.device, dtype=da.dtype)
-        ops.scatter_rows_add(da[:pk.rows], pk.pack_idx, da_d)
+        ops.scatter_rows_add(da[:pk.rows], pk.pack_idx[:pk.rows], da_d)
         dqkv_d = ops.attn_bwd(qkv_d, a_d, da_d, lse, pk.b, pk.L, heads, True)
-        dqkv = ops.gather_rows(dqkv_d, pk.pack_idx, pk.rows_pad)
+        dqkv = ops.gather_rows(dqkv_d, pk.pack_idx[:pk.rows], pk.rows_pad)
     dw.add(dqkv, h1, r.g_w_in, r.g_b_in)
     dh1 = ops.gemm(dqkv, r.w_in, b_kmajor=True, ws=ws)
     dx = _ln_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
@@ -878,8 +1033,8 @@ class TextTowerPackedFn(torch.autograd.Function):
         dtype = flat.act_dtype
         pk = packed_captions(ids, dtype)
         x = ops.text_embed_packed_fwd(pk.ids_p, pk.pos_idx, tower.token_embedding.weight.data, tower.positional_embedding.data, dtype,
-                                      pk.rows, pk.rows_pad)
-        refs = [BlockRefs(flat, blk) for blk in tower.transformer.resblocks]
+                                      pk.rows_pad, pk.rows_pad)            # (validity of a row: pos_idx >= 0)
+        refs = block_refs(flat, tower.transformer.resblocks)
         save = bool(ctx.needs_input_grad[0])
         flat.tower_forward(tower, save)
         saved_blocks = []
@@ -965,7 +1120,7 @@ class TextTowerPackedFn(torch.autograd.Function):
         te, pe = tower.token_embedding.weight, tower.positional_embedding
         V = te.shape[0]
         ops.text_embed_packed_bwd(pk.ids_p, pk.cu, dx, g(te) if te.requires_grad else None, g(pe) if pe.requires_grad else None,
-                                  pk.rows, pk.L, hot_ids=(V - 2, V - 1))        # <|startoftext|>, <|endoftext|> (no pad rows here)
+                                  pk.rows_pad, pk.L, hot_ids=(V - 2, V - 1))    # <|startoftext|>, <|endoftext|>; the padding rows carry id 0 and an exactly zero gradient row
         ctx.saved_blocks = ctx.misc = ctx.pk = None
         return (torch.zeros_like(flat.anchor), None, None, None)
 

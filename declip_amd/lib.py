@@ -42,6 +42,23 @@ class LnPart(Structure):
     _fields_ = [("part", c_void_p), ("dw", c_void_p), ("db", c_void_p), ("nb", ctypes.c_int32), ("d", ctypes.c_int32)]
 
 
+class BlockParams(Structure):
+    """dh_block_params (include/declip_hip.h)"""
+    _fields_ = ([(n, c_void_p) for n in ("w_in", "w_out", "w_fc", "w_proj", "b_in", "b_out", "b_fc", "b_proj", "ln1_w", "ln1_b", "ln2_w", "ln2_b",
+                                          "g_w_in", "g_w_out", "g_w_fc", "g_w_proj", "g_b_in", "g_b_out", "g_b_fc", "g_b_proj",
+                                          "g_ln1_w", "g_ln1_b", "g_ln2_w", "g_ln2_b")]
+                + [("eps1", c_float), ("eps2", c_float)])
+
+
+class BlockArgs(Structure):
+    """dh_block_args (include/declip_hip.h)"""
+    _fields_ = [("dtype", c_int), ("rows", c_int), ("d", c_int), ("heads", c_int), ("b", c_int), ("L", c_int), ("causal", c_int), ("save", c_int),
+                ("cu", c_void_p), ("rows_valid", c_int), ("p", BlockParams), ("x", c_void_p), ("x_out", c_void_p),
+                ("act", c_void_p), ("act_bytes", c_int64), ("ws", c_void_p), ("ws_bytes", c_int64), ("dx_out", c_void_p), ("dx", c_void_p),
+                ("scratch", c_void_p), ("scratch_bytes", c_int64), ("ln_part1", c_void_p), ("ln_part2", c_void_p), ("ln_part_bytes", c_int64),
+                ("ln_nb1", c_int), ("ln_nb2", c_int)]
+
+
 _P = c_void_p
 _PROTOS = {
     "dh_bpe_create": (c_void_p, [c_char_p, c_int64, c_int]),
@@ -61,6 +78,11 @@ _PROTOS = {
     "dh_layernorm_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int64, _P]),
     "dh_layernorm_bwd_part": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int64, _P, _P]),
     "dh_ln_reduce_many": (c_int, [_P, c_int, _P]),
+    "dh_block_act_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "dh_block_act_offsets": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int64)]),
+    "dh_block_bwd_scratch_bytes": (c_int64, [c_int, c_int, c_int]),
+    "dh_block_fwd": (c_int, [POINTER(BlockArgs), _P]),
+    "dh_block_bwd": (c_int, [POINTER(BlockArgs), _P]),
     "dh_attn_fwd": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_varlen_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -8,6 +8,7 @@ import ctypes
 import torch
 
 from . import lib as L
+from . import lib as L_
 from .lib import DH_BF16, DH_F32, EPI_DGELU, EPI_GELU, EPI_NONE, GemmArgs, NcePair, check, dt, ptr, stream
 
 
@@ -158,6 +159,44 @@ def ln_reduce_many(items):
         _req(dw.dtype == torch.float32 and db.dtype == torch.float32 and dw.numel() == d and db.numel() == d, "ln_reduce_many: dw / db fp32 [d]")
         a.part, a.dw, a.db, a.nb, a.d = ptr(part), ptr(dw), ptr(db), nb, d
     check(L.load().dh_ln_reduce_many(arr, len(items), stream()), "dh_ln_reduce_many")
+
+
+def block_native_available():
+    """True: dh_block_fwd / dh_block_bwd can take this process's tensors (the torch-CPU stand-ins of the tests replace this by False)."""
+    return True
+
+
+_BLOCK_OFFS = {}
+
+
+def block_act_layout(dtype, rows, d, heads, b, L):
+    """(total bytes, {name: byte offset}) of a block's activation slab (dh_block_act_bytes / dh_block_act_offsets)."""
+    key = (dtype, rows, d, heads, b, L)
+    lay = _BLOCK_OFFS.get(key)
+    if lay is None:
+        lib = L_.load()
+        out = (ctypes.c_int64 * 12)()
+        check(lib.dh_block_act_offsets(dtype, rows, d, heads, b, L, out), "dh_block_act_offsets")
+        names = ("h1", "qkv", "a", "x_mid", "h2", "u", "g", "mean1", "rstd1", "mean2", "rstd2", "lse")
+        lay = (int(lib.dh_block_act_bytes(dtype, rows, d, heads, b, L)), dict(zip(names, (int(v) for v in out))))
+        if len(_BLOCK_OFFS) > 256:
+            _BLOCK_OFFS.clear()
+        _BLOCK_OFFS[key] = lay
+    return lay
+
+
+def block_bwd_scratch_bytes(dtype, rows, d):
+    return int(L_.load().dh_block_bwd_scratch_bytes(dtype, rows, d))
+
+
+def block_fwd(args):
+    """One ResidualAttentionBlock forward from ONE call (dh_block_fwd; args: lib.BlockArgs filled by the engine)."""
+    check(L_.load().dh_block_fwd(ctypes.byref(args), stream()), "dh_block_fwd")
+
+
+def block_bwd(args):
+    """Its backward, incl. the block's grouped weight gradients (dh_block_bwd); writes args.ln_nb1 / ln_nb2."""
+    check(L_.load().dh_block_bwd(ctypes.byref(args), stream()), "dh_block_bwd")
 
 
 def attn_fwd(qkv, b, Lq, heads, causal):

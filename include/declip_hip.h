@@ -148,8 +148,9 @@ int dh_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, c
  * dqkv ([rows][3*d] / [rows][d]; cu_seqlens int32 [b + 1] in device memory, every length <= Lmax); lse stays [b][heads][Lmax].
  * rows = cu_seqlens[b] (the caller knows it on the host), rows_pad >= rows = the allocated row count (whole GEMM tiles): rows
  * [rows, rows_pad) of out / dqkv are written as ZEROS -- they are contraction rows of the weight-gradient GEMMs -- by the
- * attention kernel itself on the bf16 path (no separate fill launch).  Used by the packed text tower (captions computed up to
- * <|endoftext|> only). */
+ * attention kernel itself on the bf16 path (no separate fill launch).  rows = -1 (bf16, hd = 64 only): the kernel reads
+ * cu_seqlens[b] itself -- no host-side row count in the launch, so a captured step replays for ANY batch with this rows_pad.
+ * Used by the packed text tower (captions computed up to <|endoftext|> only). */
 int dh_attn_varlen_fwd(int dtype, const void* qkv, void* out, float* lse, const int* cu_seqlens, int b, int Lmax, int heads, int hd,
                        int causal, int rows, int rows_pad, dh_stream_t stream);
 int dh_attn_varlen_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
@@ -165,6 +166,47 @@ int dh_attn_pooled_fwd(int dtype, const void* q, const void* kv, void* out, floa
                        int heads, int hd, int Lmax, dh_stream_t stream);
 int dh_attn_pooled_bwd(int dtype, const void* q, const void* kv, const void* dout, const float* lse, void* dq, void* dkv,
                        const int* row0, const int* nkeys, int b, int heads, int hd, int Lmax, dh_stream_t stream);
+
+/* ---------------------------------------------------------------- one transformer block per call
+ * ResidualAttentionBlock (base_transformer.py:29-53): x_mid = x + out_proj(attn(in_proj(ln_1(x)))), x_out = x_mid +
+ * c_proj(quick_gelu(c_fc(ln_2(x_mid)))), and its backward -- enqueued by ONE call: 9 launches forward, 13 backward (the four
+ * weight gradients as one dh_gemm_group).  Same kernels and same results as the per-op entry points above; what goes away is one
+ * host round trip per kernel (csrc/block.hip).
+ *   rows x d activations of `dtype`; dense attention over b sequences of L rows (rows == b * L), or -- cu != NULL -- packed
+ *   sequences rows cu[i] .. cu[i+1] (int32 [b + 1], device memory), rows_valid = cu[b] or -1 (read it on the device, see
+ *   dh_attn_varlen_fwd), L = the longest allowed sequence.
+ *   p: weights in `dtype` ([3d,d], [d,d], [4d,d], [d,4d], the nn.Linear layouts), biases / LayerNorm parameters fp32; g_*: fp32
+ *   gradient slots, ACCUMULATED into (backward only).
+ *   act: caller-owned slab of dh_block_act_bytes() bytes, written by forward, read by backward.  save = 0 (no backward will
+ *   follow): the GELU pre-activation is not kept.
+ *   backward: dx_out -> dx; scratch: dh_block_bwd_scratch_bytes() bytes of temporaries; ln_part1 / ln_part2: one slice of
+ *   dh_layernorm_bwd_ws_bytes(rows, d) bytes each for the deferred LayerNorm weight / bias reductions of ln_1 / ln_2, alive
+ *   until dh_ln_reduce_many ran on {ln_part, ln_nb, d, g_ln_w, g_ln_b}; ln_nb1 / ln_nb2 are written by the call.
+ *   ws: the split-K / sliced-tile workspace of dh_gemm (bf16 only; may be NULL). */
+typedef struct dh_block_params {
+  const void *w_in, *w_out, *w_fc, *w_proj;
+  const float *b_in, *b_out, *b_fc, *b_proj, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+  float *g_w_in, *g_w_out, *g_w_fc, *g_w_proj, *g_b_in, *g_b_out, *g_b_fc, *g_b_proj, *g_ln1_w, *g_ln1_b, *g_ln2_w, *g_ln2_b;
+  float eps1, eps2;
+} dh_block_params;
+typedef struct dh_block_args {
+  int dtype, rows, d, heads, b, L, causal, save;
+  const int* cu; int rows_valid;
+  dh_block_params p;
+  const void* x; void* x_out;
+  void* act; int64_t act_bytes;
+  void* ws; int64_t ws_bytes;
+  const void* dx_out; void* dx;
+  void* scratch; int64_t scratch_bytes;
+  void* ln_part1; void* ln_part2; int64_t ln_part_bytes;
+  int ln_nb1, ln_nb2;
+} dh_block_args;
+int64_t dh_block_act_bytes(int dtype, int rows, int d, int heads, int b, int L);
+/* byte offsets inside the slab of h1, qkv, a (attention output), x_mid, h2, u (GELU pre-activation), g, mean1, rstd1, mean2, rstd2, lse */
+int dh_block_act_offsets(int dtype, int rows, int d, int heads, int b, int L, int64_t* out12);
+int64_t dh_block_bwd_scratch_bytes(int dtype, int rows, int d);
+int dh_block_fwd(const dh_block_args* args, dh_stream_t stream);
+int dh_block_bwd(dh_block_args* args, dh_stream_t stream);
 
 /* ---------------------------------------------------------------- embeddings ------------
  * Text: x[b,l,:] = table[ids[b,l],:] + pos[l,:]   (text_transformer.py:188-190); table/pos fp32.

@@ -9,6 +9,12 @@ import torch.nn.functional as F
 from declip_amd.lib import EPI_DGELU, EPI_GELU, EPI_NONE
 
 
+def block_native_available():
+    """the C-level block calls (dh_block_fwd / dh_block_bwd) take device pointers: with the stand-ins the engine composes the
+    block from the per-op functions below"""
+    return False
+
+
 def _gelu(x):
     return x * torch.sigmoid(1.702 * x)
 
