@@ -254,7 +254,7 @@ def main():
                     help="1: the timed steps take their batches from the input pipeline instead of one resident batch -- decoded uint8 images at "
                          "their source size + crop boxes + caption STRINGS through declip_amd.prefetch.DataPrefetcher (BPE on its worker "
                          "thread, pinned upload on a copy stream, resize / mirror / normalise on the GPU; clip_solver.py:30-63, "
-                         "imagenet_dataloader.py:36-47).  Eager steps (every batch has its own packed row count).  clip only.")
+                         "imagenet_dataloader.py:36-47).  Graphed like the resident step: one captured graph per padded packed row count (graph.GraphedStep(key=...)).  clip only.")
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="launch check only: rendezvous, communicator sanity check and the JSON line, no model and no timed steps "
                          "(runs on a box without a GPU over gloo: tests/test_bench_launch.py)")
@@ -372,18 +372,37 @@ def main():
         import tempfile
         from declip_amd.bpe import NativeTokenizer
         from declip_amd.prefetch import DataPrefetcher
-        use_graph = False                        # captions of varying length: a packed row count per batch
         pool = synth.synth_decoded_batches(b, n_batches=6, seed=rank)
         tok = NativeTokenizer(synth.synthetic_bpe_file(os.path.join(tempfile.gettempdir(), "dh_synthetic_bpe.txt.gz")))
         pipeline = DataPrefetcher(itertools.cycle(pool), dev, tokenizer=tok, context_length=77, image_size=224)
 
     from declip_amd.graph import GraphedStep
-    graphed = GraphedStep(fwd_bwd, warmup=2, enabled=use_graph, modules=(wrapped,))
+    graph_key = None
+    if pipeline is not None and use_graph:
+        # captions of varying length under a captured step: the batch lives in static buffers, and the graphs are keyed by the
+        # padded packed row count of the captions in them (engine.packed_key: the one thing besides the buffer contents that
+        # the step's launches depend on; the valid row count is read on the device) -- one graph per 256-row bucket, LRU
+        packed_text = eng_mod.text_packed_mode() == 1 and args.dtype == "bf16"
+        if packed_text or eng_mod.text_packed_mode() == 0:
+            static_images, static_ids = torch.empty_like(batch["images"]), torch.empty_like(batch["captions"])
+            batch["images"], batch["captions"] = static_images, static_ids
+            if packed_text:
+                graph_key = lambda: eng_mod.packed_key(static_ids, torch.bfloat16)      # noqa: E731
+        else:
+            use_graph = False
+    graphed = GraphedStep(fwd_bwd, warmup=2, enabled=use_graph, modules=(wrapped,), key=graph_key)
 
     def step():
         if pipeline is not None:
             nxt = pipeline.next()                # the caller's stream waits for the copy stream's event: no host synchronisation
-            batch["images"], batch["captions"] = nxt["images"], nxt["captions"]
+            if use_graph:
+                static_images.copy_(nxt["images"])
+                static_ids.copy_(nxt["captions"])
+                tag = getattr(nxt["captions"], "_dh_rows", None)
+                if tag is not None:
+                    eng_mod.set_rows_tag(static_ids, tag[1])      # the host-side row count the prefetcher's worker took
+            else:
+                batch["images"], batch["captions"] = nxt["images"], nxt["captions"]
         opt.zero_grad()
         loss = graphed()
         wrapped.sync_gradients()
@@ -399,6 +418,9 @@ def main():
         step()
     while use_graph and graphed.graph is None:
         step()             # fewer warm-up steps than the capture needs (2 eager + 1 captured): the capture must not land in the timed region
+    if use_graph and graph_key is not None:
+        for _ in range(12):   # the input pipeline cycles through 6 batches: every row-count bucket among them is captured before the timed region
+            step()
     # long-lived objects (model, optimizer tables, cached workspaces) out of the collector's way: a generation-2 pass over
     # them in the middle of a step costs the host up to ~200 ms (seen on the DeCLIP step, tools/declip_steps.py)
     import gc
@@ -589,7 +611,7 @@ def main():
                scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic" if pipeline is None else "synthetic, through the input pipeline",
                config=dict(workload=workloads[args.model],
                            global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world,
-                           tower_streams=1 + len(model.__dict__["_flat_store"].side_streams), step_graph=int(use_graph and graphed.graph is not None),
+                           tower_streams=1 + len(model.__dict__["_flat_store"].side_streams), step_graph=int(use_graph and graphed.graph is not None), graphs_captured=graphed.captures,
                            input_pipeline=(None if pipeline is None else
                                            "DataPrefetcher: uint8 canvases 256x320 (source sizes 192-256 x 256-320) + RandomResizedCrop boxes + mirror "
                                            "flags + caption strings; BPE (dh_bpe_encode) and box bookkeeping on 1 worker thread (%d host cores usable), "

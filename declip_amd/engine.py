@@ -921,10 +921,13 @@ class PackedCaptions:
         else:
             total = int(lens.sum())                                      # one host read for this tensor object
             ids._dh_rows = (ids._version, total)
-        if tag is not None and tag[0] == ids._version and hasattr(torch, "_assert_async"):
-            torch._assert_async(lens.sum() == total)                     # a host-side count that does not match fails loudly (device-side assert, no read-back)
         self.b, self.L, self.rows = b, L, total
         self.rows_pad = rows_pad = (total + tile - 1) // tile * tile
+        if tag is not None and tag[0] == ids._version and hasattr(torch, "_assert_async"):
+            # a host-side count that does not fit the device's fails loudly (device-side assert, no read-back).  What is checked is
+            # the padded size, not `total` itself: a captured step is replayed for other batches of the same rows_pad
+            n_dev = lens.sum()
+            torch._assert_async((n_dev <= rows_pad) & (n_dev > rows_pad - tile))
         # Every index tensor below has a shape that depends on rows_pad only (never on `total`), and no launch argument carries
         # `total`: the whole bookkeeping is capturable, and a step captured for one batch replays for any batch with the same
         # rows_pad (graph.GraphedStep keys its graphs by it).  The rows [total, rows_pad) are a dummy run behind the last caption:
@@ -1008,6 +1011,25 @@ def block_bwd_packed(dx_out, r, saved, pk, heads):
     dx = _ln_bwd(dh1, x, r.ln1_w, mean1, rstd1, r.g_ln1_w, r.g_ln1_b, dres=dx_mid)
     dw.flush()
     return dx
+
+
+def packed_key(ids, dtype=torch.bfloat16, heads_dim=64):
+    """What a step on these captions depends on besides the values in its input buffers: the padded row count (bf16 towers with
+    head dimension 64: the kernels read the valid row count on the device), plus the row count itself otherwise.  The key of
+    graph.GraphedStep for steps on packed captions; needs the host-side count tag of the tensor (prefetch.py / set_rows_tag)."""
+    tag = getattr(ids, "_dh_rows", None)
+    if tag is None or tag[0] != ids._version:
+        raise DeclipHipError("packed_key: the caption tensor carries no host-side row count (engine.set_rows_tag)")
+    tile = 256 if dtype == torch.bfloat16 else 8
+    rows_pad = (tag[1] + tile - 1) // tile * tile
+    return (rows_pad,) if (dtype == torch.bfloat16 and heads_dim == 64) else (rows_pad, tag[1])
+
+
+def set_rows_tag(ids, rows):
+    """Attach the host-side packed row count (tokens up to and including <|endoftext|>, summed over the batch) to a caption
+    tensor: the text tower then never reads it back from the device (prefetch.DataPrefetcher does this for the batches it uploads)."""
+    ids._dh_rows = (ids._version, int(rows))
+    return ids
 
 
 def packed_captions(ids, dtype):

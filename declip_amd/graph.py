@@ -7,7 +7,8 @@ forward + loss + backward is ONE graph launch per step; the fused AdamW stays ou
 launch arguments that change every step) as one more launch.
 
 What makes the step capturable: every engine kernel is launched on torch's current stream with arguments that do not depend on
-the data (row counts of packed captions are taken from the host copy of a batch, labels of the masked-LM head are host tensors);
+the data beyond its SHAPE (packed captions: everything depends on the batch through the padded row count alone -- the valid
+row count is read on the device -- and GraphedStep keeps one graph per padded row count; labels of the masked-LM head are host tensors);
 scratch (split-K workspace, scheduler slots) is created during the eager warm-up steps; the gradient buffer is zeroed by a
 captured memset; the two tower streams fork from and join the capture stream with events.  Inputs live in STATIC buffers that
 the caller refreshes (copy_) before each replay.  Not capturable (and refused): a distributed step whose collectives run on a
@@ -20,6 +21,8 @@ has to be redone per replay is only the `p.grad` views that `optimizer.zero_grad
 `after_replay()` restores them, which keeps torch optimizers, gradient clipping and anything else that reads `p.grad` working on
 replayed steps (the fused FlatAdamW reads the flat buffer directly and needs nothing).
 """
+import collections
+
 import torch
 
 
@@ -40,12 +43,23 @@ class GraphedStep(object):
     buffers and returns a tensor (or tuple of tensors); the first `warmup` calls run eagerly (lazy initialisation, allocator
     warm-up), the next one is captured, every later one replays the graph.  The returned tensors are the graph's static outputs:
     read them before the next call.  `modules`: the engine models (or their DistModule wrappers) that `fn` steps through; their
-    `p.grad` views are restored after every replay and a distributed reducer is checked for capturability."""
+    `p.grad` views are restored after every replay and a distributed reducer is checked for capturability.
 
-    def __init__(self, fn, warmup=2, enabled=True, modules=None):
+    `key`: a callable returning a hashable value that names the SHAPE of the step about to run -- for a text tower on packed
+    captions the padded row count of the batch in the static buffers (`engine.packed_key`): every launch argument and every
+    tensor shape of the step depends on the batch through that value alone (the valid row count is read on the device), so one
+    captured graph serves every batch with the same key.  Graphs are kept per key (LRU, `max_graphs`); they share one memory
+    pool (only one of them runs at a time and a step's tensors are dead when it ends).  The reference's step takes a new batch
+    every iteration (solver/clip_solver.py:398-402): this is what lets the captured step be the one training uses."""
+
+    def __init__(self, fn, warmup=2, enabled=True, modules=None, key=None, max_graphs=8):
         self.fn, self.warmup, self.enabled = fn, int(warmup), bool(enabled)
         self.calls, self.graph, self.out = 0, None, None
         self.stores = _flat_stores(modules)
+        self.key, self.max_graphs = key, int(max_graphs)
+        self.graphs = collections.OrderedDict()         # key -> (graph, static outputs)
+        self.pool = None
+        self.captures, self.replays = 0, 0
 
     def _check_capturable(self):
         import torch.distributed as tdist
@@ -59,10 +73,15 @@ class GraphedStep(object):
         if not self.enabled:
             return self.fn()
         self.calls += 1
-        if self.graph is not None:
+        k = self.key() if self.key is not None else None
+        hit = self.graphs.get(k)
+        if hit is not None:
+            self.graphs.move_to_end(k)
+            self.graph, self.out = hit
             for st in self.stores:
                 st.before_replay()
             self.graph.replay()
+            self.replays += 1
             for st in self.stores:
                 st.after_replay()
             return self.out
@@ -71,9 +90,15 @@ class GraphedStep(object):
         self._check_capturable()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
         # the capture stream is a fresh side stream (torch.cuda.graph's default): the engine's own side streams fork from it
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, pool=self.pool):
             out = self.fn()
+        self.captures += 1
+        self.graphs[k] = (g, out)
+        while len(self.graphs) > self.max_graphs:
+            self.graphs.popitem(last=False)              # least recently used
         self.graph, self.out = g, out
         g.replay()                              # the captured launches did not execute during capture
         for st in self.stores:

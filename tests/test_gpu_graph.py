@@ -68,6 +68,64 @@ def test_graphed_step_equals_eager_step(cfg_name, b, dtype):
     assert float((ga - ge).norm()) <= gtol * float(ge.norm())
 
 
+def test_graphed_step_follows_changing_caption_lengths():
+    """The captured step is the step training uses (solver/clip_solver.py:398-402: a new batch every iteration): CLIP ViT-B/32,
+    bf16, packed captions whose LENGTHS change from step to step.  GraphedStep(key=engine.packed_key) keeps one graph per padded
+    packed row count; inside a bucket the valid row count differs between batches and is read on the device.  Eight batches over
+    three buckets, visited twice (capture, then replay with OTHER data of the same bucket): loss trajectory and gradients equal
+    the eager run's, and the stepper captured exactly one graph per bucket."""
+    from declip_amd import engine, synth
+    from declip_amd.graph import GraphedStep
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.optim import build_adamw
+    from declip_amd.testing import build_clip
+    cfg, b, dtype = synth.VITB32, 256, "bf16"
+    crit = ClipInfoCELoss()
+    # caption sets of different total lengths: max_len shifts the mean caption length, i.e. the bucket
+    plans = [(0, None), (1, 40), (2, 60), (3, None), (4, 40), (5, 60), (6, None), (7, 40)]
+    host = [synth.synth_tokens(b, ctx=cfg["ctx"], seed=sd, vocab=cfg["vocab"], max_len=ml) for sd, ml in plans]
+    rows = [int((h.argmax(dim=-1) + 1).sum()) for h in host]
+    buckets = sorted({(r + 255) // 256 * 256 for r in rows})
+    assert len(buckets) >= 3 and len(set(rows)) == len(rows), (rows, buckets)
+
+    def run(mode):
+        model = build_clip(cfg, dtype=dtype, seed=3)
+        # lr = 0: the weights stay put, so EVERY step's gradient is comparable between the two runs (with a live optimizer two bf16
+        # runs drift apart over 16 steps by the float-atomic noise alone: measured 9 % in the final gradient at lr = 1e-4)
+        opt = build_adamw(model, lr=0.0, betas=(0.9, 0.98), weight_decay=0.1)
+        images = torch.empty(b, 3, cfg["res"], cfg["res"], device="cuda")
+        ids = torch.empty(b, cfg["ctx"], dtype=torch.int64, device="cuda")
+        batch = {"images": images, "captions": ids}
+
+        def fwd_bwd():
+            li, lt = model(batch)
+            loss, _ = crit(li, lt)
+            loss.backward()
+            return loss.detach()
+        stepper = GraphedStep(fwd_bwd, warmup=2, enabled=(mode == "graph"), modules=(model,), key=lambda: engine.packed_key(ids, torch.bfloat16))
+        ls, gs = [], []
+        for step in range(2 * len(plans)):
+            i = step % len(plans)
+            images.copy_(synth.synth_images(b, res=cfg["res"], seed=100 + step).cuda())
+            ids.copy_(host[i].cuda())
+            engine.set_rows_tag(ids, rows[i])
+            opt.zero_grad()
+            ls.append(float(stepper()))
+            if step >= len(plans):               # second pass: replays of every bucket with data the capture did not see
+                gs.append(model.__dict__["_flat_store"].flat_g.to(torch.bfloat16))
+            opt.step()
+        torch.cuda.synchronize()
+        return ls, gs, stepper
+
+    le, ge, _ = run("eager")
+    lg, gg, st = run("graph")
+    assert st.captures == len(buckets) and st.replays >= len(plans), (st.captures, st.replays, buckets)
+    for a, c in zip(lg, le):
+        assert abs(a - c) <= 3e-3 * abs(c), (lg, le)
+    for a, c in zip(gg, ge):
+        assert float((a.float() - c.float()).norm()) <= 2e-2 * float(c.float().norm())
+
+
 def _refresh_mlm_selection(labels, new_labels, dev):
     """New masked-LM labels for a batch whose labels TENSOR OBJECT stays the one the step was captured with: the selection
     (positions, label ids) lives in two device buffers cached with that object (heads._mlm_selection) and is refreshed in place --
