@@ -614,3 +614,34 @@ extern "C" int dh_scatter_rows_add(int dtype, const void* dout, const int64_t* i
   DH_CHECK_LAUNCH();
   return DH_OK;
 }
+
+// ---- NN memory bank: FIFO enqueue (nnclr_modules/memory_bank.py:71-87) with the write pointer in DEVICE memory ----------------
+// rows ptr .. ptr + b - 1 of `store` ([size + spill][D]: the bank followed by a spill region that is never searched) receive the
+// batch -- the reference drops the part of a batch that would run over the end and resets the pointer; here that tail lands in the
+// spill rows -- then ptr = 0 if ptr + b >= size else ptr + b.  No host value in either launch: a captured step advances the queue on
+// every replay.  Two launches (copy, pointer update) instead of five torch ops.
+__global__ __launch_bounds__(256) void nn_enqueue_kernel(float* __restrict__ store, const long long* __restrict__ ptr,
+                                                         const float* __restrict__ batch, int b, int D4) {
+  const long long p0 = *ptr;
+  const float4* src = reinterpret_cast<const float4*>(batch);
+  float4* dst = reinterpret_cast<float4*>(store) + p0 * D4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)b * D4; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ void nn_ptr_advance_kernel(long long* ptr, int b, int size) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const long long n = *ptr + b;
+    *ptr = n >= size ? 0 : n;
+  }
+}
+extern "C" int dh_nn_bank_enqueue(float* store, int64_t* ptr, const float* batch, int b, int size, int spill, int D, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(store && ptr && batch && b > 0 && size > 0 && D > 0 && D % 4 == 0, "dh_nn_bank_enqueue: bad args");
+  DH_REQUIRE(spill >= b, "dh_nn_bank_enqueue: spill region of %d rows for a batch of %d", spill, b);
+  DH_REQUIRE((((uintptr_t)store | (uintptr_t)batch) & 15) == 0, "dh_nn_bank_enqueue: store / batch must be 16-byte aligned");
+  int blocks = dh_cdiv((long)b * (D / 4), 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(nn_enqueue_kernel, dim3(blocks), dim3(256), 0, st, store, (const long long*)ptr, batch, b, D / 4);
+  hipLaunchKernelGGL(nn_ptr_advance_kernel, dim3(1), dim3(64), 0, st, (long long*)ptr, b, size);
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}

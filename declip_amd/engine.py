@@ -667,6 +667,23 @@ def _to_act(t, dtype):
 # ---------------------------------------------------------------------------------------------
 # vision tower (image_encoder/visual_transformer.py:55-82)
 # ---------------------------------------------------------------------------------------------
+_CLS_POOL = {}
+
+
+def _cls_pool(b, L, device):
+    """(pooled rows, first key row, key count) of the CLS rows of b images of L tokens: constants of the geometry, built once
+    (five tiny torch launches per step otherwise)."""
+    key = (b, L, str(device))
+    p = _CLS_POOL.get(key)
+    if p is None:
+        seq = torch.arange(b, device=device)
+        p = ((seq * L).contiguous(), (seq * L).to(torch.int32).contiguous(), torch.full((b,), L, device=device, dtype=torch.int32))
+        if len(_CLS_POOL) > 64:
+            _CLS_POOL.clear()
+        _CLS_POOL[key] = p
+    return p
+
+
 class VisionTowerFn(torch.autograd.Function):
     """forward(anchor, images, tower, c0, want_dense, want_feature, n_views) ->
          proj [V*b,E] fp32 (, dense [V*b,np,width] act dtype)(, feature [V*b,width] act dtype)
@@ -699,8 +716,7 @@ class VisionTowerFn(torch.autograd.Function):
         pool = None
         if pooled_last_block(width, heads, L) and not want_dense and refs:
             # the last block only for the CLS rows (their keys: the L rows of the image)
-            seq = torch.arange(b, device=images.device)
-            pool = ((seq * L).contiguous(), (seq * L).to(torch.int32).contiguous(), torch.full((b,), L, device=images.device, dtype=torch.int32))
+            pool = _cls_pool(b, L, images.device)
         for r in (refs[:-1] if pool is not None else refs):
             x, s = block_fwd(x, r, b, L, heads, False, save=save)
             saved_blocks.append(s)
@@ -947,6 +963,7 @@ class PackedCaptions:
         # is dropped again, a padded key is only seen by padded queries)
         self.unpack_idx = (cu[:-1, None] + torch.where(l < lens[:, None], l, torch.zeros_like(l))).reshape(-1).contiguous()
         self.eot_rows = (cu[1:] - 1).contiguous()
+        self.row0, self.nkeys = self.cu[:-1].contiguous(), (self.cu[1:] - self.cu[:-1]).contiguous()   # the pooled last block's key rows
 
 
 def _rows_arg(pk, x, heads):
@@ -1062,7 +1079,7 @@ class TextTowerPackedFn(torch.autograd.Function):
         saved_blocks = []
         pool = None
         if pooled_last_block(tower.width, tower.heads, ids.shape[1]) and not want_words and refs:
-            pool = (pk.eot_rows, pk.cu[:-1].contiguous(), (pk.cu[1:] - pk.cu[:-1]).contiguous())     # EOT rows; keys = the caption's rows
+            pool = (pk.eot_rows, pk.row0, pk.nkeys)                     # EOT rows; keys = the caption's rows
         for r in (refs[:-1] if pool is not None else refs):
             x, s = block_fwd_packed(x, r, pk, tower.heads, save)
             saved_blocks.append(s)

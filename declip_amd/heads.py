@@ -195,7 +195,7 @@ class NNMemoryBankModule(nn.Module):
         self.spill_rows = 1024       # rows behind the bank for the tail a wrapping enqueue drops: >= the largest batch enqueued
         self._captured = False       # an enqueue was captured into a hipGraph: the storage must not move any more
 
-    # The write pointer lives on the DEVICE: enqueue is index arithmetic + index_copy_ on the stream, with no host value baked into a
+    # The write pointer lives on the DEVICE: enqueue is dh_nn_bank_enqueue (copy + pointer update) on the stream, with no host value baked into a
     # launch -- a step captured as a hipGraph (declip_amd/graph.py) advances the queue on every replay.  `bank_ptr` (the reference's
     # attribute, memory_bank.py:66) reads it back; only tests and checkpoints do.
     @property
@@ -237,11 +237,7 @@ class NNMemoryBankModule(nn.Module):
             self._ptr = torch.full((1,), self._ptr_init, device=dev, dtype=torch.int64)
         elif self._ptr.device != dev:
             self._ptr = self._ptr.to(dev)            # the LIVE write position moves with the queue (not the initial one)
-        if self._ar is None or self._ar.numel() < b or self._ar.device != dev:
-            self._ar = torch.arange(max(b, self.spill_rows), device=dev, dtype=torch.int64)
-        self._store.index_copy_(0, self._ptr + self._ar[:b], batch)
-        nxt = self._ptr + b
-        self._ptr.copy_(torch.where(nxt >= self.size, torch.zeros_like(nxt), nxt))
+        ops.nn_bank_enqueue(self._store, self._ptr, batch, self.size)       # dh_nn_bank_enqueue: copy + pointer update on the stream
 
     @torch.no_grad()
     def forward(self, output, update=False, query=True, enqueue=None):

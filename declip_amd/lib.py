@@ -130,6 +130,7 @@ _PROTOS = {
     "dh_cos_rows_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, _P]),
     "dh_nn_bank_ws_bytes": (c_int64, [c_int, c_int]),
     "dh_nn_bank_query": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_int64, _P]),
+    "dh_nn_bank_enqueue": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "dh_gather_rows": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
     "dh_scatter_rows_add": (c_int, [c_int, _P, _P, _P, c_int, c_int, _P]),
     "dh_filip_select": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),

@@ -604,6 +604,14 @@ def nn_bank_query(q, bank):
     return idx, feats
 
 
+def nn_bank_enqueue(store, ptr_dev, batch, size):
+    """FIFO enqueue of the NN queue behind the C-ABI (dh_nn_bank_enqueue): store [size + spill, D] fp32, ptr_dev int64 [1] on the device."""
+    _req(store.dtype == torch.float32 and batch.dtype == torch.float32 and store.is_contiguous() and batch.is_contiguous() and
+         ptr_dev.dtype == torch.int64 and ptr_dev.numel() == 1 and store.shape[1] == batch.shape[1], "nn_bank_enqueue: fp32 [rows, D], int64 [1]")
+    check(L.load().dh_nn_bank_enqueue(ptr(store), ptr(ptr_dev), ptr(batch), batch.shape[0], int(size), store.shape[0] - int(size), store.shape[1],
+                                      stream()), "dh_nn_bank_enqueue")
+
+
 def gather_rows(x, idx, n_pad=None):
     n = idx.numel()
     n_pad = n_pad or max(n, 1)

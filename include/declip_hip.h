@@ -348,6 +348,11 @@ int dh_cos_rows_bwd(int dtype, const void* p, const void* z, const float* g_row,
 int64_t dh_nn_bank_ws_bytes(int rows, int size);
 int dh_nn_bank_query(const float* q, const float* bank, int rows, int size, int D, int64_t* idx_out, float* feat_out,
                      void* ws, int64_t ws_bytes, dh_stream_t stream);
+/* FIFO enqueue of the queue (nnclr_modules/memory_bank.py:71-87): store [size + spill][D] fp32 = the bank followed by `spill`
+ * rows that are never searched; rows *ptr .. *ptr + b - 1 receive `batch` [b][D] (the reference drops the part of a batch that
+ * would run over the end: here it lands in the spill rows, spill >= b), then *ptr = 0 if *ptr + b >= size else *ptr + b.  `ptr`
+ * is int64 [1] in DEVICE memory: no host value enters a launch, a captured step advances the queue on every replay. */
+int dh_nn_bank_enqueue(float* store, int64_t* ptr, const float* batch, int b, int size, int spill, int D, dh_stream_t stream);
 /* out[r,:] = x[idx[r],:] for r < n, zero rows for n <= r < n_pad (masked-LM rows, model/declip.py:326-334);
  * scatter_rows_add: dx[idx[r],:] += dout[r,:] (unique indices). */
 int dh_gather_rows(int dtype, const void* x, const int64_t* idx, void* out, int n, int n_pad, int d, dh_stream_t stream);

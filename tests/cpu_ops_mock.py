@@ -349,6 +349,12 @@ def nn_bank_query(q, bank):
     return idx, bank[idx].clone()
 
 
+def nn_bank_enqueue(store, ptr_dev, batch, size):
+    p, b = int(ptr_dev), batch.shape[0]
+    store[p:p + b] = batch
+    ptr_dev.fill_(0 if p + b >= size else p + b)
+
+
 def gather_rows(x, idx, n_pad=None):
     n = idx.numel()
     n_pad = n_pad or max(n, 1)

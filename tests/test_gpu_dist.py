@@ -370,6 +370,77 @@ def test_declip_two_ranks_on_one_gpu_match_two_reference_ranks(fixture, dtype):
     assert q.get() == "ok"
 
 
+def _slip_full_w2_worker(rank, world, port, dtype, out):
+    """SLIP at ViT-B/32 width, two ranks x b = 128 on the one GPU, against TWO reference ranks (tests/golden/slip_vitb32_b128_w2.pt;
+    model/slip.py:245-286, nt_xent.py:64-83: the SimCLR features of both views gathered, positives at rank*b + i): the two-rank
+    SLIP step on the benchmarked GEMM kernel (round 4; slip_tiny_w2 never reaches it)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from declip_amd import dist as dd
+    from declip_amd import ops, synth
+    from declip_amd.loss import ClipInfoCELoss, NT_Xent, NT_Xent_gather
+    from declip_amd.steps import slip_loss
+    from declip_amd.testing import build_slip
+    from oracle_util import check_grad_digests, load_golden
+    from test_gpu_golden_fullwidth import assert_ran_on_v4, check_bf16_grad_norms, named_grads
+    g = load_golden("slip_vitb32_b128_w2")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    B = b * world
+    sl = slice(rank * b, (rank + 1) * b)
+    model = build_slip(cfg, dtype=dtype, seed=seed)
+    wrapped = dd.DistModule(model, sync=False, bucket_bytes=48 << 20)
+    images = synth.synth_images(B, views=3, res=cfg["res"], seed=seed)[sl].cuda()
+    ids = synth.synth_tokens(B, ctx=cfg["ctx"], seed=seed, vocab=cfg["vocab"])[sl].cuda()
+    ops.gemm_stats(reset=True)
+    o = slip_loss(wrapped, {"images": images, "captions": ids}, ClipInfoCELoss(), NT_Xent_gather(b), NT_Xent(b), world_size=world)
+    o["loss"].backward()
+    wrapped.sync_gradients()
+    torch.cuda.synchronize()
+    stats = ops.gemm_stats()
+    total = o["loss"].detach().clone()
+    dist.all_reduce(total)
+    if rank == 0:
+        tol = 1e-3 if dtype == "fp32" else 2e-2
+        assert abs(float(total) - g["loss"]) <= tol * abs(g["loss"]), (float(total), g["loss"])
+        got = o["outputs"]["logits"][0]
+        got = (got.materialize() if hasattr(got, "materialize") else got).detach().float().cpu()
+        ref = g["logits_i"]
+        if torch.is_tensor(ref):
+            assert got.shape == (b, B)
+            assert float((got - ref).abs().max()) <= (1e-3 if dtype == "fp32" else 3e-2) * float(ref.abs().max())
+        if dtype == "fp32":
+            check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
+        else:
+            assert_ran_on_v4(stats, 200)
+            check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.22, z_tol=0.40)
+    dist.barrier()
+    if rank == 0:
+        out.put("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_slip_full_width_two_ranks_on_one_gpu_match_two_reference_ranks(dtype):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_slip_full_w2_worker, args=(r, 2, port, dtype, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(400)
+        if p.is_alive():
+            p.terminate()
+            p.join(10)
+            pytest.fail("rank timed out")
+        assert p.exitcode == 0
+    assert q.get() == "ok"
+
+
 def _small_w2_worker(rank, world, port, kind, out):
     """The remaining two-rank data-parallel steps on the one GPU (gloo between two processes that share it), fp32, against TWO reference
     ranks: CLIP ResNet-50 (ModifiedResNet tower, per-rank BatchNorm statistics, buckets launched from inside the tower's backward;

@@ -193,3 +193,47 @@ def test_filip_vitb32_e768_b256_matches_reference_golden(dtype):
         assert_ran_on_v4(stats, 200)
         # measured (round 3): rms z 0.052, worst |z| 0.17
         check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.10, z_tol=0.35)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_defilip_vitb32_b128_matches_reference_golden(dtype):
+    """DeFILIP (model/defilip.py:272-428; loss composition solver/defilip_solver.py:462-478) at ViT-B/32 width and a batch whose
+    tower GEMMs are whole tiles of the benchmarked kernel -- the shape family `bench.py --model defilip` runs (round 4: the one family
+    that had small-width fixtures only).  DeCLIP's terms + the FILIP token-wise max-sim term on the same towers."""
+    from declip_amd import ops
+    from declip_amd.heads import SimsiamLoss
+    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.steps import DEFILIP_WEIGHTS, declip_loss
+    from declip_amd.testing import build_defilip, defilip_batch
+    g = load_golden("defilip_vitb32_b128")
+    cfg, b, seed = g["cfg"], g["b"], g["seed"]
+    model = build_defilip(cfg, dtype=dtype, seed=seed, nn_size=g["nn_size"])
+    ops.gemm_stats(reset=True)
+    out = declip_loss(model, defilip_batch(cfg, b, seed=seed), ClipInfoCELoss(), SimsiamLoss(), None, weights=DEFILIP_WEIGHTS)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    stats = ops.gemm_stats()
+    tol = 1e-3 if dtype == "fp32" else 3e-2
+    assert abs(float(out["loss"]) - g["loss"]) <= tol * abs(g["loss"]), (float(out["loss"]), g["loss"])
+    for k in ("clip", "mlm", "filip"):
+        assert abs(float(out["parts"][k]) - g["parts"][k]) <= tol * max(1.0, abs(g["parts"][k])), k
+    # the nearest-neighbour lookup is a discrete choice over the bank (see test_declip_vitb32_b128_matches_reference_golden)
+    assert abs(float(out["parts"]["nn"]) - g["parts"]["nn"]) <= (tol if dtype == "fp32" else 0.15) * max(1.0, abs(g["parts"]["nn"]))
+    assert abs(float(out["parts"]["simsiam"]) - g["parts"]["simsiam"]) <= (1e-4 if dtype == "fp32" else 2e-2)
+    fi = out["outputs"]["filip"][0]
+    fi = (fi.materialize() if hasattr(fi, "materialize") else fi).detach().float().cpu()
+    err = (fi - g["filip_i"]).abs()
+    scale = float(g["filip_i"].abs().max())
+    if dtype == "fp32":
+        assert float(err.max()) <= 1e-3 * scale
+        # norms and projections of EVERY parameter at 1e-3; single elements at 5e-3, except in the SimSiam head, whose weight
+        # gradients pass two BatchNorm1d layers over 2 x 128 rows (sums of cancelling terms: measured on the MI355X, single
+        # elements of projector.linear1.weight differ from the reference's by up to 3 % while its norm and projection agree at 1e-3)
+        simsiam = lambda n: n.startswith("projector.") or n.startswith("predictor.")      # noqa: E731
+        check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3, only=lambda n: not simsiam(n))
+        check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=6e-2, only=simsiam)
+    else:
+        # the dense logits sit behind the top-16 token selection (check_logits_digest): a few samples may flip a token
+        assert float((err > 3e-2 * scale).float().mean()) <= 0.02 and float(err.max()) <= 0.15 * scale, (float(err.max()), scale)
+        assert_ran_on_v4(stats, 200)
+        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.15, z_tol=0.40)
