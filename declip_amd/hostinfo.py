@@ -55,10 +55,20 @@ def usable_cores(physical=True):
     return max(1, n)
 
 
+def local_world_size():
+    """ranks of this job on this node (torchrun's LOCAL_WORLD_SIZE, else WORLD_SIZE of a one-node job, else 1): they share the quota"""
+    for k in ("LOCAL_WORLD_SIZE", "WORLD_SIZE", "SLURM_NTASKS_PER_NODE"):
+        v = os.environ.get(k)
+        if v and v.isdigit() and int(v) > 0:
+            return int(v)
+    return 1
+
+
 def limit_host_threads(reserve=0):
-    """Clamp torch's intra-op CPU threads to usable_cores() - reserve (never raises them); returns the count now in force."""
+    """Clamp torch's intra-op CPU threads to this rank's share of usable_cores() - reserve (never raises them); returns the count
+    now in force.  Eight ranks of one node share the node's quota: each gets an eighth of it, not all of it."""
     import torch
-    n = max(1, usable_cores() - reserve)
+    n = max(1, (usable_cores() - reserve) // local_world_size())
     if torch.get_num_threads() > n:
         torch.set_num_threads(n)
     return torch.get_num_threads()
