@@ -510,16 +510,21 @@ extern "C" int dh_ln_reduce_many(const dh_ln_part* items, int n, dh_stream_t str
   for (int i0 = 0; i0 < n; i0 += LN_MANY) {
     LnMany m;
     memset(&m, 0, sizeof(m));
-    int cnt = 0, dmax = 0;
+    int cnt = 0, dmax = 0, nbmax = 0;
     for (int i = i0; i < n && cnt < LN_MANY; ++i) {
       const dh_ln_part& it = items[i];
       if (it.nb <= 0) continue;                      // (the scalar kernel accumulated directly)
       DH_REQUIRE(it.part && it.dw && it.db && it.d > 0, "dh_ln_reduce_many: item %d: bad pointers / width", i);
       m.part[cnt] = it.part; m.dw[cnt] = it.dw; m.db[cnt] = it.db; m.nb[cnt] = it.nb; m.d[cnt] = it.d;
       dmax = it.d > dmax ? it.d : dmax;
+      nbmax = it.nb > nbmax ? it.nb : nbmax;
       ++cnt;
     }
-    if (cnt) hipLaunchKernelGGL(ln_reduce_many_kernel, dim3(dh_cdiv(2 * dmax, 64), 16, cnt), dim3(256), 0, st, m);
+    // slices of the partial rows per item: 1 while every item is short (< 64 partial rows: ONE add per element, in a fixed
+    // order -- the pooled ln_post / ln_final and small batches stay run-to-run deterministic, and 15 of 16 blocks would add zeros),
+    // 16 for the long ones (1024 partial rows of a full tower LayerNorm: the float atomics' order is the only non-determinism)
+    const int gy = nbmax < 64 ? 1 : 16;
+    if (cnt) hipLaunchKernelGGL(ln_reduce_many_kernel, dim3(dh_cdiv(2 * dmax, 64), gy, cnt), dim3(256), 0, st, m);
   }
   DH_CHECK_LAUNCH();
   return DH_OK;

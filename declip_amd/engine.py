@@ -10,6 +10,7 @@ Every arithmetic step goes through declip_amd.ops (= the C-ABI); torch is used f
 streams and the autograd graph plumbing only.
 """
 import os
+import threading
 
 import torch
 
@@ -385,14 +386,20 @@ class LnGradBatch:
         self.items, self.off, self.pending, self.nblocks = [], 0, [], 0
         self.dist = flat.reducer is not None and flat.reducer.distributed()
         self.enabled = os.environ.get("DH_LN_BATCH", "1") == "1"
+        # LayerNorms whose partials can be alive at once (until the next flush): all of the tower's, or DIST_BLOCKS blocks' worth
+        n_ln = sum(1 for m in tower.modules() if isinstance(m, torch.nn.LayerNorm))
+        self.n_live = max(2, min(n_ln, 2 * self.DIST_BLOCKS + 2) if self.dist else n_ln)
 
     def _slice(self, n, device):
         arenas = self.flat.__dict__.setdefault("_ln_arenas", {})
         key = (self.key, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
         ar = arenas.get(key)
         if ar is None or self.off + n > ar.numel():
-            # (a grown arena replaces the old one; slices already handed out keep the old storage alive until the flush)
-            ar = torch.empty(max(2 * (self.off + n), 1 << 22), device=device, dtype=torch.float32)
+            # sized ONCE for the tower: every LayerNorm that can be pending at the same time, at the size of the one asking now
+            # (the full-row ones come first in a backward; the pooled ln_post / ln_final are smaller) -- no 2x over-allocation, no
+            # re-growth over several steps, and the first growth does not land in a captured step's private pool when the warm-up
+            # steps ran.  (A grown arena replaces the old one; slices already handed out keep the old storage alive until the flush.)
+            ar = torch.empty(max(self.off + n, self.n_live * ((n + 63) // 64 * 64)), device=device, dtype=torch.float32)
             arenas[key] = ar
             self.off = 0
         part = ar[self.off:self.off + n]
@@ -429,12 +436,19 @@ class LnGradBatch:
         self.pending, self.nblocks = [], 0
 
 
-_LNB = None        # the batch of the tower backward that is running (autograd runs the towers' backward functions one after the other)
+class _LnbSlot(threading.local):
+    """The LnGradBatch of the tower backward that is running ON THIS THREAD: autograd runs the backward functions of one device
+    on one thread, so two engine models on different GPUs in one process (or a backward inside a backward) keep their own."""
+    cur = None
+
+
+_LNB_SLOT = _LnbSlot()
 
 
 def _ln_bwd(dy, x, w, mean, rstd, dw, db, dres=None):
-    if _LNB is not None:
-        return _LNB.bwd(dy, x, w, mean, rstd, dw, db, dres=dres)
+    lnb = _LNB_SLOT.cur
+    if lnb is not None:
+        return lnb.bwd(dy, x, w, mean, rstd, dw, db, dres=dres)
     return ops.layernorm_bwd(dy, x, w, mean, rstd, dw, db, dres=dres)
 
 
@@ -522,7 +536,7 @@ def _block_bwd_native(dx_out, r, sv):
     ptr = ops.ptr
     x = sv.x
     rows, d = x.shape
-    lnb = _LNB
+    lnb = _LNB_SLOT.cur
     n = ops.layernorm_bwd_ws_elems(rows, d)
     part1, part2 = lnb._slice(n, x.device), lnb._slice(n, x.device)
     nscr = ops.block_bwd_scratch_bytes(dt(x), rows, d)
@@ -557,7 +571,7 @@ def block_fwd(x, r, b, L, heads, causal, save):
 
 def block_bwd(dx_out, r, saved, b, L, heads, causal):
     if isinstance(saved, NativeSaved):
-        if _LNB is not None and _LNB.enabled and native_blocks() and dx_out.is_contiguous():
+        if _LNB_SLOT.cur is not None and _LNB_SLOT.cur.enabled and native_blocks() and dx_out.is_contiguous():
             return _block_bwd_native(dx_out, r, saved)
         saved = saved.views()
     x, mean1, rstd1, h1, qkv, a, lse, x_mid, mean2, rstd2, h2, u, g = saved
@@ -740,16 +754,15 @@ class VisionTowerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        global _LNB
         flat = ctx.tower._flat()
         lnb = LnGradBatch(flat, ctx.tower)
-        prev, _LNB = _LNB, lnb
+        prev, _LNB_SLOT.cur = _LNB_SLOT.cur, lnb
         try:
             out = VisionTowerFn._backward_impl(ctx, lnb, *grads)
             lnb.release()                    # ONE reduce launch for the tower's LayerNorm gradients; the rest of its parameters released
             return out
         finally:
-            _LNB = prev
+            _LNB_SLOT.cur = prev
 
     @staticmethod
     def _backward_impl(ctx, lnb, *grads):
@@ -857,16 +870,15 @@ class TextTowerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        global _LNB
         flat = ctx.tower._flat()
         lnb = LnGradBatch(flat, ctx.tower)
-        prev, _LNB = _LNB, lnb
+        prev, _LNB_SLOT.cur = _LNB_SLOT.cur, lnb
         try:
             out = TextTowerFn._backward_impl(ctx, lnb, *grads)
             lnb.release()                    # ONE reduce launch for the tower's LayerNorm gradients; the rest of its parameters released
             return out
         finally:
-            _LNB = prev
+            _LNB_SLOT.cur = prev
 
     @staticmethod
     def _backward_impl(ctx, lnb, *grads):
@@ -999,7 +1011,7 @@ def block_fwd_packed(x, r, pk, heads, save):
 
 def block_bwd_packed(dx_out, r, saved, pk, heads):
     if isinstance(saved, NativeSaved):
-        if _LNB is not None and _LNB.enabled and native_blocks() and dx_out.is_contiguous():
+        if _LNB_SLOT.cur is not None and _LNB_SLOT.cur.enabled and native_blocks() and dx_out.is_contiguous():
             return _block_bwd_native(dx_out, r, saved)
         x, mean1, rstd1, h1, qkv, a, lse, x_mid, mean2, rstd2, h2, u, g = saved.views()
         saved = (x, mean1, rstd1, h1, (qkv, a), a, lse, x_mid, mean2, rstd2, h2, u, g)
@@ -1105,16 +1117,15 @@ class TextTowerPackedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        global _LNB
         flat = ctx.tower._flat()
         lnb = LnGradBatch(flat, ctx.tower)
-        prev, _LNB = _LNB, lnb
+        prev, _LNB_SLOT.cur = _LNB_SLOT.cur, lnb
         try:
             out = TextTowerPackedFn._backward_impl(ctx, lnb, *grads)
             lnb.release()                    # ONE reduce launch for the tower's LayerNorm gradients; the rest of its parameters released
             return out
         finally:
-            _LNB = prev
+            _LNB_SLOT.cur = prev
 
     @staticmethod
     def _backward_impl(ctx, lnb, *grads):

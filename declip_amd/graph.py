@@ -56,6 +56,11 @@ class GraphedStep(object):
         self.fn, self.warmup, self.enabled = fn, int(warmup), bool(enabled)
         self.calls, self.graph, self.out = 0, None, None
         self.stores = _flat_stores(modules)
+        if modules is None and self.enabled:
+            import warnings
+            warnings.warn("GraphedStep(modules=None): after optimizer.zero_grad() + a replay the parameters' .grad stay None (the fused "
+                          "FlatAdamW reads the flat buffer and does not care; torch optimizers and gradient clipping would see no "
+                          "gradients) and a distributed reducer is not checked -- pass the engine models", stacklevel=2)
         self.key, self.max_graphs = key, int(max_graphs)
         self.graphs = collections.OrderedDict()         # key -> (graph, static outputs)
         self.pool = None

@@ -69,11 +69,20 @@ class FlatAdamW(torch.optim.Optimizer):
         """accepts the torch.optim.AdamW layout (a reference / model-zoo checkpoint, or state_dict() above); anything that does
         not line up with this optimizer's parameters raises instead of silently dropping the moments."""
         flat = self.flat
-        if len(sd["param_groups"]) != len(self.param_groups):
-            raise ValueError("optimizer state has %d param groups, this optimizer %d" % (len(sd["param_groups"]), len(self.param_groups)))
+        mine = list(self.param_groups)
+        if len(sd["param_groups"]) != len(mine):
+            # LEGACY layout (checkpoints this engine wrote before round 3): typed groups without parameters were not emitted.  The
+            # groups that hold parameters come in the same order in both layouts: line those up, leave the empty ones alone.
+            non_empty = [g for g in mine if len(g["params"]) > 0]
+            if len(sd["param_groups"]) == len(non_empty) and all(len(sg["params"]) == len(g["params"]) for g, sg in zip(non_empty, sd["param_groups"])):
+                mine = non_empty
+            else:
+                raise ValueError("optimizer state has %d param groups, this optimizer %d (%d of them non-empty): neither the reference "
+                                 "layout (utils/misc.py:386-393: every typed group, empty ones too) nor the legacy one (empty groups "
+                                 "dropped)" % (len(sd["param_groups"]), len(self.param_groups), len(non_empty)))
         steps = set()
         with torch.no_grad():
-            for g, sg in zip(self.param_groups, sd["param_groups"]):
+            for g, sg in zip(mine, sd["param_groups"]):
                 if len(sg["params"]) != len(g["params"]):
                     raise ValueError("optimizer state: a param group has %d parameters, expected %d" % (len(sg["params"]), len(g["params"])))
                 for k, v in sg.items():

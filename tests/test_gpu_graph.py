@@ -43,7 +43,7 @@ def test_graphed_step_equals_eager_step(cfg_name, b, dtype):
     grads = {}
     for mode in ("eager", "graph"):
         model, opt, batch, fwd_bwd = make()
-        stepper = GraphedStep(fwd_bwd, warmup=2, enabled=(mode == "graph"))
+        stepper = GraphedStep(fwd_bwd, warmup=2, enabled=(mode == "graph"), modules=(model,))
         ls = []
         for step in range(6):                    # graph mode: 2 eager warm-up steps, 1 capture, 3 replays
             feed(batch, step)

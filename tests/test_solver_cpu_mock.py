@@ -206,6 +206,13 @@ def test_checkpoint_has_the_reference_layout_and_resumes_from_a_torch_adamw_stat
     p = s2.optimizer.param_groups[0]["params"][0]
     o, n = s2.optimizer.flat.index[id(p)]
     assert torch.allclose(s2.optimizer.m[o:o + n].view(p.shape).cpu(), tsd["state"][0]["exp_avg"])
+    # the LEGACY layout (checkpoints written before the empty typed groups were emitted: ADVICE r3) still resumes
+    legacy = dict(state=tsd["state"], param_groups=[g for g in tsd["param_groups"] if len(g["params"]) > 0])
+    assert len(legacy["param_groups"]) < len(tsd["param_groups"])
+    torch.save(dict(ck, optimizer=legacy), p2)
+    s3 = ClsSolver(str(cfgp), device="cpu")
+    assert s3.optimizer.step_count == 2
+    assert torch.allclose(s3.optimizer.m[o:o + n].view(p.shape).cpu(), tsd["state"][0]["exp_avg"])
     # a state that does not line up is refused, not dropped
     bad = dict(ck, optimizer=dict(state=tsd["state"], param_groups=tsd["param_groups"][:-1]))
     torch.save(bad, p2)
