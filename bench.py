@@ -450,6 +450,20 @@ def main():
     host_ms_per_step = host_elapsed / args.steps * 1e3
     pairs_per_s = b * world * args.steps / elapsed
 
+    # the host's real work per step: enqueue time of a step into an EMPTY queue (host_ms_per_step above saturates near the step
+    # time whenever the host is the faster side -- the launch queue fills and the runtime makes it wait -- so it cannot tell
+    # "host-bound" from "GPU-bound with a full queue")
+    enq = []
+    gc.disable()
+    for _ in range(3):
+        sync()
+        t1 = time.perf_counter()
+        step()
+        enq.append(time.perf_counter() - t1)
+    sync()
+    gc.enable()
+    host_enqueue_ms = sorted(enq)[1] * 1e3
+
     roofline = None
     if not args.no_roofline:
         # dominant kernel = the MFMA GEMM family: bracket every dh_gemm launch of 2 extra steps with
@@ -565,7 +579,7 @@ def main():
         # HBM-side traffic of the same kernels from the rocprofv3 PMC passes of tools/profile_step.sh (committed summary):
         # per-launch average next to the algorithmic bytes per launch (operands once + outputs once)
         traffic, traffic_source = None, None
-        for rnd in ("r03", "r02", "r01"):                # a COMMITTED rocprofv3 --pmc summary of this configuration (tools/profile_step.sh):
+        for rnd in ("r04", "r03", "r02", "r01"):                # a COMMITTED rocprofv3 --pmc summary of this configuration (tools/profile_step.sh):
             pmc_file = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s_b%d.json" % (rnd, args.model, b))   # not measured by this run
             if os.path.exists(pmc_file):
                 with open(pmc_file) as fh:
@@ -607,7 +621,8 @@ def main():
                     "fwd+bwd+grad-allreduce+AdamW; per-GPU batch %d (BASELINE.json configs[0]), 224x224 images, 77-token captions" % b,
     }
     out = dict(metric="image-text pairs/sec %s" % name, value=round(pairs_per_s, 2), unit="pairs/s", n_gpus=world,
-               steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), host_ms_per_step=round(host_ms_per_step, 3), higher_is_better=True,
+               steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), host_ms_per_step=round(host_ms_per_step, 3), host_enqueue_ms_empty_queue=round(host_enqueue_ms, 3),
+               higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic" if pipeline is None else "synthetic, through the input pipeline",
                config=dict(workload=workloads[args.model],
                            global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world,

@@ -96,7 +96,14 @@ __device__ __forceinline__ bf16x8_t kmask(bf16x8_t f, bool dead) {
 template <int NKB, bool VL>  // NKB: number of 16-key blocks (L16/16), compile-time so scores stay in registers
 __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
                                      int L, int heads, int causal, float scale, int nbh, const int* __restrict__ cu,
-                                     int tail0, int tail1) {
+                                     int tail0, int tail1, const int* __restrict__ seq_list, const int* __restrict__ seq_range) {
+  // seq_list / seq_range (packed sequences only): this launch takes the sequences seq_list[s0 .. s0 + n), (s0, n) = seq_range[0..1] read
+  // HERE -- length-bucketed launches (dh_attn_bucketed_*): the short captions on an instantiation with fewer key blocks, without
+  // a host-side count in the launch
+  const int nb_total = nbh / heads;
+  const int s0 = (VL && seq_list) ? seq_range[0] : 0;
+  if (VL && seq_list) nbh = seq_range[1] * heads;
+#define SEQ(i) ((VL && seq_list) ? seq_list[s0 + (i)] : (i))
   constexpr int L16 = NKB * 16;
   constexpr int NKS = (L16 + 31) / 32;          // 32-wide k-steps over the keys
   constexpr bool KTAIL = (L16 % 32) != 0;
@@ -112,21 +119,21 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6;
   TileRegs rq, rk, rv;
-  {
-    const int bh0 = blockIdx.x;
-    const int L0 = VL ? cu[bh0 / heads + 1] - cu[bh0 / heads] : L;
-    const bf16_t* qg0 = qkv + (VL ? (long)cu[bh0 / heads] * gs : (long)(bh0 / heads) * L * gs) + (bh0 % heads) * HD;
+  if ((int)blockIdx.x < nbh) {
+    const int bh0 = blockIdx.x, b0 = SEQ(bh0 / heads);
+    const int L0 = VL ? cu[b0 + 1] - cu[b0] : L;
+    const bf16_t* qg0 = qkv + (VL ? (long)cu[b0] * gs : (long)b0 * L * gs) + (bh0 % heads) * HD;
     rq = tile_load(qg0, gs, L0, tid, nthr); rk = tile_load(qg0 + d_model, gs, L0, tid, nthr); rv = tile_load(qg0 + 2 * d_model, gs, L0, tid, nthr);
   }
   for (int bh = blockIdx.x; bh < nbh; bh += gridDim.x) {
-  const int bi = bh / heads, h = bh % heads;
+  const int bi = SEQ(bh / heads), h = bh % heads;
   const int Lp = VL ? cu[bi + 1] - cu[bi] : L;              // length of this sequence (rows cu[bi] .. of qkv / out when packed)
   tile_store(rq, Qs, tid, nthr); tile_store(rk, Ks, tid, nthr); tile_store(rv, Vs, tid, nthr);
   __syncthreads();
   if (bh + (int)gridDim.x < nbh) {         // next pair's tiles: in flight during this pair's arithmetic
-    const int bn = bh + gridDim.x;
-    const int L1 = VL ? cu[bn / heads + 1] - cu[bn / heads] : L;
-    const bf16_t* qn = qkv + (VL ? (long)cu[bn / heads] * gs : (long)(bn / heads) * L * gs) + (bn % heads) * HD;
+    const int bn = bh + gridDim.x, b1 = SEQ(bn / heads);
+    const int L1 = VL ? cu[b1 + 1] - cu[b1] : L;
+    const bf16_t* qn = qkv + (VL ? (long)cu[b1] * gs : (long)b1 * L * gs) + (bn % heads) * HD;
     rq = tile_load(qn, gs, L1, tid, nthr); rk = tile_load(qn + d_model, gs, L1, tid, nthr); rv = tile_load(qn + 2 * d_model, gs, L1, tid, nthr);
   }
 
@@ -208,7 +215,7 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
   }
   __syncthreads();                         // every wave is done with the tiles before the next pair overwrites them
   }
-  if (VL) tail0 = tail0 < 0 ? cu[nbh / heads] : tail0;     // rows = -1: the valid row count is cu_seqlens[b], read here (no host value in the launch: the captured step replays for any batch of this padded size)
+  if (VL) tail0 = tail0 < 0 ? cu[nb_total] : tail0;        // rows = -1: the valid row count is cu_seqlens[b], read here (no host value in the launch: the captured step replays for any batch of this padded size)
   if (VL && tail1 > tail0) {
     // packed layout: the rows between the last caption and the whole-tile row count are ZERO (they meet the weight-gradient GEMMs as
     // contraction rows); written here instead of by a separate fill launch per attention call (24 launches per CLIP step)
@@ -228,7 +235,11 @@ template <int NKB, bool VL>
 __global__ __launch_bounds__(64 * NKB, 3) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                      const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                      bf16_t* __restrict__ dqkv, int L, int heads, int causal, float scale, int nbh,
-                                     const int* __restrict__ cu, int tail0, int tail1) {
+                                     const int* __restrict__ cu, int tail0, int tail1, const int* __restrict__ seq_list,
+                                     const int* __restrict__ seq_range) {
+  const int nb_total = nbh / heads;
+  const int s0 = (VL && seq_list) ? seq_range[0] : 0;       // (see attn_fwd_mfma_kernel)
+  if (VL && seq_list) nbh = seq_range[1] * heads;
   constexpr int L16 = NKB * 16;
   constexpr int NKS = (L16 + 31) / 32;
   constexpr bool KTAIL = (L16 % 32) != 0;
@@ -263,8 +274,8 @@ __global__ __launch_bounds__(64 * NKB, 3) void attn_bwd_mfma_kernel(const bf16_t
   };
   TileRegs rq, rk, rv, rg;
   DRegs rd;
-  {
-    const int bh0 = blockIdx.x, b0 = bh0 / heads, h0 = bh0 % heads;
+  if ((int)blockIdx.x < nbh) {
+    const int bh0 = blockIdx.x, b0 = SEQ(bh0 / heads), h0 = bh0 % heads;
     const long r0 = VL ? (long)cu[b0] : (long)b0 * L;
     const int L0 = VL ? cu[b0 + 1] - cu[b0] : L;
     const bf16_t* qg0 = qkv + r0 * gs + h0 * HD;
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(64 * NKB, 3) void attn_bwd_mfma_kernel(const bf16_t
     rd = d_load(out + r0 * d_model + h0 * HD, gg0, L0);
   }
   for (int bh = blockIdx.x; bh < nbh; bh += gridDim.x) {
-  const int bi = bh / heads, h = bh % heads;
+  const int bi = SEQ(bh / heads), h = bh % heads;
   const long row0 = VL ? (long)cu[bi] : (long)bi * L;
   const int Lp = VL ? cu[bi + 1] - cu[bi] : L;
   tile_store(rq, Qs, tid, nthr); tile_store(rk, Ks, tid, nthr); tile_store(rv, Vs, tid, nthr); tile_store(rg, Gs, tid, nthr);
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(64 * NKB, 3) void attn_bwd_mfma_kernel(const bf16_t
     lse_r[r] = qq < Lp ? lse[((long)bi * heads + h) * L + qq] : 0.f;
   }
   if (bh + (int)gridDim.x < nbh) {         // next pair's tiles: in flight during this pair's arithmetic
-    const int bn = bh + gridDim.x, b1 = bn / heads, h1 = bn % heads;
+    const int bn = bh + gridDim.x, b1 = SEQ(bn / heads), h1 = bn % heads;
     const long r1 = VL ? (long)cu[b1] : (long)b1 * L;
     const int L1 = VL ? cu[b1 + 1] - cu[b1] : L;
     const bf16_t* qn = qkv + r1 * gs + h1 * HD;
@@ -399,7 +410,8 @@ __global__ __launch_bounds__(64 * NKB, 3) void attn_bwd_mfma_kernel(const bf16_t
   }
   __syncthreads();                         // every wave is done with the tiles before the next pair overwrites them
   }
-  if (VL) tail0 = tail0 < 0 ? cu[nbh / heads] : tail0;     // (see the forward kernel)
+  if (VL) tail0 = tail0 < 0 ? cu[nb_total] : tail0;        // (see the forward kernel)
+#undef SEQ
   if (VL && tail1 > tail0) {
     // packed layout: the rows between the last caption and the whole-tile row count are ZERO (they meet the weight-gradient GEMMs as
     // contraction rows); written here instead of by a separate fill launch per attention call (24 launches per CLIP step)
@@ -530,7 +542,8 @@ static int attn_cus() {
 
 template <int NKB>
 int launch_fwd_mfma(const bf16_t* qkv, bf16_t* out, float* lse, int b, int L, int heads, int causal, float scale,
-                    hipStream_t st, const int* cu = nullptr, int tail0 = 0, int tail1 = 0) {
+                    hipStream_t st, const int* cu = nullptr, int tail0 = 0, int tail1 = 0, const int* seq_list = nullptr,
+                    const int* seq_range = nullptr) {
   constexpr int L16 = NKB * 16, TS = L16 + 8;
   size_t lds = (size_t)(3 * L16 * RS + L16 * TS + 64) * sizeof(bf16_t);
   if (cu) hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -538,13 +551,14 @@ int launch_fwd_mfma(const bf16_t* qkv, bf16_t* out, float* lse, int b, int L, in
   const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
   int grid = attn_cus() * (per_cu < 1 ? 1 : per_cu);
   if (grid > b * heads) grid = b * heads;
-  if (cu) hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKB, true>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads, cu, tail0, tail1);
-  else hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKB, false>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads, cu, 0, 0);
+  if (cu) hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKB, true>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads, cu, tail0, tail1, seq_list, seq_range);
+  else hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKB, false>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads, cu, 0, 0, (const int*)nullptr, (const int*)nullptr);
   return 0;
 }
 template <int NKB>
 int launch_bwd_mfma(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int b,
-                    int L, int heads, int causal, float scale, hipStream_t st, const int* cu = nullptr, int tail0 = 0, int tail1 = 0) {
+                    int L, int heads, int causal, float scale, hipStream_t st, const int* cu = nullptr, int tail0 = 0, int tail1 = 0,
+                    const int* seq_list = nullptr, const int* seq_range = nullptr) {
   constexpr int L16 = NKB * 16, TS = L16 + 8;
   size_t lds = (size_t)(4 * L16 * RS + 2 * L16 * TS + 64) * sizeof(bf16_t) + L16 * sizeof(float);
   if (cu) hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -555,8 +569,8 @@ int launch_bwd_mfma(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
   const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
   int grid = attn_cus() * (per_cu < 1 ? 1 : per_cu);
   if (grid > b * heads) grid = b * heads;
-  if (cu) hipLaunchKernelGGL((attn_bwd_mfma_kernel<NKB, true>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads, cu, tail0, tail1);
-  else hipLaunchKernelGGL((attn_bwd_mfma_kernel<NKB, false>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads, cu, 0, 0);
+  if (cu) hipLaunchKernelGGL((attn_bwd_mfma_kernel<NKB, true>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads, cu, tail0, tail1, seq_list, seq_range);
+  else hipLaunchKernelGGL((attn_bwd_mfma_kernel<NKB, false>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads, cu, 0, 0, (const int*)nullptr, (const int*)nullptr);
   return 0;
 }
 
@@ -658,6 +672,55 @@ extern "C" int dh_attn_varlen_bwd(int dtype, const void* qkv, const void* out, c
       DH_FAIL(DH_ERR_LAUNCH, "dh_attn_varlen_bwd: memset failed");
   }
   return attn_bwd_impl(dtype, qkv, out, dout, lse, dqkv, b, Lmax, heads, hd, causal, cu_seqlens, stream, rows, in_kernel ? rows_pad : rows);
+}
+
+// Length-bucketed packed attention (bf16, hd = 64): the sequences of `order[0 .. n_short)` are at most L_short rows long and run on
+// the instantiation with ceil(L_short / 16) key blocks (fewer waves per workgroup, less LDS, more workgroups per CU); the others on
+// the Lmax one.  order: int32 [b] (a permutation of the sequences, short ones first), ranges: int32 [4] = {0, n_short, n_short,
+// b - n_short}, both in DEVICE memory (the bookkeeping of a packed batch: no host-side count enters a launch).  Measured on 512
+// captions of 9..48 tokens (profiles/r03_small_kernels.txt): forward 38 -> 17 us, backward 57 -> 39 us through the 48-row kernels.
+extern "C" int dh_attn_bucketed_fwd(int dtype, const void* qkv, void* out, float* lse, const int* cu_seqlens, const int* order, const int* ranges,
+                                    int b, int Lmax, int L_short, int heads, int hd, int causal, int rows, int rows_pad, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(qkv && out && lse && cu_seqlens && order && ranges && b > 0 && heads > 0, "dh_attn_bucketed_fwd: bad args");
+  DH_REQUIRE(dtype == DH_BF16 && hd == 64 && Lmax <= 128 && L_short > 0 && L_short <= Lmax, "dh_attn_bucketed_fwd: bf16, hd 64, 0 < L_short <= Lmax <= 128");
+  DH_REQUIRE(rows == -1 || (rows >= 0 && rows_pad >= rows), "dh_attn_bucketed_fwd: rows %d, rows_pad %d", rows, rows_pad);
+  const float scale = 1.0f / sqrtf((float)hd);
+  const int L = Lmax;
+  {
+#define CALL(N) launch_fwd_mfma<N>((const bf16_t*)qkv, (bf16_t*)out, lse, b, Lmax, heads, causal, scale, st, cu_seqlens, 0, 0, order, ranges)
+    DISPATCH_NKB((L_short + 15) / 16, CALL)
+#undef CALL
+  }
+  {
+#define CALL(N) launch_fwd_mfma<N>((const bf16_t*)qkv, (bf16_t*)out, lse, b, Lmax, heads, causal, scale, st, cu_seqlens, rows, rows_pad, order, ranges + 2)
+    DISPATCH_NKB((Lmax + 15) / 16, CALL)
+#undef CALL
+  }
+  DH_CHECK_LAUNCH();
+  return DH_OK;
+}
+extern "C" int dh_attn_bucketed_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                    const int* cu_seqlens, const int* order, const int* ranges, int b, int Lmax, int L_short, int heads, int hd,
+                                    int causal, int rows, int rows_pad, dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DH_REQUIRE(qkv && out && dout && lse && dqkv && cu_seqlens && order && ranges && b > 0 && heads > 0, "dh_attn_bucketed_bwd: bad args");
+  DH_REQUIRE(dtype == DH_BF16 && hd == 64 && Lmax <= 128 && L_short > 0 && L_short <= Lmax, "dh_attn_bucketed_bwd: bf16, hd 64, 0 < L_short <= Lmax <= 128");
+  DH_REQUIRE(rows == -1 || (rows >= 0 && rows_pad >= rows), "dh_attn_bucketed_bwd: rows %d, rows_pad %d", rows, rows_pad);
+  const float scale = 1.0f / sqrtf((float)hd);
+  const int L = Lmax;
+  {
+#define CALL(N) launch_bwd_mfma<N>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, b, Lmax, heads, causal, scale, st, cu_seqlens, 0, 0, order, ranges)
+    DISPATCH_NKB((L_short + 15) / 16, CALL)
+#undef CALL
+  }
+  {
+#define CALL(N) launch_bwd_mfma<N>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, b, Lmax, heads, causal, scale, st, cu_seqlens, rows, rows_pad, order, ranges + 2)
+    DISPATCH_NKB((Lmax + 15) / 16, CALL)
+#undef CALL
+  }
+  DH_CHECK_LAUNCH();
+  return DH_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -64,6 +64,7 @@ int check_common(const dh_block_args* a, const char* who) {
   DH_REQUIRE(a->dtype == DH_BF16 || a->dtype == DH_F32, "%s: bad dtype", who);
   DH_REQUIRE(a->rows > 0 && a->d > 0 && a->heads > 0 && a->d % a->heads == 0 && a->b > 0 && a->L > 0, "%s: bad geometry", who);
   DH_REQUIRE(a->cu || (int64_t)a->b * a->L == a->rows, "%s: dense attention needs rows == b * L (%d vs %d x %d)", who, a->rows, a->b, a->L);
+  DH_REQUIRE(!a->seq_order || (a->cu && a->seq_ranges && a->L_short > 0 && a->L_short <= a->L), "%s: length buckets need cu, ranges and 0 < L_short <= L", who);
   DH_REQUIRE(!a->cu || a->rows_valid == -1 || (a->rows_valid > 0 && a->rows_valid <= a->rows), "%s: packed rows %d of %d", who, a->rows_valid, a->rows);
   DH_REQUIRE(a->act && a->act_bytes >= act_layout(a->dtype, a->rows, a->d, a->heads, a->b, a->L).total, "%s: activation slab too small", who);
   const dh_block_params& p = a->p;
@@ -124,7 +125,9 @@ extern "C" int dh_block_fwd(const dh_block_args* a, dh_stream_t st) {
   float* lse = (float*)(s + o.lse);
   RUN(dh_layernorm_fwd(a->dtype, a->x, p.ln1_w, p.ln1_b, h1, mean1, rstd1, R, d, p.eps1, st));
   RUN(linear(a, h1, R, d, p.w_in, 3 * d, false, p.b_in, DH_EPI_NONE, nullptr, nullptr, qkv, false, st));
-  if (a->cu) RUN(dh_attn_varlen_fwd(a->dtype, qkv, at, lse, a->cu, a->b, a->L, a->heads, hd, a->causal, a->rows_valid, R, st));
+  if (a->cu && a->seq_order) RUN(dh_attn_bucketed_fwd(a->dtype, qkv, at, lse, a->cu, a->seq_order, a->seq_ranges, a->b, a->L, a->L_short, a->heads, hd,
+                                                      a->causal, a->rows_valid, R, st));
+  else if (a->cu) RUN(dh_attn_varlen_fwd(a->dtype, qkv, at, lse, a->cu, a->b, a->L, a->heads, hd, a->causal, a->rows_valid, R, st));
   else RUN(dh_attn_fwd(a->dtype, qkv, at, lse, a->b, a->L, a->heads, hd, a->causal, st));
   RUN(linear(a, at, R, d, p.w_out, d, false, p.b_out, DH_EPI_NONE, a->x, nullptr, x_mid, true, st));
   RUN(dh_layernorm_fwd(a->dtype, x_mid, p.ln2_w, p.ln2_b, h2, mean2, rstd2, R, d, p.eps2, st));
@@ -157,7 +160,9 @@ extern "C" int dh_block_bwd(dh_block_args* a, dh_stream_t st) {
                             a->ln_part_bytes, &a->ln_nb2, st));
   // attention: x_mid = x + attn(h1) Wout^T + bout
   RUN(linear(a, dx_mid, R, d, p.w_out, d, true, nullptr, DH_EPI_NONE, nullptr, nullptr, da, true, st));
-  if (a->cu) RUN(dh_attn_varlen_bwd(a->dtype, qkv, at, da, lse, dqkv, a->cu, a->b, a->L, a->heads, hd, a->causal, a->rows_valid, R, st));
+  if (a->cu && a->seq_order) RUN(dh_attn_bucketed_bwd(a->dtype, qkv, at, da, lse, dqkv, a->cu, a->seq_order, a->seq_ranges, a->b, a->L, a->L_short,
+                                                      a->heads, hd, a->causal, a->rows_valid, R, st));
+  else if (a->cu) RUN(dh_attn_varlen_bwd(a->dtype, qkv, at, da, lse, dqkv, a->cu, a->b, a->L, a->heads, hd, a->causal, a->rows_valid, R, st));
   else RUN(dh_attn_bwd(a->dtype, qkv, at, da, lse, dqkv, a->b, a->L, a->heads, hd, a->causal, st));
   RUN(linear(a, dqkv, R, 3 * d, p.w_in, d, true, nullptr, DH_EPI_NONE, nullptr, nullptr, dh1, true, st));
   RUN(dh_layernorm_bwd_part(a->dtype, dh1, a->x, p.ln1_w, mean1, rstd1, dx_mid, a->dx, p.g_ln1_w, p.g_ln1_b, R, d, a->ln_part1,

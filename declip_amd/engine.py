@@ -475,7 +475,7 @@ def _bwd_scratch(device, nbytes):
 
 class NativeSaved(object):
     """What dh_block_bwd needs of a block forward that ran through dh_block_fwd: the input, the activation slab, the geometry."""
-    __slots__ = ("x", "act", "b", "L", "heads", "causal", "cu", "rows_valid")
+    __slots__ = ("x", "act", "b", "L", "heads", "causal", "cu", "rows_valid", "buckets")
 
     def views(self):
         """The slab as the tensors the Python composition saves (block_fwd's tuple; no copies)."""
@@ -499,13 +499,15 @@ class NativeSaved(object):
         return self.x, mean1, rstd1, h1, qkv, a, lse, x_mid, mean2, rstd2, h2, u, g
 
 
-def _block_cargs(x, r, b, L, heads, causal, cu, rows_valid):
+def _block_cargs(x, r, b, L, heads, causal, cu, rows_valid, buckets=None):
     from .lib import BlockArgs, dt
     ptr = ops.ptr
     a = BlockArgs()
     rows, d = x.shape
     a.dtype, a.rows, a.d, a.heads, a.b, a.L, a.causal = dt(x), rows, d, heads, b, L, int(bool(causal))
     a.cu, a.rows_valid = ptr(cu), int(rows_valid)
+    if buckets is not None:
+        a.seq_order, a.seq_ranges, a.L_short = ptr(buckets[0]), ptr(buckets[1]), int(buckets[2])
     a.p = r.cparams()
     if x.is_cuda and x.dtype == torch.bfloat16:
         ws = gemm_workspace(x.device)
@@ -513,21 +515,21 @@ def _block_cargs(x, r, b, L, heads, causal, cu, rows_valid):
     return a
 
 
-def _block_fwd_native(x, r, b, L, heads, causal, save, cu=None, rows_valid=0):
+def _block_fwd_native(x, r, b, L, heads, causal, save, cu=None, rows_valid=0, buckets=None):
     from .lib import dt
     ptr = ops.ptr
     rows, d = x.shape
     total, _ = ops.block_act_layout(dt(x), rows, d, heads, b, L)
     act = torch.empty(total, device=x.device, dtype=torch.uint8)
     x_out = torch.empty_like(x)
-    a = _block_cargs(x, r, b, L, heads, causal, cu, rows_valid)
+    a = _block_cargs(x, r, b, L, heads, causal, cu, rows_valid, buckets)
     a.save = int(bool(save))
     a.x, a.x_out, a.act, a.act_bytes = ptr(x), ptr(x_out), ptr(act), total
     ops.block_fwd(a)
     if not save:
         return x_out, None
     sv = NativeSaved()
-    sv.x, sv.act, sv.b, sv.L, sv.heads, sv.causal, sv.cu, sv.rows_valid = x, act, b, L, heads, causal, cu, rows_valid
+    sv.x, sv.act, sv.b, sv.L, sv.heads, sv.causal, sv.cu, sv.rows_valid, sv.buckets = x, act, b, L, heads, causal, cu, rows_valid, buckets
     return x_out, sv
 
 
@@ -542,7 +544,7 @@ def _block_bwd_native(dx_out, r, sv):
     nscr = ops.block_bwd_scratch_bytes(dt(x), rows, d)
     scratch = _bwd_scratch(x.device, nscr)
     dx = torch.empty_like(x)
-    a = _block_cargs(x, r, sv.b, sv.L, sv.heads, sv.causal, sv.cu, sv.rows_valid)
+    a = _block_cargs(x, r, sv.b, sv.L, sv.heads, sv.causal, sv.cu, sv.rows_valid, sv.buckets)
     a.x, a.act, a.act_bytes = ptr(x), ptr(sv.act), sv.act.numel()
     a.dx_out, a.dx, a.scratch, a.scratch_bytes = ptr(dx_out), ptr(dx), ptr(scratch), nscr
     a.ln_part1, a.ln_part2, a.ln_part_bytes = ptr(part1), ptr(part2), n * 4
@@ -936,6 +938,8 @@ class PackedCaptions:
     removes ~45 % of the text tower's GEMM / LayerNorm work on the synthetic captions of SURVEY.md s8(d), more on real ones.
     Index arithmetic only (torch, on the device)."""
 
+    L_SHORT = 48          # captions up to here run on the 3-key-block attention kernels (context 77: 5 blocks)
+
     def __init__(self, ids, tile, varlen=True):
         self.varlen = varlen                                             # attention on the packed rows (else: via the dense layout)
         b, L = ids.shape
@@ -976,6 +980,19 @@ class PackedCaptions:
         self.unpack_idx = (cu[:-1, None] + torch.where(l < lens[:, None], l, torch.zeros_like(l))).reshape(-1).contiguous()
         self.eot_rows = (cu[1:] - 1).contiguous()
         self.row0, self.nkeys = self.cu[:-1].contiguous(), (self.cu[1:] - self.cu[:-1]).contiguous()   # the pooled last block's key rows
+        # two length buckets for the attention kernels (dh_attn_bucketed_*): the captions of at most L_SHORT tokens first
+        short = lens <= self.L_SHORT
+        self.order = torch.sort((~short).to(torch.int32), stable=True)[1].to(torch.int32).contiguous()
+        ns = short.sum().to(torch.int32).reshape(1)
+        self.ranges = torch.cat([torch.zeros_like(ns), ns, ns, b - ns]).contiguous()
+
+
+def _buckets(pk, x, heads):
+    """(order, ranges, L_short) when the length-bucketed attention kernels apply (bf16, head dimension 64, a context longer than the
+    short bucket; DH_ATTN_BUCKETS=0 switches them off), else None."""
+    if x.dtype != torch.bfloat16 or x.shape[1] // heads != 64 or pk.L <= pk.L_SHORT or os.environ.get("DH_ATTN_BUCKETS", "1") != "1":
+        return None
+    return pk.order, pk.ranges, pk.L_SHORT
 
 
 def _rows_arg(pk, x, heads):
@@ -988,11 +1005,15 @@ def block_fwd_packed(x, r, pk, heads, save):
     """block_fwd on packed rows [rows_pad, d].  Attention: the variable-length kernels on the packed rows (pk.varlen), or -- the
     fallback that touches only long-verified kernels, DH_TEXT_PACKED=2 -- gather to the dense [b, L] layout and back."""
     if pk.varlen and native_blocks():
-        return _block_fwd_native(x, r, pk.b, pk.L, heads, True, save, cu=pk.cu, rows_valid=_rows_arg(pk, x, heads))
+        return _block_fwd_native(x, r, pk.b, pk.L, heads, True, save, cu=pk.cu, rows_valid=_rows_arg(pk, x, heads), buckets=_buckets(pk, x, heads))
     h1, mean1, rstd1 = ops.layernorm_fwd(x, r.ln1_w, r.ln1_b, r.eps1)
     qkv = ops.gemm(h1, r.w_in, bias=r.b_in)
     if pk.varlen:
-        a, lse = ops.attn_varlen_fwd(qkv, pk.cu, _rows_arg(pk, x, heads), pk.b, pk.L, heads, True)
+        bk = _buckets(pk, x, heads)
+        if bk is not None:
+            a, lse = ops.attn_bucketed_fwd(qkv, pk.cu, bk[0], bk[1], _rows_arg(pk, x, heads), pk.b, pk.L, bk[2], heads, True)
+        else:
+            a, lse = ops.attn_varlen_fwd(qkv, pk.cu, _rows_arg(pk, x, heads), pk.b, pk.L, heads, True)
         att_saved = (qkv, a)
     else:
         qkv_d = ops.gather_rows(qkv, pk.unpack_idx)
@@ -1027,7 +1048,11 @@ def block_bwd_packed(dx_out, r, saved, pk, heads):
     da = ops.gemm(dx_mid, r.w_out, b_kmajor=True, ws=ws)
     if pk.varlen:
         qkv, a_p = att_saved
-        dqkv = ops.attn_varlen_bwd(qkv, a_p, da, lse, pk.cu, _rows_arg(pk, x, heads), pk.b, pk.L, heads, True)
+        bk = _buckets(pk, x, heads)
+        if bk is not None:
+            dqkv = ops.attn_bucketed_bwd(qkv, a_p, da, lse, pk.cu, bk[0], bk[1], _rows_arg(pk, x, heads), pk.b, pk.L, bk[2], heads, True)
+        else:
+            dqkv = ops.attn_varlen_bwd(qkv, a_p, da, lse, pk.cu, _rows_arg(pk, x, heads), pk.b, pk.L, heads, True)
     else:
         qkv_d, a_d = att_saved
         # padded queries must carry a ZERO output gradient: a later (padded) query does attend to the valid keys before it

@@ -53,7 +53,7 @@ class BlockParams(Structure):
 class BlockArgs(Structure):
     """dh_block_args (include/declip_hip.h)"""
     _fields_ = [("dtype", c_int), ("rows", c_int), ("d", c_int), ("heads", c_int), ("b", c_int), ("L", c_int), ("causal", c_int), ("save", c_int),
-                ("cu", c_void_p), ("rows_valid", c_int), ("p", BlockParams), ("x", c_void_p), ("x_out", c_void_p),
+                ("cu", c_void_p), ("rows_valid", c_int), ("seq_order", c_void_p), ("seq_ranges", c_void_p), ("L_short", c_int), ("p", BlockParams), ("x", c_void_p), ("x_out", c_void_p),
                 ("act", c_void_p), ("act_bytes", c_int64), ("ws", c_void_p), ("ws_bytes", c_int64), ("dx_out", c_void_p), ("dx", c_void_p),
                 ("scratch", c_void_p), ("scratch_bytes", c_int64), ("ln_part1", c_void_p), ("ln_part2", c_void_p), ("ln_part_bytes", c_int64),
                 ("ln_nb1", c_int), ("ln_nb2", c_int)]
@@ -87,6 +87,8 @@ _PROTOS = {
     "dh_attn_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_varlen_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_varlen_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dh_attn_bucketed_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dh_attn_bucketed_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_pooled_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_pooled_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "dh_text_embed_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),

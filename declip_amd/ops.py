@@ -241,6 +241,28 @@ def attn_varlen_bwd(qkv, out, dout, lse, cu, rows, b, Lmax, heads, causal):
     return dqkv
 
 
+def attn_bucketed_fwd(qkv, cu, order, ranges, rows, b, Lmax, L_short, heads, causal):
+    """attn_varlen_fwd in two length buckets (dh_attn_bucketed_fwd): order int32 [b] (short sequences first), ranges int32 [4]."""
+    _contig(qkv, "qkv")
+    _req(cu.dtype == torch.int32 and order.dtype == torch.int32 and ranges.dtype == torch.int32 and order.numel() == b and ranges.numel() == 4,
+         "attn_bucketed_fwd: cu / order / ranges int32")
+    d = qkv.shape[-1] // 3
+    out = torch.empty(qkv.shape[0], d, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(b, heads, Lmax, device=qkv.device, dtype=torch.float32)
+    check(L.load().dh_attn_bucketed_fwd(dt(qkv), ptr(qkv), ptr(out), ptr(lse), ptr(cu), ptr(order), ptr(ranges), b, Lmax, L_short, heads, d // heads,
+                                        int(causal), int(rows), int(qkv.shape[0]), stream()), "dh_attn_bucketed_fwd")
+    return out, lse
+
+
+def attn_bucketed_bwd(qkv, out, dout, lse, cu, order, ranges, rows, b, Lmax, L_short, heads, causal):
+    _contig(qkv, "qkv"), _contig(out, "out"), _contig(dout, "dout")
+    d = qkv.shape[-1] // 3
+    dqkv = torch.empty_like(qkv)
+    check(L.load().dh_attn_bucketed_bwd(dt(qkv), ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(cu), ptr(order), ptr(ranges), b, Lmax,
+                                        L_short, heads, d // heads, int(causal), int(rows), int(qkv.shape[0]), stream()), "dh_attn_bucketed_bwd")
+    return dqkv
+
+
 def attn_pooled_fwd(q, kv, row0, nkeys, heads, Lmax):
     """one query per sequence: q [b, d], kv [rows, 2d]; keys of sequence i = kv rows row0[i] .. row0[i] + nkeys[i] - 1."""
     _contig(q, "q"), _contig(kv, "kv")

@@ -155,6 +155,16 @@ int dh_attn_varlen_fwd(int dtype, const void* qkv, void* out, float* lse, const 
                        int causal, int rows, int rows_pad, dh_stream_t stream);
 int dh_attn_varlen_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                        const int* cu_seqlens, int b, int Lmax, int heads, int hd, int causal, int rows, int rows_pad, dh_stream_t stream);
+/* The same in two LENGTH BUCKETS (bf16, hd = 64): sequences order[0 .. n_short) are at most L_short rows long and run on the kernel
+ * instantiation with ceil(L_short / 16) key blocks, the rest on the Lmax one -- a 20-token caption no longer occupies the workgroup
+ * shape of a 77-token one (text_transformer.py:136-142 pads every caption to the context length).  order int32 [b] = a permutation of
+ * the sequences, short ones first; ranges int32 [4] = {0, n_short, n_short, b - n_short}; both in device memory (the packed batch's
+ * bookkeeping), like rows = -1: nothing of a launch depends on the batch beyond rows_pad. */
+int dh_attn_bucketed_fwd(int dtype, const void* qkv, void* out, float* lse, const int* cu_seqlens, const int* order, const int* ranges,
+                         int b, int Lmax, int L_short, int heads, int hd, int causal, int rows, int rows_pad, dh_stream_t stream);
+int dh_attn_bucketed_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                         const int* cu_seqlens, const int* order, const int* ranges, int b, int Lmax, int L_short, int heads, int hd,
+                         int causal, int rows, int rows_pad, dh_stream_t stream);
 /* Pooled-query attention for the LAST block of a tower: only the pooled row's output is used downstream (CLS,
  * image_encoder/visual_transformer.py:70-72; <|endoftext|>, text_encoder/text_transformer.py:203), so that block's query projection,
  * attention, out_proj and MLP are needed for b rows, not b*L (K, V still come from every row).  q [b][d] (the pooled rows'
@@ -192,6 +202,7 @@ typedef struct dh_block_params {
 typedef struct dh_block_args {
   int dtype, rows, d, heads, b, L, causal, save;
   const int* cu; int rows_valid;
+  const int* seq_order; const int* seq_ranges; int L_short;   /* packed sequences in two length buckets (dh_attn_bucketed_fwd), or NULL */
   dh_block_params p;
   const void* x; void* x_out;
   void* act; int64_t act_bytes;

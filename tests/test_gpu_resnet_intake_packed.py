@@ -456,6 +456,40 @@ def test_attention_varlen_matches_per_sequence_reference(dtype, causal):
         assert float((dqkv[r0:r0 + n] - x.grad).abs().max()) <= tol * max(1.0, float(x.grad.abs().max())) * (1 if dtype == torch.float32 else 3), (i, n)
 
 
+@pytest.mark.parametrize("nseq,device_rows", [(240, False), (240, True), (7, True)])
+def test_attention_length_buckets_equal_the_plain_varlen_kernels(nseq, device_rows):
+    """dh_attn_bucketed_fwd / _bwd (captions of at most 48 tokens on the 3-key-block instantiation, the rest on the 5-block one;
+    sequence lists and counts read on the device) against dh_attn_varlen_*: same values per sequence (extra key blocks of the long
+    instantiation hold zero rows that the masks skip), the padding rows zero, also with rows = -1 and with one of the buckets empty."""
+    from declip_amd import ops
+    torch.manual_seed(3)
+    heads, hd, Lmax, Ls = 8, 64, 77, 48
+    base = [5, 77, 1, 33, 48, 64, 49, 16]
+    lens = (base * ((nseq + 7) // 8))[:nseq] if nseq > 8 else [60, 77, 50, 49, 70, 55, 66][:nseq]      # (7: every caption long -> empty short bucket)
+    b, d = len(lens), heads * hd
+    rows = sum(lens)
+    rows_pad = (rows + 255) // 256 * 256
+    lt = torch.tensor(lens)
+    cu = torch.tensor([0] + list(lt.cumsum(0)), dtype=torch.int32).cuda()
+    short = lt <= Ls
+    order = torch.sort((~short).to(torch.int32), stable=True)[1].to(torch.int32).cuda()
+    ns = int(short.sum())
+    ranges = torch.tensor([0, ns, ns, b - ns], dtype=torch.int32).cuda()
+    qkv = (torch.randn(rows_pad, 3 * d) * 0.7).to(torch.bfloat16).cuda()
+    dout = torch.randn(rows_pad, d).to(torch.bfloat16).cuda()
+    r = -1 if device_rows else rows
+    o0, l0 = ops.attn_varlen_fwd(qkv, cu, rows, b, Lmax, heads, True)
+    g0 = ops.attn_varlen_bwd(qkv, o0, dout, l0, cu, rows, b, Lmax, heads, True)
+    o1, l1 = ops.attn_bucketed_fwd(qkv, cu, order, ranges, r, b, Lmax, Ls, heads, True)
+    g1 = ops.attn_bucketed_bwd(qkv, o1, dout, l1, cu, order, ranges, r, b, Lmax, Ls, heads, True)
+    torch.cuda.synchronize()
+    assert float(o1[rows:].float().abs().max()) == 0.0 and float(g1[rows:].float().abs().max()) == 0.0
+    assert float((o1.float() - o0.float()).abs().max()) <= 1e-6 * float(o0.float().abs().max())
+    assert float((g1.float() - g0.float()).abs().max()) <= 1e-6 * float(g0.float().abs().max())
+    for i in range(b):                                    # lse: [b][heads][Lmax], valid entries only
+        assert torch.equal(l1[i, :, :lens[i]], l0[i, :, :lens[i]])
+
+
 def test_packed_text_tower_gather_mode_fp32_matches_reference_golden(monkeypatch):
     import test_gpu_clip as G
     monkeypatch.setenv("DH_TEXT_PACKED", "2")
