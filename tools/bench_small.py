@@ -34,6 +34,8 @@ def bf(*shape):
 
 
 which = set((os.environ.get("BENCH_SMALL") or "attn_img,attn_txt,ln").split(","))
+if "all" in which:
+    which = {"attn_img", "attn_txt", "attn_txt_short", "ln"}
 if "attn_img" in which:
     b, L, heads, d = 512, 50, 12, 768
     qkv, dout = bf(b * L, 3 * d), bf(b * L, d)
@@ -48,6 +50,10 @@ if "attn_txt" in which:
     outs = [ops.attn_varlen_fwd(q, pk.cu, pk.rows, b, L, heads, True) for q in qkv]
     timed(lambda i: ops.attn_varlen_fwd(qkv[i], pk.cu, pk.rows, b, L, heads, True), pk.rows * d * 2 * 4, "attn fwd text (%d rows, 8 heads)" % pk.rows)
     timed(lambda i: ops.attn_varlen_bwd(qkv[i], outs[i][0], dout[i], outs[i][1], pk.cu, pk.rows, b, L, heads, True), pk.rows * d * 2 * 8, "attn bwd text")
+    # round 4: the same batch in two length buckets (<= 48 tokens on the 3-key-block kernels), counts read on the device
+    timed(lambda i: ops.attn_bucketed_fwd(qkv[i], pk.cu, pk.order, pk.ranges, -1, b, L, pk.L_SHORT, heads, True), pk.rows * d * 2 * 4, "attn fwd text, length buckets")
+    timed(lambda i: ops.attn_bucketed_bwd(qkv[i], outs[i][0], dout[i], outs[i][1], pk.cu, pk.order, pk.ranges, -1, b, L, pk.L_SHORT, heads, True), pk.rows * d * 2 * 8,
+          "attn bwd text, length buckets")
 if "attn_txt_short" in which:
     # what a smaller instantiation would buy for the SHORT captions: 512 captions of 9 .. 48 tokens through the 77-token kernels
     # (five 16-key blocks, 320 threads, 68 KB of LDS) and through the 48-token ones (three blocks, 192 threads, 38 KB)
