@@ -16,6 +16,7 @@ XCDS = 8        # MI355X: 8 XCDs, one GRBM each
 
 def short(name):
     name = re.sub(r"^void ", "", name)
+    name = name.replace("(anonymous namespace)::", "")      # (else the argument-list strip below eats the whole name)
     name = re.sub(r"\(.*$", "", name)
     return name[:70]
 
@@ -66,7 +67,10 @@ def main(root):
 
 
     # machine-readable total for bench.py's roofline.traffic: HBM-side bytes of the GEMM family per profiled step
-    steps = int(os.environ.get("PMC_STEPS", "3"))
+    # steps that ran under the counters = launches of the optimizer kernel (one per step; bench.py's warm-up, timed and
+    # host-enqueue-measurement steps all count), unless PMC_STEPS says otherwise
+    adam = [k for k in agg if "adamw_seg_kernel" in k]
+    steps = int(os.environ.get("PMC_STEPS", "0")) or (max(calls[adam[0]].values()) if adam else 3)
     gemm = [k for k in agg if "gemm" in k]
     rd = sum(agg[k].get("FETCH_SIZE", 0.0) for k in gemm) * 1024 * 2
     wr = sum(agg[k].get("WRITE_SIZE", 0.0) for k in gemm) * 1024
