@@ -437,6 +437,56 @@ class ClsSolver(object):
     def _clamp_params(self):                                # kept for callers of the round-1 name
         self._param_clip_after()
 
+    # ---- the captured step (declip_amd/graph.py): forward + loss + backward as ONE hipGraph launch per iteration, for a batch that
+    # changes every iteration as the reference's does (clip_solver.py:398-402).  Opt-in: model.kwargs.engine.step_graph: true, or
+    # DH_STEP_GRAPH=1.  CLIP only (one image view, one caption per pair); the batch is copied into static buffers, graphs are kept
+    # per padded packed row count of its captions (engine.packed_key).
+    def _graph_wanted(self):
+        if self.__dict__.get("_graph_off"):
+            return False
+        eng_cfg = dict(self.config.model.get("kwargs", {}).get("engine", {}) or {})
+        want = bool(eng_cfg.get("step_graph", False)) or os.environ.get("DH_STEP_GRAPH", "0") == "1"
+        typ, _ = self._gc()
+        # parameter clips that act BETWEEN forward and backward in the reference (constant / logit_scale_param / abs_min) keep the eager step
+        ok = (want and self.kind == "clip" and self.device.type == "cuda" and typ in (None, "logit_scale_param_value", "norm", "value", "logit_scale_grad")
+              and (self.world_size == 1 or torch.distributed.get_backend() == "nccl"))
+        if not ok:
+            self._graph_off = True
+        return ok
+
+    def _graphed_loss(self, batch):
+        from . import engine
+        from .graph import GraphedStep
+        images, caps = batch["images"], batch["captions"]
+        if not (torch.is_tensor(images) and torch.is_tensor(caps) and images.is_cuda and caps.is_cuda and images.dtype == torch.float32 and caps.dim() == 2):
+            self._graph_off = True               # strings / host tensors / uint8 intake outside the prefetcher: the eager step takes them
+            return None
+        g = self.__dict__.get("_graph")
+        if g is None or g["images"].shape != images.shape or g["captions"].shape != caps.shape:
+            st = {"images": torch.empty_like(images), "captions": torch.empty_like(caps)}
+            m = self.model.module
+            dtype = m.__dict__["_flat_store"].act_dtype
+            packed = engine.text_packed_mode() == 1
+            heads_dim = int(m.encode_text.width) // int(m.encode_text.heads)
+
+            def fn():
+                out = steps.clip_loss(self.model, st, self.criterion, self.world_size)
+                out["loss"].backward()
+                return out["loss"].detach(), out["top1"].detach(), out["top5"].detach()
+            key = (lambda: engine.packed_key(st["captions"], dtype, heads_dim)) if packed else None
+            g = dict(st, step=GraphedStep(fn, warmup=2, modules=(self.model,), key=key))
+            self._graph = g
+        g["images"].copy_(images)
+        g["captions"].copy_(caps)
+        tag = getattr(caps, "_dh_rows", None)
+        if tag is None or tag[0] != caps._version:
+            rows = int((caps.argmax(dim=-1) + 1).sum())          # one read-back for a tensor that came without its host-side count
+            caps._dh_rows = (caps._version, rows)
+            tag = caps._dh_rows
+        engine.set_rows_tag(g["captions"], tag[1])
+        loss, p1, p5 = g["step"]()
+        return dict(loss=loss, top1=p1, top5=p5)
+
     def train_step(self, curr_step):
         if hasattr(self.loader, "get"):
             batch = self.loader.get(curr_step)
@@ -448,6 +498,16 @@ class ClsSolver(object):
                                    "infinite / iteration-sized sampler (data/sampler.py DistributedGivenIterationSampler in the "
                                    "reference)" % (curr_step, self.max_iter)) from None
         self.lr_scheduler.step(curr_step)
+        if self._graph_wanted():
+            self.optimizer.zero_grad()
+            self._param_clip_before()            # (a clamp the previous step's _param_clip_after already applied: a no-op here)
+            out = self._graphed_loss(batch)
+            if out is not None:
+                self.model.sync_gradients()
+                self._grad_clip_before()
+                self.optimizer.step()
+                self._param_clip_after()
+                return out
         out = self._loss(batch)
         self.optimizer.zero_grad()
         self._param_clip_before()

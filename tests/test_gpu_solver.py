@@ -34,6 +34,40 @@ def test_solver_reduces_loss_on_a_fixed_batch(kind):
     assert 3.0 <= float(s.model.module.logit_scale.detach()) <= 6.0
 
 
+@pytest.mark.parametrize("heads", [8, 2])
+def test_solver_graphed_step_matches_the_eager_step(heads, monkeypatch):
+    """model.kwargs.engine.step_graph: the CLIP solver's forward + loss + backward replayed from captured graphs (one per packed-row
+    key of the caption batch; declip_amd/graph.py) while the loader hands a DIFFERENT batch every iteration (clip_solver.py:398-402),
+    against the same run stepped eagerly: same loss trajectory and temperature.  heads = 2: head dimension 64 (the key is the padded
+    row count, the valid count is read on the device); heads = 8: head dimension 16 (the key carries the exact count)."""
+    from declip_amd.solver import ClsSolver
+
+    def run(graph):
+        cfg = _config("clip")
+        cfg["model"]["kwargs"]["text_encode"]["transformer_heads"] = heads
+        cfg["model"]["kwargs"]["engine"] = dict(dtype="bf16", step_graph=graph)
+        torch.manual_seed(0)
+        s = ClsSolver(cfg)
+        rec, orig = [], s.train_step
+
+        def wrapped(step):
+            out = orig(step)
+            rec.append(out["loss"].detach().clone())
+            return out
+        s.train_step = wrapped
+        s.train(max_steps=10)
+        torch.cuda.synchronize()
+        return s, [float(x) for x in rec]
+
+    se, le = run(False)
+    sg, lg = run(True)
+    assert sg.__dict__.get("_graph") is not None and sg._graph["step"].replays >= 3 and sg._graph["step"].captures >= 1
+    assert se.__dict__.get("_graph") is None
+    for a, c in zip(lg, le):
+        assert abs(a - c) <= 5e-3 * abs(c), (lg, le)
+    assert abs(float(sg.model.module.logit_scale) - float(se.model.module.logit_scale)) <= 1e-3
+
+
 def test_solver_prefetcher_bytes_and_strings_match_floats_and_ids(tmp_path):
     """A user loader that yields what a decoder yields -- uint8 HWC images and caption strings -- through the prefetcher
     (background tokenisation, pinned staging, copies on a side stream, bytes normalised on the GPU) gives the same first losses as
