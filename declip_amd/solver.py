@@ -471,6 +471,7 @@ class ClsSolver(object):
 
             def fn():
                 out = steps.clip_loss(self.model, st, self.criterion, self.world_size)
+                self._param_clip_before()        # between forward and backward, where the reference has it (clip_solver.py:489-505): device-side clamps, captured with the step
                 out["loss"].backward()
                 return out["loss"].detach(), out["top1"].detach(), out["top5"].detach()
             key = (lambda: engine.packed_key(st["captions"], dtype, heads_dim)) if packed else None
@@ -500,7 +501,6 @@ class ClsSolver(object):
         self.lr_scheduler.step(curr_step)
         if self._graph_wanted():
             self.optimizer.zero_grad()
-            self._param_clip_before()            # (a clamp the previous step's _param_clip_after already applied: a no-op here)
             out = self._graphed_loss(batch)
             if out is not None:
                 self.model.sync_gradients()
