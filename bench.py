@@ -279,7 +279,13 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1:
+    # DH_DIST_FORCE=1 on one GPU: the step of a multi-GPU rank (RCCL process group of ONE rank, packed all-gather + reduce-scatter,
+    # bucketed all-reduce inside backward, dynamic tile distribution, eager) -- everything of the W > 1 path but a second rank
+    forced = world == 1 and os.environ.get("DH_DIST_FORCE") == "1"
+    if forced:
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("DH_V4_DYNAMIC", "1")
+    if world > 1 or forced:
         dh_dist.initialize("nccl")
     else:
         torch.cuda.set_device(0)
@@ -294,7 +300,7 @@ def main():
     b = args.batch if args.batch is not None else {"clip_r50": 32, "filip": 256, "defilip": 256}.get(args.model, 512)
     crit = ClipInfoCELoss()
     if args.model in ("clip", "clip_r50"):
-        model = build_clip(cfg, dtype=args.dtype, use_allgather=(world > 1), seed=0, load_synth=False)
+        model = build_clip(cfg, dtype=args.dtype, use_allgather=(world > 1 or forced), seed=0, load_synth=False)
         images = synth.synth_images(b, seed=rank).to(dev)
         ids = synth.synth_tokens(b, seed=rank).to(dev)
         batch = {"images": images, "captions": ids}
@@ -329,7 +335,7 @@ def main():
     # default: on for one GPU where a graph == eager test gates it (tests/test_gpu_graph.py: clip, clip_r50, declip, defilip, filip);
     # multi-GPU runs capture the RCCL collectives with the step only when asked to (--graph 1 / DH_STEP_GRAPH=1; the capture of a
     # one-rank RCCL step is tested in tests/test_gpu_dist.py, W > 1 has not run anywhere yet) and never over a gloo group
-    graph_default = "1" if (world == 1 and args.model in ("clip", "clip_r50", "filip", "declip", "defilip")) else "0"
+    graph_default = "1" if (world == 1 and not forced and args.model in ("clip", "clip_r50", "filip", "declip", "defilip")) else "0"
     use_graph = (args.graph if args.graph is not None else os.environ.get("DH_STEP_GRAPH", graph_default)) == "1"
     if world > 1 and torch.distributed.get_backend() != "nccl":
         use_graph = False
@@ -632,7 +638,8 @@ def main():
                                            "flags + caption strings; BPE (dh_bpe_encode) and box bookkeeping on 1 worker thread (%d host cores usable), "
                                            "pinned H2D on a copy stream, dh_image_resized_crop_u8 on the GPU" % hostinfo.usable_cores()),
                            host_threads=host_threads,
-                           rccl_ranks=rccl_ranks, dist_backend=(torch.distributed.get_backend() if world > 1 else None),
+                           rccl_ranks=rccl_ranks, dist_backend=(torch.distributed.get_backend() if (world > 1 or forced) else None),
+                           one_rank_rccl_group=int(forced),
                            ranks=[list(x) for x in devs], self_launched=int(os.environ.get("DH_BENCH_SELF_LAUNCHED", "0")),
                            dynamic_tiles=int(os.environ.get("DH_V4_DYNAMIC", "0")), comm_native=int(dh_dist.native_comm() is not None) if world > 1 else 0,
                            native_blocks=int(eng_mod.native_blocks()),
@@ -648,7 +655,7 @@ def main():
         pipeline.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         torch.distributed.destroy_process_group()
 
 
