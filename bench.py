@@ -223,7 +223,7 @@ def dry_run_launch(args):
                                           ranks=[list(x) for x in ranks], self_launched=int(os.environ.get("DH_BENCH_SELF_LAUNCHED", "0")))),
                          **({} if ok else dict(error="communicator does not match the launch"))), flush=True)
     if world > 1:
-        tdist.barrier()
+        dh_dist.barrier()
         tdist.destroy_process_group()
     return 0 if ok else 3
 
@@ -437,7 +437,7 @@ def main():
 
     def sync():
         if world > 1:
-            torch.distributed.barrier()
+            dh_dist.barrier()
         torch.cuda.synchronize()
 
     sync()

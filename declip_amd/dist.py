@@ -63,7 +63,12 @@ def initialize(backend="nccl"):
     else:
         backend = "gloo"
     kw = {}
-    if backend == "nccl" and torch.cuda.is_available():
+    # NO `device_id=` for the process group (round 4): with it ProcessGroupNCCL (torch 2.10 / RCCL 2.26) initialises the communicator
+    # eagerly in a mode that costs ~0.35 ms of GPU-visible stall per collective -- measured with a one-rank group on the MI355X: the
+    # CLIP step 29.3 ms with device_id against 24.1 ms without (23.7 ms with no process group at all), i.e. a fifth of the step for
+    # its ~15 collectives.  The device is bound by torch.cuda.set_device above; barrier() names it explicitly (dist.barrier).
+    # DH_PG_DEVICE_ID=1 restores the old call (A/B switch).
+    if backend == "nccl" and torch.cuda.is_available() and os.environ.get("DH_PG_DEVICE_ID", "0") == "1":
         kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
     tdist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     if os.environ.get("DH_COMM_NATIVE", "0") == "1" and torch.cuda.is_available():
@@ -88,7 +93,10 @@ def barrier():
     """linklink.barrier as reference-style callers use it for HOST-side ordering (rank 0 writes a file the other ranks read,
     result dumps of evaluate(), checkpoint hand-off): a real barrier over the process group when one is initialised."""
     if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
-        tdist.barrier()
+        if tdist.get_backend() == "nccl" and torch.cuda.is_available():
+            tdist.barrier(device_ids=[torch.cuda.current_device()])      # (the group was created without device_id: name the device here)
+        else:
+            tdist.barrier()
     return None
 
 
@@ -303,6 +311,8 @@ class DistModule(torch.nn.Module):
 
     def __init__(self, module, sync=False, bucket_bytes=48 << 20, grad_dtype=None):
         super().__init__()
+        if os.environ.get("DH_BUCKET_MB"):                 # A/B knob: size of the gradient all-reduce buckets
+            bucket_bytes = int(float(os.environ["DH_BUCKET_MB"]) * (1 << 20))
         self.module = module
         self.sync = sync
         flat = module.__dict__.get("_flat_store")
