@@ -130,10 +130,15 @@ __device__ __forceinline__ float block_max256(float v, float* red) {
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+#ifdef DH_GELU_ABL   // ablation builds only (tools/build_lib_variant.sh abl -DDH_GELU_ABL): what the activation's arithmetic costs the epilogues
+__device__ __forceinline__ float quick_gelu_f(float x) { return x * 0.5f; }
+__device__ __forceinline__ float quick_gelu_grad_f(float x) { return 0.5f + 0.001f * x; }
+#else
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float quick_gelu_grad_f(float x) {
   float s = 1.f / (1.f + __expf(-1.702f * x));
   return s * (1.f + 1.702f * x * (1.f - s));
 }
+#endif
 
 static inline int dh_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
