@@ -220,6 +220,39 @@ def test_attention_varlen_matches_per_sequence_reference(dtype, causal):
         assert float((lse[i, :, :n] - ref_lse).abs().max()) <= (1e-4 if dtype == F32 else 3e-2)
 
 
+@pytest.mark.parametrize("lens", [[5, 77, 1, 33, 48, 64, 49, 16, 20, 70], [60, 77, 50, 49], [3, 48, 17]])
+def test_attention_length_buckets_and_device_side_rows_on_the_emulation(lens):
+    """dh_attn_bucketed_fwd / _bwd (round 4): captions of at most 48 tokens on the 3-key-block instantiation, the rest on the 5-block one,
+    the sequence lists, the two (start, count) ranges AND the valid row count (rows = -1 -> cu_seqlens[b]) read on the device -- against
+    dh_attn_varlen_* with host-side rows on the same packed batch: same values, zero padding rows, lse equal on the valid entries; a mixed
+    batch, one with an empty short bucket, one with an empty long bucket."""
+    torch.manual_seed(4)
+    heads, hd, Lmax, Ls = 2, 64, 77, 48
+    b, d = len(lens), heads * hd
+    rows = sum(lens)
+    rows_pad = (rows + 255) // 256 * 256
+    lt = torch.tensor(lens)
+    cu = torch.tensor([0] + list(lt.cumsum(0)), dtype=torch.int32)
+    short = lt <= Ls
+    order = torch.sort((~short).to(torch.int32), stable=True)[1].to(torch.int32)
+    ns = int(short.sum())
+    ranges = torch.tensor([0, ns, ns, b - ns], dtype=torch.int32)
+    qkv = (torch.randn(rows_pad, 3 * d) * 0.7).to(BF16)
+    dout = torch.randn(rows_pad, d).to(BF16)
+    with emulated_gpu() as ops:
+        o0, l0 = ops.attn_varlen_fwd(qkv, cu, rows, b, Lmax, heads, True)
+        g0 = ops.attn_varlen_bwd(qkv, o0, dout, l0, cu, rows, b, Lmax, heads, True)
+        o1, l1 = ops.attn_bucketed_fwd(qkv, cu, order, ranges, -1, b, Lmax, Ls, heads, True)
+        g1 = ops.attn_bucketed_bwd(qkv, o1, dout, l1, cu, order, ranges, -1, b, Lmax, Ls, heads, True)
+        o2, _ = ops.attn_varlen_fwd(qkv, cu, -1, b, Lmax, heads, True)                      # plain kernels, device-side row count
+    assert float(o1[rows:].float().abs().max()) == 0.0 and float(g1[rows:].float().abs().max()) == 0.0 and float(o2[rows:].float().abs().max()) == 0.0
+    assert torch.equal(o2[:rows], o0[:rows])
+    assert float((o1.float() - o0.float()).abs().max()) <= 1e-6 * float(o0.float().abs().max())
+    assert float((g1.float() - g0.float()).abs().max()) <= 1e-6 * float(g0.float().abs().max())
+    for i, n in enumerate(lens):
+        assert torch.equal(l1[i, :, :n], l0[i, :, :n])
+
+
 @pytest.mark.parametrize("L,causal", [(50, False), (64, True), (33, True)])
 def test_attention_dense_mfma_matches_reference(L, causal):
     """dh_attn_fwd / _bwd, bf16 (the MFMA kernels; L = 50 / 64: four 16-key blocks, the image tower's instantiation; L = 33: three, with
