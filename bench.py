@@ -171,9 +171,18 @@ def self_launch(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
+    # a rank that hangs (a communicator that never forms, a collective whose peer died without exiting) must not hang the caller
+    # for ever: DH_BENCH_LAUNCH_TIMEOUT seconds for the whole job (default 30 minutes), then every rank is killed and the line
+    # says so
+    deadline = time.time() + float(os.environ.get("DH_BENCH_LAUNCH_TIMEOUT", "1800"))
     try:
         pending = dict(enumerate(procs))
         while pending:
+            if time.time() > deadline:
+                for q in pending.values():
+                    q.kill()
+                print(json.dumps(dict(error="self-launched job timed out (DH_BENCH_LAUNCH_TIMEOUT)", n_gpus=n, ranks_still_running=sorted(pending))), flush=True)
+                return 4
             for r, p in list(pending.items()):
                 code = p.poll()
                 if code is None:
@@ -188,7 +197,7 @@ def self_launch(n):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    if rc not in (0, 3):
+    if rc not in (0, 3, 4):
         print(json.dumps(dict(error="a rank of the self-launched job exited with code %d" % rc, n_gpus=n)), flush=True)
     return rc
 

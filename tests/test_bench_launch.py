@@ -57,3 +57,10 @@ def test_bench_self_launched_two_ranks_share_the_gpu_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["self_launched"] == 1 and d["value"] > 0
     assert d["config"]["global_batch"] == 512 and len(d["config"]["ranks"]) == 2
+
+
+def test_bench_self_launch_times_out_instead_of_hanging(tmp_path):
+    """a rank that never finishes: the launcher kills the job after DH_BENCH_LAUNCH_TIMEOUT and prints a JSON error (exit 4)"""
+    rc, lines, err = _run(["--gpus", "2", "--dry-run-launch"], {"DH_DIST_BACKEND": "gloo", "DH_BENCH_LAUNCH_TIMEOUT": "0.0"})
+    assert rc == 4
+    assert len(lines) >= 1 and "timed out" in json.loads(lines[-1])["error"]
