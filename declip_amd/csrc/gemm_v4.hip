@@ -176,6 +176,11 @@ struct KArgs {
   int* sched;
   EpiParams e;
   int group_m;                            // tile order (tile_from_logical)
+  // tail-sliced launches (S > 0): 0 = the slices leave fp32 tiles for tail_fixup_kernel; 1 (round 5) = IN-KERNEL fix-up: every slice
+  // parks its accumulators in the workspace, counts itself on its tile's word of tail_cnt, and the LAST slice to arrive sums the S
+  // parked tiles in slice order and runs the ordinary bf16 epilogue -- no second launch, no waiting (nobody spins on anybody)
+  int tail_mode;
+  int* tail_cnt;                          // [tail tiles] arrival counters, zero at rest (the last arriver restores the zero)
   // MODE_GROUP only
   int T, ngrp;                            // tiles of all problems together; problems
   long zs, cs_zs;                         // floats per K-slice slab: partial tiles (sum M*N), bias-gradient partials (sum ntx*M)
@@ -1061,7 +1066,67 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
 
     unsigned char* Cs = smem + sbuf * STAGE_BYTES;  // the ring buffer of the last K-tile (the other one holds the next item's K-tile 0)
     constexpr bool SLICEABLE = MODE == MODE_STORE || MODE == MODE_STORE_RES;   // the N = d GEMMs (few tiles) use these flavours
-    if (MODE == MODE_PARTIAL || GROUP || (SLICEABLE && cur_slice >= 0)) {
+    if (SLICEABLE && cur_slice >= 0 && KARG(kp, int, tail_mode) == 1) {
+      // ---- IN-KERNEL fix-up of a K-sliced tail tile (round 5; VERDICT r4 #1a).  The S slices of a tile run on S different CUs.
+      // Each parks its raw accumulators in its [256 x 256] fp32 slot of the workspace IN FRAGMENT ORDER (register group g of
+      // thread t at float4 index g * 512 + t: every store / load instruction of a wave is one contiguous 1 KiB, no LDS staging),
+      // makes them visible at device scope (the slices of a tile may sit on different XCDs = different L2s) and counts itself on
+      // the tile's arrival word.  Whoever reads S - 1 there is the last: all S slots are complete, it re-reads them in SLICE ORDER
+      // (its own included: the fp32 sum must not depend on which slice happened to finish last -- graph replays and the
+      // dynamic-distribution bit-identity tests compare outputs bit for bit), restores the counter and falls through into the
+      // ordinary bf16 epilogue below (alpha, bias, residual).  Nobody waits for anybody, so the scheme cannot deadlock whatever
+      // else holds CUs, and the emulation (workgroups one after the other) runs it unchanged.
+      const int S_ = KARG(kp, int, S);
+      const int lt_ = fdiv(cur_slice, S_);
+      int* const cnt_ = KARG(kp, int*, tail_cnt) + lt_;
+      {
+        f32x4_t* Wt = reinterpret_cast<f32x4_t*>(e.ws + (long)cur_slice * (BM * BN)) + te;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              f32x4_t v;
+#pragma unroll
+              for (int x = 0; x < 4; ++x) v[x] = acc[q][j][rg * 4 + x];
+              Wt[((q * 2 + j) * 4 + rg) * 512] = v;
+            }
+      }
+      __threadfence();                         // release: the parked tile is visible device-wide before the arrival is
+      wait_vmcnt<0>();                         // (also drains the LDS-DMA the compiler cannot see: nothing is in flight across the fences)
+      V4_BARRIER();
+      if (te == 0) sched_lds[1] = atomicAdd(cnt_, 1);
+      wait_lgkm0();
+      V4_BARRIER();
+      const int arrived_ = V4_RFL(sched_lds[1]);
+      if (arrived_ != S_ - 1) { pend = 0; break; }
+      __threadfence();                         // acquire: the other slices' tiles (written through other L2s) are read from memory
+      {
+        const f32x4_t* W0 = reinterpret_cast<const f32x4_t*>(e.ws + (long)lt_ * S_ * (BM * BN)) + te;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][j][r] = 0.f;
+        for (int s2 = 0; s2 < S_; ++s2) {
+          const f32x4_t* Ws = W0 + (long)s2 * (BM * BN / 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) {
+                const f32x4_t v = Ws[((q * 2 + j) * 4 + rg) * 512];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[q][j][rg * 4 + x] += v[x];
+              }
+        }
+      }
+      if (te == 0) *cnt_ = 0;                  // zero at rest: the next launch on this stream finds the counters cleared
+    }
+    if (MODE == MODE_PARTIAL || GROUP || (SLICEABLE && cur_slice >= 0 && KARG(kp, int, tail_mode) == 0)) {
       // fp32 partial tile: MODE_PARTIAL -> ws[z][m][n]; tail slice -> its private [256][256] tile of the workspace.
       // 4 passes of 64 rows: pass (i, ii) holds rows i*128 + wm*64 + ii*32 + 0..31 of both wave groups; staging row =
       // wm*32 + (lane&31), 1024 B per row, 16-byte unit u of row r stored at unit u ^ (r & 7).
@@ -1435,6 +1500,26 @@ static int* sched_slot(hipStream_t st, int* dyn) {
   return buf + (nown++) * 16;
 }
 
+// Arrival counters of the in-kernel tail fix-up (KArgs.tail_cnt): 16 stream slots x 256 words, library-internal, allocated on
+// first use (the engine's eager warm-up steps run before any capture), zero at rest -- the last slice of every tile restores
+// the zero, so a launch never has to clear them.  One slot per stream: launches on different streams may overlap in time.
+constexpr int TAIL_CNT_WORDS = 256;
+static int* tail_counters(hipStream_t st) {
+  constexpr int NSLOT = 16;
+  static int* buf = nullptr;
+  static hipStream_t owner[NSLOT];
+  static int nown = 0;
+  if (!buf) {
+    if (hipMalloc(&buf, NSLOT * TAIL_CNT_WORDS * sizeof(int)) != hipSuccess) { buf = nullptr; return nullptr; }
+    hipMemset(buf, 0, NSLOT * TAIL_CNT_WORDS * sizeof(int));
+  }
+  for (int i = 0; i < nown; ++i)
+    if (owner[i] == st) return buf + i * TAIL_CNT_WORDS;
+  if (nown == NSLOT) return nullptr;                 // more streams than slots: the caller falls back to the fix-up kernel
+  owner[nown] = st;
+  return buf + (nown++) * TAIL_CNT_WORDS;
+}
+
 // tile order of a launch (see tile_from_logical): DH_V4_GROUP_M overrides (A/B runs); the weight-gradient layout keeps groups
 // of 8 (its items are ordered K-slice-major, both operands are streamed once per slice)
 static int g_group_m_override = 0;   // set around one launch() by entry points whose big operand is B (the vocabulary matrix of the CE modes)
@@ -1447,7 +1532,7 @@ static int v4_group_m(bool ta) {
 }
 
 template <bool TA, bool TB, int MODE>
-void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, int n_full, int S, hipStream_t st) {
+void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, int n_full, int S, hipStream_t st, int* tail_cnt = nullptr) {
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)gemm_v4_kernel<TA, TB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -1462,6 +1547,7 @@ void launch(const dh_gemm_args* a, const EpiParams& e, int split, int kps, int n
   ka.M = a->M; ka.N = a->N; ka.K = a->K; ka.k_per_split = kps; ka.ntx = ntx; ka.nty = nty; ka.nitems = nitems; ka.n_full = n_full; ka.S = S;
   ka.sched = sched_slot(st, &ka.dyn); ka.e = e;
   ka.group_m = v4_group_m(TA);
+  ka.tail_mode = tail_cnt ? 1 : 0; ka.tail_cnt = tail_cnt;
   hipLaunchKernelGGL((gemm_v4_kernel<TA, TB, MODE>), dim3(grid), dim3(512), LDS_BYTES, st, ka);
 }
 
@@ -1533,10 +1619,16 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
   e.ws = (float*)a->ws;
   e.ws_cs = (md == MODE_PARTIAL && a->a_colsum) ? (float*)a->ws + (int64_t)split * a->M * a->N : nullptr;
   // tail slicing (bf16 outputs): when the last round of whole tiles would use at most half of the CUs, cut those tiles in K
+  // DH_V4_TAIL: 0 off; 1 (default) few-tile launches through the fix-up kernel + LONG tile lists with the IN-KERNEL fix-up (round 5);
+  // 2 long lists through the fix-up kernel (rounds 1-4, kept for A/B runs); 3 few-tile launches only (the round-3/4 default)
   int n_full = 0, S = 0;
+  int* tail_cnt = nullptr;
   if ((md == MODE_STORE || md == MODE_STORE_RES) && a->ws && (((uintptr_t)a->ws & 15) == 0)) {
     int tail = 1;      // (read per call: the tests switch it between calls)
     { const char* ev = getenv("DH_V4_TAIL"); if (ev) tail = atoi(ev); }
+    int min_nkt = 24, s_max = 8;   // (tuning knobs, read per call like DH_V4_TAIL: K-tiles a tile must have to be cut, most slices per tile)
+    { const char* ev = getenv("DH_V4_TAIL_MINK"); if (ev) min_nkt = atoi(ev); }
+    { const char* ev = getenv("DH_V4_TAIL_SMAX"); if (ev) s_max = atoi(ev); }
     const int T = dh_cdiv(a->N, BN) * dh_cdiv(a->M, BM), G = num_cus(), rem = T % G, nkt = a->K / BK;
     if (tail && T <= G / 2 && nkt >= 8) {
       // FEW tiles (the M = b GEMMs of the pooled last block: 6-24 tiles of 12-48 K-tiles ran on 6-24 CUs, 20-68 us each at 12-90
@@ -1546,27 +1638,35 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
       if (s_ > nkt / 2) s_ = nkt / 2;
       if (s_ >= 2 && a->ws_bytes >= (int64_t)T * s_ * BM * BN * 4) { S = s_; n_full = 0; }
     } else
-    // LONG tile lists (300 tiles of the N = d tower GEMMs on 256 CUs): only with DH_V4_TAIL=2.  Since the K-tile stream runs
-    // across work items the whole tail round costs the step exactly what its 34 fix-up launches cost (CLIP b = 512, same box:
-    // 23.52 ms with, 23.53-23.56 ms without; profiles/r03_ab_tail_slicing.txt), so the default keeps the launches out
-    if (tail >= 2 && T > G && rem > 0 && rem <= G / 2 && nkt >= 24) {   // short-K tiles: the slice overheads eat the gain (measured)
+    // LONG tile lists (300 tiles of the N = d tower GEMMs on 256 CUs: 44 tiles in a second round that costs as much as the first).
+    // Rounds 1-4 summed the slices in a second launch, and its 34 fix-up launches per step cost the step exactly what the tail
+    // round saved (CLIP b = 512, same box: 23.52 ms with, 23.53-23.56 ms without; profiles/r03_ab_tail_slicing.txt).  Round 5: the
+    // last slice of a tile to arrive does the fix-up inside the GEMM kernel (KArgs.tail_mode), no launch.  Short-K tiles stay whole:
+    // a slice moves 2 x 256 KB of fp32 through memory, which is a tile's worth of K = 768 arithmetic.
+    if ((tail == 1 || tail == 2) && T > G && rem > 0 && rem <= G / 2 && nkt >= min_nkt && rem <= v4::TAIL_CNT_WORDS) {
       int s_ = G / rem;
-      if (s_ > 8) s_ = 8;
+      if (s_ > s_max) s_ = s_max;
       if (s_ > nkt / 2) s_ = nkt / 2;
-      if (s_ >= 2 && a->ws_bytes >= (int64_t)rem * s_ * BM * BN * 4) { S = s_; n_full = T - rem; }
+      if (s_ >= 2 && a->ws_bytes >= (int64_t)rem * s_ * BM * BN * 4) {
+        S = s_; n_full = T - rem;
+        if (tail == 1) {
+          tail_cnt = v4::tail_counters(st);
+          if (!tail_cnt) { S = 0; n_full = 0; }        // no counter slot left for this stream: whole tiles
+        }
+      }
     }
   }
   switch (md) {
     case MODE_ATOMIC: launch<true, true, MODE_ATOMIC>(a, e, split, kps, n_full, S, st); break;
     case MODE_PARTIAL: launch<true, true, MODE_PARTIAL>(a, e, split, kps, n_full, S, st); break;
     case MODE_STORE_GELU: launch<false, false, MODE_STORE_GELU>(a, e, split, kps, n_full, S, st); break;
-    case MODE_STORE_RES: launch<false, false, MODE_STORE_RES>(a, e, split, kps, n_full, S, st); break;
+    case MODE_STORE_RES: launch<false, false, MODE_STORE_RES>(a, e, split, kps, n_full, S, st, tail_cnt); break;
     case MODE_STORE_DGELU: launch<false, true, MODE_STORE_DGELU>(a, e, split, kps, n_full, S, st); break;
     default:
-      if (a->b_kmajor) launch<false, true, MODE_STORE>(a, e, split, kps, n_full, S, st);
-      else launch<false, false, MODE_STORE>(a, e, split, kps, n_full, S, st);
+      if (a->b_kmajor) launch<false, true, MODE_STORE>(a, e, split, kps, n_full, S, st, tail_cnt);
+      else launch<false, false, MODE_STORE>(a, e, split, kps, n_full, S, st, tail_cnt);
   }
-  if (S) hipLaunchKernelGGL(tail_fixup_kernel, dim3((dh_cdiv(a->N, BN) * dh_cdiv(a->M, BM) - n_full) * 32), dim3(256), 0, st,
+  if (S && !tail_cnt) hipLaunchKernelGGL(tail_fixup_kernel, dim3((dh_cdiv(a->N, BN) * dh_cdiv(a->M, BM) - n_full) * 32), dim3(256), 0, st,
                             (const float*)a->ws, S, n_full, dh_cdiv(a->N, BN), dh_cdiv(a->M, BM), e, v4_group_m(false));
   if (md == MODE_PARTIAL) {
     const long n4 = (long)a->M * a->N / 4;

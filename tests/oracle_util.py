@@ -13,6 +13,65 @@ def load_golden(name):
     return torch.load(os.path.join(GOLDEN, name + ".pt"), weights_only=False)
 
 
+# ---- bf16 parity gates at 3 x what the MI355X measured ------------------------------------------------------
+# The bf16 path (the one bench.py times) has no closed-form error bound, so its gates used to be round numbers 20-200 x looser
+# than what the hardware delivers -- loose enough to let a dropped K-tile in a small-magnitude region pass.  Now every bf16 gate
+# goes through `margin(key, measured, cap)`: tests/golden/bf16_margins.json holds the value measured on the MI355X for each key
+# (written by a run with DH_MARGIN_RECORD=<path>, which checks the caps only; committed with the kernels it was measured on), and
+# the assertion is   measured <= min(cap, max(3 x recorded, floor)).   `cap` is the old documented bound (never exceeded), `floor`
+# keeps a quantity that was measured at ~0 (a loss that happened to round well) from becoming a noise detector.
+_MARGIN_FILE = os.path.join(GOLDEN, "bf16_margins.json")
+_MARGINS = None
+
+
+def _margins():
+    global _MARGINS
+    if _MARGINS is None:
+        import json
+        try:
+            with open(_MARGIN_FILE) as f:
+                _MARGINS = json.load(f)
+        except FileNotFoundError:
+            _MARGINS = {}
+    return _MARGINS
+
+
+def margin(key, measured, cap, floor=0.0, factor=3.0):
+    import json
+    measured = float(measured)
+    rec_path = os.environ.get("DH_MARGIN_RECORD")
+    if rec_path:
+        try:
+            with open(rec_path) as f:
+                cur = json.load(f)
+        except (FileNotFoundError, ValueError):
+            cur = {}
+        cur[key] = max(measured, float(cur.get(key, 0.0)))       # several runs of a key (parametrised ranks): keep the worst
+        os.makedirs(os.path.dirname(os.path.abspath(rec_path)), exist_ok=True)
+        with open(rec_path, "w") as f:
+            json.dump(cur, f, indent=1, sort_keys=True)
+        bound = cap
+    else:
+        rec = _margins().get(key)
+        bound = cap if rec is None else min(cap, max(factor * float(rec), floor))
+    print("margin %-64s measured %.4g  bound %.4g  (cap %.4g)" % (key, measured, bound, cap))
+    assert measured <= bound, (key, "measured", measured, "bound", bound, "cap", cap)
+    return measured
+
+
+def assert_bf16_close(key, out, ref, rel=2.0 ** -7, abs_rms=2.0 ** -8):
+    """Per-element gate for a bf16 result against an fp64 reference: |err| <= rel |ref| + abs_rms rms(ref) for EVERY element (one bf16
+    rounding is 2^-9 |ref|; staged epilogues round twice; the rms term covers elements that are small because large terms cancel).
+    Replaces `max|err| <= 1.2e-2 max|ref|`, which a wrong value in a small-magnitude region passes.  The worst ratio err / bound
+    is recorded as a margin."""
+    out, ref = out.detach().double().cpu(), ref.detach().double().cpu()
+    rms = float(ref.pow(2).mean().sqrt())
+    bound = rel * ref.abs() + abs_rms * rms
+    ratio = float(((out - ref).abs() / bound).max())
+    assert ratio <= 1.0, (key, "worst err / bound", ratio, "rms", rms)
+    margin(key, ratio, 1.0, floor=0.5)
+
+
 def grad_digest_of(name, idx, g):
     g = g.detach().double().flatten()
     gen = torch.Generator().manual_seed(4242 + idx)
@@ -104,7 +163,7 @@ def bf16_grad_direction_stats(golden_grads, grads, numels=None):
     return rms, abs(worst[1]), worst[0], zs
 
 
-def check_bf16_grad_directions(golden_grads, grads, rms_tol=0.10, z_tol=0.35, allowed_frac=0.02):
+def check_bf16_grad_directions(golden_grads, grads, rms_tol=0.10, z_tol=0.35, allowed_frac=0.02, key=None):
     """The bf16 (benchmarked) path's gradients against the reference fixture by direction, not only by norm:
     RMS over the parameters of the projection z-score <= rms_tol, and |z| <= z_tol for all but `allowed_frac` of them."""
     rms, wz, wname, zs = bf16_grad_direction_stats(golden_grads, grads)
@@ -113,6 +172,9 @@ def check_bf16_grad_directions(golden_grads, grads, rms_tol=0.10, z_tol=0.35, al
     print("bf16 gradient direction vs reference: %d parameters, rms z = %.4f, worst |z| = %.4f (%s)" % (len(zs), rms, wz, wname))
     assert rms <= rms_tol, ("rms projection z-score", rms, "worst", wname, wz)
     assert len(bad) <= max(1, int(allowed_frac * len(zs))), bad[:8]
+    if key:                   # 3 x the MI355X's own numbers (see `margin`); one z is a single sample, so the worst one gets a floor
+        margin(key + "/rms_z", rms, rms_tol, floor=0.02)
+        margin(key + "/worst_z", wz, 1.0, floor=0.15)           # (cap 1.0: a gradient pointing the wrong way has |z| ~ 1.4)
     return rms, wz
 
 

@@ -13,7 +13,7 @@ DESIGN.md s2) -- the same documented bounds as the small bf16 tests, now against
 import pytest
 import torch
 
-from oracle_util import check_bf16_grad_directions, check_grad_digests, load_golden
+from oracle_util import check_bf16_grad_directions, check_grad_digests, load_golden, margin
 
 pytestmark = pytest.mark.gpu
 
@@ -28,7 +28,7 @@ def digest_of(l, label0):
                 absmax=float(l.abs().max()), proj=float((l * r).sum() / (b * B) ** 0.5))
 
 
-def check_logits_digest(got, ref, tol, label0=0, outlier_frac=0.0, outlier_cap=1.0):
+def check_logits_digest(got, ref, tol, label0=0, outlier_frac=0.0, outlier_cap=1.0, key=None):
     """`outlier_frac` > 0 (FILIP in bf16 only): the dense logits sit behind a DISCRETE choice -- the 16 tokens per sample with the
     largest summed similarity (filip.py:80-82) -- and a near-tie that bf16 towers resolve differently from the fp32 reference
     swaps a token of the selected set, which moves that sample's row / column of logits by a few per cent while everything else
@@ -37,32 +37,42 @@ def check_logits_digest(got, ref, tol, label0=0, outlier_frac=0.0, outlier_cap=1
     assert tuple(got.shape) == tuple(ref["shape"])
     d = digest_of(got, label0)
     s = ref["absmax"]
-    for key in ("corner", "diag", "lse"):
-        err = (d[key] - ref[key]).abs()
+    for k in ("corner", "diag", "lse"):
+        err = (d[k] - ref[k]).abs()
         if outlier_frac > 0.0:
-            assert float((err > tol * s).float().mean()) <= outlier_frac, (key, float(err.max()), float((err > tol * s).float().mean()))
-            assert float(err.max()) <= outlier_cap * tol * s, (key, float(err.max()))
+            assert float((err > tol * s).float().mean()) <= outlier_frac, (k, float(err.max()), float((err > tol * s).float().mean()))
+            assert float(err.max()) <= outlier_cap * tol * s, (k, float(err.max()))
         else:
-            assert float(err.max()) <= tol * s, (key, float(err.max()), tol * s)
+            assert float(err.max()) <= tol * s, (k, float(err.max()), tol * s)
+        if key:               # bf16 runs: 3 x the MI355X's own number (oracle_util.margin); with token-selection flips (FILIP) the median
+            stat = float(err.median()) if outlier_frac > 0.0 else float(err.max())
+            margin("%s/%s_%s" % (key, k, "med" if outlier_frac > 0.0 else "max"), stat / s, tol, floor=2e-3)
     assert abs(d["proj"] - ref["proj"]) <= tol * s          # a unit-variance projection of b*B entries, each within tol*s
+    if key:
+        margin(key + "/proj", abs(d["proj"] - ref["proj"]) / s, tol, floor=1e-3)
     assert abs(d["absmax"] - s) <= (outlier_cap if outlier_frac > 0.0 else 1.0) * tol * s
 
 
-def check_bf16_grad_norms(golden_grads, grads, tol=8e-2, allowed_frac=0.02, rms_tol=0.10, z_tol=0.35):
+def check_bf16_grad_norms(golden_grads, grads, tol=8e-2, allowed_frac=0.02, rms_tol=0.10, z_tol=0.35, key=None):
     """Size AND direction of the bf16 path's gradients against the reference fixture: per-parameter norms within `tol`, and the
     seeded-projection digest of every parameter as a z-score of its relative error (oracle_util.check_bf16_grad_directions: a
     gradient of the right size pointing the wrong way has |z| ~ 1.4; VERDICT r2 weak #1)."""
-    check_bf16_grad_directions(golden_grads, grads, rms_tol=rms_tol, z_tol=z_tol, allowed_frac=allowed_frac)
+    check_bf16_grad_directions(golden_grads, grads, rms_tol=rms_tol, z_tol=z_tol, allowed_frac=allowed_frac, key=key)
     gmax = max(v["norm"] for v in golden_grads.values() if v is not None)
-    bad, n = [], 0
+    bad, n, errs = [], 0, []
     for name, ref in golden_grads.items():
         if ref is None or ref["norm"] < 1e-3 * gmax:
             continue
         n += 1
         got = float(grads[name].double().norm())
+        errs.append(abs(got - ref["norm"]) / ref["norm"])
         if abs(got - ref["norm"]) > tol * ref["norm"]:
             bad.append((name, got, ref["norm"]))
     assert len(bad) <= max(1, int(allowed_frac * n)), bad[:8]
+    if key:                   # 3 x measured: the median and the 95th percentile of the per-parameter norm errors
+        errs.sort()
+        margin(key + "/norm_err_median", errs[len(errs) // 2], tol, floor=5e-3)
+        margin(key + "/norm_err_p95", errs[int(0.95 * (len(errs) - 1))], tol, floor=1e-2)
 
 
 def named_grads(model):
@@ -90,17 +100,21 @@ def test_clip_vitb32_b256_matches_reference_golden(dtype):
     loss.backward()
     torch.cuda.synchronize()
     stats = ops.gemm_stats()
-    tol = 1e-3 if dtype == "fp32" else 1e-2
+    # bf16: caps (loss 5e-4, logits 1e-2 of their largest value: VERDICT r4 #2) AND 3 x the values the MI355X measured (`margin`)
+    tol = 1e-3 if dtype == "fp32" else 5e-4
     assert abs(float(loss.detach()) - g["loss"]) <= tol * abs(g["loss"]), (float(loss.detach()), g["loss"])
-    ltol = 1e-3 if dtype == "fp32" else 3e-2
-    check_logits_digest(li.materialize(), g["logits_i_digest"], ltol)
-    check_logits_digest(lt.materialize(), g["logits_t_digest"], ltol)
+    ltol = 1e-3 if dtype == "fp32" else 1e-2
+    K = "clip_vitb32_b256" if dtype == "bf16" else None
+    if K:
+        margin(K + "/loss", abs(float(loss.detach()) - g["loss"]) / abs(g["loss"]), tol, floor=1e-4)
+    check_logits_digest(li.materialize(), g["logits_i_digest"], ltol, key=K and K + "/logits_i")
+    check_logits_digest(lt.materialize(), g["logits_t_digest"], ltol, key=K and K + "/logits_t")
     if dtype == "fp32":
         check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
     else:
         assert_ran_on_v4(stats, 200)
         # measured on the MI355X (round 3): rms z 0.027, worst |z| 0.086 over 302 parameters
-        check_bf16_grad_norms(g["grads"], named_grads(model), rms_tol=0.06, z_tol=0.25)
+        check_bf16_grad_norms(g["grads"], named_grads(model), rms_tol=0.06, z_tol=0.25, key=K)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -120,15 +134,22 @@ def test_declip_vitb32_b128_matches_reference_golden(dtype):
     torch.cuda.synchronize()
     stats = ops.gemm_stats()
     tol = 1e-3 if dtype == "fp32" else 2e-2
+    K = "declip_vitb32_b128" if dtype == "bf16" else None
     assert abs(float(out["loss"]) - g["loss"]) <= tol * abs(g["loss"])
     for k in ("clip", "mlm", "convirt"):
         assert abs(float(out["parts"][k]) - g["parts"][k]) <= tol * max(1.0, abs(g["parts"][k])), k
+    if K:
+        margin(K + "/loss", abs(float(out["loss"]) - g["loss"]) / abs(g["loss"]), tol, floor=5e-4)
+        for k in ("clip", "mlm", "convirt"):
+            margin(K + "/part_" + k, abs(float(out["parts"][k]) - g["parts"][k]) / max(1.0, abs(g["parts"][k])), tol, floor=5e-4)
     # nearest-neighbour lookup = a discrete choice over the bank: bf16 towers may resolve a near-tie differently
     assert abs(float(out["parts"]["nn"]) - g["parts"]["nn"]) <= (tol if dtype == "fp32" else 0.15) * max(1.0, abs(g["parts"]["nn"]))
     assert abs(float(out["parts"]["simsiam"]) - g["parts"]["simsiam"]) <= (1e-4 if dtype == "fp32" else 2e-2)
     assert model.nn_replacer_text.bank_ptr == g["bank_ptr"]
     li1 = out["outputs"]["logits"][0].materialize().detach().cpu()
     assert float((li1 - g["logits_i1"]).abs().max()) <= (1e-3 if dtype == "fp32" else 3e-2) * float(g["logits_i1"].abs().max())
+    if K:
+        margin(K + "/logits_i1_max", float((li1 - g["logits_i1"]).abs().max()) / float(g["logits_i1"].abs().max()), 3e-2, floor=2e-3)
     if dtype == "fp32":
         check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
         assert abs(float(model.nn_replacer_text.bank.double().sum()) - g["bank_sum"]) <= 1e-3 * max(1.0, abs(g["bank_sum"]))
@@ -136,7 +157,7 @@ def test_declip_vitb32_b128_matches_reference_golden(dtype):
         assert_ran_on_v4(stats, 200)
         # measured (round 3): rms z 0.081, worst |z| 0.46 on projector.bn1.weight -- the affine gradients of the SimSiam head's
         # BatchNorm1d layers are sums of cancelling terms over 128 rows, the towers sit at 0.03-0.05 like CLIP's
-        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.15, z_tol=0.35)
+        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.15, z_tol=0.35, key=K)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -154,16 +175,21 @@ def test_slip_vitb32_b128_matches_reference_golden(dtype):
     torch.cuda.synchronize()
     stats = ops.gemm_stats()
     tol = 1e-3 if dtype == "fp32" else 2e-2
+    K = "slip_vitb32_b128" if dtype == "bf16" else None
     assert abs(float(out["loss"]) - g["loss"]) <= tol * abs(g["loss"])
     for k in ("clip", "simclr", "nt_xent"):
         assert abs(float(out["parts"][k]) - g["parts"][k]) <= tol * max(1.0, abs(g["parts"][k])), k
+    if K:
+        margin(K + "/loss", abs(float(out["loss"]) - g["loss"]) / abs(g["loss"]), tol, floor=5e-4)
+        for k in ("clip", "simclr", "nt_xent"):
+            margin(K + "/part_" + k, abs(float(out["parts"][k]) - g["parts"][k]) / max(1.0, abs(g["parts"][k])), tol, floor=5e-4)
     if dtype == "fp32":
         check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
     else:
         assert_ran_on_v4(stats, 200)
         # measured (round 3): rms z 0.137, worst |z| 0.50 on predictor_sim.bn1.bias: the SimCLR head (768-4096-4096-256 with two
         # BatchNorm1d over 2 x 128 rows, NT-Xent at temperature 0.1) is the most ill-conditioned gradient path of the five families
-        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.22, z_tol=0.40)
+        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.22, z_tol=0.40, key=K)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -182,17 +208,20 @@ def test_filip_vitb32_e768_b256_matches_reference_golden(dtype):
     torch.cuda.synchronize()
     stats = ops.gemm_stats()
     tol = 1e-3 if dtype == "fp32" else 3e-2
+    K = "filip_vitb32_e768_b256" if dtype == "bf16" else None
     assert abs(float(out["loss"]) - g["loss"]) <= tol * abs(g["loss"])
+    if K:
+        margin(K + "/loss", abs(float(out["loss"]) - g["loss"]) / abs(g["loss"]), tol, floor=5e-4)
     dli, dlt = out["outputs"]["dense_logits"]
     sel = dict(outlier_frac=0.02, outlier_cap=5.0) if dtype == "bf16" else {}       # token-selection flips (see check_logits_digest)
-    check_logits_digest(dli, g["dense_logits_i_digest"], tol, **sel)
-    check_logits_digest(dlt, g["dense_logits_t_digest"], tol, **sel)
+    check_logits_digest(dli, g["dense_logits_i_digest"], tol, key=K and K + "/dense_i", **sel)
+    check_logits_digest(dlt, g["dense_logits_t_digest"], tol, key=K and K + "/dense_t", **sel)
     if dtype == "fp32":
         check_grad_digests(g["grads"], named_grads(model), rtol=1e-3, head_rtol=5e-3)
     else:
         assert_ran_on_v4(stats, 200)
         # measured (round 3): rms z 0.052, worst |z| 0.17
-        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.10, z_tol=0.35)
+        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.10, z_tol=0.35, key=K)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -214,9 +243,14 @@ def test_defilip_vitb32_b128_matches_reference_golden(dtype):
     torch.cuda.synchronize()
     stats = ops.gemm_stats()
     tol = 1e-3 if dtype == "fp32" else 3e-2
+    K = "defilip_vitb32_b128" if dtype == "bf16" else None
     assert abs(float(out["loss"]) - g["loss"]) <= tol * abs(g["loss"]), (float(out["loss"]), g["loss"])
     for k in ("clip", "mlm", "filip"):
         assert abs(float(out["parts"][k]) - g["parts"][k]) <= tol * max(1.0, abs(g["parts"][k])), k
+    if K:
+        margin(K + "/loss", abs(float(out["loss"]) - g["loss"]) / abs(g["loss"]), tol, floor=5e-4)
+        for k in ("clip", "mlm", "filip"):
+            margin(K + "/part_" + k, abs(float(out["parts"][k]) - g["parts"][k]) / max(1.0, abs(g["parts"][k])), tol, floor=5e-4)
     # the nearest-neighbour lookup is a discrete choice over the bank (see test_declip_vitb32_b128_matches_reference_golden)
     assert abs(float(out["parts"]["nn"]) - g["parts"]["nn"]) <= (tol if dtype == "fp32" else 0.15) * max(1.0, abs(g["parts"]["nn"]))
     assert abs(float(out["parts"]["simsiam"]) - g["parts"]["simsiam"]) <= (1e-4 if dtype == "fp32" else 2e-2)
@@ -236,4 +270,4 @@ def test_defilip_vitb32_b128_matches_reference_golden(dtype):
         # the dense logits sit behind the top-16 token selection (check_logits_digest): a few samples may flip a token
         assert float((err > 3e-2 * scale).float().mean()) <= 0.02 and float(err.max()) <= 0.15 * scale, (float(err.max()), scale)
         assert_ran_on_v4(stats, 200)
-        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.15, z_tol=0.40)
+        check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.15, z_tol=0.40, key=K)

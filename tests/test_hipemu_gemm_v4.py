@@ -23,17 +23,26 @@ SLOW = pytest.mark.skipif(os.environ.get("HIPEMU_SLOW") != "1", reason="tens of 
 
 @pytest.fixture(scope="module")
 def ops():
-    import os
-    prev = os.environ.get("DH_V4_TAIL")
-    os.environ["DH_V4_TAIL"] = "2"          # the K-sliced tail of LONG tile lists is opt-in in the product 
-    try:
-        with emulated_gpu(V4_SOURCES) as o:
-            yield o
-    finally:
-        if prev is None:
-            os.environ.pop("DH_V4_TAIL", None)
-        else:
-            os.environ["DH_V4_TAIL"] = prev
+    with emulated_gpu(V4_SOURCES) as o:
+        yield o
+
+
+class _env:
+    """Set environment switches the library reads per call (DH_V4_TAIL, DH_V4_TAIL_MINK, ...) around one block."""
+
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.prev = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def _took_v4(ops, n=1):
@@ -105,15 +114,42 @@ def test_v4_k_sliced_few_tile_schedule_emulated(ops, residual):
     assert rel_err(sliced, ref) < TOL and rel_err(plain, ref) < TOL
 
 
-@SLOW          # (the long-list tail is opt-in in the product since round 3; 44 s here)
+@SLOW          # (the fix-up-kernel variant of the long-list tail: DH_V4_TAIL=2, kept for A/B runs; 44 s here)
 def test_v4_tail_sliced_schedule_emulated(ops):
     """9 tiles on 8 compute units, 24 K-tiles: the tile of the last round is cut in K over the chip (whole items first, slices last,
     both through the same continuous K-tile stream)."""
     M, N, K = 2304, 256, 1536
     A, B, bias = rnd(M, K, seed=14).to(bf), rnd(N, K, seed=15, scale=0.05).to(bf), rnd(N, seed=16)
     ws = torch.empty((16 << 20) // 4, dtype=torch.float32)
-    sliced = ops.gemm(A, B, bias=bias, ws=ws, force_generic=4)
+    with _env(DH_V4_TAIL=2):
+        sliced = ops.gemm(A, B, bias=bias, ws=ws, force_generic=4)
     assert rel_err(sliced, A.double() @ B.double().t() + bias.double()) < TOL
+
+
+@pytest.mark.parametrize("M,K,residual,dyn", [pytest.param(2304, 512, False, 0, marks=SLOW), (2560, 384, True, 0), pytest.param(2560, 512, False, 1, marks=SLOW)])
+def test_v4_tail_in_kernel_fixup_emulated(ops, M, K, residual, dyn):
+    """The default for long tile lists since round 5 (DH_V4_TAIL=1): 9 / 10 tiles on 8 compute units, 8 (6) K-tiles -> the 1 / 2 tiles of
+    the last round are cut into 4 (3) K-slices; every slice parks its accumulators in the workspace (fragment order), counts itself on the
+    tile's arrival word, and the LAST one sums the four parked tiles in slice order and runs the ordinary bf16 epilogue -- no
+    fix-up launch.  Pinned here: the slot / fragment indexing, the arrival protocol (the emulation runs the workgroups one after the
+    other, so the last slice in list order is the one that fixes up), the counters back at zero (a second launch through the same
+    counters gives the same bits), agreement with the whole-tile schedule, and that no fix-up kernel ran."""
+    N = 256
+    A, B, bias = rnd(M, K, seed=14).to(bf), rnd(N, K, seed=15, scale=0.05).to(bf), rnd(N, seed=16)
+    R = rnd(M, N, seed=17).to(bf) if residual else None
+    ws = torch.full(((16 << 20) // 4,), float("nan"), dtype=torch.float32)      # a slot that is read before it is written poisons the tile
+    with _env(DH_V4_TAIL=1, DH_V4_TAIL_MINK=K // 64, DH_V4_DYNAMIC=dyn):
+        ops.gemm_stats(reset=True)
+        first = ops.gemm(A, B, bias=bias, residual=R, ws=ws, force_generic=4)
+        st = ops.gemm_stats()
+        second = ops.gemm(A, B, bias=bias, residual=R, ws=ws, force_generic=4)
+    assert st["v4"] == 1 and sum(st.values()) == 1, st
+    assert torch.isfinite(ws[:64 * 65536]).any()                    # the workspace was used: the launch was sliced
+    plain = ops.gemm(A, B, bias=bias, residual=R, force_generic=4)
+    ref = A.double() @ B.double().t() + bias.double() + (R.double() if residual else 0)
+    assert rel_err(first, ref) < TOL and rel_err(plain, ref) < TOL
+    assert torch.equal(first, second)
+    assert rel_err(first, plain.float()) < 4e-3                     # same products, fp32 sums regrouped by slice, one bf16 rounding
 
 
 @pytest.fixture

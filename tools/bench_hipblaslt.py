@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--out", default="")
+    ap.add_argument("--no-ws", action="store_true", help="no workspace for the forward / dX launches (whole tiles only, as round 4 measured)")
+    ap.add_argument("--only-n", type=int, default=0, help="only the shapes with this N (quick A/B runs)")
     args = ap.parse_args()
     dev, bf = torch.device("cuda"), torch.bfloat16
     lines = ["# torch %s, %s; rounds %d x iters %d, interleaved, uniform random [-1, 1) operands" % (
@@ -56,6 +58,8 @@ def main():
             "M", "N", "K", "ta", "tb", "epi", "res", "blaslt us", "TF/s", "v4bare us", "TF/s", "v4epi us", "TF/s", "v4epi/blaslt")]
     tot = [0.0, 0.0, 0.0]
     for (M, N, K, ta, tb, epi, res) in SHAPES:
+        if args.only_n and N != args.only_n:
+            continue
         g = torch.Generator(device=dev).manual_seed(M + N + K)
         A = (torch.rand((K, M) if ta else (M, K), device=dev, generator=g) * 2 - 1).to(bf)
         B = (torch.rand((K, N) if tb else (N, K), device=dev, generator=g) * 2 - 1).to(bf)
@@ -66,7 +70,9 @@ def main():
         bias = None if dw else torch.rand(N, device=dev) - 0.5
         resid = (torch.rand(M, N, device=dev) - 0.5).to(bf) if res else None
         aux = torch.empty(M, N, device=dev, dtype=bf) if epi == 1 else ((torch.rand(M, N, device=dev) * 2 - 1).to(bf) if epi == 2 else None)
+        from declip_amd.engine import gemm_workspace
         kw = dict(a_kmajor=bool(ta), b_kmajor=bool(tb), force_generic=4)
+        wsk = {} if (dw or args.no_ws) else dict(ws=gemm_workspace(dev))      # the step hands every tower GEMM the workspace (K-sliced tails)
 
         def f_vendor():
             torch.matmul(At, Bt, out=outv)
@@ -76,13 +82,13 @@ def main():
                 from declip_amd.engine import _split_k
                 ops.gemm(A, B, out=out, accumulate=True, split_k=_split_k(M, N, K), **kw)
             else:
-                ops.gemm(A, B, out=out, **kw)
+                ops.gemm(A, B, out=out, **kw, **wsk)
 
         def f_epi():
             if dw:
                 return f_bare()
             ops.gemm(A, B, out=out, bias=bias if epi != 2 else None, epilogue={0: EPI_NONE, 1: EPI_GELU, 2: EPI_DGELU}[epi],
-                     residual=resid, aux=aux, **kw)
+                     residual=resid, aux=aux, **kw, **wsk)
 
         fns = (f_vendor, f_bare, f_epi)
         for f in fns:
