@@ -205,7 +205,8 @@ constexpr int STAGE_BYTES = 4 * HALF_BYTES;       // A0 A1 B0 B1
 constexpr int BIAS_OFF = 2 * STAGE_BYTES;         // behind the ring: the whole bias vector (fp32, N <= MAX_BIAS_N), loaded once per workgroup
 constexpr int MAX_BIAS_N = 4096;
 constexpr int SCHED_OFF = BIAS_OFF + MAX_BIAS_N * 4;   // one word: the work item after next (dynamic scheduling)
-constexpr int LDS_BYTES = SCHED_OFF + 16;            // 144 KiB + 16 B
+constexpr int MAX_TAIL_TILES = 128;                    // tail tiles of a launch (<= half the CUs) = most fix-ups one workgroup can be left with
+constexpr int LDS_BYTES = SCHED_OFF + 16 + MAX_TAIL_TILES * 4;   // 144 KiB + [0] next item, [1] arrival broadcast, [2] deferred fix-ups, [4..] their tiles
 // MODE: what happens to the finished tile.  The bf16 epilogue flavours are separate instantiations (straight-line code:
 // the kernel lives at the 256-VGPR cap, runtime epilogue switches cost spills).
 constexpr int MODE_STORE = 0, MODE_STORE_GELU = 1, MODE_STORE_DGELU = 2, MODE_STORE_RES = 3, MODE_ATOMIC = 4, MODE_PARTIAL = 5, MODE_GROUP = 6, MODE_MAXSIM = 7, MODE_CE_FWD = 8, MODE_CE_BWD = 9;
@@ -250,6 +251,60 @@ __device__ __forceinline__ void wait_lgkm0() { }
 #else
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #endif
+
+// Parked accumulators of the in-kernel tail fix-up (see the kernel): 16-byte buffer stores / loads with the sc1 cache policy
+// (device scope on gfx950: written through to / served from the level all XCDs share, no cache-wide write-back or invalidate).
+// Buffer instructions rather than device-scope atomics: the compiler keeps relaxed atomic loads in program order with two in
+// flight (load, load, wait, add ...: one memory latency per pair); plain buffer loads it batches by the dozen.
+struct ParkBuf {
+#if V4_EMU
+  unsigned char* base;
+#else
+  __amdgpu_buffer_rsrc_t r;
+#endif
+};
+__device__ __forceinline__ ParkBuf park_buf(float* base, int bytes) {
+  ParkBuf b;
+#if V4_EMU
+  b.base = reinterpret_cast<unsigned char*>(base); (void)bytes;
+#else
+  b.r = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
+#endif
+  return b;
+}
+typedef __attribute__((ext_vector_type(4))) uint32_t park_u32x4;
+__device__ __forceinline__ void park_store(const ParkBuf& b, uint32_t byte_off, const f32x4_t& v) {
+#if V4_EMU
+  memcpy(b.base + byte_off, &v, 16);
+#else
+  park_u32x4 w = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+  __builtin_amdgcn_raw_buffer_store_b128(w, b.r, byte_off, 0, 16 /* sc1 */);
+#endif
+}
+__device__ __forceinline__ f32x4_t park_load(const ParkBuf& b, uint32_t byte_off) {
+  f32x4_t v;
+#if V4_EMU
+  memcpy(&v, b.base + byte_off, 16);
+#else
+  const park_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(b.r, byte_off, 0, 16 /* sc1 */);
+  v[0] = __uint_as_float(w[0]); v[1] = __uint_as_float(w[1]); v[2] = __uint_as_float(w[2]); v[3] = __uint_as_float(w[3]);
+#endif
+  return v;
+}
+__device__ __forceinline__ int arrive_add(int* p) {
+#if V4_EMU
+  return atomicAdd(p, 1);
+#else
+  return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void arrive_reset(int* p) {
+#if V4_EMU
+  *p = 0;
+#else
+  __hip_atomic_store(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 
 // fragment of a K-contiguous half-tile: rows r0 + (lane&31), k = 16*s + 8*(lane>>5) .. +7
 __device__ __forceinline__ bf16x8_t frag_kcontig(const unsigned char* tile, int r0, int s, int lane) {
@@ -541,13 +596,15 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
   // in this toolchain (amdgpu_num_vgpr is ignored under __launch_bounds__), so the fetch is synchronous now: it sits at the very
   // end of the epilogue, behind the wait that already covers everything older than the epilogue's stores, and costs the store
   // drain + one L2 atomic round trip per item (measured: see DESIGN.md s4).
+  // (launch constants of this workgroup's XCD, computed once: the fetch at the end of every epilogue needs nothing else alive)
+  const int my_wgs = V4_RFL(wgs_on_xcd(xcd, grid)), my_len = V4_RFL(list_len(xcd));
 #if V4_EMU
-#define FETCH(RAW) do { RAW = 1 << 22; if (wgs_on_xcd(xcd, grid) < list_len(xcd)) RAW = atomicAdd(sched + xcd, 1); } while (0)
+#define FETCH(RAW) do { RAW = 1 << 22; if (my_wgs < my_len) RAW = atomicAdd(sched + xcd, 1); } while (0)
 #else
 #define FETCH(RAW)                                                                                             \
   do {                                                                                                        \
     RAW = 1 << 22;                                                                                            \
-    if (wgs_on_xcd(xcd, grid) < list_len(xcd)) {                                                              \
+    if (my_wgs < my_len) {                                                                                    \
       const int one_ = 1;                                                                                     \
       int* p_ = sched + xcd;                                                                                  \
       asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(RAW) : "v"(p_), "v"(one_) : "memory"); \
@@ -556,8 +613,8 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
 #endif
   // packed position of the next item, or -1
   auto fetch_finish = [&](int raw) -> int {
-    const int l0 = wgs_on_xcd(xcd, grid) + raw;
-    return l0 < list_len(xcd) ? ((xcd << 24) | l0) : -1;
+    const int l0 = my_wgs + raw;
+    return l0 < my_len ? ((xcd << 24) | l0) : -1;
   };
   Item nxt;
   bool have;
@@ -569,6 +626,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       if (dyn) { int r0; FETCH(r0); v = fetch_finish(r0); }
       else { const int l = my_l + wgs_on_xcd(xcd, grid); v = (xcd << 24) | l; }     // static partition (validity checked at decode)
       sched_lds[0] = v;
+      sched_lds[2] = 0;                                                    // deferred tail fix-ups of this workgroup
     }
   }
   // FAST hand-over to the next item (the forward / dX launches: one K-slice, row-major tile order, static partition, no tail
@@ -579,14 +637,19 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
   // ~1.8 k cycles per wave group in the in-kernel trace -- three MFMA segments, which nothing can hide.  It stays for the
   // launches that need it (grouped / split-K weight gradients, tail slices, dynamic scheduling, the ragged vocabulary of the
   // cross-entropy modes): their items are 50+ K-tiles long.
-  const bool fast = !GROUP && !RAGGED_B && dyn == 0 && S == 0 && nitems == ntx * nty && KARG(kp, int, group_m) == 1;
-  int left = 0, sx_f = 0, sy_f = 0, d_m = 0, d_n = 0;
+  // Round 5: the DYNAMIC distribution (every rank of a multi-GPU job) takes the fast hand-over too.  Its next position l comes from
+  // the XCD's counter instead of l + s, but for these launches a position is still just a row-major tile index (chunk start + l):
+  // one reciprocal division gives the tile, and the sources move by the same wave-uniform offsets.  The general decode was most of
+  // what the dynamic mode cost when nothing else ran (~2 % of the step).
+  const bool fast = !GROUP && !RAGGED_B && (dyn == 0 || dyn == 1) && S == 0 && nitems == ntx * nty && KARG(kp, int, group_m) == 1;
+  int left = 0, sx_f = 0, sy_f = 0, d_m = 0, d_n = 0, sf_f = 0;
   const int ntx_f = ntx;
   if (fast) {
     int sf, lf;
     chunk_of(nitems, xcd, sf, lf);
+    sf_f = sf;
     const int st = wgs_on_xcd(xcd, grid), my_l = blockIdx.x >> 3;
-    left = fdiv(lf - my_l + st - 1, st);               // items of this workgroup, the current one included
+    left = fdiv(lf - my_l + st - 1, st);               // items of this workgroup, the current one included (static partition)
     sy_f = fdiv(st, ntx);
     sx_f = st - sy_f * ntx;
   }
@@ -679,7 +742,17 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
       else { ISSUE_H(bp, BDHQ, 3, nbuf_); ISSUE_H(ap, a_dh, 1, nbuf_); wait_vmcnt_plus<8>(pk_); }                                 \
     } else { WAITV(0); }                                                                                                         \
     if ((KIND) == 1) {                  /* the next item: which one, and its tile coordinates (scalar work in a load segment that requests little) */ \
-      if (fast) {                                                                                                                \
+      if (fast && dyn) {                /* position from the XCD's counter (published by thread 0 at the end of the previous epilogue) */ \
+        const int packed_ = V4_RFL(sched_lds[0]);                                                                                \
+        nxt_packed = packed_;                                                                                                    \
+        have = packed_ >= 0;                                                                                                     \
+        if (have) {                                                                                                              \
+          const int lg_ = sf_f + (packed_ & 0xffffff);                                                                           \
+          const int ty_ = fdiv(lg_, ntx_f), tx_ = lg_ - ty_ * ntx_f;                                                             \
+          d_m = (ty_ - nxt.tile_y) * BM; d_n = (tx_ - nxt.tile_x) * BN;                                                          \
+          nxt.tile_x = tx_; nxt.tile_y = ty_;                                                                                    \
+        }                                                                                                                        \
+      } else if (fast) {                                                                                                         \
         left -= 1;                                                                                                               \
         have = left > 0;                                                                                                         \
         if (have) {                                                                                                              \
@@ -1067,64 +1140,40 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     unsigned char* Cs = smem + sbuf * STAGE_BYTES;  // the ring buffer of the last K-tile (the other one holds the next item's K-tile 0)
     constexpr bool SLICEABLE = MODE == MODE_STORE || MODE == MODE_STORE_RES;   // the N = d GEMMs (few tiles) use these flavours
     if (SLICEABLE && cur_slice >= 0 && KARG(kp, int, tail_mode) == 1) {
-      // ---- IN-KERNEL fix-up of a K-sliced tail tile (round 5; VERDICT r4 #1a).  The S slices of a tile run on S different CUs.
-      // Each parks its raw accumulators in its [256 x 256] fp32 slot of the workspace IN FRAGMENT ORDER (register group g of
-      // thread t at float4 index g * 512 + t: every store / load instruction of a wave is one contiguous 1 KiB, no LDS staging),
-      // makes them visible at device scope (the slices of a tile may sit on different XCDs = different L2s) and counts itself on
-      // the tile's arrival word.  Whoever reads S - 1 there is the last: all S slots are complete, it re-reads them in SLICE ORDER
-      // (its own included: the fp32 sum must not depend on which slice happened to finish last -- graph replays and the
-      // dynamic-distribution bit-identity tests compare outputs bit for bit), restores the counter and falls through into the
-      // ordinary bf16 epilogue below (alpha, bias, residual).  Nobody waits for anybody, so the scheme cannot deadlock whatever
-      // else holds CUs, and the emulation (workgroups one after the other) runs it unchanged.
+      // ---- IN-KERNEL fix-up of a K-sliced tail tile, part 1 (round 5; VERDICT r4 #1a).  The S slices of a tile run on S different
+      // CUs.  Each parks its raw accumulators in its [256 x 256] fp32 slot of the workspace IN FRAGMENT ORDER (register group g of
+      // thread t at byte g * 8192 + t * 16: every store / load instruction of a wave is one contiguous 1 KiB, no LDS staging) and
+      // counts itself on the tile's arrival word.  Whoever reads S - 1 there is the last: all S slots are complete, and that
+      // workgroup owes the tile its fix-up -- noted in LDS and paid AFTER the persistent loop (part 2, at the end of the kernel),
+      // where nothing of the main loop is alive any more.  (Done right here, the fold's 64 registers of loads in flight beside the
+      // 128 accumulators made the allocator spill loop-carried addresses of the MAIN LOOP: 200-900 spills with scratch loads inside
+      // the K-tiles, whose counted vmcnt waits must see the LDS-DMA and nothing else.)  Nobody waits for anybody, so the scheme
+      // cannot deadlock whatever else holds CUs, and the emulation (workgroups one after the other) runs it unchanged.
+      // Coherence without fences: the slices of a tile may sit on different XCDs (different L2s).  The parked tiles are written and
+      // read with the sc1 cache policy (device scope: written through to / served from the level all XCDs share), the stores are
+      // waited for (vmcnt(0)) before the arrival is counted, and the counter is a device-scope atomic.  The first version used
+      // __threadfence() on both sides (buffer_wbl2 + buffer_inv sc1: write back / invalidate the XCD's WHOLE L2, per wave, while 31
+      // other workgroups of that XCD stream operand panels through it) and lost 30 % against whole tiles
+      // (profiles/r05_tail_in_kernel.txt).
       const int S_ = KARG(kp, int, S);
       const int lt_ = fdiv(cur_slice, S_);
-      int* const cnt_ = KARG(kp, int*, tail_cnt) + lt_;
-      {
-        f32x4_t* Wt = reinterpret_cast<f32x4_t*>(e.ws + (long)cur_slice * (BM * BN)) + te;
+      const ParkBuf pb = park_buf(e.ws + (long)cur_slice * (BM * BN), BM * BN * 4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-              f32x4_t v;
+          for (int rg = 0; rg < 4; ++rg) {
+            f32x4_t v;
 #pragma unroll
-              for (int x = 0; x < 4; ++x) v[x] = acc[q][j][rg * 4 + x];
-              Wt[((q * 2 + j) * 4 + rg) * 512] = v;
-            }
-      }
-      __threadfence();                         // release: the parked tile is visible device-wide before the arrival is
-      wait_vmcnt<0>();                         // (also drains the LDS-DMA the compiler cannot see: nothing is in flight across the fences)
+            for (int x = 0; x < 4; ++x) v[x] = acc[q][j][rg * 4 + x];
+            park_store(pb, (uint32_t)(((q * 2 + j) * 4 + rg) * 8192 + te * 16), v);
+          }
+      wait_vmcnt<0>();                         // the parked tile has left this CU (and the LDS-DMA the compiler cannot see has landed)
       V4_BARRIER();
-      if (te == 0) sched_lds[1] = atomicAdd(cnt_, 1);
-      wait_lgkm0();
-      V4_BARRIER();
-      const int arrived_ = V4_RFL(sched_lds[1]);
-      if (arrived_ != S_ - 1) { pend = 0; break; }
-      __threadfence();                         // acquire: the other slices' tiles (written through other L2s) are read from memory
-      {
-        const f32x4_t* W0 = reinterpret_cast<const f32x4_t*>(e.ws + (long)lt_ * S_ * (BM * BN)) + te;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][j][r] = 0.f;
-        for (int s2 = 0; s2 < S_; ++s2) {
-          const f32x4_t* Ws = W0 + (long)s2 * (BM * BN / 4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-              for (int rg = 0; rg < 4; ++rg) {
-                const f32x4_t v = Ws[((q * 2 + j) * 4 + rg) * 512];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) acc[q][j][rg * 4 + x] += v[x];
-              }
-        }
-      }
-      if (te == 0) *cnt_ = 0;                  // zero at rest: the next launch on this stream finds the counters cleared
+      if (te == 0 && arrive_add(KARG(kp, int*, tail_cnt) + lt_) == S_ - 1) { const int n_ = sched_lds[2]; sched_lds[4 + n_] = lt_; sched_lds[2] = n_ + 1; }
+      pend = 0;
+      break;
     }
     if (MODE == MODE_PARTIAL || GROUP || (SLICEABLE && cur_slice >= 0 && KARG(kp, int, tail_mode) == 0)) {
       // fp32 partial tile: MODE_PARTIAL -> ws[z][m][n]; tail slice -> its private [256][256] tile of the workspace.
@@ -1335,6 +1384,79 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
     wait_lgkm0();
     V4_BARRIER();
     TRACE();                                 // [n] epilogue done
+  }
+  if (MODE == MODE_STORE || MODE == MODE_STORE_RES) {
+    // ---- IN-KERNEL fix-up of K-sliced tail tiles, part 2: this workgroup was the last slice to arrive at `n_def` tiles (normally 0
+    // or 1).  For each: sum the S parked tiles in SLICE ORDER -- ((p0 + p1) + p2) + ..., whoever arrived last: graph replays and the
+    // dynamic-distribution bit-identity tests compare outputs bit for bit -- then alpha, bias, residual, one bf16 rounding, and
+    // straight to memory from the fragment registers (a lane owns 4 consecutive columns of a row: 8-byte stores, lanes l and l + 32
+    // side by side; issue-bound at ~9 k cycles per tile, which only the launch's last few tiles pay).
+    wait_lgkm0();
+    V4_BARRIER();
+    const int n_def = V4_RFL(sched_lds[2]);
+    if (n_def > 0) {
+      kargp_t kq = V4_KARGP(ka_unused);
+      V4_OPAQUE_S(kq);
+      const int S_ = KARG(kq, int, S), ntx_ = KARG(kq, int, ntx), nty_ = KARG(kq, int, nty), nfull_ = KARG(kq, int, n_full), gm_ = KARG(kq, int, group_m);
+      const float alpha_ = KARG(kq, float, e.alpha);
+      float* const ws_ = KARG(kq, float*, e.ws);
+      unsigned char* const C_ = reinterpret_cast<unsigned char*>(KARG(kq, void*, e.C));
+      const unsigned char* const R_ = reinterpret_cast<const unsigned char*>(KARG(kq, const void*, e.residual));
+      const long ldc_ = KARG(kq, long, e.ldc), ldr_ = KARG(kq, long, e.ldr);
+      constexpr uint32_t SLOT = BM * BN * 4;
+      int tf = t;
+      V4_OPAQUE_V(tf);
+      const int lf = tf & 63;
+      for (int d = 0; d < n_def; ++d) {
+        const int lt_ = V4_RFL(sched_lds[4 + d]);
+        int tx_, ty_;
+        tile_from_logical(nfull_ + lt_, ntx_, nty_, tx_, ty_, gm_);
+        const int m0 = ty_ * BM, n0 = tx_ * BN;
+        const ParkBuf pb = park_buf(ws_ + (long)lt_ * S_ * (BM * BN), S_ * (int)SLOT);
+        // two half-tiles (A-half i: fragments q = 2i, 2i + 1) so that 64 accumulators + 64 registers of loads in flight are live at most
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          f32x4_t sum[16];
+          for (int s2 = 0; s2 < S_; ++s2) {
+            f32x4_t tv[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) tv[g] = park_load(pb, (uint32_t)s2 * SLOT + (uint32_t)((i * 16 + g) * 8192 + tf * 16));
+            __builtin_amdgcn_sched_barrier(0);          // all 16 loads issued before the first add: one memory latency per pass
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sum[g] = s2 == 0 ? tv[g] : sum[g] + tv[g];
+          }
+          uint2 r2[16];
+          if (MODE == MODE_STORE_RES) {                 // the 16 residual pieces of this half-tile: one batch of loads, no store between them
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+              const int q = i * 2 + (g >> 3), j = (g >> 2) & 1, rg = g & 3;
+              const int row = m0 + (q >> 1) * 128 + wm * 64 + (q & 1) * 32 + (lf & 31);
+              const int col = n0 + j * 128 + br + 8 * rg + 4 * (lf >> 5);
+              r2[g] = *reinterpret_cast<const uint2*>(R_ + ((long)row * ldr_ + col) * 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            const int q = i * 2 + (g >> 3), j = (g >> 2) & 1, rg = g & 3;
+            const int row = m0 + (q >> 1) * 128 + wm * 64 + (q & 1) * 32 + (lf & 31);
+            const int col = n0 + j * 128 + br + 8 * rg + 4 * (lf >> 5);
+            const float4 bv = *reinterpret_cast<const float4*>(smem + BIAS_OFF + 4 * col);        // (zeros when the launch has no bias)
+            float v0 = sum[g][0] * alpha_ + bv.x, v1 = sum[g][1] * alpha_ + bv.y, v2 = sum[g][2] * alpha_ + bv.z, v3 = sum[g][3] * alpha_ + bv.w;
+            if (MODE == MODE_STORE_RES) {
+              // like the staged epilogue: the bf16 value of (acc + bias) is what the residual is added to
+              const uint32_t p0 = pack2bf_hw(v0, v1), p1 = pack2bf_hw(v2, v3);
+              v0 = __uint_as_float(p0 << 16) + __uint_as_float(r2[g].x << 16); v1 = __uint_as_float(p0 & 0xffff0000u) + __uint_as_float(r2[g].x & 0xffff0000u);
+              v2 = __uint_as_float(p1 << 16) + __uint_as_float(r2[g].y << 16); v3 = __uint_as_float(p1 & 0xffff0000u) + __uint_as_float(r2[g].y & 0xffff0000u);
+            }
+            uint2 o;
+            o.x = pack2bf_hw(v0, v1); o.y = pack2bf_hw(v2, v3);
+            *reinterpret_cast<uint2*>(C_ + ((long)row * ldc_ + col) * 2) = o;
+          }
+        }
+        if (tf == 0) arrive_reset(KARG(kq, int*, tail_cnt) + lt_);       // zero at rest: the next launch on this stream finds the counters cleared
+      }
+    }
   }
   if (dyn && t == 0) {
     // self-resetting scheduler state: the last workgroup to leave zeroes the counters for the next launch on this stream
@@ -1619,14 +1741,16 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
   e.ws = (float*)a->ws;
   e.ws_cs = (md == MODE_PARTIAL && a->a_colsum) ? (float*)a->ws + (int64_t)split * a->M * a->N : nullptr;
   // tail slicing (bf16 outputs): when the last round of whole tiles would use at most half of the CUs, cut those tiles in K
-  // DH_V4_TAIL: 0 off; 1 (default) few-tile launches through the fix-up kernel + LONG tile lists with the IN-KERNEL fix-up (round 5);
-  // 2 long lists through the fix-up kernel (rounds 1-4, kept for A/B runs); 3 few-tile launches only (the round-3/4 default)
+  // DH_V4_TAIL: 0 off; 1 (default; 3 = the same) few-tile launches through the fix-up kernel; 2 = 1 + LONG tile lists through the
+  // fix-up kernel (rounds 1-3); 4 = 1 + long tile lists with the IN-KERNEL fix-up (round 5).  Both long-list variants are opt-in:
+  // each wins on the launch alone and loses in the step, where the other tower's stream fills the idle CUs of a ragged last round
+  // anyway (numbers at the long-list branch below)
   int n_full = 0, S = 0;
   int* tail_cnt = nullptr;
   if ((md == MODE_STORE || md == MODE_STORE_RES) && a->ws && (((uintptr_t)a->ws & 15) == 0)) {
     int tail = 1;      // (read per call: the tests switch it between calls)
     { const char* ev = getenv("DH_V4_TAIL"); if (ev) tail = atoi(ev); }
-    int min_nkt = 24, s_max = 8;   // (tuning knobs, read per call like DH_V4_TAIL: K-tiles a tile must have to be cut, most slices per tile)
+    int min_nkt = 24, s_max = tail == 4 ? 3 : 8;   // (tuning knobs, read per call like DH_V4_TAIL: K-tiles a tile must have to be cut, most slices per tile)
     { const char* ev = getenv("DH_V4_TAIL_MINK"); if (ev) min_nkt = atoi(ev); }
     { const char* ev = getenv("DH_V4_TAIL_SMAX"); if (ev) s_max = atoi(ev); }
     const int T = dh_cdiv(a->N, BN) * dh_cdiv(a->M, BM), G = num_cus(), rem = T % G, nkt = a->K / BK;
@@ -1639,17 +1763,21 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
       if (s_ >= 2 && a->ws_bytes >= (int64_t)T * s_ * BM * BN * 4) { S = s_; n_full = 0; }
     } else
     // LONG tile lists (300 tiles of the N = d tower GEMMs on 256 CUs: 44 tiles in a second round that costs as much as the first).
-    // Rounds 1-4 summed the slices in a second launch, and its 34 fix-up launches per step cost the step exactly what the tail
-    // round saved (CLIP b = 512, same box: 23.52 ms with, 23.53-23.56 ms without; profiles/r03_ab_tail_slicing.txt).  Round 5: the
-    // last slice of a tile to arrive does the fix-up inside the GEMM kernel (KArgs.tail_mode), no launch.  Short-K tiles stay whole:
-    // a slice moves 2 x 256 KB of fp32 through memory, which is a tile's worth of K = 768 arithmetic.
-    if ((tail == 1 || tail == 2) && T > G && rem > 0 && rem <= G / 2 && nkt >= min_nkt && rem <= v4::TAIL_CNT_WORDS) {
+    // Rounds 1-3 summed the slices in a second launch (tail = 2): its 34 fix-up launches per step cost the step what the tail round
+    // saved (CLIP b = 512, same box: 23.52 ms with, 23.53-23.56 ms without; profiles/r03_ab_tail_slicing.txt).  Round 5 (tail = 4):
+    // the last slice of a tile to arrive does the fix-up inside the GEMM kernel (KArgs.tail_mode), no launch, no spinning.  Measured
+    // (profiles/r05_tail_in_kernel.txt): alone on the chip 25600 x 768 x 3072 runs in 130.8 us with 3 slices per tail tile against
+    // 140.3 us whole (2 slices 132.9, 5 slices 134.6; dX layout 136.3 -> 127.5); in the CLIP step, where a second tower stream is
+    // there to fill idle CUs, 23.17-23.18 ms against 23.04-23.07 ms: the parked tiles (S x 256 KB written, S x 256 KB read back by
+    // ONE workgroup per tile) and the general hand-over that a sliced launch needs for all of its items are extra work, and the
+    // step pays for work, not for the length of one launch's last round.  Short-K tiles (K = 768) lose even alone (42.8 -> 54.8 us).
+    if ((tail == 2 || tail == 4) && T > G && rem > 0 && rem <= G / 2 && nkt >= min_nkt && rem <= v4::MAX_TAIL_TILES && rem <= v4::TAIL_CNT_WORDS) {
       int s_ = G / rem;
       if (s_ > s_max) s_ = s_max;
       if (s_ > nkt / 2) s_ = nkt / 2;
       if (s_ >= 2 && a->ws_bytes >= (int64_t)rem * s_ * BM * BN * 4) {
         S = s_; n_full = T - rem;
-        if (tail == 1) {
+        if (tail == 4) {
           tail_cnt = v4::tail_counters(st);
           if (!tail_cnt) { S = 0; n_full = 0; }        // no counter slot left for this stream: whole tiles
         }

@@ -59,14 +59,16 @@ def margin(key, measured, cap, floor=0.0, factor=3.0):
     return measured
 
 
-def assert_bf16_close(key, out, ref, rel=2.0 ** -7, abs_rms=2.0 ** -8):
+def assert_bf16_close(key, out, ref, rel=2.0 ** -7, abs_rms=2.0 ** -8, mag=None):
     """Per-element gate for a bf16 result against an fp64 reference: |err| <= rel |ref| + abs_rms rms(ref) for EVERY element (one bf16
     rounding is 2^-9 |ref|; staged epilogues round twice; the rms term covers elements that are small because large terms cancel).
     Replaces `max|err| <= 1.2e-2 max|ref|`, which a wrong value in a small-magnitude region passes.  The worst ratio err / bound
     is recorded as a margin."""
     out, ref = out.detach().double().cpu(), ref.detach().double().cpu()
     rms = float(ref.pow(2).mean().sqrt())
-    bound = rel * ref.abs() + abs_rms * rms
+    # `mag`: sum of the magnitudes that were rounded on the way (a staged epilogue rounds an intermediate that may be much larger than
+    # the result when the residual cancels it); default: the result itself
+    bound = rel * (ref.abs() if mag is None else mag.detach().double().cpu()) + abs_rms * rms
     ratio = float(((out - ref).abs() / bound).max())
     assert ratio <= 1.0, (key, "worst err / bound", ratio, "rms", rms)
     margin(key, ratio, 1.0, floor=0.5)

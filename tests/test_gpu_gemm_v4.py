@@ -82,7 +82,8 @@ def test_v4_forward_gelu_and_residual(M, N, K):
     assert rel_err(out, quick_gelu(aux.double().cpu())) < 6e-3
     out = ops.gemm(A.to(cuda), B.to(cuda), bias=bias.to(cuda), residual=R.to(cuda), force_generic=4)
     assert rel_err(out, pre + R.double()) < TOL
-    close("residual_%dx%dx%d" % (M, N, K), out, pre + R.double())
+    # (two roundings: bf16(acc + bias), then bf16(that + residual) -- the bound of each is relative to ITS operand)
+    close("residual_%dx%dx%d" % (M, N, K), out, pre + R.double(), mag=pre.abs() + (pre + R.double()).abs())
 
 
 @pytest.mark.parametrize("M,N,K", [(768, 512, 320), (2560, 3072, 768)])
@@ -136,11 +137,11 @@ class _env:
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("tail", [1, 2])
+@pytest.mark.parametrize("tail", [4, 2])
 @pytest.mark.parametrize("residual", [False, True])
 def test_v4_tail_sliced_schedule(residual, tail):
-    """300 tiles on 256 CUs: the 44 tiles of the last round are cut in K over all CUs (needs the workspace).  tail = 1 (the default
-    since round 5): the last slice of a tile to arrive sums the parked slices and applies the epilogue INSIDE the GEMM kernel;
+    """300 tiles on 256 CUs: the 44 tiles of the last round are cut in K over all CUs (needs the workspace).  tail = 4 (round 5,
+    opt-in): the last slice of a tile to arrive sums the parked slices and applies the epilogue INSIDE the GEMM kernel;
     tail = 2: the fix-up kernel of rounds 1-4.  Either must agree with the unsliced schedule up to the regrouped fp32 sums."""
     ops = _ops()
     M, N, K = 25600, 768, 2304
@@ -160,9 +161,11 @@ def test_v4_tail_sliced_schedule(residual, tail):
         ref = ref + R.double().cpu()
     assert rel_err(sliced, ref) < TOL
     assert rel_err(plain, ref) < TOL
-    close("tail%d_res%d_sliced" % (tail, int(residual)), sliced, ref)
-    close("tail%d_res%d_plain" % (tail, int(residual)), plain, ref)
-    assert rel_err(sliced, plain.float()) < 4e-3
+    pre = A.double() @ B.double().t() + bias.double()
+    mag = (pre.abs() + ref.abs()) if residual else None
+    close("tail%d_res%d_sliced" % (tail, int(residual)), sliced, ref, mag=mag)
+    close("tail%d_res%d_plain" % (tail, int(residual)), plain, ref, mag=mag)
+    assert rel_err(sliced, plain.float()) < 8e-3        # (one bf16 ulp of the largest element where a regrouped fp32 sum rounds the other way)
     assert torch.isfinite(sliced.float()).all()
     # the rows of the whole tiles are the same work items in both schedules: bit-identical
     assert torch.equal(sliced[:256 * 85], plain[:256 * 85])
@@ -179,7 +182,7 @@ def test_v4_tail_in_kernel_fixup_is_deterministic_and_leaves_its_counters_clean(
     side = torch.cuda.Stream()
     outs = []
     for it in range(20):
-        with _env(DH_V4_TAIL=1, DH_V4_DYNAMIC=(it // 2) % 2):
+        with _env(DH_V4_TAIL=4, DH_V4_DYNAMIC=(it // 2) % 2):
             if it % 2:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
@@ -193,7 +196,7 @@ def test_v4_tail_in_kernel_fixup_is_deterministic_and_leaves_its_counters_clean(
         assert torch.equal(o, outs[0])
     ref = A.double().cpu() @ B.double().cpu().t() + bias.double().cpu() + R.double().cpu()
     assert rel_err(outs[0], ref) < TOL
-    close("tail_in_kernel_25600x768x3072_res", outs[0], ref)
+    close("tail_in_kernel_25600x768x3072_res", outs[0], ref, mag=(ref - R.double().cpu()).abs() + ref.abs())
 
 
 def test_v4_tail_in_kernel_fixup_under_concurrent_launches():
@@ -205,7 +208,7 @@ def test_v4_tail_in_kernel_fixup_under_concurrent_launches():
     W2 = rnd(K, N, seed=37, scale=0.05).to(bf).to(cuda)            # dX layout: B contraction-major
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     ws1, ws2 = _ws(), _ws()
-    with _env(DH_V4_TAIL=1):
+    with _env(DH_V4_TAIL=4):
         single1 = ops.gemm(A, B, bias=bias, ws=ws1, force_generic=4)
         single2 = ops.gemm(A, W2, b_kmajor=True, ws=ws2, force_generic=4)
         torch.cuda.synchronize()
@@ -288,25 +291,6 @@ def test_v4_group_falls_back_for_shapes_it_cannot_take():
     ops.gemm_dw_group(probs, ws=_ws())
     for (dy, x, gw, gb), (rw, rb) in zip(probs, refs):
         assert rel_err(gw, rw) < 2e-5 and rel_err(gb, rb) < 2e-5
-
-
-class _env:
-    def __init__(self, **kv):
-        self.kv, self.prev = kv, {}
-
-    def __enter__(self):
-        import os
-        for k, v in self.kv.items():
-            self.prev[k] = os.environ.get(k)
-            os.environ[k] = v
-
-    def __exit__(self, *a):
-        import os
-        for k, v in self.prev.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def test_v4_dynamic_tile_distribution_is_bit_identical_to_the_static_one():

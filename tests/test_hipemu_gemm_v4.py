@@ -128,7 +128,8 @@ def test_v4_tail_sliced_schedule_emulated(ops):
 
 @pytest.mark.parametrize("M,K,residual,dyn", [pytest.param(2304, 512, False, 0, marks=SLOW), (2560, 384, True, 0), pytest.param(2560, 512, False, 1, marks=SLOW)])
 def test_v4_tail_in_kernel_fixup_emulated(ops, M, K, residual, dyn):
-    """The default for long tile lists since round 5 (DH_V4_TAIL=1): 9 / 10 tiles on 8 compute units, 8 (6) K-tiles -> the 1 / 2 tiles of
+    """The in-kernel fix-up of K-sliced tail tiles (round 5, DH_V4_TAIL=4; opt-in like the fix-up-kernel variant -- it wins alone on the chip
+    and loses in the two-stream step): 9 / 10 tiles on 8 compute units, 8 (6) K-tiles -> the 1 / 2 tiles of
     the last round are cut into 4 (3) K-slices; every slice parks its accumulators in the workspace (fragment order), counts itself on the
     tile's arrival word, and the LAST one sums the four parked tiles in slice order and runs the ordinary bf16 epilogue -- no
     fix-up launch.  Pinned here: the slot / fragment indexing, the arrival protocol (the emulation runs the workgroups one after the
@@ -138,7 +139,7 @@ def test_v4_tail_in_kernel_fixup_emulated(ops, M, K, residual, dyn):
     A, B, bias = rnd(M, K, seed=14).to(bf), rnd(N, K, seed=15, scale=0.05).to(bf), rnd(N, seed=16)
     R = rnd(M, N, seed=17).to(bf) if residual else None
     ws = torch.full(((16 << 20) // 4,), float("nan"), dtype=torch.float32)      # a slot that is read before it is written poisons the tile
-    with _env(DH_V4_TAIL=1, DH_V4_TAIL_MINK=K // 64, DH_V4_DYNAMIC=dyn):
+    with _env(DH_V4_TAIL=4, DH_V4_TAIL_MINK=K // 64, DH_V4_TAIL_SMAX=4, DH_V4_DYNAMIC=dyn):
         ops.gemm_stats(reset=True)
         first = ops.gemm(A, B, bias=bias, residual=R, ws=ws, force_generic=4)
         st = ops.gemm_stats()
