@@ -130,14 +130,23 @@ __device__ __forceinline__ float block_max256(float v, float* red) {
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// QuickGELU and its derivative from ONE sigmoid (round 5): the forward epilogue (DH_EPI_GELU) stores the derivative as its aux
+// output, so the backward epilogue (DH_EPI_DGELU) is a plain multiply -- the two transcendentals per element that the dX GEMM of
+// c_proj used to spend on re-deriving QuickGELU'(u) from the stored pre-activation are gone, the forward pays three more VALU.
 #ifdef DH_GELU_ABL   // ablation builds only (tools/build_lib_variant.sh abl -DDH_GELU_ABL): what the activation's arithmetic costs the epilogues
 __device__ __forceinline__ float quick_gelu_f(float x) { return x * 0.5f; }
 __device__ __forceinline__ float quick_gelu_grad_f(float x) { return 0.5f + 0.001f * x; }
+__device__ __forceinline__ void quick_gelu_both_f(float x, float& g, float& d) { g = x * 0.5f; d = 0.5f + 0.001f * x; }
 #else
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float quick_gelu_grad_f(float x) {
   float s = 1.f / (1.f + __expf(-1.702f * x));
   return s * (1.f + 1.702f * x * (1.f - s));
+}
+__device__ __forceinline__ void quick_gelu_both_f(float x, float& g, float& d) {
+  const float s = 1.f / (1.f + __expf(-1.702f * x));
+  g = x * s;
+  d = s + 1.702f * g * (1.f - s);            // = s (1 + 1.702 x (1 - s))
 }
 #endif
 

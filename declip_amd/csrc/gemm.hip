@@ -32,12 +32,13 @@ __device__ __forceinline__ void epilogue_store(const EpiParams& e, int m, int n,
     return;
   }
   if (e.bias) v += e.bias[n];
-  if (e.epilogue == DH_EPI_GELU) {
-    if (e.aux) st<TO>(reinterpret_cast<TO*>(e.aux) + (long)m * e.ldaux + n, v);
-    v = quick_gelu_f(v);
+  if (e.epilogue == DH_EPI_GELU) {           // aux = QuickGELU'(pre): what DH_EPI_DGELU multiplies by
+    float g, d;
+    quick_gelu_both_f(v, g, d);
+    if (e.aux) st<TO>(reinterpret_cast<TO*>(e.aux) + (long)m * e.ldaux + n, d);
+    v = g;
   } else if (e.epilogue == DH_EPI_DGELU) {
-    float u = ld<TI>(reinterpret_cast<const TI*>(e.aux) + (long)m * e.ldaux + n);
-    v *= quick_gelu_grad_f(u);
+    v *= ld<TI>(reinterpret_cast<const TI*>(e.aux) + (long)m * e.ldaux + n);
   }
   if (e.residual) v += ld<TO>(reinterpret_cast<const TO*>(e.residual) + (long)m * e.ldr + n);
   st<TO>(reinterpret_cast<TO*>(e.C) + (long)m * e.ldc + n, v);

@@ -98,15 +98,16 @@ __device__ __forceinline__ void epilogue8(const EpiParams& e, int m, int n, floa
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] += bv[i];
   }
-  if (e.epilogue == DH_EPI_GELU) {
-    if (e.aux) st8(reinterpret_cast<TO*>(e.aux) + (long)m * e.ldaux + n, v);
+  if (e.epilogue == DH_EPI_GELU) {           // aux = QuickGELU'(pre): what DH_EPI_DGELU multiplies by
+    float d[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = quick_gelu_f(v[i]);
+    for (int i = 0; i < 8; ++i) quick_gelu_both_f(v[i], v[i], d[i]);
+    if (e.aux) st8(reinterpret_cast<TO*>(e.aux) + (long)m * e.ldaux + n, d);
   } else if (e.epilogue == DH_EPI_DGELU) {
     float u[8];
     ld8(reinterpret_cast<const TI*>(e.aux) + (long)m * e.ldaux + n, u);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] *= quick_gelu_grad_f(u[i]);
+    for (int i = 0; i < 8; ++i) v[i] *= u[i];
   }
   if (e.residual) {
     float r[8];

@@ -1334,10 +1334,13 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
               float v[8];
 #pragma unroll
               for (int x = 0; x < 4; ++x) { v[2 * x] = __uint_as_float(wv[x] << 16); v[2 * x + 1] = __uint_as_float(wv[x] & 0xffff0000u); }
-              if (is_gelu) {
-                store_c16<NT_OUT>(Xb + mu * e.ldaux * 2 + x_off, raw);
+              if (is_gelu) {      // aux = QuickGELU' of the staged (bf16) pre-activation: the factor the dX GEMM of c_proj multiplies by
+                float dv[8];
 #pragma unroll
-                for (int x = 0; x < 8; ++x) v[x] = quick_gelu_f(v[x]);
+                for (int x = 0; x < 8; ++x) quick_gelu_both_f(v[x], v[x], dv[x]);
+                uint4 dk;
+                dk.x = pack2bf_hw(dv[0], dv[1]); dk.y = pack2bf_hw(dv[2], dv[3]); dk.z = pack2bf_hw(dv[4], dv[5]); dk.w = pack2bf_hw(dv[6], dv[7]);
+                store_c16<NT_OUT>(Xb + mu * e.ldaux * 2 + x_off, dk);
               }
               if (has_pre) {
                 const uint4 pr = i == 0 ? pre0[xo] : pre1[xo];
@@ -1347,7 +1350,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
                 for (int x = 0; x < 4; ++x) { pf[2 * x] = __uint_as_float(pw[x] << 16); pf[2 * x + 1] = __uint_as_float(pw[x] & 0xffff0000u); }
                 if (is_dgelu) {
 #pragma unroll
-                  for (int x = 0; x < 8; ++x) v[x] *= quick_gelu_grad_f(pf[x]);
+                  for (int x = 0; x < 8; ++x) v[x] *= pf[x];
                 } else {
 #pragma unroll
                   for (int x = 0; x < 8; ++x) v[x] += pf[x];
@@ -1563,14 +1566,15 @@ __global__ __launch_bounds__(256) void tail_fixup_kernel(const float* __restrict
   }
   bf16_t* C = reinterpret_cast<bf16_t*>(e.C);
   if (e.epilogue == DH_EPI_GELU) {
-    if (e.aux) st8_hw(reinterpret_cast<bf16_t*>(e.aux) + m * e.ldaux + n, v);
+    float d[8];
 #pragma unroll
-    for (int x = 0; x < 8; ++x) v[x] = quick_gelu_f(bf2f(f2bf(v[x])));      // like the in-kernel path: GELU of the stored pre-activation
+    for (int x = 0; x < 8; ++x) quick_gelu_both_f(bf2f(f2bf(v[x])), v[x], d[x]);      // like the in-kernel path: of the bf16-rounded pre-activation
+    if (e.aux) st8_hw(reinterpret_cast<bf16_t*>(e.aux) + m * e.ldaux + n, d);
   } else if (e.epilogue == DH_EPI_DGELU) {
     float u[8];
     ld8(reinterpret_cast<const bf16_t*>(e.aux) + m * e.ldaux + n, u);
 #pragma unroll
-    for (int x = 0; x < 8; ++x) v[x] *= quick_gelu_grad_f(u[x]);
+    for (int x = 0; x < 8; ++x) v[x] *= u[x];
   }
   if (e.residual) {
     float r[8];

@@ -52,8 +52,9 @@ int dh_device_info(int device, int* out4);
  * (dX: b_kmajor=1; dW: a_kmajor=b_kmajor=1 with accumulate).
  * Epilogues:
  *   DH_EPI_NONE
- *   DH_EPI_GELU   aux_out[m,n] = pre-activation, C = QuickGELU(pre)   (base_transformer.py:24-26)
- *   DH_EPI_DGELU  C = value * QuickGELU'(aux_in[m,n])                 (backward of the above)
+ *   DH_EPI_GELU   C = QuickGELU(pre), aux_out[m,n] = QuickGELU'(pre)  (base_transformer.py:24-26; the derivative is what autograd's
+ *                 backward of x * sigmoid(1.702 x) multiplies by -- both come from one sigmoid, round 5)
+ *   DH_EPI_DGELU  C = value * aux_in[m,n]                              (backward of the above: aux_in = the forward's aux_out)
  *   residual != NULL: C += residual[m,n] (type c_dtype)               (base_transformer.py:51-52)
  *   accumulate = 1: C is fp32 and is atomically accumulated into (split_k > 1 allowed).
  *   a_colsum (with a_kmajor): the weight-gradient call dW = dY^T X also emits db = colsum(dY) from the dY

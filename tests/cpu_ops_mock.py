@@ -48,12 +48,12 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, 
         return out
     if bias is not None:
         v = v + bias
-    if epilogue == EPI_GELU:
+    if epilogue == EPI_GELU:                  # aux = QuickGELU'(pre) (include/declip_hip.h)
         if aux is not None:
-            aux.copy_(v)
+            aux.copy_(_dgelu(v))
         v = _gelu(v)
     elif epilogue == EPI_DGELU:
-        v = v * _dgelu(aux.float())
+        v = v * aux.float()
     if residual is not None:
         v = v + residual.float()
     if out is None:

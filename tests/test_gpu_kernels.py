@@ -63,15 +63,20 @@ def test_gemm_epilogues(dtype):
     # bias + residual
     out = ops.gemm(A.to(cuda), B.to(cuda), bias=bias.to(cuda), residual=R.to(cuda))
     assert rel_err(out, pre + R.double()) < tol
-    # GELU epilogue with pre-activation side output
+    # GELU epilogue with the derivative as side output (what DH_EPI_DGELU multiplies by)
     aux = torch.empty(M, N, device=cuda, dtype=dtype)
     out = ops.gemm(A.to(cuda), B.to(cuda), bias=bias.to(cuda), epilogue=EPI_GELU, aux=aux)
-    assert rel_err(aux, pre) < tol
+    assert rel_err(aux, quick_gelu_grad(pre)) < tol
     assert rel_err(out, quick_gelu(pre)) < tol
-    # DGELU epilogue
+    # DGELU epilogue: value * aux
     U = rnd(M, N, seed=7).to(dtype)
     out = ops.gemm(A.to(cuda), B.to(cuda), epilogue=EPI_DGELU, aux=U.to(cuda))
-    assert rel_err(out, (A.double() @ B.double().t()) * quick_gelu_grad(U.double())) < tol
+    assert rel_err(out, (A.double() @ B.double().t()) * U.double()) < tol
+    # the pair is the backward of x * sigmoid(1.702 x): d/dpre of sum(w * gelu(pre)) = w * aux
+    w = rnd(M, N, seed=8).double()
+    pre_t = pre.clone().requires_grad_(True)
+    (w * quick_gelu(pre_t)).sum().backward()
+    assert rel_err(w * aux.double().cpu(), pre_t.grad) < tol
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -522,7 +527,7 @@ def test_gemm_v3_tiles(monkeypatch, mode, a_km, b_km, M, N, K):
         aux = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
         out = ops.gemm(Ad, Bd, a_kmajor=a_km, b_kmajor=b_km, bias=bias.to(cuda), epilogue=EPI_GELU, aux=aux)
         pre = ref + bias.double()
-        assert rel_err(aux, pre) < 1.5e-2
+        assert rel_err(aux, quick_gelu_grad(pre)) < 1.5e-2
         assert rel_err(out, quick_gelu(pre)) < 1.5e-2
         out32 = ops.gemm(Ad, Bd, a_kmajor=a_km, b_kmajor=b_km, out_dtype=torch.float32)
         assert rel_err(out32, ref) < 2e-3
