@@ -202,6 +202,45 @@ def self_launch(n):
     return rc
 
 
+def _arm_watchdog(seconds, what):
+    """Last line of defence for the DEFAULT multi-GPU configuration (captured step with RCCL collectives in the graph), which has
+    never run on more than one rank: if `what` makes no progress for `seconds`, this rank re-executes itself with --graph 0.  A hang
+    inside a collective stops every rank, so every rank's watchdog fires and the re-executed ranks meet again in a fresh rendezvous
+    (torchrun: the agent's store with the next attempt prefix; self-launched: the next port).  exec closes the device files, so
+    the driver tears down the hung queues of the old image.  The line then carries `graph_fallback`.  Returns the timer (cancel())."""
+    import threading
+
+    def fire():
+        msg = "watchdog: %s made no progress in %d s; rank re-executed with --graph 0" % (what, int(seconds))
+        sys.stderr.write("bench.py: " + msg + "\n")
+        sys.stderr.flush()
+        env = dict(os.environ, DH_BENCH_GRAPH_FALLBACK=msg)
+        if env.get("TORCHELASTIC_USE_AGENT_STORE") == "True":
+            env["TORCHELASTIC_RESTART_COUNT"] = str(int(env.get("TORCHELASTIC_RESTART_COUNT", "0")) + 1)     # fresh key prefix in the agent's store
+        elif env.get("MASTER_PORT", "").isdigit():
+            env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + 1)                                              # rank 0 hosts the store itself: next port
+        argv, skip = [], False
+        for a in sys.argv[1:]:
+            if skip:
+                skip = False
+                continue
+            if a == "--graph":
+                skip = True
+                continue
+            if a.startswith("--graph="):
+                continue
+            argv.append(a)
+        try:
+            os.closerange(3, 4096)                # sockets of the old rendezvous, the device files of the hung queues
+        except OSError:
+            pass
+        os.execve(sys.executable, [sys.executable, os.path.abspath(__file__)] + argv + ["--graph", "0"], env)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def dry_run_launch(args):
     """--dry-run-launch: everything `bench.py --gpus N` does around the timed steps -- process group from the environment, the
     SUM-of-ones check of the communicator, (host, device) of every rank, ONE JSON line from rank 0 -- without a model.  Works on a
@@ -344,10 +383,16 @@ def main():
     # default: on for one GPU where a graph == eager test gates it (tests/test_gpu_graph.py: clip, clip_r50, declip, defilip, filip);
     # multi-GPU runs capture the RCCL collectives with the step only when asked to (--graph 1 / DH_STEP_GRAPH=1; the capture of a
     # one-rank RCCL step is tested in tests/test_gpu_dist.py, W > 1 has not run anywhere yet) and never over a gloo group
-    graph_default = "1" if (world == 1 and not forced and args.model in ("clip", "clip_r50", "filip", "declip", "defilip")) else "0"
+    # Round 5: a multi-GPU rank runs the captured step by DEFAULT too (RCCL collectives captured with it; the one-rank capture is tested in
+    # tests/test_gpu_dist.py, DH_DIST_FORCE=1 runs it here) -- with two safety nets, because W > 1 has never executed anywhere: a capture
+    # that raises falls back to the eager step on EVERY rank (GraphedStep(fallback=True, agree=...)), and a warm-up that makes no progress
+    # (a collective hanging inside a replay) re-executes the rank with --graph 0 (`_arm_watchdog`); either way the line says so in
+    # `graph_fallback`.  Never over a gloo group (host-side collectives).
+    graph_default = "1" if args.model in ("clip", "clip_r50", "filip", "declip", "defilip", "slip") else "0"
     use_graph = (args.graph if args.graph is not None else os.environ.get("DH_STEP_GRAPH", graph_default)) == "1"
     if world > 1 and torch.distributed.get_backend() != "nccl":
         use_graph = False
+    graph_fallback = os.environ.get("DH_BENCH_GRAPH_FALLBACK")        # set by a watchdog re-execution of this rank
     # sanity of a multi-GPU launch before anything is timed: every rank of the launch is in the communicator (a SUM all-reduce of
     # ones over RCCL must count `world` ranks) and sits on its own device
     rccl_ranks = 1
@@ -405,7 +450,16 @@ def main():
                 graph_key = lambda: eng_mod.packed_key(static_ids, torch.bfloat16)      # noqa: E731
         else:
             use_graph = False
-    graphed = GraphedStep(fwd_bwd, warmup=2, enabled=use_graph, modules=(wrapped,), key=graph_key)
+    dist_on = world > 1 or forced
+
+    def agree(ok):
+        if not dist_on:
+            return ok
+        flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        return bool(float(flag) > 0.5)
+    graphed = GraphedStep(fwd_bwd, warmup=2, enabled=use_graph, modules=(wrapped,), key=graph_key, fallback=dist_on, agree=agree if dist_on else None)
+    watchdog = _arm_watchdog(float(os.environ.get("DH_GRAPH_WATCHDOG_S", "240")), "the warm-up of the captured multi-GPU step") if (dist_on and use_graph) else None
 
     def step():
         if pipeline is not None:
@@ -431,8 +485,18 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    while use_graph and graphed.graph is None:
+    while use_graph and graphed.enabled and graphed.graph is None:
         step()             # fewer warm-up steps than the capture needs (2 eager + 1 captured): the capture must not land in the timed region
+    if watchdog is not None:
+        if graphed.enabled and graphed.graph is not None:
+            if os.environ.get("DH_BENCH_TEST_HANG") == "1" and not graph_fallback:      # test hook: a replay that never returns (tests/test_gpu_bench_fallback.py)
+                time.sleep(3600)
+            step()             # two replays, waited for, before the watchdog is disarmed: a collective that hangs in a replay hangs here
+            step()
+            torch.cuda.synchronize()
+        watchdog.cancel()
+    if graphed.fallback_reason and not graph_fallback:
+        graph_fallback = graphed.fallback_reason
     if use_graph and graph_key is not None:
         for _ in range(12):   # the input pipeline cycles through 6 batches: every row-count bucket among them is captured before the timed region
             step()
@@ -457,8 +521,12 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    per_rank_ms = [round(elapsed / args.steps * 1e3, 3)]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        all_t = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(all_t, t)
+        per_rank_ms = [round(float(x) / args.steps * 1e3, 3) for x in all_t]
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
     ms_per_step = elapsed / args.steps * 1e3
@@ -478,6 +546,32 @@ def main():
     sync()
     gc.enable()
     host_enqueue_ms = sorted(enq)[1] * 1e3
+
+    # where a multi-GPU step's time goes, so that whatever scaling efficiency comes out can be attributed without another session:
+    # three EAGER steps with event pairs around the collectives (dist.TIMING): the feature all-gather and its reduce-scatter backward on
+    # the communication stream, and the tail of the gradient all-reduce that the backward pass could not hide (from "backward fully
+    # enqueued" to "all buckets reduced" on the compute stream)
+    comm_timing = None
+    if dist_on:
+        was = graphed.enabled
+        graphed.enabled = False
+        step()
+        sync()
+        dh_dist.TIMING = {}
+        ncomm = 3
+        for _ in range(ncomm):
+            step()
+        sync()
+        ts = dh_dist.timing_summary()
+        dh_dist.TIMING = None
+        graphed.enabled = was
+        bb = ts.get("bucket_bytes", [])
+        comm_timing = dict(allreduce_exposed_ms=round(ts.get("allreduce_exposed_ms", 0.0) / ncomm, 3),
+                           allgather_ms=round(ts.get("allgather_ms", 0.0) / ncomm, 3), allgathers_per_step=ts.get("allgather_count", 0) // ncomm,
+                           reduce_scatter_ms=round(ts.get("reduce_scatter_ms", 0.0) / ncomm, 3),
+                           bucket_mb=[round(x / 2 ** 20, 1) for x in bb[:len(bb) // ncomm]],
+                           bucket_mb_configured=round(wrapped._flat.reducer.bucket_elems * 4 / 2 ** 20, 1),
+                           note="event pairs of 3 eager steps after the timed region, rank 0; allreduce_exposed = gradient all-reduce left after the backward pass was enqueued")
 
     roofline = None
     if not args.no_roofline:
@@ -641,7 +735,7 @@ def main():
                scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic" if pipeline is None else "synthetic, through the input pipeline",
                config=dict(workload=workloads[args.model],
                            global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world,
-                           tower_streams=1 + len(model.__dict__["_flat_store"].side_streams), step_graph=int(use_graph and graphed.graph is not None), graphs_captured=graphed.captures,
+                           tower_streams=1 + len(model.__dict__["_flat_store"].side_streams), step_graph=int(use_graph and graphed.enabled and graphed.graph is not None), graphs_captured=graphed.captures,
                            input_pipeline=(None if pipeline is None else
                                            "DataPrefetcher: uint8 canvases 256x320 (source sizes 192-256 x 256-320) + RandomResizedCrop boxes + mirror "
                                            "flags + caption strings; BPE (dh_bpe_encode) and box bookkeeping on 1 worker thread (%d host cores usable), "
@@ -654,6 +748,10 @@ def main():
                            native_blocks=int(eng_mod.native_blocks()),
                            text_packed=eng_mod.text_packed_mode(), pooled_last=int(eng_mod.pooled_last_block())),   # captions computed up to <|endoftext|> only; last block for the pooled rows only (same outputs, fewer executed flops: see roofline.executed_gemm_gflop_per_pair)
                loss=round(float(loss.detach()) * world, 5))
+    out["per_rank_ms"] = per_rank_ms
+    out["graph_fallback"] = graph_fallback          # None: the step ran as configured (config.step_graph)
+    if comm_timing is not None:
+        out.update(comm_timing)
     if roofline is not None:
         out["roofline"] = roofline
     if rank == 0 and world == 1 and args.model == "clip" and not args.no_loss_delta:

@@ -113,7 +113,8 @@ class _AllGatherPacked(torch.autograd.Function):
         x = x.contiguous()
         W = tdist.get_world_size()
         out = torch.empty((W * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
-        tdist.all_gather_into_tensor(out, x)
+        with _timed("allgather"):
+            tdist.all_gather_into_tensor(out, x)
         return out
 
     @staticmethod
@@ -123,7 +124,8 @@ class _AllGatherPacked(torch.autograd.Function):
         b = g.shape[0] // W
         if _backend_has_reduce_scatter():
             out = torch.empty((b,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
-            tdist.reduce_scatter_tensor(out, g, op=tdist.ReduceOp.SUM)
+            with _timed("reduce_scatter"):
+                tdist.reduce_scatter_tensor(out, g, op=tdist.ReduceOp.SUM)
             return out
         g = g.clone()
         tdist.all_reduce(g)
@@ -146,6 +148,48 @@ def all_gather_cat(x):
 def all_gather_cat_many(tensors):
     """Gather several [b, D_k] feature tensors with ONE collective (packed along the feature dim)."""
     return all_gather_cat_many_async(tensors).result()
+
+
+# ---- optional event timing of the step's collectives (bench.py --gpus N: `per_rank_ms`, `allreduce_exposed_ms`, `allgather_ms`) ------
+# TIMING = {} switches it on for EAGER steps (events cannot be timed inside a capture): the all-gather / reduce-scatter of the
+# features append (start, end) event pairs recorded on the stream they run on, FlatReducer.finish() appends the pair that brackets
+# what is left of the gradient all-reduce once the backward pass has been enqueued (the part of the communication the step could NOT
+# hide behind compute), and every bucket's byte count is listed.  None (default): no events, nothing recorded.
+TIMING = None
+
+
+def _timed(kind, stream=None):
+    """context manager: event pair around a block on `stream` (default: current), appended to TIMING[kind]"""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        if TIMING is None or not torch.cuda.is_available():
+            yield
+            return
+        st = stream or torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        try:
+            yield
+        finally:
+            e1.record(st)
+            TIMING.setdefault(kind, []).append((e0, e1))
+    return cm()
+
+
+def timing_summary():
+    """ms per kind (sum over the pairs recorded since TIMING was set) + bucket sizes; call after a synchronize"""
+    out = {}
+    if TIMING is None:
+        return out
+    for k, v in TIMING.items():
+        if k == "bucket_bytes":
+            out[k] = list(v)
+        else:
+            out[k + "_ms"] = sum(a.elapsed_time(b) for a, b in v)
+            out[k + "_count"] = len(v)
+    return out
 
 
 # ---- the feature all-gather as an asynchronous step on an engine-owned communication stream --------------------------------
@@ -253,6 +297,8 @@ class FlatReducer:
                     cur.wait_event(ev)
         if is_dist():
             seg = self.flat.flat_g[lo:hi]
+            if TIMING is not None:
+                TIMING.setdefault("bucket_bytes", []).append(int(hi - lo) * (2 if self.grad_dtype == torch.bfloat16 else 4))
             comm = native_comm()
             if comm is not None and seg.is_cuda:
                 comm.allreduce_bucket(seg, bf16=(self.grad_dtype == torch.bfloat16))
@@ -284,24 +330,27 @@ class FlatReducer:
                 self.runs.append((a, b))
 
     def finish(self):
-        self.runs = []
-        cur = 0
-        for lo, hi in sorted(self.done):
-            if lo > cur:
-                self._launch(cur, lo)
-            cur = max(cur, hi)
-        if cur < self.flat.total:
-            self._launch(cur, self.flat.total)
-        for w in self.works:
-            w.wait()
-        self.works = []
-        for w, lo, hi, low in self.staged:
-            w.wait()
-            self.flat.flat_g[lo:hi].copy_(low)
-        self.staged = []
-        if self.native is not None:
-            self.native.wait(self.flat.flat_g.device)
-            self.native = None
+        # (TIMING: the event pair brackets everything from "backward fully enqueued" to "all gradients reduced" on the compute
+        # stream = the part of the all-reduce that compute did not hide: the buckets launched here + the waits)
+        with _timed("allreduce_exposed"):
+            self.runs = []
+            cur = 0
+            for lo, hi in sorted(self.done):
+                if lo > cur:
+                    self._launch(cur, lo)
+                cur = max(cur, hi)
+            if cur < self.flat.total:
+                self._launch(cur, self.flat.total)
+            for w in self.works:
+                w.wait()
+            self.works = []
+            for w, lo, hi, low in self.staged:
+                w.wait()
+                self.flat.flat_g[lo:hi].copy_(low)
+            self.staged = []
+            if self.native is not None:
+                self.native.wait(self.flat.flat_g.device)
+                self.native = None
 
 
 class DistModule(torch.nn.Module):

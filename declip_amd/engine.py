@@ -323,6 +323,11 @@ def _split_k(mg, ng, kg):
 
 
 _GEMM_WS = {}
+# Scratch buffers that were replaced by larger ones.  A hipGraph captured earlier keeps the OLD address baked into its launches; if
+# that buffer went back to the caching allocator it could be handed to an unrelated tensor that a later replay of the older graph
+# then scribbles over.  Replaced buffers are therefore kept alive for the life of the process (a handful of growths:
+# the row count of packed captions is bounded by b * L).
+_RETIRED_SCRATCH = []
 
 
 def gemm_workspace(device, nbytes=256 << 20):
@@ -331,6 +336,8 @@ def gemm_workspace(device, nbytes=256 << 20):
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _GEMM_WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
+        if ws is not None:
+            _RETIRED_SCRATCH.append(ws)          # a captured graph may hold its address (see _RETIRED_SCRATCH)
         ws = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
         _GEMM_WS[key] = ws
     return ws
@@ -399,6 +406,8 @@ class LnGradBatch:
             # (the full-row ones come first in a backward; the pooled ln_post / ln_final are smaller) -- no 2x over-allocation, no
             # re-growth over several steps, and the first growth does not land in a captured step's private pool when the warm-up
             # steps ran.  (A grown arena replaces the old one; slices already handed out keep the old storage alive until the flush.)
+            if ar is not None:
+                _RETIRED_SCRATCH.append(ar)      # an earlier capture may hold its address
             ar = torch.empty(max(self.off + n, self.n_live * ((n + 63) // 64 * 64)), device=device, dtype=torch.float32)
             arenas[key] = ar
             self.off = 0
@@ -468,6 +477,8 @@ def _bwd_scratch(device, nbytes):
     key = (device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _BWD_SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _RETIRED_SCRATCH.append(buf)
         buf = torch.empty(nbytes, device=device, dtype=torch.uint8)
         _BWD_SCRATCH[key] = buf
     return buf

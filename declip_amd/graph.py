@@ -52,7 +52,13 @@ class GraphedStep(object):
     pool (only one of them runs at a time and a step's tensors are dead when it ends).  The reference's step takes a new batch
     every iteration (solver/clip_solver.py:398-402): this is what lets the captured step be the one training uses."""
 
-    def __init__(self, fn, warmup=2, enabled=True, modules=None, key=None, max_graphs=8):
+    def __init__(self, fn, warmup=2, enabled=True, modules=None, key=None, max_graphs=8, fallback=False, agree=None):
+        """`fallback=True`: a capture (or first replay) that raises does not end the run -- the step is executed eagerly from then on
+        and `fallback_reason` says why.  `agree`: a callable bool -> bool that makes that decision UNIFORM across the ranks of a
+        data-parallel job (an all-reduce MIN of the flag over the process group, outside any capture): one rank replaying RCCL
+        collectives from a graph while its peer issues them eagerly is fine, but the ranks must not disagree on whether a
+        capture's collectives were ever launched."""
+        self.fallback, self.agree, self.fallback_reason = bool(fallback), agree, None
         self.fn, self.warmup, self.enabled = fn, int(warmup), bool(enabled)
         self.calls, self.graph, self.out = 0, None, None
         self.stores = _flat_stores(modules)
@@ -92,14 +98,42 @@ class GraphedStep(object):
             return self.out
         if self.calls <= self.warmup:
             return self.fn()
-        self._check_capturable()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        if self.pool is None:
-            self.pool = torch.cuda.graph_pool_handle()
-        # the capture stream is a fresh side stream (torch.cuda.graph's default): the engine's own side streams fork from it
-        with torch.cuda.graph(g, pool=self.pool):
-            out = self.fn()
+        if not self.fallback:
+            self._check_capturable()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            if self.pool is None:
+                self.pool = torch.cuda.graph_pool_handle()
+            # the capture stream is a fresh side stream (torch.cuda.graph's default): the engine's own side streams fork from it
+            with torch.cuda.graph(g, pool=self.pool):
+                out = self.fn()
+        else:
+            g, out, err = None, None, None
+            try:
+                self._check_capturable()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                if self.pool is None:
+                    self.pool = torch.cuda.graph_pool_handle()
+                with torch.cuda.graph(g, pool=self.pool):
+                    out = self.fn()
+            except Exception as e:              # noqa: BLE001  (whatever the runtime raises: the eager step is the answer to all of it)
+                err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+            ok = err is None
+            if self.agree is not None:
+                try:
+                    torch.cuda.synchronize()
+                except Exception:               # noqa: BLE001
+                    pass
+                all_ok = bool(self.agree(ok))
+                if ok and not all_ok:
+                    err = "a peer rank could not capture its step"
+                ok = all_ok
+            if not ok:
+                self.enabled, self.fallback_reason = False, "capture failed, step runs eagerly (%s)" % err
+                for st in self.stores:          # a backward that died inside the capture never reached its end-of-pass callback
+                    st._in_backward = False
+                return self.fn()
         self.captures += 1
         self.graphs[k] = (g, out)
         while len(self.graphs) > self.max_graphs:

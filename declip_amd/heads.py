@@ -237,7 +237,14 @@ class NNMemoryBankModule(nn.Module):
             self._ptr = torch.full((1,), self._ptr_init, device=dev, dtype=torch.int64)
         elif self._ptr.device != dev:
             self._ptr = self._ptr.to(dev)            # the LIVE write position moves with the queue (not the initial one)
-        ops.nn_bank_enqueue(self._store, self._ptr, batch, self.size)       # dh_nn_bank_enqueue: copy + pointer update on the stream
+        if self._store.dtype == torch.float32 and self._store.shape[1] % 4 == 0 and self._store.data_ptr() % 16 == 0:
+            ops.nn_bank_enqueue(self._store, self._ptr, batch.float().contiguous(), self.size)       # dh_nn_bank_enqueue: copy + pointer update on the stream
+        else:
+            # a bank assigned from outside in another dtype, or a feature width the 16-byte kernel does not take: the
+            # same FIFO through torch (index_copy_ + pointer arithmetic on the device; still no host value in a launch)
+            rows = self._ptr + torch.arange(b, device=dev)
+            self._store.index_copy_(0, rows, batch.to(self._store.dtype))
+            self._ptr.copy_(torch.where(self._ptr + b >= self.size, torch.zeros_like(self._ptr), self._ptr + b))
 
     @torch.no_grad()
     def forward(self, output, update=False, query=True, enqueue=None):

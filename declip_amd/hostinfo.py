@@ -56,11 +56,25 @@ def usable_cores(physical=True):
 
 
 def local_world_size():
-    """ranks of this job on this node (torchrun's LOCAL_WORLD_SIZE, else WORLD_SIZE of a one-node job, else 1): they share the quota"""
-    for k in ("LOCAL_WORLD_SIZE", "WORLD_SIZE", "SLURM_NTASKS_PER_NODE"):
-        v = os.environ.get(k)
-        if v and v.isdigit() and int(v) > 0:
-            return int(v)
+    """ranks of this job on THIS node: they share the node's quota.  torchrun's LOCAL_WORLD_SIZE, else SLURM_NTASKS_PER_NODE, else
+    WORLD_SIZE as the one-node fallback -- capped by the node's GPU count, because dist.initialize() writes the GLOBAL world size
+    into WORLD_SIZE also for multi-node SLURM launches (64 ranks on 8 nodes are 8 per node, not 64)."""
+    def _int(k):
+        v = os.environ.get(k, "")
+        v = v.split("(")[0].split(",")[0]           # SLURM_NTASKS_PER_NODE may read "8(x4)"
+        return int(v) if v.isdigit() and int(v) > 0 else None
+    for k in ("LOCAL_WORLD_SIZE", "SLURM_NTASKS_PER_NODE"):
+        n = _int(k)
+        if n:
+            return n
+    n = _int("WORLD_SIZE")
+    if n:
+        try:
+            import torch
+            gpus = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        except Exception:
+            gpus = 0
+        return min(n, gpus) if gpus > 0 else n
     return 1
 
 

@@ -448,8 +448,24 @@ class ClsSolver(object):
         want = bool(eng_cfg.get("step_graph", False)) or os.environ.get("DH_STEP_GRAPH", "0") == "1"
         typ, _ = self._gc()
         # parameter clips that act BETWEEN forward and backward in the reference (constant / logit_scale_param / abs_min) keep the eager step
-        ok = (want and self.kind == "clip" and self.device.type == "cuda" and typ in (None, "logit_scale_param_value", "norm", "value", "logit_scale_grad")
-              and (self.world_size == 1 or torch.distributed.get_backend() == "nccl"))
+        ok = (want and self.kind == "clip" and self.device.type == "cuda" and typ in (None, "logit_scale_param_value", "norm", "value", "logit_scale_grad"))
+        # One graph per padded row count needs a step whose launches depend on the captions through that count ALONE.  That holds for
+        # padded captions (mode 0: no key at all) and for packed captions on bf16 towers with head dimension 64 (mode 1: the kernels
+        # read the valid row count on the device).  Mode 2 bakes the host-side row count into the capture (pack_idx[:rows]) and the
+        # fp32 / other-head-size kernels take the row count as a launch argument: there a graph would be replayed for a batch it
+        # was not captured for (wrong rows gathered) or re-captured almost every step -- the eager step takes those, as bench.py does.
+        if ok:
+            from . import engine
+            m = self.model.module
+            mode = engine.text_packed_mode()
+            bf16 = m.__dict__["_flat_store"].act_dtype == torch.bfloat16
+            heads_dim = int(m.encode_text.width) // int(m.encode_text.heads)
+            ok = mode == 0 or (mode == 1 and bf16 and heads_dim == 64)
+        # Data parallelism: graphs are keyed by each RANK's padded row count, so on one step some ranks would replay while others
+        # synchronise and capture, with their peers already inside replayed collectives.  Until the key is made rank-uniform the
+        # captured step of the solver is for one process; bench.py captures multi-rank steps of a resident batch (one key).
+        if ok and self.world_size > 1:
+            ok = False
         if not ok:
             self._graph_off = True
         return ok

@@ -138,7 +138,7 @@ def _refresh_mlm_selection(labels, new_labels, dev):
     tag[3].copy_(lab[sel].to(dev))
 
 
-@pytest.mark.parametrize("family,cfg_name,b", [("declip", "VITB32", 128), ("defilip", "VITB32", 128), ("filip", "FILIP_VITB32", 256)])
+@pytest.mark.parametrize("family,cfg_name,b", [("declip", "VITB32", 128), ("defilip", "VITB32", 128), ("filip", "FILIP_VITB32", 256), ("slip", "VITB32", 128)])
 def test_graphed_multiview_step_equals_eager_step(family, cfg_name, b):
     """The models whose step bench.py replays from a hipGraph by default, at a batch whose tower GEMMs all run on gemm_v4, bf16:
     graph == eager over six optimiser steps with inputs that change every step (images re-drawn, captions and their masked-LM
@@ -150,13 +150,14 @@ def test_graphed_multiview_step_equals_eager_step(family, cfg_name, b):
     from declip_amd import ops, synth
     from declip_amd.graph import GraphedStep
     from declip_amd.heads import SimsiamLoss
-    from declip_amd.loss import ClipInfoCELoss
+    from declip_amd.loss import ClipInfoCELoss, NT_Xent_gather
     from declip_amd.optim import build_adamw
-    from declip_amd.steps import DEFILIP_WEIGHTS, declip_loss, filip_loss
-    from declip_amd.testing import (build_declip, build_defilip, build_filip, declip_batch, defilip_batch, filip_batch)
+    from declip_amd.steps import DEFILIP_WEIGHTS, declip_loss, filip_loss, slip_loss
+    from declip_amd.testing import (build_declip, build_defilip, build_filip, build_slip, declip_batch, defilip_batch, filip_batch, slip_batch)
     cfg = getattr(synth, cfg_name)
     nn_size, steps = 600, 6
     crit, sim = ClipInfoCELoss(), SimsiamLoss()
+    simclr = NT_Xent_gather(b)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     def make():
@@ -166,6 +167,9 @@ def test_graphed_multiview_step_equals_eager_step(family, cfg_name, b):
         elif family == "defilip":
             model = build_defilip(cfg, dtype="bf16", seed=3, nn_size=nn_size)
             batch = defilip_batch(cfg, b, seed=0)
+        elif family == "slip":                 # (round 5: SLIP's step is replayed from a graph by default in bench.py too; slip_solver.py:439-571)
+            model = build_slip(cfg, dtype="bf16", seed=3)
+            batch = slip_batch(cfg, b, seed=0)
         else:
             model = build_filip(cfg, dtype="bf16", seed=3)
             batch = filip_batch(cfg, b, seed=0)
@@ -176,25 +180,27 @@ def test_graphed_multiview_step_equals_eager_step(family, cfg_name, b):
                 loss = declip_loss(model, batch, crit, sim, None, with_accuracy=False)["loss"]
             elif family == "defilip":
                 loss = declip_loss(model, batch, crit, sim, None, weights=DEFILIP_WEIGHTS, with_accuracy=False)["loss"]
+            elif family == "slip":
+                loss = slip_loss(model, batch, crit, simclr, None, with_accuracy=False)["loss"]
             else:
                 loss = filip_loss(model, batch, crit, with_accuracy=False)["loss"]
             loss.backward()
             return loss.detach()
         return model, opt, batch, fwd_bwd
 
-    views = 2
+    views = 3 if family == "slip" else 2
     caps0 = labels0 = None
 
     def feed(batch, step):
         nonlocal caps0, labels0
         if caps0 is None:
-            caps0, labels0 = batch["captions"].detach().cpu().clone(), batch["mlm_labels"].clone()
+            caps0, labels0 = batch["captions"].detach().cpu().clone(), (batch["mlm_labels"].clone() if "mlm_labels" in batch else None)
         batch["images"].copy_(synth.synth_images(b, views=views, res=cfg["res"], seed=100 + step).to(dev))
         perm = torch.arange(b).roll(step)
         rows = batch["captions"]._dh_rows[1]                    # rolling captions through the batch keeps the packed row count
         batch["captions"].copy_(caps0[perm].to(dev))
         batch["captions"]._dh_rows = (batch["captions"]._version, rows)
-        if step > 0 and hasattr(batch["mlm_labels"], "_dh_mlm"):   # (the selection is created by the first forward; FILIP has no MLM loss)
+        if step > 0 and "mlm_labels" in batch and hasattr(batch["mlm_labels"], "_dh_mlm"):   # (the selection is created by the first forward; FILIP has no MLM loss)
             _refresh_mlm_selection(batch["mlm_labels"], labels0[perm], dev)
 
     results = {}
@@ -213,7 +219,7 @@ def test_graphed_multiview_step_equals_eager_step(family, cfg_name, b):
             ls.append(float(loss))
             assert model.visual.proj.grad is not None          # p.grad views survive zero_grad() + replay (FlatParams.after_replay)
             opt.step()
-            if family != "filip":
+            if family not in ("filip", "slip"):
                 ptrs.append(model.nn_replacer_text.bank_ptr)
         torch.cuda.synchronize()
         stats = ops.gemm_stats()
@@ -222,9 +228,9 @@ def test_graphed_multiview_step_equals_eager_step(family, cfg_name, b):
         else:
             assert stats["v4"] >= 0.8 * sum(stats.values()), stats          # the batch routes through the benchmarked kernel
         results[mode] = dict(losses=ls, ptrs=ptrs, grad=model.__dict__["_flat_store"].flat_g.clone(),
-                             bank=(model.nn_replacer_text.bank.clone() if family != "filip" else None))
+                             bank=(model.nn_replacer_text.bank.clone() if family not in ("filip", "slip") else None))
     e, g = results["eager"], results["graph"]
-    if family != "filip":
+    if family not in ("filip", "slip"):
         want, p = [], 0
         for _ in range(steps):
             for _enq in range(2):                               # two enqueues of b rows per step (declip.py:282-288)

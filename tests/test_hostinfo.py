@@ -56,3 +56,20 @@ def test_prefetcher_counts_caption_rows_without_torch_cpu_reductions():
     b = pf.next()
     assert b["captions"]._dh_rows == (b["captions"]._version, 3 + 7 + 1 + 4)
     pf.close()
+
+
+def test_local_world_size_prefers_per_node_counts_over_the_global_world_size(monkeypatch):
+    """dist.initialize() writes the GLOBAL world size into WORLD_SIZE, also for multi-node SLURM launches; the per-node
+    counts win, and WORLD_SIZE alone is capped by the node's GPU count (no GPUs here: taken as is)."""
+    from declip_amd import hostinfo
+    for k in ("LOCAL_WORLD_SIZE", "SLURM_NTASKS_PER_NODE", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    assert hostinfo.local_world_size() == 1
+    monkeypatch.setenv("WORLD_SIZE", "64")
+    monkeypatch.setenv("SLURM_NTASKS_PER_NODE", "8(x8)")
+    assert hostinfo.local_world_size() == 8
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert hostinfo.local_world_size() == 4
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    monkeypatch.delenv("SLURM_NTASKS_PER_NODE")
+    assert hostinfo.local_world_size() == 64          # (one-node fallback; a GPU box caps it at its device count)
