@@ -140,6 +140,29 @@ def loss_delta_vs_cpu_ref(dev):
     return out
 
 
+# The contract is ONE JSON line on stdout.  Libraries underneath print there too (RCCL 2.26 writes a five-line version banner to
+# stdout when its first communicator comes up -- AFTER our line in the pipe, because C stdio is flushed at exit), so a rank keeps the
+# real stdout for `_emit` alone and points file descriptor 1 at stderr for everybody else (`_claim_stdout`).
+_JSON_FD = None
+
+
+def _claim_stdout():
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def _free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -159,8 +182,8 @@ def self_launch(n):
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
     dry = "--dry-run-launch" in sys.argv
     if backend == "nccl" and ndev < n and not dry:
-        print(json.dumps(dict(error="--gpus %d needs %d devices, this box has %d" % (n, n, ndev), n_gpus=n, devices_visible=ndev,
-                              hint="DH_DIST_BACKEND=gloo lets several ranks share one device (functional check only)")), flush=True)
+        _emit(dict(error="--gpus %d needs %d devices, this box has %d" % (n, n, ndev), n_gpus=n, devices_visible=ndev,
+                              hint="DH_DIST_BACKEND=gloo lets several ranks share one device (functional check only)"))
         return 3
     port = _free_port()
     procs = []
@@ -181,7 +204,7 @@ def self_launch(n):
             if time.time() > deadline:
                 for q in pending.values():
                     q.kill()
-                print(json.dumps(dict(error="self-launched job timed out (DH_BENCH_LAUNCH_TIMEOUT)", n_gpus=n, ranks_still_running=sorted(pending))), flush=True)
+                _emit(dict(error="self-launched job timed out (DH_BENCH_LAUNCH_TIMEOUT)", n_gpus=n, ranks_still_running=sorted(pending)))
                 return 4
             for r, p in list(pending.items()):
                 code = p.poll()
@@ -198,7 +221,7 @@ def self_launch(n):
             if p.poll() is None:
                 p.kill()
     if rc not in (0, 3, 4):
-        print(json.dumps(dict(error="a rank of the self-launched job exited with code %d" % rc, n_gpus=n)), flush=True)
+        _emit(dict(error="a rank of the self-launched job exited with code %d" % rc, n_gpus=n))
     return rc
 
 
@@ -230,10 +253,11 @@ def _arm_watchdog(seconds, what):
             if a.startswith("--graph="):
                 continue
             argv.append(a)
-        try:
-            os.closerange(3, 4096)                # sockets of the old rendezvous, the device files of the hung queues
-        except OSError:
-            pass
+        # (no closing of other descriptors here: helper threads of the runtime abort the process when their sockets vanish under
+        # them, before exec gets to run -- seen on the MI355X.  The device files are opened O_CLOEXEC by the ROCm runtime, so exec
+        # itself releases the hung queues; sockets of the old rendezvous that survive are harmless, the new one uses another port.)
+        if _JSON_FD is not None:
+            os.dup2(_JSON_FD, 1)                  # the new image claims the real stdout again
         os.execve(sys.executable, [sys.executable, os.path.abspath(__file__)] + argv + ["--graph", "0"], env)
     t = threading.Timer(seconds, fire)
     t.daemon = True
@@ -249,7 +273,7 @@ def dry_run_launch(args):
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(json.dumps(dict(error="--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))), flush=True)
+            _emit(dict(error="--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)))
         return 3
     dh_dist.initialize("nccl")
     import torch.distributed as tdist
@@ -265,11 +289,11 @@ def dry_run_launch(args):
         ranks = [me]
     ok = int(round(float(ones))) == world
     if rank == 0:
-        print(json.dumps(dict(metric="image-text pairs/sec CLIP ViT-B/32", value=0.0, unit="pairs/s", n_gpus=world, steps=0, warmup=0,
+        _emit(dict(metric="image-text pairs/sec CLIP ViT-B/32", value=0.0, unit="pairs/s", n_gpus=world, steps=0, warmup=0,
                               dry_run=True, scaling="weak", higher_is_better=True,
                               config=dict(rccl_ranks=int(round(float(ones))), dist_backend=(tdist.get_backend() if world > 1 else None),
                                           ranks=[list(x) for x in ranks], self_launched=int(os.environ.get("DH_BENCH_SELF_LAUNCHED", "0")))),
-                         **({} if ok else dict(error="communicator does not match the launch"))), flush=True)
+                         **({} if ok else dict(error="communicator does not match the launch")))
     if world > 1:
         dh_dist.barrier()
         tdist.destroy_process_group()
@@ -310,6 +334,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))         # `python bench.py --gpus N`: this process becomes the launcher of N ranks
+    _claim_stdout()                              # from here on stdout carries the JSON line and nothing else
     if args.dry_run_launch:
         sys.exit(dry_run_launch(args))
 
@@ -339,7 +364,7 @@ def main():
         torch.cuda.set_device(0)
     if world != args.gpus:                    # (a launcher that set WORLD_SIZE to something else)
         if rank == 0:
-            print(json.dumps(dict(error="--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))), flush=True)
+            _emit(dict(error="--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)))
         sys.exit(3)
     dev = torch.device("cuda", torch.cuda.current_device())
 
@@ -405,8 +430,8 @@ def main():
         torch.distributed.all_gather_object(devs, (os.uname().nodename, torch.cuda.current_device()))
         if rccl_ranks != world or torch.distributed.get_world_size() != world or (torch.distributed.get_backend() == "nccl" and len(set(devs)) != world):
             if rank == 0:
-                print(json.dumps(dict(error="communicator does not match the launch", world=world, rccl_ranks=rccl_ranks,
-                                      group_size=torch.distributed.get_world_size(), devices=devs)), flush=True)
+                _emit(dict(error="communicator does not match the launch", world=world, rccl_ranks=rccl_ranks,
+                                      group_size=torch.distributed.get_world_size(), devices=devs))
             sys.exit(3)
 
     def fwd_bwd():
@@ -761,7 +786,7 @@ def main():
     if pipeline is not None:
         pipeline.close()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        _emit(out)
     if world > 1 or forced:
         torch.distributed.destroy_process_group()
 

@@ -72,6 +72,15 @@ class GraphedStep(object):
         self.pool = None
         self.captures, self.replays = 0, 0
 
+    @staticmethod
+    def _capture_mode():
+        """Stream-capture error mode.  With a process group alive, ProcessGroupNCCL's watchdog THREAD polls the events of earlier
+        collectives (hipEventQuery); under the default `global` mode any such call from any thread while a capture is open is an
+        error -- and the watchdog turns it into std::terminate ("operation not permitted when stream is capturing"; seen in one of
+        four runs of a one-rank RCCL step on the MI355X, round 5).  `thread_local` confines the restriction to the capturing thread."""
+        import torch.distributed as tdist
+        return "thread_local" if (tdist.is_available() and tdist.is_initialized()) else "global"
+
     def _check_capturable(self):
         import torch.distributed as tdist
         for st in self.stores:
@@ -105,7 +114,7 @@ class GraphedStep(object):
             if self.pool is None:
                 self.pool = torch.cuda.graph_pool_handle()
             # the capture stream is a fresh side stream (torch.cuda.graph's default): the engine's own side streams fork from it
-            with torch.cuda.graph(g, pool=self.pool):
+            with torch.cuda.graph(g, pool=self.pool, capture_error_mode=self._capture_mode()):
                 out = self.fn()
         else:
             g, out, err = None, None, None
@@ -115,7 +124,7 @@ class GraphedStep(object):
                 g = torch.cuda.CUDAGraph()
                 if self.pool is None:
                     self.pool = torch.cuda.graph_pool_handle()
-                with torch.cuda.graph(g, pool=self.pool):
+                with torch.cuda.graph(g, pool=self.pool, capture_error_mode=self._capture_mode()):
                     out = self.fn()
             except Exception as e:              # noqa: BLE001  (whatever the runtime raises: the eager step is the answer to all of it)
                 err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")

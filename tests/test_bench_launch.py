@@ -29,6 +29,16 @@ def test_bench_self_launch_two_ranks_dry_run_over_gloo():
     assert "error" not in d
 
 
+@pytest.mark.parametrize("n", [4, 8])
+def test_bench_self_launch_four_and_eight_ranks_dry_run_over_gloo(n):
+    """the launch of the driver's scaling points (N = 4, 8), without a model: N processes, one communicator of N ranks, ONE line"""
+    rc, lines, err = _run(["--gpus", str(n), "--dry-run-launch"], {"DH_DIST_BACKEND": "gloo"})
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["config"]["rccl_ranks"] == n and len(d["config"]["ranks"]) == n and "error" not in d
+
+
 def test_bench_self_launch_without_enough_devices_is_a_json_error_not_an_assertion():
     import torch
     if torch.cuda.is_available() and torch.cuda.device_count() >= 64:

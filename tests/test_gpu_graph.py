@@ -205,8 +205,8 @@ def test_graphed_multiview_step_equals_eager_step(family, cfg_name, b):
 
     results = {}
     for mode in ("eager", "eager2", "graph"):        # eager twice: the run-to-run noise floor of this model (see the end of the test)
-        if mode == "eager2" and family != "filip":
-            continue                                    # (only FILIP needs the measured floor: see below)
+        if mode == "eager2" and family not in ("filip", "slip"):
+            continue                                    # (only FILIP and SLIP need the measured floor: see below)
         caps0 = labels0 = None
         model, opt, batch, fwd_bwd = make()
         stepper = GraphedStep(fwd_bwd, warmup=2, enabled=(mode == "graph"), modules=(model,))
@@ -246,6 +246,16 @@ def test_graphed_multiview_step_equals_eager_step(family, cfg_name, b):
         assert abs(a - c) <= 1e-2 * abs(c), (g["losses"], e["losses"])
     gdiff = float((g["grad"] - e["grad"]).norm()) / float(e["grad"].norm())
     gtol = 6e-2
+    if family == "slip":
+        # SLIP: the SimCLR head (768-4096-4096-256 with two BatchNorm1d over 2 x 128 rows, NT-Xent at temperature 0.1) is the most
+        # ill-conditioned gradient path of the five families (bf16 direction z-scores 3-5 x CLIP's); after six optimiser steps two
+        # runs that differ by atomic ordering alone are tens of per cent apart in the full gradient while their losses agree to
+        # 1e-2 (measured on the MI355X: graph vs eager 0.28) -- bound by this model's own eager-vs-eager floor, like FILIP below
+        e2 = results["eager2"]
+        floor = float((e2["grad"] - e["grad"]).norm()) / float(e["grad"].norm())
+        print("SLIP gradient after %d steps: graph vs eager %.4f, eager vs eager %.4f" % (steps, gdiff, floor))
+        gtol = max(gtol, 2.5 * floor)
+        assert gtol < 1.0, floor
     if family == "filip":
         # FILIP's whole gradient passes through arg-max choices (filip.py:96-105: max over the 16 selected tokens, top-16 selection
         # itself): after six optimiser steps two EAGER runs that differ by atomic ordering alone sit tens of per cent apart (measured

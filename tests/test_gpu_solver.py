@@ -39,7 +39,9 @@ def test_solver_graphed_step_matches_the_eager_step(heads, monkeypatch):
     """model.kwargs.engine.step_graph: the CLIP solver's forward + loss + backward replayed from captured graphs (one per packed-row
     key of the caption batch; declip_amd/graph.py) while the loader hands a DIFFERENT batch every iteration (clip_solver.py:398-402),
     against the same run stepped eagerly: same loss trajectory and temperature.  heads = 2: head dimension 64 (the key is the padded
-    row count, the valid count is read on the device); heads = 8: head dimension 16 (the key carries the exact count)."""
+    row count, the valid count is read on the device).  heads = 8: head dimension 16 -- those kernels take the exact row count as a
+    launch argument, a graph would have to be re-captured for almost every batch, so the solver keeps the EAGER step there (round 5,
+    ADVICE r4: the same rule as bench.py) and the run must simply equal the eager run."""
     from declip_amd.solver import ClsSolver
 
     def run(graph):
@@ -61,7 +63,10 @@ def test_solver_graphed_step_matches_the_eager_step(heads, monkeypatch):
 
     se, le = run(False)
     sg, lg = run(True)
-    assert sg.__dict__.get("_graph") is not None and sg._graph["step"].replays >= 3 and sg._graph["step"].captures >= 1
+    if heads == 2:
+        assert sg.__dict__.get("_graph") is not None and sg._graph["step"].replays >= 3 and sg._graph["step"].captures >= 1
+    else:
+        assert sg.__dict__.get("_graph") is None and sg.__dict__.get("_graph_off") is True
     assert se.__dict__.get("_graph") is None
     for a, c in zip(lg, le):
         assert abs(a - c) <= 5e-3 * abs(c), (lg, le)
