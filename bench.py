@@ -713,17 +713,23 @@ def main():
         # HBM-side traffic of the same kernels from the rocprofv3 PMC passes of tools/profile_step.sh (committed summary):
         # per-launch average next to the algorithmic bytes per launch (operands once + outputs once)
         traffic, traffic_source = None, None
-        for rnd in ("r04", "r03", "r02", "r01"):                # a COMMITTED rocprofv3 --pmc summary of this configuration (tools/profile_step.sh):
+        traffic_sha, traffic_head = None, None
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):         # a COMMITTED rocprofv3 --pmc summary of this configuration (tools/profile_step.sh):
             pmc_file = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s_b%d.json" % (rnd, args.model, b))   # not measured by this run
             if os.path.exists(pmc_file):
                 with open(pmc_file) as fh:
                     pm = json.load(fh)
                 traffic = round((pm["gemm_read_bytes_per_step"] + pm["gemm_write_bytes_per_step"]) / max(pm["gemm_launches_per_step"], 1), 1)
                 traffic_source = "profiles/%s (committed rocprofv3 --pmc passes of this configuration; NOT re-measured by this run)" % os.path.basename(pmc_file)
+                import hashlib
+                with open(pmc_file, "rb") as fh:
+                    traffic_sha = hashlib.sha256(fh.read()).hexdigest()[:16]          # which file was quoted ...
+                traffic_head = pm.get("measured_at_head")                              # ... and the commit its passes ran on (a stale figure is visible in the line)
                 break
         roofline = dict(bound="mfma", kernel="v4::gemm_v4_kernel family (every tower GEMM of a step: fwd, dX, dW)", achieved=round(achieved, 2),
                         peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic,
                         traffic_unit="bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)", traffic_source=traffic_source,
+                        traffic_file_sha16=traffic_sha, traffic_measured_at_head=traffic_head,
                         algorithmic_bytes_per_launch=round(sum(gemm_bytes) / max(len(gemm_bytes), 1), 1),
                         launches_per_step=len(records) // nprof, gemm_ms_per_step=round(ms / nprof, 3),
                         gemm_ms_per_step_raw_brackets=round(ms_raw / nprof, 3), empty_bracket_us=round(pair_ms * 1e3, 2),

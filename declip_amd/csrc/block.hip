@@ -180,7 +180,7 @@ extern "C" int dh_block_bwd(dh_block_args* a, dh_stream_t st) {
     g4.dtype = a->dtype; g4.c_dtype = DH_F32; g4.a_kmajor = 1; g4.b_kmajor = 1;
     g4.M = outs[i]; g4.N = ins[i]; g4.K = R;
     g4.A = dys[i]; g4.lda = outs[i]; g4.B = xs[i]; g4.ldb = ins[i]; g4.C = gws[i]; g4.ldc = ins[i];
-    g4.accumulate = 1; g4.alpha = 1.f; g4.a_colsum = gbs[i];
+    g4.accumulate = a->dw_first_touch ? 2 : 1; g4.alpha = 1.f; g4.a_colsum = gbs[i];
     const int tiles = ((outs[i] + 127) / 128) * ((ins[i] + 127) / 128);
     int sk = 1024 / (tiles > 0 ? tiles : 1);
     if (sk > R / 512) sk = R / 512;

@@ -378,6 +378,17 @@ extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
     return DH_OK;
   }
   DH_REQUIRE(a->force_generic != 4, "dh_gemm: the v4 kernel does not support this problem");
+  dh_gemm_args first_touch;
+  if (a->accumulate == 2) {
+    // first touch through the other kernel families (fp32 atomics into C): clear the slot here, then accumulate as usual
+    if (a->ldc == a->N) hipMemsetAsync(a->C, 0, sizeof(float) * (size_t)a->M * a->N, st);
+    else hipMemset2DAsync(a->C, sizeof(float) * a->ldc, 0, sizeof(float) * a->N, a->M, st);
+    if (a->a_colsum) hipMemsetAsync(a->a_colsum, 0, sizeof(float) * (size_t)a->M, st);
+    first_touch = *a;
+    first_touch.accumulate = 1;
+    a = &first_touch;
+    e.accumulate = 1;
+  }
   if (a->force_generic == 0 && dh_gemm_try_v3(a, split, st)) {
     ++g_gemm_family_calls[1];
     DH_CHECK_LAUNCH();

@@ -1533,7 +1533,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       a += __shfl_xor(a, 1, 64);
       a += __shfl_xor(a, 2, 64);
       a += __shfl_xor(a, 4, 64);
-      if (part == 0) colsum[m] += a;
+      if (part == 0) colsum[m] = accumulate ? colsum[m] + a : a;
     }
   }
 }
@@ -1788,6 +1788,11 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
       }
     }
   }
+  if (md == MODE_ATOMIC && a->accumulate == 2) {           // first touch through the atomic path: clear, then add
+    if (a->ldc == a->N) hipMemsetAsync(a->C, 0, sizeof(float) * (size_t)a->M * a->N, st);
+    else hipMemset2DAsync(a->C, sizeof(float) * a->ldc, 0, sizeof(float) * a->N, a->M, st);
+    if (a->a_colsum) hipMemsetAsync(a->a_colsum, 0, sizeof(float) * (size_t)a->M, st);
+  }
   switch (md) {
     case MODE_ATOMIC: launch<true, true, MODE_ATOMIC>(a, e, split, kps, n_full, S, st); break;
     case MODE_PARTIAL: launch<true, true, MODE_PARTIAL>(a, e, split, kps, n_full, S, st); break;
@@ -1804,8 +1809,9 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
     const long n4 = (long)a->M * a->N / 4;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
+    // accumulate == 2 (first touch of this gradient in the step): the reduce pass WRITES the sum -- C is neither zeroed beforehand nor read
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a->ws, (float*)a->C, (long)a->ldc, a->M,
-                       a->N, split, 1, (const float*)e.ws_cs, a->a_colsum, split * dh_cdiv(a->N, BN));
+                       a->N, split, a->accumulate == 2 ? 0 : 1, (const float*)e.ws_cs, a->a_colsum, split * dh_cdiv(a->N, BN));
   }
   return true;
 }
@@ -1813,6 +1819,7 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
 // ---- grouped weight gradients (MODE_GROUP) -------------------------------------------------------------------------------------
 namespace v4 {
 struct GReduce {
+  int overwrite[MAX_GROUP];       // problem is the FIRST gradient contribution of the step: the sum is written, the slot not read (dh_gemm_args.accumulate == 2)
   float* out[MAX_GROUP];          // gradient [M][N], contiguous (ldc == N)
   float* colsum[MAX_GROUP];       // bias gradient [M] or null
   long ws_off[MAX_GROUP + 1];     // float offsets inside a slab (ascending; [n] = zs)
@@ -1843,7 +1850,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const float* _
 #pragma unroll
     for (int q = 0; q < MAX_GROUP; ++q) if (q == p) { op = g.out[q]; off = g.ws_off[q]; }
     f32x4_t* o = reinterpret_cast<f32x4_t*>(op + (e - off));
-    *o = *o + (s0 + s1);
+    bool ow = false;
+#pragma unroll
+    for (int q = 0; q < MAX_GROUP; ++q) if (q == p) ow = g.overwrite[q] != 0;
+    *o = ow ? (s0 + s1) : (*o + (s0 + s1));
   }
   if (cs) {
     // the LAST threads of the grid take the (short) bias-gradient job: one thread per (problem, row)
@@ -1856,7 +1866,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const float* _
         float a = 0.f;
         for (int z = 0; z < nsplit; ++z)
           for (int tx = 0; tx < g.ntx[q]; ++tx) a += cs[(long)z * cs_zs + g.cs_off[q] + (long)tx * Mq + gt];
-        g.colsum[q][gt] += a;
+        g.colsum[q][gt] = g.overwrite[q] ? a : g.colsum[q][gt] + a;
       }
       gt -= Mq;
     }
@@ -1893,6 +1903,7 @@ bool dh_gemm_try_v4_group(const dh_gemm_args* a, int n, hipStream_t st) {
     GProb& g = ka.gp[p];
     g.A = (const bf16_t*)q.A; g.B = (const bf16_t*)q.B; g.lda = q.lda; g.ldb = q.ldb; g.M = q.M; g.N = q.N;
     g.ntx = q.N / BN; g.nty = q.M / BM; g.tile0 = T; g.ws_off = zs; g.cs_off = cs_zs; g.a_colsum = (float*)q.a_colsum;
+    gr.overwrite[p] = q.accumulate == 2;
     gr.out[p] = (float*)q.C; gr.colsum[p] = (float*)q.a_colsum; gr.ws_off[p] = zs; gr.cs_off[p] = cs_zs; gr.M[p] = q.M; gr.ntx[p] = g.ntx;
     T += g.ntx * g.nty;
     zs += (long)q.M * q.N;

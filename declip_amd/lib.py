@@ -56,7 +56,7 @@ class BlockArgs(Structure):
                 ("cu", c_void_p), ("rows_valid", c_int), ("seq_order", c_void_p), ("seq_ranges", c_void_p), ("L_short", c_int), ("p", BlockParams), ("x", c_void_p), ("x_out", c_void_p),
                 ("act", c_void_p), ("act_bytes", c_int64), ("ws", c_void_p), ("ws_bytes", c_int64), ("dx_out", c_void_p), ("dx", c_void_p),
                 ("scratch", c_void_p), ("scratch_bytes", c_int64), ("ln_part1", c_void_p), ("ln_part2", c_void_p), ("ln_part_bytes", c_int64),
-                ("ln_nb1", c_int), ("ln_nb2", c_int)]
+                ("ln_nb1", c_int), ("ln_nb2", c_int), ("dw_first_touch", c_int)]
 
 
 _P = c_void_p
@@ -74,6 +74,7 @@ _PROTOS = {
     "dh_gemm_stats": (c_int, [_P, c_int]),
     "dh_colsum": (c_int, [c_int, _P, c_int64, c_int, c_int, _P, c_int, _P]),
     "dh_layernorm_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P]),
+    "dh_zero_ranges": (c_int, [_P, _P, c_int, c_int64, _P]),
     "dh_layernorm_bwd_ws_bytes": (c_int64, [c_int, c_int]),
     "dh_layernorm_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int64, _P]),
     "dh_layernorm_bwd_part": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int64, _P, _P]),

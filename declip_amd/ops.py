@@ -68,9 +68,11 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, 
     return out
 
 
-def gemm_dw_group(problems, ws=None):
+def gemm_dw_group(problems, ws=None, first_touch=False):
     """problems: list of (dy [rows, out], x [rows, in], gw [out, in] fp32, gb [out] fp32 or None), all with the same `rows`:
-    gw += dy^T x and gb += colsum(dy) for every problem in ONE launch of the persistent kernel (dh_gemm_group)."""
+    gw += dy^T x and gb += colsum(dy) for every problem in ONE launch of the persistent kernel (dh_gemm_group).
+    first_touch: these are the first contributions of the step to gw / gb: they are WRITTEN (dh_gemm_args.accumulate = 2; the slots
+    need not be zero and are not read)."""
     n = len(problems)
     arr = (GemmArgs * n)()
     for a, (dy, x, gw, gb) in zip(arr, problems):
@@ -81,7 +83,7 @@ def gemm_dw_group(problems, ws=None):
         a.a_kmajor, a.b_kmajor = 1, 1
         a.M, a.N, a.K = dy.shape[1], x.shape[1], dy.shape[0]
         a.A, a.lda, a.B, a.ldb, a.C, a.ldc = ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(gw), gw.stride(0)
-        a.accumulate, a.alpha = 1, 1.0
+        a.accumulate, a.alpha = (2 if first_touch else 1), 1.0
         a.split_k = max(1, min(1024 // max(((a.M + 127) // 128) * ((a.N + 127) // 128), 1), a.K // 512))   # used only on the one-by-one path
         if gb is not None:
             _req(gb.dtype == torch.float32 and gb.numel() == a.M, 'gb.dtype == torch.float32 and gb.numel() == a.M')
@@ -89,6 +91,12 @@ def gemm_dw_group(problems, ws=None):
         if ws is not None:
             a.ws, a.ws_bytes = ptr(ws), ws.numel() * ws.element_size()
     check(L.load().dh_gemm_group(arr, n, stream()), "dh_gemm_group")
+
+
+def zero_ranges(base, table_dev, n, max_len):
+    """base[lo:hi] = 0 for the n (lo, hi) rows of the int64 device table (dh_zero_ranges)."""
+    _req(base.dtype == torch.float32 and table_dev.dtype == torch.int64 and table_dev.is_contiguous(), "zero_ranges: fp32 buffer, int64 [n, 2] table")
+    check(L.load().dh_zero_ranges(ptr(base), ptr(table_dev), int(n), int(max_len), stream()), "dh_zero_ranges")
 
 
 def gemm_stats(reset=False):

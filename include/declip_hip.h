@@ -57,6 +57,8 @@ int dh_device_info(int device, int* out4);
  *   DH_EPI_DGELU  C = value * aux_in[m,n]                              (backward of the above: aux_in = the forward's aux_out)
  *   residual != NULL: C += residual[m,n] (type c_dtype)               (base_transformer.py:51-52)
  *   accumulate = 1: C is fp32 and is atomically accumulated into (split_k > 1 allowed).
+ *   accumulate = 2: the same product as the FIRST contribution to C in this step: C (and a_colsum) are overwritten -- the caller
+ *                   need not have zeroed them, and the split-K reduce pass does not read them (torch's "grad is None -> assign").
  *   a_colsum (with a_kmajor): the weight-gradient call dW = dY^T X also emits db = colsum(dY) from the dY
  *   tiles it already staged in LDS (nn.Linear bias gradient without re-reading dY from HBM).
  */
@@ -212,7 +214,12 @@ typedef struct dh_block_args {
   void* scratch; int64_t scratch_bytes;
   void* ln_part1; void* ln_part2; int64_t ln_part_bytes;
   int ln_nb1, ln_nb2;
+  int dw_first_touch;      /* dh_block_bwd: the block's weight / bias gradients are the first contribution of this step to their slots: written
+                              (dh_gemm_args.accumulate = 2), the caller need not have zeroed the slots */
 } dh_block_args;
+/* base[lo, hi) = 0 for the n ranges of table_dev ([n][2] int64 element offsets on the device, multiples of 4; max_len = the longest hi - lo):
+ * the flat gradient buffer minus the slots whose first writer of the step is a weight-gradient GEMM with accumulate = 2 (csrc/fill.hip). */
+int dh_zero_ranges(float* base, const int64_t* table_dev, int n, int64_t max_len, dh_stream_t stream);
 int64_t dh_block_act_bytes(int dtype, int rows, int d, int heads, int b, int L);
 /* byte offsets inside the slab of h1, qkv, a (attention output), x_mid, h2, u (GELU pre-activation), g, mean1, rstd1, mean2, rstd2, lse */
 int dh_block_act_offsets(int dtype, int rows, int d, int heads, int b, int L, int64_t* out12);

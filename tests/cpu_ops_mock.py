@@ -41,8 +41,14 @@ def gemm(A, B, *, a_kmajor=False, b_kmajor=False, bias=None, epilogue=EPI_NONE, 
             bb[:min(N, bias.numel())] = bias[:min(N, bias.numel())]
             bias = bb
     if a_colsum is not None:
-        a_colsum += a.sum(1)
+        if accumulate == 2:                   # first touch: the slots are written (include/declip_hip.h)
+            a_colsum.copy_(a.sum(1))
+        else:
+            a_colsum += a.sum(1)
     v = alpha * (a @ b)
+    if accumulate == 2:
+        out.copy_(v[:out.shape[0], :out.shape[1]])
+        return out
     if accumulate:
         out += v[:out.shape[0], :out.shape[1]]
         return out
@@ -270,11 +276,21 @@ def cast(src, dst):
     return dst
 
 
-def gemm_dw_group(problems, ws=None):
+def gemm_dw_group(problems, ws=None, first_touch=False):
     for dy, x, gw, gb in problems:
+        if first_touch:                       # accumulate = 2: the slots are written (include/declip_hip.h)
+            gw.copy_(dy.float().t() @ x.float())
+            if gb is not None:
+                gb.copy_(dy.float().sum(0))
+            continue
         gw.add_(dy.float().t() @ x.float())
         if gb is not None:
             gb.add_(dy.float().sum(0))
+
+
+def zero_ranges(base, table_dev, n, max_len):
+    for lo, hi in table_dev[:n].tolist():
+        base[lo:hi] = 0
 
 
 def adamw_segmented(p, g, m, v, p_bf16, seg_start, seg_lr, seg_wd, beta1, beta2, eps, step, grad_scale=1.0):

@@ -669,3 +669,57 @@ def test_nn_queue_pointer_survives_a_device_change_and_storage_is_sized_once(moc
     m._captured = True
     m.spill_rows += 1
     assert m._store is store                                          # (growing the wish alone changes nothing)
+
+
+@pytest.mark.parametrize("family", ["clip", "declip", "accumulate"])
+def test_first_touch_weight_gradients_need_no_cleared_buffer(mocked_engine, monkeypatch, family):
+    """Round 5: begin_backward no longer clears the block-weight slots of the flat gradient buffer -- the first
+    weight-gradient GEMM of the step that reaches a block WRITES them (accumulate = 2), a second view through the same tower (DeCLIP:
+    two image views, two caption views) accumulates, and a backward over live gradients (no zero_grad) accumulates everything.
+    The buffer is poisoned with NaN before every backward pass: a slot that is neither cleared nor written first shows up at once,
+    and the gradients must equal the DH_FIRST_TOUCH=0 run bit for bit (the mock computes the same sums either way)."""
+    import os
+    from declip_amd import synth
+    from declip_amd.heads import SimsiamLoss
+    from declip_amd.loss import ClipInfoCELoss, NTXentLoss
+    from declip_amd.steps import declip_loss
+    from declip_amd.testing import build_clip, build_declip, declip_batch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
+    def run(mode):
+        monkeypatch.setenv("DH_FIRST_TOUCH", mode)
+        cfg = synth.TINY
+        if family == "declip":
+            model = build_declip(cfg, dtype="fp32", seed=2, nn_size=32, device="cpu")
+            batch = declip_batch(cfg, 4, seed=2, device="cpu")
+            step = lambda: declip_loss(model, batch, ClipInfoCELoss(), SimsiamLoss(), NTXentLoss(4))["loss"].backward()     # noqa: E731
+        else:
+            model = build_clip(cfg, dtype="fp32", seed=2, device="cpu")
+            images, ids = synth.synth_images(4, res=cfg["res"], seed=2), synth.synth_tokens(4, ctx=cfg["ctx"], seed=2)
+            crit = ClipInfoCELoss()
+
+            def step():
+                li, lt = model({"images": images, "captions": ids})
+                crit(li, lt)[0].backward()
+        flat = model._flat_store
+        flat.ensure()
+        poison = mode == "force"
+        if poison:
+            flat.flat_g.fill_(float("nan"))
+        step()
+        if family == "accumulate":              # second backward WITHOUT zero_grad: live gradients, everything accumulates
+            step()
+        else:                                   # zero_grad(set_to_none=True) + another step: the protocol re-arms
+            for p in model.parameters():
+                p.grad = None
+            if poison:
+                flat.flat_g.fill_(float("nan"))
+            step()
+        if poison:
+            plan = flat._first_touch_plan()
+            assert plan is not None and plan["n"] > 4 and len(plan["ids"]) == 4 * (cfg["v_layers"] + cfg["t_layers"])
+        return flat.flat_g.clone()
+
+    ref, got = run("0"), run("force")
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref)

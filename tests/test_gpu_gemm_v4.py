@@ -279,6 +279,38 @@ def test_v4_grouped_weight_gradients(K, shapes):
     assert rel_err(gw, rw) < 2e-5
 
 
+def test_weight_gradients_first_touch_write_their_slots_without_reading_them():
+    """dh_gemm_args.accumulate = 2 (round 5): the first weight-gradient GEMM of a step WRITES gw / gb -- the slots are poisoned with
+    NaN here, so a path that reads them, or leaves a part unwritten, cannot pass.  All routes: the grouped persistent launch (reduce
+    pass without the read), the single split-K launch through the workspace, the fp32-atomic launch (clears first), the fall-back
+    kernels for shapes the persistent kernel does not take; then a second contribution accumulates on top."""
+    ops = _ops()
+    K = 2048
+    nan = float("nan")
+    shapes = [(768, 768), (768, 256), (256, 768), (512, 256)]
+    probs, refs = [], []
+    for i, (M, N) in enumerate(shapes):
+        dy, x = rnd(K, M, seed=70 + i).to(bf), rnd(K, N, seed=80 + i).to(bf)
+        probs.append((dy.to(cuda), x.to(cuda), torch.full((M, N), nan, device=cuda), torch.full((M,), nan, device=cuda) if i != 1 else None))
+        refs.append((dy.double().t() @ x.double(), dy.double().sum(0)))
+    ops.gemm_stats(reset=True)
+    ops.gemm_dw_group(probs, ws=_ws(), first_touch=True)
+    torch.cuda.synchronize()
+    assert ops.gemm_stats()["v4"] == len(shapes)
+    for (dy, x, gw, gb), (rw, rb) in zip(probs, refs):
+        assert rel_err(gw, rw) < 2e-5 and (gb is None or rel_err(gb, rb) < 2e-5)
+    ops.gemm_dw_group(probs, ws=_ws())                                        # a second view through the same weights accumulates
+    for (dy, x, gw, gb), (rw, rb) in zip(probs, refs):
+        assert rel_err(gw, 2 * rw) < 2e-5 and (gb is None or rel_err(gb, 2 * rb) < 2e-5)
+    # single launches: split-K through the workspace (v4), fp32 atomics (v4 without workspace), the fall-back kernels (ragged shape)
+    for (M, N, use_ws, force) in [(768, 768, True, 4), (768, 768, False, 4), (384, 200, False, 0), (384, 200, True, 0)]:
+        dy, x = rnd(K, M, seed=90).to(bf), rnd(K, N, seed=91).to(bf)
+        gw, gb = torch.full((M, N), nan, device=cuda), torch.full((M,), nan, device=cuda)
+        ops.gemm(dy.to(cuda), x.to(cuda), a_kmajor=True, b_kmajor=True, out=gw, accumulate=2, split_k=4, a_colsum=gb, ws=_ws() if use_ws else None,
+                 force_generic=force)
+        assert rel_err(gw, dy.double().t() @ x.double()) < 2e-4 and rel_err(gb, dy.double().sum(0)) < 2e-4, (M, N, use_ws, force)
+
+
 def test_v4_group_falls_back_for_shapes_it_cannot_take():
     """a problem that is not whole 256-tiles: the group is issued one by one (same results, other kernels)."""
     ops = _ops()
