@@ -4,6 +4,7 @@
 // dgamma/dbeta through per-block partials + a second tiny reduce kernel (no atomics storm).
 #include "dh_common.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -29,12 +30,11 @@ template <> struct Raw8<float> {
 // NCH = 16-byte chunks per lane (d <= 512 * NCH); two rows per wave per iteration, and the NEXT iteration's two rows are
 // requested (packed, 4 registers per chunk) before the current ones are reduced: the kernel is latency-bound (load ->
 // two dependent wave reductions -> store), a wave that handles one iteration at a time leaves HBM idle most of the time
-template <typename T, int NCH>
+template <typename T, int NCH, int R = 2>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                      int d, float eps) {
-  constexpr int R = 2;
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
@@ -405,11 +405,17 @@ extern "C" int dh_layernorm_fwd(int dtype, const void* x, const float* w, const 
   hipStream_t st = (hipStream_t)stream;
   DH_REQUIRE(x && w && b && y && rows > 0 && d > 0, "dh_layernorm_fwd: bad args");
   const bool vec = (d % 8 == 0) && d <= 8 * 64 * LN_MAXC;
-  dim3 grid(vec ? ln_balanced_grid(rows, 8, 1024) : ln_grid(rows));      // vector kernel: 4 waves x 2 rows per iteration
+  // tuning knobs (read once): rows per wave and iteration (2 / 4), cap of the grid
+  static int ln_r = 0, ln_cap = 0;
+  if (!ln_r) { const char* ev = getenv("DH_LN_FWD_R"); ln_r = ev ? atoi(ev) : 2; if (ln_r != 4) ln_r = 2; }
+  if (!ln_cap) { const char* ev = getenv("DH_LN_FWD_CAP"); ln_cap = ev ? atoi(ev) : 1024; if (ln_cap < 64) ln_cap = 64; }
+  dim3 grid(vec ? ln_balanced_grid(rows, 4 * ln_r, ln_cap) : ln_grid(rows));      // vector kernel: 4 waves x R rows per iteration
   const int nch = dh_cdiv(d / 8, 64);
 #define LN_FWD(TT)                                                                                                                       \
   {                                                                                                                                      \
-    if (nch <= 1) hipLaunchKernelGGL((ln_fwd_kernel<TT, 1>), grid, dim3(256), 0, st, (const TT*)x, w, b, (TT*)y, mean, rstd, rows, d, eps);       \
+    if (ln_r == 4 && nch <= 1) hipLaunchKernelGGL((ln_fwd_kernel<TT, 1, 4>), grid, dim3(256), 0, st, (const TT*)x, w, b, (TT*)y, mean, rstd, rows, d, eps);       \
+    else if (ln_r == 4 && nch == 2) hipLaunchKernelGGL((ln_fwd_kernel<TT, 2, 4>), grid, dim3(256), 0, st, (const TT*)x, w, b, (TT*)y, mean, rstd, rows, d, eps);  \
+    else if (nch <= 1) hipLaunchKernelGGL((ln_fwd_kernel<TT, 1>), grid, dim3(256), 0, st, (const TT*)x, w, b, (TT*)y, mean, rstd, rows, d, eps);       \
     else if (nch == 2) hipLaunchKernelGGL((ln_fwd_kernel<TT, 2>), grid, dim3(256), 0, st, (const TT*)x, w, b, (TT*)y, mean, rstd, rows, d, eps);  \
     else hipLaunchKernelGGL((ln_fwd_kernel<TT, LN_MAXC>), grid, dim3(256), 0, st, (const TT*)x, w, b, (TT*)y, mean, rstd, rows, d, eps);          \
   }
