@@ -77,7 +77,7 @@ def main(root):
     launches = sum(calls[k].get("FETCH_SIZE", 0) for k in gemm)
     import json
     print("JSON " + json.dumps(dict(gemm_read_bytes_per_step=rd / steps, gemm_write_bytes_per_step=wr / steps, gemm_launches_per_step=launches / steps,
-                                    steps=steps, note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md s.HBM); L2-miss traffic incl. Infinity-Cache hits")))
+                                    steps=steps, measured_at_head=os.environ.get("DH_HEAD") or None, note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md s.HBM); L2-miss traffic incl. Infinity-Cache hits")))
 
 
 if __name__ == "__main__":
