@@ -630,16 +630,16 @@ def main():
 
         orig_group = ops.gemm_dw_group
 
-        def timed_group(problems, ws=None):
+        def timed_group(problems, ws=None, first_touch=False):
             # the grouped weight gradients of a block: ONE launch (+ one reduce pass) for all its problems
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            orig_group(problems, ws=ws)
+            orig_group(problems, ws=ws, first_touch=first_touch)
             e1.record()
             fl, nb = 0.0, 0
             for dy, x, gw, gb in problems:
                 fl += 2.0 * dy.shape[1] * x.shape[1] * dy.shape[0]
-                nb += (dy.numel() + x.numel()) * dy.element_size() + 2 * gw.numel() * 4
+                nb += (dy.numel() + x.numel()) * dy.element_size() + (1 if first_touch else 2) * gw.numel() * 4     # (first touch: the gradient is written, not read-modify-written)
             gemm_bytes.append(nb)
             dy0 = problems[0][0]
             records.append((e0, e1, fl, dy0.dtype, (sum(p[0].shape[1] * p[1].shape[1] for p in problems) // max(problems[0][1].shape[1], 1),

@@ -38,3 +38,20 @@ def test_a_hanging_warm_up_of_the_captured_step_reexecutes_the_rank_eagerly():
     assert "watchdog" in err
     assert d["graph_fallback"] and d["graph_fallback"].startswith("watchdog"), d["graph_fallback"]
     assert d["config"]["step_graph"] == 0 and d["value"] > 0
+
+
+def test_the_default_line_with_its_roofline_pass_runs_end_to_end():
+    """`python bench.py` as the driver runs it, roofline pass included (per-op composition with event brackets around every GEMM and
+    every grouped weight-gradient launch): the instrumented wrappers must follow the ops' signatures -- round 5 added `first_touch`
+    to gemm_dw_group and the first profiling session found the wrapper without it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "DH_DIST_FORCE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-loss-delta"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                       # ONE line on stdout, nothing else
+    d = json.loads(lines[0])
+    r = d["roofline"]
+    assert d["value"] > 0 and d["config"]["step_graph"] == 1 and d["graph_fallback"] is None
+    assert r["bound"] == "mfma" and 0.2 < r["frac"] < 1.0 and r["launches_per_step"] > 150 and r["achieved"] > 500
+    assert r["traffic"] is None or (r["traffic_file_sha16"] and len(r["traffic_file_sha16"]) == 16)
