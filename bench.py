@@ -554,6 +554,7 @@ def main():
         per_rank_ms = [round(float(x) / args.steps * 1e3, 3) for x in all_t]
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
+    step_graph_used = int(use_graph and graphed.enabled and graphed.graph is not None)      # (read before the instrumented passes below switch the graph off)
     ms_per_step = elapsed / args.steps * 1e3
     host_ms_per_step = host_elapsed / args.steps * 1e3
     pairs_per_s = b * world * args.steps / elapsed
@@ -766,7 +767,7 @@ def main():
                scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic" if pipeline is None else "synthetic, through the input pipeline",
                config=dict(workload=workloads[args.model],
                            global_batch=b * world, per_gpu_batch=b, parallelism="dp%d" % world,
-                           tower_streams=1 + len(model.__dict__["_flat_store"].side_streams), step_graph=int(use_graph and graphed.enabled and graphed.graph is not None), graphs_captured=graphed.captures,
+                           tower_streams=1 + len(model.__dict__["_flat_store"].side_streams), step_graph=step_graph_used, graphs_captured=graphed.captures,
                            input_pipeline=(None if pipeline is None else
                                            "DataPrefetcher: uint8 canvases 256x320 (source sizes 192-256 x 256-320) + RandomResizedCrop boxes + mirror "
                                            "flags + caption strings; BPE (dh_bpe_encode) and box bookkeeping on 1 worker thread (%d host cores usable), "

@@ -81,6 +81,20 @@ class GraphedStep(object):
         import torch.distributed as tdist
         return "thread_local" if (tdist.is_available() and tdist.is_initialized()) else "global"
 
+    @staticmethod
+    def _drain_process_group():
+        """Called right before a capture, after torch.cuda.synchronize().  ProcessGroupNCCL's watchdog thread keeps every eager
+        collective in a list until its next sweep (every 100 ms) finds the end event complete -- it polls with hipEventQuery.  Once
+        the capture pulls the group's internal stream in, HIP answers such a query with hipErrorCapturedEvent ("event last recorded
+        in a capturing stream": it looks at the stream's state NOW, not at the record), the watchdog rethrows and the process dies
+        (seen in 1 of ~10 captured one-rank RCCL steps on the MI355X, round 5).  Everything enqueued is complete at this point, so
+        one second lets the watchdog retire the whole list; collectives issued DURING the capture are never handed to it."""
+        import time
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized() and tdist.get_backend() == "nccl":
+            import os
+            time.sleep(float(os.environ.get("DH_GRAPH_PG_DRAIN_S", "1.0")))
+
     def _check_capturable(self):
         import torch.distributed as tdist
         for st in self.stores:
@@ -110,6 +124,7 @@ class GraphedStep(object):
         if not self.fallback:
             self._check_capturable()
             torch.cuda.synchronize()
+            self._drain_process_group()
             g = torch.cuda.CUDAGraph()
             if self.pool is None:
                 self.pool = torch.cuda.graph_pool_handle()
@@ -121,6 +136,7 @@ class GraphedStep(object):
             try:
                 self._check_capturable()
                 torch.cuda.synchronize()
+                self._drain_process_group()
                 g = torch.cuda.CUDAGraph()
                 if self.pool is None:
                     self.pool = torch.cuda.graph_pool_handle()
