@@ -311,10 +311,10 @@ def main():
                     help="clip = BASELINE.json metric; declip / slip / filip = configs[2] / [3] / [4] at their per-GPU batches (512 / 512 / 256); "
                          "clip_r50 = configs[0] (CLIP ResNet-50, batch 32; add --dtype fp32)")
     ap.add_argument("--text-packed", choices=["0", "1", "2"], default=None,
-                    help="text tower on the caption rows up to <|endoftext|> only (DESIGN.md s11; 1 = variable-length attention, "
+                    help="text tower on the caption rows up to <|endoftext|> only (DESIGN_HISTORY.md s11; 1 = variable-length attention, "
                          "2 = attention via the dense layout, 0 = padded as the reference computes them); default: DH_TEXT_PACKED, else 1")
     ap.add_argument("--pooled-last", choices=["0", "1"], default=None,
-                    help="last block of each tower for the pooled row only (DESIGN.md s12); default: DH_POOLED_LAST, else 1")
+                    help="last block of each tower for the pooled row only (DESIGN_HISTORY.md s12); default: DH_POOLED_LAST, else 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-loss-delta", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

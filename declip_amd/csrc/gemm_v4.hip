@@ -595,7 +595,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v4_kernel(const KArgs ka_unused) 
   // (test_v4_dynamic_tile_distribution_is_bit_identical_to_the_static_one found it).  No register reservation mechanism exists
   // in this toolchain (amdgpu_num_vgpr is ignored under __launch_bounds__), so the fetch is synchronous now: it sits at the very
   // end of the epilogue, behind the wait that already covers everything older than the epilogue's stores, and costs the store
-  // drain + one L2 atomic round trip per item (measured: see DESIGN.md s4).
+  // drain + one L2 atomic round trip per item (measured: see DESIGN_HISTORY.md s4).
   // (launch constants of this workgroup's XCD, computed once: the fetch at the end of every epilogue needs nothing else alive)
   const int my_wgs = V4_RFL(wgs_on_xcd(xcd, grid)), my_len = V4_RFL(list_len(xcd));
 #if V4_EMU

@@ -7,7 +7,7 @@ grad_clip / optimizer(+pconfig) / lr_scheduler / loss weights / saver), the step
 clamp), iteration-based training, checkpoint key layout ('model' with 'module.' prefix, 'optimizer', 'last_iter').
 What changes: no per-meter host sync (meters are read every print_freq), no barriers in the step, gradient
 reduction is the engine's bucketed flat all-reduce.  Data: `data.read_from: fake` / `data.type: synthetic`
-produce seeded synthetic batches resident on the GPU (the I/O pipeline is out of scope); any
+produce seeded synthetic batches resident on the GPU (the I/O pipeline is out of scope, DESIGN_HISTORY.md s7); any
 iterable of reference-style batch dicts can be injected with `ClsSolver(config, train_loader=...)`.
 """
 import argparse
@@ -352,7 +352,7 @@ class ClsSolver(object):
             return
         if d.get("read_from", "fake") not in ("fake", "synthetic") and d.get("type", "clip") != "synthetic":
             raise NotImplementedError(
-                "only data.read_from: fake / synthetic is built in (the I/O pipeline is out of scope, DESIGN.md s7); "
+                "only data.read_from: fake / synthetic is built in (the I/O pipeline is out of scope, DESIGN_HISTORY.md s7); "
                 "pass train_loader= an iterable of {'images','captions'} batch dicts for real data")
         m = self.model.module
         ctx = int((m.text_encoder if hasattr(m, "text_encoder") else m.encode_text).context_length)

@@ -153,7 +153,7 @@ int dh_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, c
  * [rows, rows_pad) of out / dqkv are written as ZEROS -- they are contraction rows of the weight-gradient GEMMs -- by the
  * attention kernel itself on the bf16 path (no separate fill launch).  rows = -1 (bf16, hd = 64 only): the kernel reads
  * cu_seqlens[b] itself -- no host-side row count in the launch, so a captured step replays for ANY batch with this rows_pad.
- * Used by the packed text tower (captions computed up to <|endoftext|> only). */
+ * Used by the packed text tower (captions computed up to <|endoftext|> only; DESIGN_HISTORY.md s11). */
 int dh_attn_varlen_fwd(int dtype, const void* qkv, void* out, float* lse, const int* cu_seqlens, int b, int Lmax, int heads, int hd,
                        int causal, int rows, int rows_pad, dh_stream_t stream);
 int dh_attn_varlen_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,

@@ -232,7 +232,7 @@ def test_clip_bf16_vitb32_b256_v4_gemm_matches_v2_gemm():
         L.dh_gemm_v4_enable(prev)
     assert abs(a["loss"] - ref["loss"]) <= 2e-3 * abs(ref["loss"])
     scale = float(ref["logits_i"].abs().max())
-    assert float((a["logits_i"] - ref["logits_i"]).abs().max()) <= 3e-2 * scale      # the documented bf16 bound
+    assert float((a["logits_i"] - ref["logits_i"]).abs().max()) <= 3e-2 * scale      # the documented bf16 bound (DESIGN_HISTORY.md s2)
     worst, min_cos = 0.0, (2.0, "")
     for n, g in ref["grads"].items():
         if g is None:

@@ -6,7 +6,7 @@ checked through properties that do not depend on the size (the small-size parity
   * the two logits matrices are transposes of each other and the fused InfoNCE kernel equals an fp64 evaluation of
     loss.py:37-47 on the engine's own features;
   * backward is linear in the upstream gradient (loss * 4 -> every gradient * 4, a power of two: exact up to the run-to-run
-    atomics noise documented in DESIGN.md s2) and the bias gradients equal column sums recomputed by torch;
+    atomics noise documented in DESIGN_HISTORY.md s2) and the bias gradients equal column sums recomputed by torch;
   * a directional finite difference of the loss agrees with <grad, direction> in fp32 validation mode."""
 import pytest
 import torch
@@ -107,7 +107,7 @@ def test_fullsize_backward_is_linear_and_bias_grads_are_column_sums(setup):
         if m == 0.0:
             continue
         worst = max(worst, float((g4[n] - 4 * g).abs().max()) / (4 * m))
-    assert worst <= 1e-2, worst                 # noise floor of two bf16 runs is ~3e-3
+    assert worst <= 1e-2, worst                 # noise floor of two bf16 runs is ~3e-3 (DESIGN_HISTORY.md s2)
     # every gradient is finite and the frozen patch embedding has none (visual_transformer.py:45-51)
     assert all(torch.isfinite(g).all() for g in g1.values())
     assert "visual.conv1.weight" not in g1 or float(g1["visual.conv1.weight"].abs().max()) == 0.0

@@ -9,7 +9,7 @@ row log-sum-exp, a seeded projection).
 fp32 mode (validation arithmetic: VALU GEMM): the north_star 1e-3 on loss, logits and every gradient digest.
 bf16 mode (the path bench.py measures; the test asserts that the v4 kernel took the tower GEMMs): loss 1e-2 relative, logits 3e-2 of
 their largest value, per-parameter gradient norms within 8 % for all but 2 % of the parameters (8 mantissa bits through 12 layers,
-DESIGN.md s2) -- the same documented bounds as the small bf16 tests, now against the reference at the benchmarked shapes."""
+DESIGN_HISTORY.md s2) -- the same documented bounds as the small bf16 tests, now against the reference at the benchmarked shapes."""
 import pytest
 import torch
 
@@ -159,7 +159,7 @@ def test_declip_vitb32_b128_matches_reference_golden(dtype):
     else:
         assert_ran_on_v4(stats, 200)
         # measured (round 3): rms z 0.081, worst |z| 0.46 on projector.bn1.weight -- the affine gradients of the SimSiam head's
-        # BatchNorm1d layers are sums of cancelling terms over 128 rows, the towers sit at 0.03-0.05 like CLIP's
+        # BatchNorm1d layers are sums of cancelling terms over 128 rows (DESIGN_HISTORY.md s2), the towers sit at 0.03-0.05 like CLIP's
         check_bf16_grad_norms(g["grads"], named_grads(model), tol=0.10, allowed_frac=0.04, rms_tol=0.15, z_tol=0.35, key=K)
 
 

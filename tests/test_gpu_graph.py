@@ -56,7 +56,7 @@ def test_graphed_step_equals_eager_step(cfg_name, b, dtype):
             assert stepper.graph is not None
         losses[mode] = ls
         grads[mode] = model.__dict__["_flat_store"].flat_g.clone()
-    tol = 1e-5 if dtype == "fp32" else 3e-3      # two bf16 runs differ by the float-atomic noise of the loss backward
+    tol = 1e-5 if dtype == "fp32" else 3e-3      # two bf16 runs differ by the float-atomic noise of the loss backward (DESIGN_HISTORY.md s2)
     for a, c in zip(losses["graph"], losses["eager"]):
         assert abs(a - c) <= tol * abs(c), (losses["graph"], losses["eager"])
     ga, ge = grads["graph"], grads["eager"]
@@ -240,7 +240,7 @@ def test_graphed_multiview_step_equals_eager_step(family, cfg_name, b):
         assert 0 in want[:-1]                                   # the queue wrapped inside the replayed steps
         # same rows written in both modes: a frozen pointer would leave most of the queue at its initial contents
         assert float((g["bank"] - e["bank"]).norm()) <= 3e-2 * float(e["bank"].norm()), float((g["bank"] - e["bank"]).norm())
-    # two bf16 runs of the same arithmetic differ by the float-atomic noise of the loss backward, which six optimiser
+    # two bf16 runs of the same arithmetic differ by the float-atomic noise of the loss backward (DESIGN_HISTORY.md s2), which six optimiser
     # steps and the discrete choices of these models (nearest neighbour, top-16 tokens) amplify a little
     for a, c in zip(g["losses"], e["losses"]):
         assert abs(a - c) <= 1e-2 * abs(c), (g["losses"], e["losses"])

@@ -1,6 +1,6 @@
 """The hand-scheduled GEMM issues LDS transpose reads as inline asm and waits for them a whole segment later: the compiler must not
 touch a register such a read is still filling (tools/check_isa_async.py; the hazard class of the scheduler-fetch bug of round 3,
-DESIGN.md s4).  Checked on the gfx950 code object of the in-tree build; skipped where the object or llvm-objdump is missing."""
+DESIGN_HISTORY.md s4).  Checked on the gfx950 code object of the in-tree build; skipped where the object or llvm-objdump is missing."""
 import os
 import sys
 

@@ -4,7 +4,7 @@ is still filling must not be touched before the wait that covers it.
 gemm_v4 issues its transpose reads (`ds_read_b64_tr_b16`) as inline asm with plain "=v" outputs and waits for them much later
 (`s_waitcnt lgkmcnt(0)` at the end of the load segment): the compiler does not know that the outputs are not valid yet.  If it
 copies, spills or re-uses such a register before the wait, the kernel computes garbage from time to time -- the same class of bug
-as the scheduler fetch of the dynamic tile distribution that round 3 found on the hardware.  This tool
+as the scheduler fetch of the dynamic tile distribution that round 3 found on the hardware (DESIGN_HISTORY.md s4).  This tool
 disassembles the gfx950 code object inside a built object file and scans every kernel linearly:
 
     ds_read_b64_tr_b16 v[a:b], ...     -> a..b are PENDING

@@ -1,5 +1,5 @@
 """Register / spill table of the kernels of one HIP source (hipcc -Rpass-analysis=kernel-resource-usage), as the spill audits of
-DESIGN.md s4 use it:   python tools/kernel_resources.py declip_amd/csrc/gemm_v4.hip [substring of the kernel name]"""
+DESIGN_HISTORY.md s4 use it:   python tools/kernel_resources.py declip_amd/csrc/gemm_v4.hip [substring of the kernel name]"""
 import re
 import subprocess
 import sys

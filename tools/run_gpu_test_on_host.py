@@ -1,4 +1,4 @@
-"""Run one `-m gpu` test function on the CPU through the host emulation of the kernels (tests/hipemu).
+"""Run one `-m gpu` test function on the CPU through the host emulation of the kernels (tests/hipemu; DESIGN_HISTORY.md s10).
 
     python tools/run_gpu_test_on_host.py test_gpu_kernels test_attention "(torch.bfloat16, 2, 77, 8, True)"
     python tools/run_gpu_test_on_host.py test_gpu_clip test_clip_fp32_matches_reference_golden "('clip_tiny',)"
