@@ -75,7 +75,7 @@ def emu_ops(sources, symbols):
 
 # Everything of declip_amd/csrc that is plain HIP C++ (MFMA builtins, shuffles, LDS): all kernels except the three GEMM families
 # written with inline ISA, whose place in the dispatcher is taken by stubs that decline (tests/hipemu/emu_stubs.cpp).
-ALL_SOURCES = ["embed.hip", "layernorm.hip", "declip_ops.hip", "filip.hip", "infonce.hip", "attention.hip", "gemm.hip", "resnet_ops.hip",
+ALL_SOURCES = ["embed.hip", "fill.hip", "layernorm.hip", "declip_ops.hip", "filip.hip", "infonce.hip", "attention.hip", "gemm.hip", "resnet_ops.hip",
                "block.hip", "emu_stubs.cpp", "emu_stubs_v4.cpp"]
 # ... and the same with the benchmarked persistent GEMM itself (gemm_v4.hip keeps its inline ISA behind macros): kernel-level tests only
 V4_SOURCES = [s for s in ALL_SOURCES if s != "emu_stubs_v4.cpp"] + ["gemm_v4.hip"]
