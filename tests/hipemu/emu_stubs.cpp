@@ -8,3 +8,4 @@
 
 bool dh_gemm_try_glds(const dh_gemm_args*, int, hipStream_t) { return false; }
 bool dh_gemm_try_v3(const dh_gemm_args*, int, hipStream_t) { return false; }
+bool dh_gemm_try_v6(const dh_gemm_args*, hipStream_t) { return false; }   // gemm_v6.hip (round-5 experiment) is hardware-only

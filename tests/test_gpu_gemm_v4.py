@@ -399,3 +399,38 @@ def test_clip_bf16_step_under_the_dynamic_tile_distribution_matches_the_referenc
     import test_gpu_golden_fullwidth as T
     with _env(DH_V4_DYNAMIC="1"):
         T.test_clip_vitb32_b256_matches_reference_golden("bf16")
+
+
+@pytest.mark.parametrize("M,N,K,res,epi", [(1280, 768, 768, False, 0), (25600, 768, 768, True, 0), (22016, 512, 2048, True, 0), (5632, 1536, 512, False, 0),
+                                           (2560, 3072, 768, False, 1), (2560, 1024, 96, False, 2)])
+def test_gemm_v6_two_workgroups_per_cu_matches_the_reference_and_v4(M, N, K, res, epi):
+    """gemm_v6 (round-5 experiment, opt-in DH_GEMM_V6: two independent 4-wave workgroups per CU on 128 x 256 x 32 tiles, so that one's
+    epilogue runs beside the other's MFMAs): every element within the bf16 gate of the fp64 product, bit-identical from run to run
+    (the first version raced on its staging buffer once two workgroups shared a CU: a raw s_barrier does not wait for LDS writes),
+    and within one bf16 rounding of what gemm_v4 gives for the same call."""
+    from declip_amd.lib import EPI_DGELU, EPI_GELU
+    ops = _ops()
+    A, B, bias = rnd(M, K, seed=1).to(bf), rnd(N, K, seed=2, scale=0.1).to(bf), (rnd(N, seed=3) if epi != 2 else None)
+    R = rnd(M, N, seed=4).to(bf) if res else None
+    U = rnd(M, N, seed=5).to(bf) if epi == 2 else None
+    pre = A.double() @ B.double().t() + (bias.double() if bias is not None else 0)
+    ref = quick_gelu(pre) if epi == 1 else (pre * U.double() if epi == 2 else pre)
+    mag = None
+    if res:
+        ref, mag = pre + R.double(), pre.abs() + (pre + R.double()).abs()
+    kw = dict(bias=bias.to(cuda) if bias is not None else None, residual=R.to(cuda) if res else None, epilogue={0: 0, 1: EPI_GELU, 2: EPI_DGELU}[epi])
+    outs = []
+    with _env(DH_GEMM_V6=1):
+        for _ in range(3):
+            aux = torch.empty(M, N, device=cuda, dtype=bf) if epi == 1 else (U.to(cuda) if epi == 2 else None)
+            outs.append((ops.gemm(A.to(cuda), B.to(cuda), aux=aux, force_generic=6, **kw), aux))
+    torch.cuda.synchronize()
+    close("v6_%dx%dx%d_res%d_epi%d" % (M, N, K, int(res), epi), outs[0][0], ref, mag=mag)
+    for o, x in outs[1:]:
+        assert torch.equal(o, outs[0][0]) and (epi != 1 or torch.equal(x, outs[0][1]))
+    if epi == 1:
+        assert rel_err(outs[0][1], quick_gelu_grad(pre)) < TOL
+    if M % 256 == 0 and N % 256 == 0 and K % 64 == 0:
+        aux4 = torch.empty(M, N, device=cuda, dtype=bf) if epi == 1 else (U.to(cuda) if epi == 2 else None)
+        v4 = ops.gemm(A.to(cuda), B.to(cuda), aux=aux4, force_generic=4, **kw)
+        assert rel_err(outs[0][0], v4.float()) < 8e-3
