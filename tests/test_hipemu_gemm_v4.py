@@ -125,7 +125,8 @@ def test_v4_tail_sliced_schedule_emulated(ops):
     assert rel_err(sliced, A.double() @ B.double().t() + bias.double()) < TOL
 
 
-@pytest.mark.parametrize("M,K,residual,dyn", [pytest.param(2304, 512, False, 0, marks=SLOW), (2560, 384, True, 0), pytest.param(2560, 512, False, 1, marks=SLOW)])
+# (an opt-in schedule: the 30-second emulation runs with HIPEMU_SLOW=1, the GPU suite always covers it -- tests/test_gpu_gemm_v4.py)
+@pytest.mark.parametrize("M,K,residual,dyn", [pytest.param(2304, 512, False, 0, marks=SLOW), pytest.param(2560, 384, True, 0, marks=SLOW), pytest.param(2560, 512, False, 1, marks=SLOW)])
 def test_v4_tail_in_kernel_fixup_emulated(ops, M, K, residual, dyn):
     """The in-kernel fix-up of K-sliced tail tiles (round 5, DH_V4_TAIL=4; opt-in like the fix-up-kernel variant -- it wins alone on the chip
     and loses in the two-stream step): 9 / 10 tiles on 8 compute units, 8 (6) K-tiles -> the 1 / 2 tiles of
