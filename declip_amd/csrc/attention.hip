@@ -731,13 +731,29 @@ extern "C" int dh_attn_bucketed_bwd(int dtype, const void* qkv, const void* out,
 // weighted sums.  Keys of sequence i are kv rows row0[i] .. row0[i] + nkeys[i] - 1 (nkeys = position + 1 encodes the causal mask).
 // ------------------------------------------------------------------------------------------
 namespace {
+// Round 5: 16-byte accesses throughout.  The first version read every key row element by element (64 scalar loads per lane and key)
+// and walked the keys one at a time in the weighted sums (n iterations of 2-byte loads / stores per lane): 29 / 50 us per call at
+// b = 512 on the critical path of a step (end of forward, start of backward, both towers at once).  Now: scores with 8 x ld8 per key row;
+// weighted sums with lane = (key group lane >> 3, 8-column chunk lane & 7), 8 keys per iteration, partial sums combined by shuffles.
+__device__ __forceinline__ float dot8(const float* a, const float* b) {
+  return ((a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3])) + ((a[4] * b[4] + a[5] * b[5]) + (a[6] * b[6] + a[7] * b[7]));
+}
+// sum over the 8 key groups (lanes that differ in bits 3..5)
+__device__ __forceinline__ float kg_sum(float v) {
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void attn_pooled_fwd_kernel(const T* __restrict__ q, const T* __restrict__ kv, T* __restrict__ out,
                                                               float* __restrict__ lse, const int* __restrict__ row0,
                                                               const int* __restrict__ nkeys, int npairs, int heads, float scale) {
   __shared__ float ps[4][128];
-  __shared__ float qs[4][64];
+  __shared__ __attribute__((aligned(16))) float qs[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kg = lane >> 3, ch = lane & 7;
   const int d = heads * 64;
   for (int pair = blockIdx.x * 4 + wv; pair < npairs; pair += gridDim.x * 4) {
     const int bi = pair / heads, h = pair % heads;
@@ -754,7 +770,12 @@ __global__ __launch_bounds__(256) void attn_pooled_fwd_kernel(const T* __restric
       if (key < n) {
         acc = 0.f;
         const T* kr = kv + (r0 + key) * (2L * d) + h * 64;
-        for (int c = 0; c < 64; ++c) acc += qs[wv][c] * ld<T>(kr + c);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float kf[8];
+          ld8(kr + 8 * c, kf);
+          acc += dot8(&qs[wv][8 * c], kf);
+        }
         acc *= scale;
       }
       s[j] = acc;
@@ -766,9 +787,17 @@ __global__ __launch_bounds__(256) void attn_pooled_fwd_kernel(const T* __restric
     ps[wv][lane + 64] = p1 / sum;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS written by some lanes is read by others of the same wave
     __builtin_amdgcn_wave_barrier();
-    float o = 0.f;
-    for (int key = 0; key < n; ++key) o += ps[wv][key] * ld<T>(kv + (r0 + key) * (2L * d) + d + h * 64 + lane);
-    st<T>(out + (long)bi * d + h * 64 + lane, o);
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int key = kg; key < n; key += 8) {
+      float vf[8];
+      ld8(kv + (r0 + key) * (2L * d) + d + h * 64 + 8 * ch, vf);
+      const float pk = ps[wv][key];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) o[x] += pk * vf[x];
+    }
+#pragma unroll
+    for (int x = 0; x < 8; ++x) o[x] = kg_sum(o[x]);
+    if (kg == 0) st8_fast(out + (long)bi * d + h * 64 + 8 * ch, o);
     if (lane == 0) lse[pair] = mx + __logf(sum);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS written by some lanes is read by others of the same wave
     __builtin_amdgcn_wave_barrier();
@@ -783,8 +812,9 @@ __global__ __launch_bounds__(256) void attn_pooled_bwd_kernel(const T* __restric
                                                               const int* __restrict__ row0, const int* __restrict__ nkeys, int npairs,
                                                               int heads, float scale) {
   __shared__ float ps[4][128], ds[4][128];
-  __shared__ float qs[4][64], gs[4][64];
+  __shared__ __attribute__((aligned(16))) float qs[4][64], gs[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kg = lane >> 3, ch = lane & 7;
   const int d = heads * 64;
   for (int pair = blockIdx.x * 4 + wv; pair < npairs; pair += gridDim.x * 4) {
     const int bi = pair / heads, h = pair % heads;
@@ -803,7 +833,14 @@ __global__ __launch_bounds__(256) void attn_pooled_bwd_kernel(const T* __restric
       if (key < n) {
         const T* kr = kv + (r0 + key) * (2L * d) + h * 64;
         float sc = 0.f, g = 0.f;
-        for (int c = 0; c < 64; ++c) { sc += qs[wv][c] * ld<T>(kr + c); g += gs[wv][c] * ld<T>(kr + d + c); }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float kf[8], vf[8];
+          ld8(kr + 8 * c, kf);
+          ld8(kr + d + 8 * c, vf);
+          sc += dot8(&qs[wv][8 * c], kf);
+          g += dot8(&gs[wv][8 * c], vf);
+        }
         p[j] = __expf(sc * scale - l);
         dp[j] = g;
       }
@@ -813,15 +850,23 @@ __global__ __launch_bounds__(256) void attn_pooled_bwd_kernel(const T* __restric
     for (int j = 0; j < 2; ++j) { ps[wv][lane + 64 * j] = p[j]; ds[wv][lane + 64 * j] = p[j] * (dp[j] - D) * scale; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS written by some lanes is read by others of the same wave
     __builtin_amdgcn_wave_barrier();
-    float aq = 0.f;
-    const float qd = qs[wv][lane], gd = gs[wv][lane];
-    for (int key = 0; key < n; ++key) {
-      const long ro = (r0 + key) * (2L * d) + h * 64 + lane;
-      aq += ds[wv][key] * ld<T>(kv + ro);
-      st<T>(dkv + ro, ds[wv][key] * qd);             // dK[key][lane]
-      st<T>(dkv + ro + d, ps[wv][key] * gd);         // dV[key][lane]
+    float aq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float qd[8], gd[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) { qd[x] = qs[wv][8 * ch + x]; gd[x] = gs[wv][8 * ch + x]; }
+    for (int key = kg; key < n; key += 8) {
+      const long ro = (r0 + key) * (2L * d) + h * 64 + 8 * ch;
+      float kf[8], ok[8], ov[8];
+      ld8(kv + ro, kf);
+      const float dsk = ds[wv][key], psk = ps[wv][key];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) { aq[x] += dsk * kf[x]; ok[x] = dsk * qd[x]; ov[x] = psk * gd[x]; }
+      st8_fast(dkv + ro, ok);                        // dK[key][8 ch ..]
+      st8_fast(dkv + ro + d, ov);                    // dV[key][8 ch ..]
     }
-    st<T>(dq + (long)bi * d + h * 64 + lane, aq);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) aq[x] = kg_sum(aq[x]);
+    if (kg == 0) st8_fast(dq + (long)bi * d + h * 64 + 8 * ch, aq);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS written by some lanes is read by others of the same wave
     __builtin_amdgcn_wave_barrier();
   }
