@@ -657,7 +657,7 @@ def _w_clip_world4(rank, world, port, out):
         out.put("ok")
 
 
-@pytest.mark.parametrize("world", [4])
+@pytest.mark.parametrize("world", [4, 8])          # (8: the driver's largest scaling point; b = 3 per rank, B = 24)
 def test_world4_clip_step(world):
     port = _free_port()
     ctx = mp.get_context("spawn")
