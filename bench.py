@@ -459,7 +459,10 @@ def main():
         from declip_amd.prefetch import DataPrefetcher
         pool = synth.synth_decoded_batches(b, n_batches=6, seed=rank)
         tok = NativeTokenizer(synth.synthetic_bpe_file(os.path.join(tempfile.gettempdir(), "dh_synthetic_bpe.txt.gz")))
-        pipeline = DataPrefetcher(itertools.cycle(pool), dev, tokenizer=tok, context_length=77, image_size=224)
+        # W > 1: the padded packed row count of every batch is the MAX over the ranks (dist.RowsSync on the prefetcher's worker thread),
+        # so that all ranks key, capture and replay their step graphs in lock-step
+        pipeline = DataPrefetcher(itertools.cycle(pool), dev, tokenizer=tok, context_length=77, image_size=224,
+                                  rows_sync=dh_dist.RowsSync() if (world > 1 or forced) else None)
 
     from declip_amd.graph import GraphedStep
     graph_key = None
@@ -494,7 +497,8 @@ def main():
                 static_ids.copy_(nxt["captions"])
                 tag = getattr(nxt["captions"], "_dh_rows", None)
                 if tag is not None:
-                    eng_mod.set_rows_tag(static_ids, tag[1])      # the host-side row count the prefetcher's worker took
+                    pad = getattr(nxt["captions"], "_dh_rows_pad", None)
+                    eng_mod.set_rows_tag(static_ids, tag[1], rows_pad=None if pad is None else pad[1])      # the host-side row count the prefetcher's worker took (+ the job-wide padded count)
             else:
                 batch["images"], batch["captions"] = nxt["images"], nxt["captions"]
         opt.zero_grad()
@@ -780,6 +784,7 @@ def main():
                            native_blocks=int(eng_mod.native_blocks()),
                            text_packed=eng_mod.text_packed_mode(), pooled_last=int(eng_mod.pooled_last_block())),   # captions computed up to <|endoftext|> only; last block for the pooled rows only (same outputs, fewer executed flops: see roofline.executed_gemm_gflop_per_pair)
                loss=round(float(loss.detach()) * world, 5))
+    out["peak_mem_gb"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)      # torch allocator high-water mark of this rank (activations of a step + parameters + moments + workspaces)
     out["per_rank_ms"] = per_rank_ms
     out["graph_fallback"] = graph_fallback          # None: the step ran as configured (config.step_graph)
     if comm_timing is not None:

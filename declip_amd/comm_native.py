@@ -1,8 +1,8 @@
 """The step's collectives through the library's own communicator context (include/declip_hip.h: dh_init, dh_allgather_packed,
 dh_reducescatter_packed, dh_allreduce_bucket -- RCCL on a library-owned communication stream, csrc/comm.hip).
 
-Opt-in (`DH_COMM_NATIVE=1`, read by declip_amd.dist.initialize): the default data-parallel path runs the same three collectives
-through torch.distributed's ProcessGroupNCCL (= RCCL).  What this path changes: the feature tensors are packed by one kernel
+The default under an nccl process group since round 6 (`DH_COMM_NATIVE=0` opts out; read by declip_amd.dist.initialize): the alternative
+runs the same three collectives through torch.distributed's ProcessGroupNCCL (= RCCL) and is never captured into a step graph.  What this path changes: the feature tensors are packed by one kernel
 straight into the own slot of the gathered buffer (no torch.cat, in-place all-gather), the gradient split after the
 reduce-scatter is one kernel, the bf16 bucket casts run on the communication stream, and the ordering against the compute
 streams is the context's two events instead of ProcessGroupNCCL's bookkeeping.  The process group is still used to hand the

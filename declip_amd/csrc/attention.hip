@@ -10,6 +10,7 @@
 //         dV = P^T dO, dK = dS^T Q, dQ = dS K  (all five products on MFMA).
 // fp32 path (validation precision): same math, scalar FMA, any head dim <= 64.
 #include "dh_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -575,6 +576,8 @@ int launch_bwd_mfma(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
 }
 
 }  // namespace
+
+
 
 #define DISPATCH_NKB(nkb, CALL)                 \
   switch (nkb) {                                \

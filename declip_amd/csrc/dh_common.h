@@ -114,6 +114,35 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// Wave reductions on the DPP cross-lane path (round 6).  __shfl_xor compiles to ds_bpermute_b32 -- a round trip through the LDS
+// crossbar, ~100 cycles each, six of them in a dependent chain per reduction: the LayerNorm kernels (two / four dependent
+// reductions per row) spent most of a row's time there.  Here: quad_perm x2, row_half_mirror, row_mirror (every lane of a 16-lane
+// row then holds the row's value), row_bcast15 / row_bcast31 (lane 63 holds the wave's), one v_readlane -- 6 VALU + 1 readlane, no LDS.
+// The summation ORDER differs from the xor butterfly (same value up to fp32 rounding); index-producing kernels keep wave_sum / wave_max.
+#ifndef DH_HOST_EMU
+#define DH_DPP(old, v, ctrl, rm) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(v)), (ctrl), (rm), 0xF, false))
+__device__ __forceinline__ float wave_sum_fast(float v) {
+  v += DH_DPP(0.f, v, 0xB1, 0xF);      // quad_perm [1,0,3,2]
+  v += DH_DPP(0.f, v, 0x4E, 0xF);      // quad_perm [2,3,0,1]
+  v += DH_DPP(0.f, v, 0x141, 0xF);     // row_half_mirror
+  v += DH_DPP(0.f, v, 0x140, 0xF);     // row_mirror: every lane of a row holds the row sum
+  v += DH_DPP(0.f, v, 0x142, 0xA);     // row_bcast15 into rows 1, 3
+  v += DH_DPP(0.f, v, 0x143, 0xC);     // row_bcast31 into rows 2, 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_fast(float v) {
+  v = fmaxf(v, DH_DPP(v, v, 0xB1, 0xF));
+  v = fmaxf(v, DH_DPP(v, v, 0x4E, 0xF));
+  v = fmaxf(v, DH_DPP(v, v, 0x141, 0xF));
+  v = fmaxf(v, DH_DPP(v, v, 0x140, 0xF));
+  v = fmaxf(v, DH_DPP(v, v, 0x142, 0xA));
+  v = fmaxf(v, DH_DPP(v, v, 0x143, 0xC));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#else
+__device__ __forceinline__ float wave_sum_fast(float v) { return wave_sum(v); }
+__device__ __forceinline__ float wave_max_fast(float v) { return wave_max(v); }
+#endif
 // block reductions for blockDim.x == 256 (4 waves); `red` is >= 8 floats of LDS
 __device__ __forceinline__ float block_sum256(float v, float* red) {
   v = wave_sum(v);

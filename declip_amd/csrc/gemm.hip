@@ -317,7 +317,6 @@ int launch_mfma(const dh_gemm_args* a, const EpiParams& e, int split, int kps, h
 bool dh_gemm_try_glds(const dh_gemm_args* a, int split, hipStream_t st);  // gemm_glds.hip
 bool dh_gemm_try_v3(const dh_gemm_args* a, int split, hipStream_t st);    // gemm_v3.hip
 bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st);
-bool dh_gemm_try_v6(const dh_gemm_args* a, hipStream_t st);    // gemm_v4.hip
 
 // launches per kernel family since the last reset: [0] v4 persistent 256x256, [1] v3, [2] v2 LDS-DMA 128x128, [3] v1 MFMA tiles,
 // [4] generic (VALU).  The parity tests assert with it that a fixture really ran on the benchmarked kernel.
@@ -373,12 +372,6 @@ extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
 
   if (a->a_colsum) DH_REQUIRE(a->a_kmajor, "dh_gemm: a_colsum needs a_kmajor");
   // v2 (LDS-DMA + transpose-read) kernel when shapes/alignments allow it (fuses a_colsum)
-  if ((a->force_generic == 0 || a->force_generic == 6) && dh_gemm_try_v6(a, st)) {      // round-5 experiment, opt-in (DH_GEMM_V6=1): two 4-wave workgroups per CU
-    ++g_gemm_family_calls[0];
-    DH_CHECK_LAUNCH();
-    return DH_OK;
-  }
-  DH_REQUIRE(a->force_generic != 6, "dh_gemm: the v6 kernel does not take this problem (or DH_GEMM_V6 is not 1)");
   if ((a->force_generic == 0 || a->force_generic == 4) && dh_gemm_try_v4(a, split, st)) {
     ++g_gemm_family_calls[0];
     DH_CHECK_LAUNCH();
@@ -396,12 +389,13 @@ extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
     a = &first_touch;
     e.accumulate = 1;
   }
-  if (a->force_generic == 0 && dh_gemm_try_v3(a, split, st)) {
+  if ((a->force_generic == 0 || (a->force_generic >= 31 && a->force_generic <= 33)) && dh_gemm_try_v3(a, split, st)) {
     ++g_gemm_family_calls[1];
     DH_CHECK_LAUNCH();
     return DH_OK;
   }
-  if ((a->force_generic == 0 || a->force_generic == 3) && dh_gemm_try_glds(a, split, st)) {
+  const bool v3_pref = a->force_generic >= 31 && a->force_generic <= 33;     // (a preference, not a demand: what v3 declines goes on like auto)
+  if ((a->force_generic == 0 || a->force_generic == 3 || v3_pref) && dh_gemm_try_glds(a, split, st)) {
     ++g_gemm_family_calls[2];
     DH_CHECK_LAUNCH();
     return DH_OK;

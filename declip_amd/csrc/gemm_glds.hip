@@ -358,7 +358,9 @@ bool dh_gemm_try_glds(const dh_gemm_args* a, int split, hipStream_t st) {
   int wmr = 2;
   const long tiles256 = (long)dh_cdiv(a->M, 256) * dh_cdiv(a->N, BN) * split;
   (void)tiles256;   // measured: 128 x 128 (2 blocks/CU) beats 256 x 128 (1 block/CU) on every tower shape
-  if (const char* ev = getenv("DH_GEMM_TILE")) { int v = atoi(ev); if (v == 128) wmr = 2; else if (v == 256 && a->M >= 256) wmr = 4; }
+  static int tile_env = -1;     // DH_GEMM_TILE (A/B switch), read once
+  if (tile_env < 0) { const char* ev = getenv("DH_GEMM_TILE"); tile_env = ev ? atoi(ev) : 0; }
+  if (tile_env == 256 && a->M >= 256) wmr = 4;
   if (a->a_kmajor && a->b_kmajor) launch<true, true>(a, e, split, kps, wmr, st);
   else if (a->a_kmajor) launch<true, false>(a, e, split, kps, wmr, st);
   else if (a->b_kmajor) launch<false, true>(a, e, split, kps, wmr, st);

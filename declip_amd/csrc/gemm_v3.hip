@@ -324,9 +324,10 @@ bool dh_gemm_try_v3(const dh_gemm_args* a, int split, hipStream_t st) {
   static int mode = -2;
   if (mode == -2) { const char* ev = getenv("DH_GEMM_V3"); mode = ev ? atoi(ev) : -1; }
   int m = mode;
-  if (const char* ev = getenv("DH_GEMM_V3_DYN")) m = atoi(ev);   // re-read per call (micro-benchmarks)
+  const bool forced = a->force_generic >= 31 && a->force_generic <= 33;     // dh_gemm_args.force_generic 31 / 32 / 33: this kernel with tile mode 1 / 2 / 3 (tests)
+  if (forced) m = a->force_generic - 30;
   if (m == 0) return false;
-  if (a->dtype != DH_BF16 || a->force_generic) return false;
+  if (a->dtype != DH_BF16 || (a->force_generic && !forced)) return false;
   if ((a->lda % 8) || (a->ldb % 8) || ((uintptr_t)a->A & 15) || ((uintptr_t)a->B & 15)) return false;
   if (a->M < 256 && m != 3) return false;
   if (!a->pad_ok) {

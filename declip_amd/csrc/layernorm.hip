@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     if (row0 + nwaves * R < rows) fetch(row0 + nwaves * R);
     float mu[R], rs[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) mu[r] = wave_sum(s[r]) / d;
+    for (int r = 0; r < R; ++r) mu[r] = wave_sum_fast(s[r]) / d;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       float q = 0.f;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
           for (int i = 0; i < 8; ++i) { float t = v[r][c][i] - mu[r]; q += t * t; }
         }
-      rs[r] = rsqrtf(wave_sum(q) / d + eps);
+      rs[r] = rsqrtf(wave_sum_fast(q) / d + eps);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, NCH <= 2 ? 4 : 2) void ln_bwd_bf16_kernel(cons
         }
       }
     }
-    const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
+    const float c1 = wave_sum_fast(s1) / d, c2 = wave_sum_fast(s2) / d;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       // opaque to the optimiser: the unpacked floats of the statistics pass must die there, not be carried to this pass

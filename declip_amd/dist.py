@@ -60,6 +60,9 @@ def initialize(backend="nccl"):
     backend = os.environ.get("DH_DIST_BACKEND", backend)     # e.g. gloo: several ranks sharing one GPU (RCCL refuses that)
     if torch.cuda.is_available():
         torch.cuda.set_device(get_local_rank())
+        if "DH_V4_DYNAMIC" in os.environ:       # the library reads the environment once, at its first launch: say it explicitly
+            from . import ops
+            ops.set_v4_dynamic(int(os.environ["DH_V4_DYNAMIC"]))
     else:
         backend = "gloo"
     kw = {}
@@ -71,14 +74,18 @@ def initialize(backend="nccl"):
     if backend == "nccl" and torch.cuda.is_available() and os.environ.get("DH_PG_DEVICE_ID", "0") == "1":
         kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
     tdist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
-    if os.environ.get("DH_COMM_NATIVE", "0") == "1" and torch.cuda.is_available():
-        # the step's three collectives on the library's own communicator context (csrc/comm.hip) instead of ProcessGroupNCCL
+    if backend == "nccl" and torch.cuda.is_available() and os.environ.get("DH_COMM_NATIVE", "1") == "1":
+        # the step's three collectives on the library's own communicator context (csrc/comm.hip) instead of ProcessGroupNCCL: the
+        # DEFAULT since round 6 -- a step captured with them contains no ProcessGroupNCCL work object and never pulls the group's
+        # internal stream into a capture (graph.GraphedStep._check_capturable); measured equal or faster than the process group on a
+        # one-rank group (profiles/r05_multi_gpu_default_path.txt).  The process group stays for parameter broadcast, barriers and
+        # object exchange.  DH_COMM_NATIVE=0: ProcessGroupNCCL collectives, eager step only.
         from . import comm_native
         comm_native.bootstrap(get_local_rank())
 
 
 def native_comm():
-    """The library-owned communicator context (declip_amd.comm_native) when DH_COMM_NATIVE=1 set one up, else None."""
+    """The library-owned communicator context (declip_amd.comm_native; the default under an nccl group, DH_COMM_NATIVE=0 opts out), else None."""
     from . import comm_native
     return comm_native.context()
 
@@ -390,6 +397,32 @@ class DistModule(torch.nn.Module):
         self._flat.params_changed()
         for b in self.module.buffers():
             tdist.broadcast(b, 0)
+
+
+class RowsSync(object):
+    """Rank-uniform padded row count of a packed caption batch: MAX over the ranks of each rank's own padded count, as ONE host-side
+    all-reduce of one integer on a gloo group of its own -- issued by the input prefetcher's worker thread one batch ahead of the
+    step (prefetch.DataPrefetcher(rows_sync=...)), so it never sits on the step's critical path and never touches a GPU stream.
+    Every rank pads its packed rows up to that count (engine.PackedCaptions), which makes the shape of the step -- the key of its
+    captured graph (engine.packed_key) -- the same on all ranks: they capture and replay in lock-step (VERDICT r5 #4b; the
+    reference's ranks run identical eager steps, utils/dist.py:63-88).  Not distributed: the identity."""
+
+    def __init__(self, dtype=torch.bfloat16):
+        self.dtype = dtype
+        self.group = None
+        if is_dist():
+            self.group = tdist.new_group(backend="gloo")      # (collective: every rank constructs its RowsSync at the same point)
+        self.calls = 0
+
+    def __call__(self, rows):
+        from .engine import padded_rows
+        mine = padded_rows(rows, self.dtype)
+        self.calls += 1
+        if self.group is None:
+            return mine
+        t = torch.tensor([mine], dtype=torch.int64)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX, group=self.group)
+        return int(t[0])
 
 
 def broadcast_object(obj, src=0):

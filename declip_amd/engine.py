@@ -1048,11 +1048,20 @@ class PackedCaptions:
             ids._dh_rows = (ids._version, total)
         self.b, self.L, self.rows = b, L, total
         self.rows_pad = rows_pad = (total + tile - 1) // tile * tile
+        # a job-wide padded row count (set_rows_tag(rows_pad=...): the MAX over the ranks of a data-parallel job, dist.RowsSync) pads
+        # this rank's rows further, so that every rank runs -- and captures -- a step of the same shape; the extra rows are more of
+        # the zero rows behind the last caption
+        forced = getattr(ids, "_dh_rows_pad", None)
+        forced = forced[1] if (forced is not None and forced[0] == ids._version) else None
+        if forced is not None:
+            if forced < rows_pad or forced % tile:
+                raise DeclipHipError("PackedCaptions: job-wide padded row count %d does not hold this rank's %d rows (tile %d)" % (forced, total, tile))
+            self.rows_pad = rows_pad = forced
         if tag is not None and tag[0] == ids._version and hasattr(torch, "_assert_async"):
             # a host-side count that does not fit the device's fails loudly (device-side assert, no read-back).  What is checked is
             # the padded size, not `total` itself: a captured step is replayed for other batches of the same rows_pad
             n_dev = lens.sum()
-            torch._assert_async((n_dev <= rows_pad) & (n_dev > rows_pad - tile))
+            torch._assert_async((n_dev <= rows_pad) if forced is not None else ((n_dev <= rows_pad) & (n_dev > rows_pad - tile)))
         # Every index tensor below has a shape that depends on rows_pad only (never on `total`), and no launch argument carries
         # `total`: the whole bookkeeping is capturable, and a step captured for one batch replays for any batch with the same
         # rows_pad (graph.GraphedStep keys its graphs by it).  The rows [total, rows_pad) are a dummy run behind the last caption:
@@ -1169,13 +1178,27 @@ def packed_key(ids, dtype=torch.bfloat16, heads_dim=64):
         raise DeclipHipError("packed_key: the caption tensor carries no host-side row count (engine.set_rows_tag)")
     tile = 256 if dtype == torch.bfloat16 else 8
     rows_pad = (tag[1] + tile - 1) // tile * tile
+    forced = getattr(ids, "_dh_rows_pad", None)
+    if forced is not None and forced[0] == ids._version:
+        rows_pad = max(rows_pad, forced[1])              # the job-wide padded row count: the same key on every rank
     return (rows_pad,) if (dtype == torch.bfloat16 and heads_dim == 64) else (rows_pad, tag[1])
 
 
-def set_rows_tag(ids, rows):
+def padded_rows(rows, dtype=torch.bfloat16):
+    """Padded packed row count of a batch with `rows` caption rows (whole 256-row GEMM tiles in bf16)."""
+    tile = 256 if dtype == torch.bfloat16 else 8
+    return (int(rows) + tile - 1) // tile * tile
+
+
+def set_rows_tag(ids, rows, rows_pad=None):
     """Attach the host-side packed row count (tokens up to and including <|endoftext|>, summed over the batch) to a caption
-    tensor: the text tower then never reads it back from the device (prefetch.DataPrefetcher does this for the batches it uploads)."""
+    tensor: the text tower then never reads it back from the device (prefetch.DataPrefetcher does this for the batches it uploads).
+    `rows_pad`: the job-wide padded row count (dist.RowsSync) this rank pads up to."""
     ids._dh_rows = (ids._version, int(rows))
+    if rows_pad is not None:
+        ids._dh_rows_pad = (ids._version, int(rows_pad))
+    elif hasattr(ids, "_dh_rows_pad"):
+        del ids._dh_rows_pad
     return ids
 
 

@@ -81,27 +81,24 @@ class GraphedStep(object):
         import torch.distributed as tdist
         return "thread_local" if (tdist.is_available() and tdist.is_initialized()) else "global"
 
-    @staticmethod
-    def _drain_process_group():
-        """Called right before a capture, after torch.cuda.synchronize().  ProcessGroupNCCL's watchdog thread keeps every eager
-        collective in a list until its next sweep (every 100 ms) finds the end event complete -- it polls with hipEventQuery.  Once
-        the capture pulls the group's internal stream in, HIP answers such a query with hipErrorCapturedEvent ("event last recorded
-        in a capturing stream": it looks at the stream's state NOW, not at the record), the watchdog rethrows and the process dies
-        (seen in 1 of ~10 captured one-rank RCCL steps on the MI355X, round 5).  Everything enqueued is complete at this point, so
-        one second lets the watchdog retire the whole list; collectives issued DURING the capture are never handed to it."""
-        import time
-        import torch.distributed as tdist
-        if tdist.is_available() and tdist.is_initialized() and tdist.get_backend() == "nccl":
-            import os
-            time.sleep(float(os.environ.get("DH_GRAPH_PG_DRAIN_S", "1.0")))
-
     def _check_capturable(self):
+        """A data-parallel step is captured only when its three collectives run on the LIBRARY's communicator (csrc/comm.hip through
+        declip_amd.comm_native: RCCL on a library-owned stream, ordered with two events).  Then no ProcessGroupNCCL work object is
+        created inside the capture and the group's internal stream is never pulled into it -- which is what made the watchdog
+        thread's event polling fatal in round 5 (hipErrorCapturedEvent, 1 run in ~10; it was papered over with a one-second sleep
+        before every capture, removed in round 6).  Collectives on a ProcessGroup (gloo: host-side; nccl without the library
+        communicator) are refused: the step runs eagerly."""
         import torch.distributed as tdist
+        from . import dist as dh_dist
         for st in self.stores:
             red = getattr(st, "reducer", None)
-            if red is not None and red.distributed() and tdist.is_initialized() and tdist.get_backend() != "nccl":
-                raise RuntimeError("GraphedStep: the gradient collectives of this step run on a '%s' process group (host-side "
-                                   "collectives cannot be captured in a HIP graph); run the step eagerly" % tdist.get_backend())
+            if red is not None and red.distributed() and tdist.is_initialized():
+                if tdist.get_backend() != "nccl":
+                    raise RuntimeError("GraphedStep: the gradient collectives of this step run on a '%s' process group (host-side "
+                                       "collectives cannot be captured in a HIP graph); run the step eagerly" % tdist.get_backend())
+                if dh_dist.native_comm() is None:
+                    raise RuntimeError("GraphedStep: a data-parallel step is captured only with the library communicator "
+                                       "(DH_COMM_NATIVE=1, the default under an nccl group); ProcessGroupNCCL collectives are not captured")
 
     def __call__(self):
         if not self.enabled:
@@ -124,47 +121,66 @@ class GraphedStep(object):
         if not self.fallback:
             self._check_capturable()
             torch.cuda.synchronize()
-            self._drain_process_group()
             g = torch.cuda.CUDAGraph()
             if self.pool is None:
                 self.pool = torch.cuda.graph_pool_handle()
             # the capture stream is a fresh side stream (torch.cuda.graph's default): the engine's own side streams fork from it
             with torch.cuda.graph(g, pool=self.pool, capture_error_mode=self._capture_mode()):
                 out = self.fn()
+            g.replay()                          # the captured launches did not execute during capture
         else:
+            # fallback mode (every rank of a data-parallel job): the capture AND the first replay (RCCL errors surface at launch, not at
+            # capture) sit inside the try, and the ranks agree on the outcome after each of the two -- a rank whose first graph launch
+            # fails must not leave its peers waiting in replayed collectives
             g, out, err = None, None, None
+
+            def _agreed(ok, what):
+                if self.agree is None:
+                    return ok, None
+                try:
+                    torch.cuda.synchronize()
+                except Exception:               # noqa: BLE001
+                    pass
+                all_ok = bool(self.agree(ok))
+                return all_ok, ("a peer rank could not %s its step" % what if ok and not all_ok else None)
+
             try:
                 self._check_capturable()
                 torch.cuda.synchronize()
-                self._drain_process_group()
                 g = torch.cuda.CUDAGraph()
                 if self.pool is None:
                     self.pool = torch.cuda.graph_pool_handle()
                 with torch.cuda.graph(g, pool=self.pool, capture_error_mode=self._capture_mode()):
                     out = self.fn()
             except Exception as e:              # noqa: BLE001  (whatever the runtime raises: the eager step is the answer to all of it)
-                err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
-            ok = err is None
-            if self.agree is not None:
+                err = "capture: %s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+            ok, peer = _agreed(err is None, "capture")
+            err = err or peer
+            if ok:
                 try:
+                    g.replay()                  # the captured launches did not execute during capture
                     torch.cuda.synchronize()
-                except Exception:               # noqa: BLE001
-                    pass
-                all_ok = bool(self.agree(ok))
-                if ok and not all_ok:
-                    err = "a peer rank could not capture its step"
-                ok = all_ok
+                except Exception as e:          # noqa: BLE001
+                    err = "first replay: %s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+                ok, peer = _agreed(err is None, "replay")
+                err = err or peer
+                if not ok and err.startswith("a peer"):
+                    # this rank's replay DID run (its gradients and outputs are those of one step): hand them out, go eager from the next call on
+                    self.enabled, self.fallback_reason = False, "first replay failed on a peer rank, step runs eagerly from now on (%s)" % err
+                    for st in self.stores:
+                        st.after_replay()
+                    return out
             if not ok:
                 self.enabled, self.fallback_reason = False, "capture failed, step runs eagerly (%s)" % err
                 for st in self.stores:          # a backward that died inside the capture never reached its end-of-pass callback
                     st._in_backward = False
+                assert not torch.cuda.is_current_stream_capturing(), "GraphedStep: the stream is still capturing after a failed capture"
                 return self.fn()
         self.captures += 1
         self.graphs[k] = (g, out)
         while len(self.graphs) > self.max_graphs:
             self.graphs.popitem(last=False)              # least recently used
         self.graph, self.out = g, out
-        g.replay()                              # the captured launches did not execute during capture
         for st in self.stores:
             st.after_replay()
         return self.out

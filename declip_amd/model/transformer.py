@@ -48,7 +48,13 @@ class Transformer(nn.Module):
 
     def __init__(self, width, layers, heads, attn_mask=None, checkpoint=False, dropout=0.0, emb_dropout=0.0):
         super().__init__()
-        self.width, self.layers, self.heads, self.checkpoint = width, layers, heads, checkpoint
+        if checkpoint:
+            # base_transformer.py:66-79 recomputes the blocks in the backward pass (torch.utils.checkpoint) to save activation memory.
+            # This engine keeps every block's activations (15 GB per step at b = 512 of the 288 GB) and has no
+            # recompute path: refuse the option instead of silently ignoring it (no shipped config sets it).
+            raise NotImplementedError("Transformer(checkpoint=True): activation recomputation is not implemented by the MI355X engine "
+                                      "(activations fit in HBM at the reference's batch sizes); build the model with checkpoint=False")
+        self.width, self.layers, self.heads, self.checkpoint = width, layers, heads, False
         self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask, dropout) for _ in range(layers)])
 
 

@@ -106,6 +106,11 @@ def gemm_stats(reset=False):
     return dict(v4=out[0], v3=out[1], glds=out[2], mfma_tiles=out[3], generic=out[4])
 
 
+def set_v4_dynamic(mode):
+    """Tile distribution of the persistent GEMM (0 static, 1 dynamic: include/declip_hip.h dh_gemm_v4_set_dynamic); returns the previous mode."""
+    return int(L.load().dh_gemm_v4_set_dynamic(int(mode)))
+
+
 def colsum(X, out, accumulate=True):
     _req(X.dim() == 2 and X.stride(1) == 1 and out.dtype == torch.float32 and out.numel() == X.shape[1], 'X.dim() == 2 and X.stride(1) == 1 and out.dtype == torch.float32 and out.numel() == X.shape[1]')
     check(L.load().dh_colsum(dt(X), ptr(X), X.stride(0), X.shape[0], X.shape[1], ptr(out), int(accumulate), stream()),

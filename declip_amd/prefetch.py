@@ -53,7 +53,7 @@ _END = object()
 HOST_KEYS = ("mlm_labels",)       # batch entries the step consumes on the host (never uploaded by the prefetcher)
 
 class DataPrefetcher(object):
-    def __init__(self, loader, device="cuda", tokenizer=None, context_length=77, depth=2, image_size=224, text_prep=None):
+    def __init__(self, loader, device="cuda", tokenizer=None, context_length=77, depth=2, image_size=224, text_prep=None, rows_sync=None):
         self.device = torch.device(device)
         self.image_hw = (image_size, image_size) if isinstance(image_size, int) else tuple(image_size)
         self.tokenizer, self.context_length = tokenizer, context_length
@@ -61,6 +61,10 @@ class DataPrefetcher(object):
         # this worker thread (DECLIP.prepare_captions: caption sampling, EDA augmentation, BPE, MLM masking -- declip.py:203-230
         # runs them inside forward(), a per-caption Python loop on the critical path)
         self.text_prep = text_prep
+        # rows_sync(rows) -> padded packed row count of the batch that EVERY rank of a data-parallel job will use (dist.RowsSync: MAX
+        # over the ranks of each rank's own padded count, a host-side collective on this worker thread, one batch ahead of the step):
+        # the key of the captured step (engine.packed_key) is then the same on all ranks, so they capture and replay in lock-step
+        self.rows_sync = rows_sync
         self._it = iter(loader)
         self._q = queue.Queue(maxsize=max(1, depth))
         self._cuda = self.device.type == "cuda"
@@ -89,6 +93,8 @@ class DataPrefetcher(object):
             # (numpy, NOT torch: a torch CPU reduction wakes an OpenMP team sized by the node's visible cores, whose spin-waiting
             # burns a container's CPU quota and gets the enqueueing thread throttled -- hostinfo.py)
             out["_caption_rows"] = int((caps.numpy().argmax(axis=-1) + 1).sum())
+            if self.rows_sync is not None:
+                out["_caption_rows_pad"] = int(self.rows_sync(out["_caption_rows"]))
         if self._cuda:
             for k, v in out.items():
                 if torch.is_tensor(v) and not v.is_cuda and not v.is_pinned():
@@ -98,9 +104,12 @@ class DataPrefetcher(object):
     @staticmethod
     def _tag_rows(batch):
         rows = batch.pop("_caption_rows", None)
+        rows_pad = batch.pop("_caption_rows_pad", None)
         caps = batch.get("captions")
         if rows is not None and torch.is_tensor(caps):
             caps._dh_rows = (caps._version, rows)       # all captions of the tensor ([b, ctx], or every variant of [b, k, ctx])
+            if rows_pad is not None:
+                caps._dh_rows_pad = (caps._version, rows_pad)   # the job-wide padded row count (engine.PackedCaptions pads up to it)
         return batch
 
     def _work(self):

@@ -461,14 +461,30 @@ class ClsSolver(object):
             bf16 = m.__dict__["_flat_store"].act_dtype == torch.bfloat16
             heads_dim = int(m.encode_text.width) // int(m.encode_text.heads)
             ok = mode == 0 or (mode == 1 and bf16 and heads_dim == 64)
-        # Data parallelism: graphs are keyed by each RANK's padded row count, so on one step some ranks would replay while others
-        # synchronise and capture, with their peers already inside replayed collectives.  Until the key is made rank-uniform the
-        # captured step of the solver is for one process; bench.py captures multi-rank steps of a resident batch (one key).
+        # Data parallelism: the graphs' key must be the same on every rank (a rank that captures while its peers replay would leave them
+        # waiting inside replayed collectives).  Round 6: it is -- the padded packed row count is the MAX over the ranks (dist.RowsSync, one
+        # host-side integer all-reduce per batch on the prefetcher's worker thread), every rank pads up to it -- and the step's collectives
+        # run on the library communicator, the only ones GraphedStep captures (graph._check_capturable).  Without it: the eager step.
         if ok and self.world_size > 1:
-            ok = False
+            from . import dist as dh_dist
+            if dh_dist.native_comm() is None:
+                ok = False
+                why = "world_size > 1 without the library communicator (DH_COMM_NATIVE=0 or a non-nccl process group)"
         if not ok:
             self._graph_off = True
+            if want and self.rank == 0:          # (say once why a requested captured step was declined)
+                self.logger.info("engine.step_graph / DH_STEP_GRAPH=1 declined, the step runs eagerly: %s" % (
+                    locals().get("why") or "needs kind == clip on a GPU, packed mode 0 or 1 with bf16 towers and head dimension 64, "
+                                           "and a grad_clip type that acts after backward"))
         return ok
+
+    def _rows_sync(self):
+        """dist.RowsSync of this solver (created on first use, on every rank at the same point of the step loop)."""
+        rs = self.__dict__.get("_rows_sync_obj")
+        if rs is None:
+            from . import dist as dh_dist
+            rs = self._rows_sync_obj = dh_dist.RowsSync(self.model.module.__dict__["_flat_store"].act_dtype)
+        return rs
 
     def _graphed_loss(self, batch):
         from . import engine
@@ -491,7 +507,13 @@ class ClsSolver(object):
                 out["loss"].backward()
                 return out["loss"].detach(), out["top1"].detach(), out["top5"].detach()
             key = (lambda: engine.packed_key(st["captions"], dtype, heads_dim)) if packed else None
-            g = dict(st, step=GraphedStep(fn, warmup=2, modules=(self.model,), key=key))
+            dist_on = self.world_size > 1
+
+            def agree(ok):
+                flag = torch.tensor([1.0 if ok else 0.0], device=self.device)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                return bool(float(flag) > 0.5)
+            g = dict(st, step=GraphedStep(fn, warmup=2, modules=(self.model,), key=key, fallback=dist_on, agree=agree if dist_on else None))
             self._graph = g
         g["images"].copy_(images)
         g["captions"].copy_(caps)
@@ -500,7 +522,11 @@ class ClsSolver(object):
             rows = int((caps.argmax(dim=-1) + 1).sum())          # one read-back for a tensor that came without its host-side count
             caps._dh_rows = (caps._version, rows)
             tag = caps._dh_rows
-        engine.set_rows_tag(g["captions"], tag[1])
+        pad = getattr(caps, "_dh_rows_pad", None)
+        pad = pad[1] if (pad is not None and pad[0] == caps._version) else None
+        if pad is None and self.world_size > 1 and engine.text_packed_mode() == 1:
+            pad = self._rows_sync()(tag[1])      # a batch that did not come through the prefetcher: the job-wide padded row count, here
+        engine.set_rows_tag(g["captions"], tag[1], rows_pad=pad)
         loss, p1, p5 = g["step"]()
         return dict(loss=loss, top1=p1, top5=p5)
 
@@ -551,8 +577,10 @@ class ClsSolver(object):
                 # them inside forward())
                 prep = m.prepare_captions if (hasattr(m, "prepare_captions") and getattr(tower, "_bpe_path", None)
                                               and os.path.exists(tower._bpe_path)) else None
+                from . import engine
+                rows_sync = self._rows_sync() if (self.world_size > 1 and self._graph_wanted() and engine.text_packed_mode() == 1) else None
                 self._iter = DataPrefetcher(self.loader, self.device, tokenizer=tok, context_length=int(tower.context_length), text_prep=prep,
-                                            image_size=int(d.get("input_size", 224)))
+                                            image_size=int(d.get("input_size", 224)), rows_sync=rows_sync)
             else:
                 self._iter = iter(self.loader)
         start = self.state["last_iter"] + 1

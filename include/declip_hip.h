@@ -81,7 +81,7 @@ typedef struct dh_gemm_args {
   int accumulate;
   int split_k;           /* >=1; >1 requires accumulate */
   float alpha;
-  int force_generic;     /* tests: 1 = VALU fp32-FMA kernel, 2 = v1 register-staged MFMA kernel, 3 = v2 LDS-DMA kernel, 4 = v4 256x256 ping-pong kernel (error if unsupported), 0 = auto */
+  int force_generic;     /* tests: 1 = VALU fp32-FMA kernel, 2 = v1 register-staged MFMA kernel, 3 = v2 LDS-DMA kernel, 4 = v4 256x256 ping-pong kernel (error if unsupported), 31 / 32 / 33 = prefer gemm_v3 with tile mode 1 / 2 / 3, 0 = auto */
   float* a_colsum;       /* optional, a_kmajor only: a_colsum[m] += sum_k A(m,k) (bias gradient fused into dW) */
   int pad_ok;            /* caller guarantees operand rows are readable (finite) up to the next multiple of 8
                             elements / 128 rows beyond M,N: lifts the M%8 / N%8 conditions of the MFMA kernels */
@@ -99,6 +99,10 @@ int dh_gemm_group(const dh_gemm_args* args, int n, dh_stream_t stream);
 /* Auto-dispatch switch for the 256 x 256 persistent kernel (on by default; DH_GEMM_V4=0 in the environment turns it off).
  * Returns the previous setting (-1 = default).  Used by the parity tests to run one model through both GEMM families. */
 int dh_gemm_v4_enable(int on);
+/* Tile distribution of the persistent kernel: 0 = static XCD-contiguous partition (one process per node), 1 = every workgroup's
+ * items after its first come from per-XCD counters (multi-GPU ranks: RCCL kernels hold CUs during the overlapped gradient
+ * all-reduce of utils/dist.py:63-88).  DH_V4_DYNAMIC in the environment is the default, read once.  Returns the previous setting. */
+int dh_gemm_v4_set_dynamic(int mode);
 /* dh_gemm launches per kernel family since the last reset: out5[0] persistent 256x256 (gemm_v4.hip), [1] gemm_v3.hip, [2] LDS-DMA
  * 128x128 (gemm_glds.hip), [3] MFMA-builtin tiles, [4] generic VALU kernel (gemm.hip).  Test instrumentation: lets a parity test
  * assert that a fixture ran on the kernel that bench.py measures.  Host counters, not thread-safe. */

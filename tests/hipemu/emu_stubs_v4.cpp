@@ -10,3 +10,4 @@ bool dh_maxsim_try_v4(const void*, const void*, int, int, int, int, int, float*,
 bool dh_ce_try_v4_fwd(const void*, const void*, const float*, const long long*, int, int, int, int, float*, float*, float*, int64_t, hipStream_t) { return false; }
 bool dh_ce_try_v4_bwd(const void*, const void*, const float*, const long long*, const float*, const float*, int, int, int, int, void*, int64_t, hipStream_t) { return false; }
 extern "C" int dh_gemm_v4_enable(int) { return 0; }
+extern "C" int dh_gemm_v4_set_dynamic(int) { return 0; }

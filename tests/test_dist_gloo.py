@@ -657,6 +657,48 @@ def _w_clip_world4(rank, world, port, out):
         out.put("ok")
 
 
+def _w_rows_sync_keys(rank, world, port, out):
+    """VERDICT r5 #4b: ranks whose caption batches have DIFFERENT packed row counts get the SAME step-graph key (the MAX over the ranks of
+    the padded count, one host-side all-reduce per batch on the prefetcher's worker thread), and each rank's PackedCaptions pads up to it."""
+    _init(rank, world, port)
+    from declip_amd import dist as dd
+    from declip_amd import engine
+    from declip_amd.prefetch import DataPrefetcher
+    ctx, V = 77, 49408
+    g = torch.Generator().manual_seed(100 + rank)
+
+    def batch(i):
+        # rank 0: short captions (a few hundred rows), rank 1: long ones -- different 256-row buckets in every batch
+        lo, hi = (3, 8) if rank == 0 else (40, 76)
+        b = 40 + 8 * i
+        ids = torch.zeros(b, ctx, dtype=torch.int64)
+        for r in range(b):
+            n = int(torch.randint(lo, hi, (1,), generator=g))
+            ids[r, :n] = torch.randint(1, V - 2, (n,), generator=g)
+            ids[r, n] = V - 1                                             # <|endoftext|> = the largest id
+        return {"captions": ids}
+    sync = dd.RowsSync(torch.bfloat16)
+    pf = DataPrefetcher([batch(i) for i in range(4)], "cpu", rows_sync=sync)
+    keys, own = [], []
+    for _ in range(4):
+        nb = pf.next()
+        caps = nb["captions"]
+        keys.append(engine.packed_key(caps, torch.bfloat16, 64))
+        own.append(engine.padded_rows(caps._dh_rows[1]))
+        pk = engine.PackedCaptions(caps, 256)
+        assert pk.rows_pad == keys[-1][0] and pk.rows == caps._dh_rows[1]
+        assert int((pk.pos_idx >= 0).sum()) == pk.rows                    # the extra rows are padding rows
+    assert pf.next() is None and sync.calls == 4
+    gathered = [None] * world
+    torch.distributed.all_gather_object(gathered, (keys, own))
+    assert gathered[0][0] == gathered[1][0], gathered                     # same keys on both ranks ...
+    for i in range(4):
+        assert gathered[0][0][i][0] == max(gathered[0][1][i], gathered[1][1][i])   # ... = the MAX of the ranks' own padded counts
+        assert gathered[0][1][i] < gathered[1][1][i]                      # (the ranks really differed)
+    if rank == 0:
+        out.put("ok")
+
+
 @pytest.mark.parametrize("world", [4, 8])          # (8: the driver's largest scaling point; b = 3 per rank, B = 24)
 def test_world4_clip_step(world):
     port = _free_port()
@@ -672,7 +714,7 @@ def test_world4_clip_step(world):
 
 
 @pytest.mark.parametrize("fn", [_w_meters_packed, _w_gather, _w_reducer, _w_reducer_gap, _w_clip, _w_clip_tower_twice, _w_clip_packed_pooled, _w_clip_r50, _w_clip_r50_syncbn, _w_zero_shot, _w_declip, _w_declip_global_bank, _w_filip, _w_slip, _w_defilip,
-                                _w_clip_bf16_buckets])
+                                _w_clip_bf16_buckets, _w_rows_sync_keys])
 def test_world2(fn):
     port = _free_port()
     ctx = mp.get_context("spawn")

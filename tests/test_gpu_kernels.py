@@ -505,10 +505,10 @@ def test_ce_rows_bwd_padded_layout():
 @pytest.mark.parametrize("mode", ["1", "2", "3"])                  # 256x128 / 256x256 / 128x128x3 tiles
 @pytest.mark.parametrize("a_km,b_km", [(False, False), (False, True), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(600, 520, 96), (256, 256, 32), (1000, 768, 320), (777, 264, 64)])
-def test_gemm_v3_tiles(monkeypatch, mode, a_km, b_km, M, N, K):
+def test_gemm_v3_tiles(mode, a_km, b_km, M, N, K):
     ops = _ops()
     from declip_amd.lib import EPI_GELU
-    monkeypatch.setenv("DH_GEMM_V3_DYN", mode)
+    fg = 30 + int(mode)                      # dh_gemm_args.force_generic 31 / 32 / 33: gemm_v3 with this tile mode (or an error)
     if a_km and M % 8:
         M = M // 8 * 8 + 8
     A = rnd(M, K, seed=1).to(torch.bfloat16)
@@ -520,16 +520,16 @@ def test_gemm_v3_tiles(monkeypatch, mode, a_km, b_km, M, N, K):
     if a_km and b_km:                                               # weight-gradient form: fp32 accumulate + fused colsum
         out = torch.zeros(M, N, device=cuda)
         cs = torch.zeros(M, device=cuda)
-        ops.gemm(Ad, Bd, a_kmajor=True, b_kmajor=True, out=out, accumulate=True, split_k=2 if K >= 64 else 1, a_colsum=cs)
+        ops.gemm(Ad, Bd, a_kmajor=True, b_kmajor=True, out=out, accumulate=True, split_k=2 if K >= 64 else 1, a_colsum=cs, force_generic=fg)
         assert rel_err(out, ref) < 2e-3
         assert rel_err(cs, A.double().sum(1)) < 1e-3
     else:
         aux = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
-        out = ops.gemm(Ad, Bd, a_kmajor=a_km, b_kmajor=b_km, bias=bias.to(cuda), epilogue=EPI_GELU, aux=aux)
+        out = ops.gemm(Ad, Bd, a_kmajor=a_km, b_kmajor=b_km, bias=bias.to(cuda), epilogue=EPI_GELU, aux=aux, force_generic=fg)
         pre = ref + bias.double()
         assert rel_err(aux, quick_gelu_grad(pre)) < 1.5e-2
         assert rel_err(out, quick_gelu(pre)) < 1.5e-2
-        out32 = ops.gemm(Ad, Bd, a_kmajor=a_km, b_kmajor=b_km, out_dtype=torch.float32)
+        out32 = ops.gemm(Ad, Bd, a_kmajor=a_km, b_kmajor=b_km, out_dtype=torch.float32, force_generic=fg)
         assert rel_err(out32, ref) < 2e-3
 
 

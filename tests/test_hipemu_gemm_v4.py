@@ -36,8 +36,15 @@ class _env:
     def __enter__(self):
         self.prev = {k: os.environ.get(k) for k in self.kv}
         os.environ.update(self.kv)
+        self.prev_dyn = None
+        if "DH_V4_DYNAMIC" in self.kv:          # (the library reads this switch once: set it through the C entry point)
+            from declip_amd import ops as _o
+            self.prev_dyn = _o.set_v4_dynamic(int(self.kv["DH_V4_DYNAMIC"]))
 
     def __exit__(self, *exc):
+        if self.prev_dyn is not None:
+            from declip_amd import ops as _o
+            _o.set_v4_dynamic(self.prev_dyn)
         for k, v in self.prev.items():
             if v is None:
                 os.environ.pop(k, None)
@@ -113,58 +120,12 @@ def test_v4_k_sliced_few_tile_schedule_emulated(ops, residual):
     assert rel_err(sliced, ref) < TOL and rel_err(plain, ref) < TOL
 
 
-@SLOW          # (the fix-up-kernel variant of the long-list tail: DH_V4_TAIL=2, kept for A/B runs; 44 s here)
-def test_v4_tail_sliced_schedule_emulated(ops):
-    """9 tiles on 8 compute units, 24 K-tiles: the tile of the last round is cut in K over the chip (whole items first, slices last,
-    both through the same continuous K-tile stream)."""
-    M, N, K = 2304, 256, 1536
-    A, B, bias = rnd(M, K, seed=14).to(bf), rnd(N, K, seed=15, scale=0.05).to(bf), rnd(N, seed=16)
-    ws = torch.empty((16 << 20) // 4, dtype=torch.float32)
-    with _env(DH_V4_TAIL=2):
-        sliced = ops.gemm(A, B, bias=bias, ws=ws, force_generic=4)
-    assert rel_err(sliced, A.double() @ B.double().t() + bias.double()) < TOL
-
-
-# (an opt-in schedule: the 30-second emulation runs with HIPEMU_SLOW=1, the GPU suite always covers it -- tests/test_gpu_gemm_v4.py)
-@pytest.mark.parametrize("M,K,residual,dyn", [pytest.param(2304, 512, False, 0, marks=SLOW), pytest.param(2560, 384, True, 0, marks=SLOW), pytest.param(2560, 512, False, 1, marks=SLOW)])
-def test_v4_tail_in_kernel_fixup_emulated(ops, M, K, residual, dyn):
-    """The in-kernel fix-up of K-sliced tail tiles (round 5, DH_V4_TAIL=4; opt-in like the fix-up-kernel variant -- it wins alone on the chip
-    and loses in the two-stream step): 9 / 10 tiles on 8 compute units, 8 (6) K-tiles -> the 1 / 2 tiles of
-    the last round are cut into 4 (3) K-slices; every slice parks its accumulators in the workspace (fragment order), counts itself on the
-    tile's arrival word, and the LAST one sums the four parked tiles in slice order and runs the ordinary bf16 epilogue -- no
-    fix-up launch.  Pinned here: the slot / fragment indexing, the arrival protocol (the emulation runs the workgroups one after the
-    other, so the last slice in list order is the one that fixes up), the counters back at zero (a second launch through the same
-    counters gives the same bits), agreement with the whole-tile schedule, and that no fix-up kernel ran."""
-    N = 256
-    A, B, bias = rnd(M, K, seed=14).to(bf), rnd(N, K, seed=15, scale=0.05).to(bf), rnd(N, seed=16)
-    R = rnd(M, N, seed=17).to(bf) if residual else None
-    ws = torch.full(((16 << 20) // 4,), float("nan"), dtype=torch.float32)      # a slot that is read before it is written poisons the tile
-    with _env(DH_V4_TAIL=4, DH_V4_TAIL_MINK=K // 64, DH_V4_TAIL_SMAX=4, DH_V4_DYNAMIC=dyn):
-        ops.gemm_stats(reset=True)
-        first = ops.gemm(A, B, bias=bias, residual=R, ws=ws, force_generic=4)
-        st = ops.gemm_stats()
-        second = ops.gemm(A, B, bias=bias, residual=R, ws=ws, force_generic=4)
-    assert st["v4"] == 1 and sum(st.values()) == 1, st
-    assert torch.isfinite(ws[:64 * 65536]).any()                    # the workspace was used: the launch was sliced
-    plain = ops.gemm(A, B, bias=bias, residual=R, force_generic=4)
-    ref = A.double() @ B.double().t() + bias.double() + (R.double() if residual else 0)
-    assert rel_err(first, ref) < TOL and rel_err(plain, ref) < TOL
-    assert torch.equal(first, second)
-    assert rel_err(first, plain.float()) < 4e-3                     # same products, fp32 sums regrouped by slice, one bf16 rounding
-
-
 @pytest.fixture
 def dynamic_tiles():
     """DH_V4_DYNAMIC=1 for one test: what declip_amd.dist.initialize selects for every multi-GPU job (items after a workgroup's first
     one come from per-XCD atomic counters; the general hand-over, never the incremental one)."""
-    import os
-    prev = os.environ.get("DH_V4_DYNAMIC")
-    os.environ["DH_V4_DYNAMIC"] = "1"
-    yield
-    if prev is None:
-        os.environ.pop("DH_V4_DYNAMIC", None)
-    else:
-        os.environ["DH_V4_DYNAMIC"] = prev
+    with _env(DH_V4_DYNAMIC=1):
+        yield
 
 
 def test_v4_dynamic_tile_distribution_emulated(ops, dynamic_tiles):

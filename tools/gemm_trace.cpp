@@ -1,5 +1,5 @@
 // Timeline of one v4 GEMM launch (trace build of the library: tools/build_trace.sh):
-//   LD_LIBRARY_PATH=build/trace tools/gemm_trace M N K epi(0 none,1 gelu)
+//   LD_LIBRARY_PATH=build/trace tools/gemm_trace M N K epi(0 none,1 gelu,2 dgelu [dX layout],3 residual,4 plain dX layout) dw stamps-per-tile
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <stdio.h>
@@ -9,7 +9,10 @@
 #include "declip_hip.h"
 int main(int argc, char** argv) {
   int M = argc > 1 ? atoi(argv[1]) : 25600, N = argc > 2 ? atoi(argv[2]) : 2304, K = argc > 3 ? atoi(argv[3]) : 768, epi = argc > 4 ? atoi(argv[4]) : 0;
-  int dw = argc > 5 ? atoi(argv[5]) : 0;   // 1: weight-gradient call (both operands contraction-major, fp32 accumulate, workspace, bias gradient)
+  int dw = argc > 5 ? atoi(argv[5]) : 0;
+  const int flavour = epi;                 // 2: dGELU (B contraction-major, aux = stored QuickGELU'); 3: residual; 4: plain dX layout
+  const bool bkm = flavour == 2 || flavour == 4;
+  if (flavour >= 3) epi = 0;   // 1: weight-gradient call (both operands contraction-major, fp32 accumulate, workspace, bias gradient)
   void* h = dlopen("libdeclip_hip.so", RTLD_NOW | RTLD_GLOBAL);
   auto rd = (int (*)(long*, int))dlsym(h, "dh_v4_trace_read");
   auto clr = (int (*)())dlsym(h, "dh_v4_trace_clear");
@@ -25,6 +28,9 @@ int main(int argc, char** argv) {
   dh_gemm_args g; memset(&g, 0, sizeof(g));
   g.dtype = DH_BF16; g.c_dtype = DH_BF16; g.M = M; g.N = N; g.K = K; g.A = A; g.lda = K; g.B = B; g.ldb = K; g.C = C; g.ldc = N;
   g.bias = bias; g.epilogue = epi; g.aux = epi ? X : nullptr; g.ldaux = N; g.alpha = 1.f; g.force_generic = 4; g.split_k = 1;
+  if (bkm) { g.b_kmajor = 1; g.ldb = N; g.bias = nullptr; }
+  if (flavour == 3) { g.residual = X; g.ldr = N; }
+  if (flavour == 2) hipMemset(X, 0x3f, (size_t)M * N * 2);
   if (dw) { g.a_kmajor = g.b_kmajor = 1; g.lda = M; g.ldb = N; g.c_dtype = DH_F32; g.accumulate = 1; g.bias = nullptr; g.ws = ws; g.ws_bytes = 256u << 20; g.a_colsum = bias; g.split_k = 8; }
   for (int i = 0; i < 200; ++i) dh_gemm(&g, nullptr);     // warm clocks
   hipDeviceSynchronize();
@@ -32,7 +38,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0); dh_gemm(&g, nullptr); hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  printf("M=%d N=%d K=%d epi=%d dw=%d: %.1f us (incl. the reduce pass for dw)\n", M, N, K, epi, dw, ms * 1e3);
+  printf("M=%d N=%d K=%d flavour=%d dw=%d: %.1f us (incl. the reduce pass for dw)\n", M, N, K, flavour, dw, ms * 1e3);
   std::vector<long> tb(6 * 256);
   rd(tb.data(), 6 * 256);
   // stamps per tile: 10 since the continuous K-tile stream of round 3 (tile started, K-tiles 0..nk-3 done, K-tile nk-2 done, main
