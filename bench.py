@@ -22,6 +22,32 @@ import torch  # noqa: E402
 
 GFLOP_PER_PAIR = 43.87          # CLIP ViT-B/32 fwd+bwd, SURVEY.md s8(d) / BASELINE.md s3
 GFLOP_PER_PAIR_R50 = 53.9       # CLIP ResNet-50 (configs[0]): trunk 10.73 + attention pool 1.28 + text 5.96 fwd, x3 minus the stem's dX
+
+
+def dense_gflop_per_pair(model, B):
+    """Algorithmic fwd + bwd GFLOP per image-text pair as the REFERENCE spends them (dense towers, 2 flop per MAC, conv1 frozen), per
+    model family -- SURVEY.md s8(d) / BASELINE.md s3.  `B` = global batch (the token-wise terms of FILIP grow with it).
+      clip      vision 8.818 + text 5.960 fwd; bwd 2 x (fwd - conv1)                                        = 43.87
+      declip    2 image + 2 text passes, MLM head on the masked rows, NN search, SimSiam MLPs, 12 logits     = 89.9
+      slip      3 image + 1 text passes + the SimCLR head 768-4096-4096-256                                  = 96.1
+      filip     towers 14.777 + dense mappings 0.040 + token GEMMs 2 * 256 * 16 * B * (49 + 77) fwd; bwd = 2 x (towers - conv1 +
+                mappings) + the token GEMMs' backward with the arg-max sparsity (1 of the 16 selected tokens receives a gradient:
+                2/16 of their forward)                                                                        = 46.4 at B = 2048
+      defilip   declip + the mappings of both views + FOUR token-wise logits (defilip.py:336-339), each as in filip"""
+    tok = 2.0 * 256 * 16 * B * (49 + 77) / 1e9
+    if model == "clip":
+        return GFLOP_PER_PAIR
+    if model == "clip_r50":
+        return GFLOP_PER_PAIR_R50
+    if model == "declip":
+        return 89.9
+    if model == "slip":
+        return 96.1
+    if model == "filip":
+        return round((14.777 + 0.040 + tok) + 2.0 * (14.777 - 0.2312 + 0.040) + tok * 2.0 / 16.0, 2)
+    if model == "defilip":
+        return round(89.9 + 2 * 0.040 * 3 + 4 * (tok + tok * 2.0 / 16.0), 2)
+    raise ValueError(model)
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
@@ -742,13 +768,13 @@ def main():
                              "queued behind a 60 ms spin kernel (no host waits inside a bracket), minus the duration of an empty bracket",
                         gemm_gflop_per_step=round(flops / nprof / 1e9, 1),
                         executed_gemm_gflop_per_pair=round(flops / nprof / 1e9 / b, 2),
-                        dense_gflop_per_pair={"clip": GFLOP_PER_PAIR, "clip_r50": GFLOP_PER_PAIR_R50}.get(args.model, 89.9),
+                        dense_gflop_per_pair=dense_gflop_per_pair(args.model, b * world),
                         # step-level fractions.  `_executed`: the flops the engine runs (packed captions + pooled last block leave
                         # out work that cannot reach the loss) -- THE roofline fraction of the step.  `_dense_equivalent`: the same
                         # throughput priced at the dense flop count the reference spends for the same outputs (a speed-up figure,
                         # not a utilisation)
                         step_mfma_frac_executed=round(pairs_per_s / b * (flops / nprof) / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
-                        step_mfma_frac_dense_equivalent=round(pairs_per_s * {"clip": GFLOP_PER_PAIR, "clip_r50": GFLOP_PER_PAIR_R50}.get(args.model, 89.9) / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
+                        step_mfma_frac_dense_equivalent=round(pairs_per_s * dense_gflop_per_pair(args.model, b * world) / 1e3 / (PEAK_BF16_TFLOPS * world), 4))
 
     name = {"clip": "CLIP ViT-B/32", "declip": "DeCLIP ViT-B/32", "slip": "SLIP ViT-B/32", "filip": "FILIP ViT-B/32", "defilip": "DeFILIP ViT-B/32",
             "clip_r50": "CLIP ResNet-50"}[args.model]
@@ -780,7 +806,7 @@ def main():
                            rccl_ranks=rccl_ranks, dist_backend=(torch.distributed.get_backend() if (world > 1 or forced) else None),
                            one_rank_rccl_group=int(forced),
                            ranks=[list(x) for x in devs], self_launched=int(os.environ.get("DH_BENCH_SELF_LAUNCHED", "0")),
-                           dynamic_tiles=int(os.environ.get("DH_V4_DYNAMIC", "0")), comm_native=int(dh_dist.native_comm() is not None) if world > 1 else 0,
+                           dynamic_tiles=int(os.environ.get("DH_V4_DYNAMIC", "0")), comm_native=int(dh_dist.native_comm() is not None) if (world > 1 or forced) else 0,
                            native_blocks=int(eng_mod.native_blocks()),
                            text_packed=eng_mod.text_packed_mode(), pooled_last=int(eng_mod.pooled_last_block())),   # captions computed up to <|endoftext|> only; last block for the pooled rows only (same outputs, fewer executed flops: see roofline.executed_gemm_gflop_per_pair)
                loss=round(float(loss.detach()) * world, 5))

@@ -76,8 +76,10 @@ class NativeComm(object):
         ptrs, ccols, cols, es = self._table(tensors)
         rows = tensors[0].shape[0]
         out = torch.empty((self.world * rows, sum(cols)), device=tensors[0].device, dtype=tensors[0].dtype)
-        L.check(self.lib.dh_allgather_packed(self.ctx, ptrs, ccols, len(tensors), rows, es, _ptr(out), _cur(out.device)),
-                "dh_allgather_packed")
+        from . import dist as dh_dist
+        with dh_dist._timed("allgather", stream=self.stream):      # (bench.py's attribution fields: event pair on the communication stream, eager steps only)
+            L.check(self.lib.dh_allgather_packed(self.ctx, ptrs, ccols, len(tensors), rows, es, _ptr(out), _cur(out.device)),
+                    "dh_allgather_packed")
         for t in tensors:
             t.record_stream(self.stream)
         out.record_stream(self.stream)
@@ -91,8 +93,10 @@ class NativeComm(object):
         scratch = torch.empty((rows, g.shape[1]), device=g.device, dtype=g.dtype)
         n = len(outs)
         ptrs, ccols = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs]), (ctypes.c_int * n)(*cols)
-        L.check(self.lib.dh_reducescatter_packed(self.ctx, _ptr(g), ptrs, ccols, n, rows, g.element_size(), _ptr(scratch),
-                                                 _cur(g.device)), "dh_reducescatter_packed")
+        from . import dist as dh_dist
+        with dh_dist._timed("reduce_scatter", stream=self.stream):
+            L.check(self.lib.dh_reducescatter_packed(self.ctx, _ptr(g), ptrs, ccols, n, rows, g.element_size(), _ptr(scratch),
+                                                     _cur(g.device)), "dh_reducescatter_packed")
         for t in outs + [g, scratch]:
             t.record_stream(self.stream)
         return outs

@@ -94,7 +94,7 @@ __device__ __forceinline__ bf16x8_t kmask(bf16x8_t f, bool dead) {
 // ------------------------------------------------------------------------------------------
 // VL: variable-length (packed) sequences -- pair (bi, h) owns rows cu[bi] .. cu[bi+1] of qkv / out instead of bi*L .. bi*L + L
 // (lse stays [b][heads][L]); the dense instantiation is the code it was before the template parameter existed.
-template <int NKB, bool VL>  // NKB: number of 16-key blocks (L16/16), compile-time so scores stay in registers
+template <int NKB, bool VL, int PF = 1>  // NKB: number of 16-key blocks (L16/16), compile-time so scores stay in registers; PF: pairs prefetched ahead
 __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
                                      int L, int heads, int causal, float scale, int nbh, const int* __restrict__ cu,
                                      int tail0, int tail1, const int* __restrict__ seq_list, const int* __restrict__ seq_range) {
@@ -119,24 +119,30 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
   const long gs = 3L * d_model;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6;
-  TileRegs rq, rk, rv;
-  if ((int)blockIdx.x < nbh) {
-    const int bh0 = blockIdx.x, b0 = SEQ(bh0 / heads);
-    const int L0 = VL ? cu[b0 + 1] - cu[b0] : L;
-    const bf16_t* qg0 = qkv + (VL ? (long)cu[b0] * gs : (long)b0 * L * gs) + (bh0 % heads) * HD;
-    rq = tile_load(qg0, gs, L0, tid, nthr); rk = tile_load(qg0 + d_model, gs, L0, tid, nthr); rv = tile_load(qg0 + 2 * d_model, gs, L0, tid, nthr);
-  }
-  for (int bh = blockIdx.x; bh < nbh; bh += gridDim.x) {
-  const int bi = SEQ(bh / heads), h = bh % heads;
-  const int Lp = VL ? cu[bi + 1] - cu[bi] : L;              // length of this sequence (rows cu[bi] .. of qkv / out when packed)
-  tile_store(rq, Qs, tid, nthr); tile_store(rk, Ks, tid, nthr); tile_store(rv, Vs, tid, nthr);
-  __syncthreads();
-  if (bh + (int)gridDim.x < nbh) {         // next pair's tiles: in flight during this pair's arithmetic
-    const int bn = bh + gridDim.x, b1 = SEQ(bn / heads);
+  // PF pairs ahead: the tiles of pair bh + PF * grid are requested while pair bh is multiplied (registers, 24 per stage).  PF = 1
+  // (rounds 1-5) left the packed text tower latency-bound: 2-4 pairs per workgroup, each iteration waiting most of a memory round
+  // trip for tiles requested one short iteration earlier (2.1-2.4 TB/s against 4.1 of the image tower, whose iterations are longer).
+  // The loop is unrolled by PF so that every stage keeps its own registers (a rotating copy would have to wait for the loads).
+  TileRegs rq[PF], rk[PF], rv[PF];
+  auto fetch = [&](int bn, TileRegs& q_, TileRegs& k_, TileRegs& v_) {
+    const int b1 = SEQ(bn / heads);
     const int L1 = VL ? cu[b1 + 1] - cu[b1] : L;
     const bf16_t* qn = qkv + (VL ? (long)cu[b1] * gs : (long)b1 * L * gs) + (bn % heads) * HD;
-    rq = tile_load(qn, gs, L1, tid, nthr); rk = tile_load(qn + d_model, gs, L1, tid, nthr); rv = tile_load(qn + 2 * d_model, gs, L1, tid, nthr);
-  }
+    q_ = tile_load(qn, gs, L1, tid, nthr); k_ = tile_load(qn + d_model, gs, L1, tid, nthr); v_ = tile_load(qn + 2 * d_model, gs, L1, tid, nthr);
+  };
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+    if ((int)blockIdx.x + s * (int)gridDim.x < nbh) fetch(blockIdx.x + s * gridDim.x, rq[s], rk[s], rv[s]);
+  for (int bh0 = blockIdx.x; bh0 < nbh; bh0 += PF * gridDim.x) {
+#pragma unroll
+  for (int stage = 0; stage < PF; ++stage) {
+  const int bh = bh0 + stage * (int)gridDim.x;
+  if (bh >= nbh) break;
+  const int bi = SEQ(bh / heads), h = bh % heads;
+  const int Lp = VL ? cu[bi + 1] - cu[bi] : L;              // length of this sequence (rows cu[bi] .. of qkv / out when packed)
+  tile_store(rq[stage], Qs, tid, nthr); tile_store(rk[stage], Ks, tid, nthr); tile_store(rv[stage], Vs, tid, nthr);
+  __syncthreads();
+  if (bh + PF * (int)gridDim.x < nbh) fetch(bh + PF * gridDim.x, rq[stage], rk[stage], rv[stage]);   // in flight during PF pairs' arithmetic
 
   const int qb = wave;
   const int q = qb * 16 + (lane & 15);  // this lane's query (column of S^T)
@@ -216,6 +222,7 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
   }
   __syncthreads();                         // every wave is done with the tiles before the next pair overwrites them
   }
+  }
   if (VL) tail0 = tail0 < 0 ? cu[nb_total] : tail0;        // rows = -1: the valid row count is cu_seqlens[b], read here (no host value in the launch: the captured step replays for any batch of this padded size)
   if (VL && tail1 > tail0) {
     // packed layout: the rows between the last caption and the whole-tile row count are ZERO (they meet the weight-gradient GEMMs as
@@ -232,8 +239,8 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
 // __launch_bounds__: without it the compiler budgets registers for 1024-thread workgroups (128 VGPRs) and the packed-caption
 // instantiation spilled 22 of them to scratch; 64 * NKB threads with >= 3 waves per SIMD leaves 168 (image tower: 80.6 vs 87.5 us
 // per call on one box, text tower 78.1 vs 80.4; profiles/r03_attn_bwd_variants.txt)
-template <int NKB, bool VL>
-__global__ __launch_bounds__(64 * NKB, 3) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+template <int NKB, bool VL, int PF = 1>
+__global__ __launch_bounds__(64 * NKB, PF == 2 ? 2 : 3) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                      const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                      bf16_t* __restrict__ dqkv, int L, int heads, int causal, float scale, int nbh,
                                      const int* __restrict__ cu, int tail0, int tail1, const int* __restrict__ seq_list,
@@ -273,26 +280,34 @@ __global__ __launch_bounds__(64 * NKB, 3) void attn_bwd_mfma_kernel(const bf16_t
     }
     return r;
   };
-  TileRegs rq, rk, rv, rg;
-  DRegs rd;
-  if ((int)blockIdx.x < nbh) {
-    const int bh0 = blockIdx.x, b0 = SEQ(bh0 / heads), h0 = bh0 % heads;
-    const long r0 = VL ? (long)cu[b0] : (long)b0 * L;
-    const int L0 = VL ? cu[b0 + 1] - cu[b0] : L;
-    const bf16_t* qg0 = qkv + r0 * gs + h0 * HD;
-    const bf16_t* gg0 = dout + r0 * d_model + h0 * HD;
-    rq = tile_load(qg0, gs, L0, tid, nthr); rk = tile_load(qg0 + d_model, gs, L0, tid, nthr); rv = tile_load(qg0 + 2 * d_model, gs, L0, tid, nthr);
-    rg = tile_load(gg0, d_model, L0, tid, nthr);
-    rd = d_load(out + r0 * d_model + h0 * HD, gg0, L0);
-  }
-  for (int bh = blockIdx.x; bh < nbh; bh += gridDim.x) {
+  // PF pairs ahead (see the forward kernel): 48 registers per stage
+  TileRegs rq[PF], rk[PF], rv[PF], rg[PF];
+  DRegs rd[PF];
+  auto fetch = [&](int bn, TileRegs& q_, TileRegs& k_, TileRegs& v_, TileRegs& g_, DRegs& d_) {
+    const int b1 = SEQ(bn / heads), h1 = bn % heads;
+    const long r1 = VL ? (long)cu[b1] : (long)b1 * L;
+    const int L1 = VL ? cu[b1 + 1] - cu[b1] : L;
+    const bf16_t* qn = qkv + r1 * gs + h1 * HD;
+    const bf16_t* gn = dout + r1 * d_model + h1 * HD;
+    q_ = tile_load(qn, gs, L1, tid, nthr); k_ = tile_load(qn + d_model, gs, L1, tid, nthr); v_ = tile_load(qn + 2 * d_model, gs, L1, tid, nthr);
+    g_ = tile_load(gn, d_model, L1, tid, nthr);
+    d_ = d_load(out + r1 * d_model + h1 * HD, gn, L1);
+  };
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+    if ((int)blockIdx.x + s * (int)gridDim.x < nbh) fetch(blockIdx.x + s * gridDim.x, rq[s], rk[s], rv[s], rg[s], rd[s]);
+  for (int bh0 = blockIdx.x; bh0 < nbh; bh0 += PF * gridDim.x) {
+#pragma unroll
+  for (int stage = 0; stage < PF; ++stage) {
+  const int bh = bh0 + stage * (int)gridDim.x;
+  if (bh >= nbh) break;
   const int bi = SEQ(bh / heads), h = bh % heads;
   const long row0 = VL ? (long)cu[bi] : (long)bi * L;
   const int Lp = VL ? cu[bi + 1] - cu[bi] : L;
-  tile_store(rq, Qs, tid, nthr); tile_store(rk, Ks, tid, nthr); tile_store(rv, Vs, tid, nthr); tile_store(rg, Gs, tid, nthr);
+  tile_store(rq[stage], Qs, tid, nthr); tile_store(rk[stage], Ks, tid, nthr); tile_store(rv[stage], Vs, tid, nthr); tile_store(rg[stage], Gs, tid, nthr);
   {
-    const uint32_t* ow = reinterpret_cast<const uint32_t*>(rd.o);
-    const uint32_t* gw = reinterpret_cast<const uint32_t*>(rd.g);
+    const uint32_t* ow = reinterpret_cast<const uint32_t*>(rd[stage].o);
+    const uint32_t* gw = reinterpret_cast<const uint32_t*>(rd[stage].g);
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -310,16 +325,7 @@ __global__ __launch_bounds__(64 * NKB, 3) void attn_bwd_mfma_kernel(const bf16_t
     const int qq = wave * 16 + 4 * (lane >> 4) + r;
     lse_r[r] = qq < Lp ? lse[((long)bi * heads + h) * L + qq] : 0.f;
   }
-  if (bh + (int)gridDim.x < nbh) {         // next pair's tiles: in flight during this pair's arithmetic
-    const int bn = bh + gridDim.x, b1 = SEQ(bn / heads), h1 = bn % heads;
-    const long r1 = VL ? (long)cu[b1] : (long)b1 * L;
-    const int L1 = VL ? cu[b1 + 1] - cu[b1] : L;
-    const bf16_t* qn = qkv + r1 * gs + h1 * HD;
-    const bf16_t* gn = dout + r1 * d_model + h1 * HD;
-    rq = tile_load(qn, gs, L1, tid, nthr); rk = tile_load(qn + d_model, gs, L1, tid, nthr); rv = tile_load(qn + 2 * d_model, gs, L1, tid, nthr);
-    rg = tile_load(gn, d_model, L1, tid, nthr);
-    rd = d_load(out + r1 * d_model + h1 * HD, gn, L1);
-  }
+  if (bh + PF * (int)gridDim.x < nbh) fetch(bh + PF * gridDim.x, rq[stage], rk[stage], rv[stage], rg[stage], rd[stage]);   // in flight during PF pairs' arithmetic
 
   // ---- phase 1: wave owns query block qb: S[q][key] (rows q), dP[q][key]
   {
@@ -410,6 +416,7 @@ __global__ __launch_bounds__(64 * NKB, 3) void attn_bwd_mfma_kernel(const bf16_t
     }
   }
   __syncthreads();                         // every wave is done with the tiles before the next pair overwrites them
+  }
   }
   if (VL) tail0 = tail0 < 0 ? cu[nb_total] : tail0;        // (see the forward kernel)
 #undef SEQ
@@ -547,12 +554,19 @@ int launch_fwd_mfma(const bf16_t* qkv, bf16_t* out, float* lse, int b, int L, in
                     const int* seq_range = nullptr) {
   constexpr int L16 = NKB * 16, TS = L16 + 8;
   size_t lds = (size_t)(3 * L16 * RS + L16 * TS + 64) * sizeof(bf16_t);
-  if (cu) hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static int pf_env = -1;         // DH_ATTN_PF (read once): prefetch depth of the packed (text) forward kernel: 1 (default), 2, 3 = 2 for the short bucket only (measured: profiles/r06_attention_variants.txt -- no gain, the kernel is not waiting for its loads)
+  if (pf_env < 0) { const char* ev = getenv("DH_ATTN_PF"); pf_env = ev ? atoi(ev) : 1; }
+  const bool pf2 = cu && (pf_env == 2 || (pf_env == 3 && NKB <= 4));      // (3: only the short bucket -- the 5-block instantiation spills two registers at depth 2)
+  if (pf2) hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  else if (cu) hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   else hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NKB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
+  static int cap_env = -1;        // DH_ATTN_WG_CAP (read once): most workgroups per CU (LDS permitting)
+  if (cap_env < 0) { const char* ev = getenv("DH_ATTN_WG_CAP"); cap_env = ev ? atoi(ev) : 4; }
+  const int per_cu = (int)((160 * 1024) / lds) > cap_env ? cap_env : (int)((160 * 1024) / lds);
   int grid = attn_cus() * (per_cu < 1 ? 1 : per_cu);
   if (grid > b * heads) grid = b * heads;
-  if (cu) hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKB, true>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads, cu, tail0, tail1, seq_list, seq_range);
+  if (pf2) hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKB, true, 2>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads, cu, tail0, tail1, seq_list, seq_range);
+  else if (cu) hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKB, true>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads, cu, tail0, tail1, seq_list, seq_range);
   else hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKB, false>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, lse, L, heads, causal, scale, b * heads, cu, 0, 0, (const int*)nullptr, (const int*)nullptr);
   return 0;
 }
@@ -570,6 +584,13 @@ int launch_bwd_mfma(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
   const int per_cu = (int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds);
   int grid = attn_cus() * (per_cu < 1 ? 1 : per_cu);
   if (grid > b * heads) grid = b * heads;
+  static int pf_env = -1;         // DH_ATTN_PF_BWD (read once): prefetch depth of the packed (text) backward kernel: 1, 2 (default), 3 = 2 for the short bucket only
+  if (pf_env < 0) { const char* ev = getenv("DH_ATTN_PF_BWD"); pf_env = ev ? atoi(ev) : 1; }
+  const bool pf2 = cu && (pf_env == 2 || (pf_env == 3 && NKB <= 4));
+  if (pf2) {
+    hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NKB, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_bwd_mfma_kernel<NKB, true, 2>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads, cu, tail0, tail1, seq_list, seq_range);
+  } else
   if (cu) hipLaunchKernelGGL((attn_bwd_mfma_kernel<NKB, true>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads, cu, tail0, tail1, seq_list, seq_range);
   else hipLaunchKernelGGL((attn_bwd_mfma_kernel<NKB, false>), dim3(grid), dim3(64 * NKB), lds, st, qkv, out, dout, lse, dqkv, L, heads, causal, scale, b * heads, cu, 0, 0, (const int*)nullptr, (const int*)nullptr);
   return 0;
