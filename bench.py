@@ -745,7 +745,7 @@ def main():
         # per-launch average next to the algorithmic bytes per launch (operands once + outputs once)
         traffic, traffic_source = None, None
         traffic_sha, traffic_head = None, None
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):         # a COMMITTED rocprofv3 --pmc summary of this configuration (tools/profile_step.sh):
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):         # a COMMITTED rocprofv3 --pmc summary of this configuration (tools/profile_step.sh):
             pmc_file = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s_b%d.json" % (rnd, args.model, b))   # not measured by this run
             if os.path.exists(pmc_file):
                 with open(pmc_file) as fh:
