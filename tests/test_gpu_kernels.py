@@ -701,3 +701,26 @@ def test_ce_fused_forward_and_backward(n, V, K):
     assert float(got[n:].abs().max() if n_pad > n else 0.0) == 0.0 and float(got[:, V:].abs().max() if ldd > V else 0.0) == 0.0
     # row sums of dl vanish (softmax - onehot), up to bf16 rounding of ~V entries
     assert float(got[:n].sum(1).abs().max()) <= 0.05 * float(g.max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("b,L,d", [(512, 77, 512), (37, 16, 128), (1100, 12, 520)])
+def test_packed_positional_gradient(dtype, b, L, d):
+    """dh_packed_pos_grad: dpos[p] += sum over the captions longer than p of dx[cu[i] + p] (text_transformer.py:196: x + positional_embedding,
+    on the packed rows).  bf16 takes the 16-byte-load kernel of round 6 (b > 1024: the caption offsets go through LDS in two chunks;
+    d = 520: a second, partly empty column block), fp32 the scalar one."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(b + d)
+    lens = torch.randint(1, L + 1, (b,), generator=g)
+    cu = torch.zeros(b + 1, dtype=torch.int32)
+    cu[1:] = lens.cumsum(0).to(torch.int32)
+    rows = int(cu[-1])
+    dx = rnd(rows, d, seed=7).to(dtype)
+    ids_p = torch.zeros(rows, dtype=torch.int64)
+    base = rnd(L, d, seed=8)
+    dpos = base.clone().to(cuda)
+    ops.text_embed_packed_bwd(ids_p.to(cuda), cu.to(cuda), dx.to(cuda), None, dpos, rows, L)
+    ref = base.double()
+    pos = torch.cat([torch.arange(int(n)) for n in lens])
+    ref.index_add_(0, pos, dx.double())
+    assert rel_err(dpos, ref) < 1e-5

@@ -30,7 +30,8 @@ def main(path):
     if len(marks) < 3:
         print("fewer than 3 steps in the trace")
         return
-    a, b = marks[-3], marks[-2]                      # one replayed step
+    spans = sorted((rows[y][2] - rows[x][2], x, y) for x, y in zip(marks[:-1], marks[1:]))
+    _, a, b = spans[len(spans) // 2]                 # the step with the median span (a replayed, undisturbed one)
     seg = rows[a + 1:b + 1]
     t0, t1 = rows[a][2], rows[b][2]
     queues = sorted(set(r[3] for r in seg), key=lambda x: -sum(r[2] - r[1] for r in seg if r[3] == x))
