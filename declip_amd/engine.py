@@ -746,7 +746,7 @@ def block_bwd_pooled(dx_out, r, saved, sel, row0, nkeys, Lmax, heads):
     dx_mid = _ln_bwd(dh2, x_mid, r.ln2_w, mean2, rstd2, r.g_ln2_w, r.g_ln2_b, dres=dx_out)       # [b, d]
     dw.add(dx_mid, a, r.g_w_out, r.g_b_out)
     da = ops.gemm(dx_mid, r.w_out, b_kmajor=True, ws=ws)
-    dq, dkv = ops.attn_pooled_bwd(q, kv, da, lse, row0, nkeys, heads, Lmax)
+    dq, dkv = ops.attn_pooled_bwd(q, kv, da, lse, row0, nkeys, heads, Lmax, ordered=True)   # row0 = i * L (CLS, padded captions) or cu_seqlens[i] (packed)
     dw.add(dq, h1s, r.g_w_in[:d], r.g_b_in[:d])
     dw.add(dkv, h1, r.g_w_in[d:], r.g_b_in[d:])
     dh1 = ops.gemm(dkv, r.w_in[d:], b_kmajor=True, ws=ws)                 # [R, d]

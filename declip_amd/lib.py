@@ -92,7 +92,7 @@ _PROTOS = {
     "dh_attn_bucketed_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_bucketed_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_attn_pooled_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "dh_attn_pooled_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "dh_attn_pooled_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dh_text_embed_fwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "dh_text_embed_bwd": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, POINTER(c_int64), c_int, _P]),
     "dh_embed_table_grad_ws_bytes": (c_int64, [c_int, c_int]),

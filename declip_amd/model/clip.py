@@ -149,8 +149,10 @@ class CLIP(nn.Module):
         self._flat_store.begin_step()
         images = input["images"]
         texts = self.sample_captions(input["captions"])
-        img, txt = self.features(images, texts)
+        # exp / clamp of the temperature BEFORE the towers: four one-element kernels that then run beside the towers instead of between
+        # the join of the two tower streams and the loss kernel (same values; their backward nodes move behind the text tower's)
         scale = self.logit_scale_value()
+        img, txt = self.features(images, texts)
         if self.training and self.use_allgather or all_gather:
             g_img, g_txt = dh_dist.all_gather_cat_many([img, txt])
             label0 = dh_dist.get_rank() * img.shape[0]

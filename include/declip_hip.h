@@ -177,12 +177,13 @@ int dh_attn_bucketed_bwd(int dtype, const void* qkv, const void* out, const void
  * attention, out_proj and MLP are needed for b rows, not b*L (K, V still come from every row).  q [b][d] (the pooled rows'
  * queries), kv [rows][2*d] (k | v, head-major, of every row); sequence i's keys are kv rows row0[i] .. row0[i] + nkeys[i] - 1
  * (row0, nkeys int32 [b] in device memory; nkeys = position + 1 is the causal mask of the text tower, nkeys <= Lmax <= 128);
- * hd == 64.  out [b][d], lse [b][heads].  bwd writes dq [b][d] and the dkv rows of every sequence's keys (the caller
- * zero-fills dkv: rows no sequence owns stay zero). */
+ * hd == 64.  out [b][d], lse [b][heads].  bwd writes dq [b][d] and the dkv rows of every sequence's keys; total_rows > 0
+ * (row0 ascending, kv / dkv have total_rows rows): the rows no sequence owns are zeroed by the same launch, dkv may be uninitialised;
+ * total_rows = 0: those rows stay as the caller initialised them. */
 int dh_attn_pooled_fwd(int dtype, const void* q, const void* kv, void* out, float* lse, const int* row0, const int* nkeys, int b,
                        int heads, int hd, int Lmax, dh_stream_t stream);
 int dh_attn_pooled_bwd(int dtype, const void* q, const void* kv, const void* dout, const float* lse, void* dq, void* dkv,
-                       const int* row0, const int* nkeys, int b, int heads, int hd, int Lmax, dh_stream_t stream);
+                       const int* row0, const int* nkeys, int b, int heads, int hd, int Lmax, int total_rows, dh_stream_t stream);
 
 /* ---------------------------------------------------------------- one transformer block per call
  * ResidualAttentionBlock (base_transformer.py:29-53): x_mid = x + out_proj(attn(in_proj(ln_1(x)))), x_out = x_mid +

@@ -497,8 +497,11 @@ def test_packed_text_tower_gather_mode_fp32_matches_reference_golden(monkeypatch
 
 
 # ------------------------------------------------------------------------------------------------ last block for the pooled rows (DH_POOLED_LAST=1)
+@pytest.mark.parametrize("ordered", [False, True])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_attention_pooled_query_matches_reference(dtype):
+def test_attention_pooled_query_matches_reference(dtype, ordered):
+    """ordered: the launch zeroes the dkv rows no sequence owns (uninitialised buffer handed over: the allocator's free block of that
+    size is poisoned with NaN first); else the caller's fill does."""
     from declip_amd import ops
     torch.manual_seed(1)
     heads, hd, L, b = 12, 64, 50, 300
@@ -509,8 +512,13 @@ def test_attention_pooled_query_matches_reference(dtype):
     row0 = (torch.arange(b) * L).to(torch.int32)
     nkeys = torch.randint(1, L + 1, (b,), generator=torch.Generator().manual_seed(2)).to(torch.int32)
     out, lse = ops.attn_pooled_fwd(q.cuda(), kv.cuda(), row0.cuda(), nkeys.cuda(), heads, L)
-    dq, dkv = ops.attn_pooled_bwd(q.cuda(), kv.cuda(), dout.cuda(), lse, row0.cuda(), nkeys.cuda(), heads, L)
+    kv_d = kv.cuda()
+    poison = torch.full_like(kv_d, float("nan"))
+    del poison
+    dq, dkv = ops.attn_pooled_bwd(q.cuda(), kv_d, dout.cuda(), lse, row0.cuda(), nkeys.cuda(), heads, L, ordered=ordered)
     out, dq, dkv = out.float().cpu(), dq.float().cpu(), dkv.float().cpu()
+    unowned = (torch.arange(L)[None, :] >= nkeys[:, None]).reshape(-1)
+    assert float(dkv[unowned].abs().max()) == 0.0 and bool(torch.isfinite(dkv).all())
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     for i in (0, 1, 17, b - 1):
         r0, n = int(row0[i]), int(nkeys[i])

@@ -277,10 +277,12 @@ def test_attention_dense_mfma_matches_reference(L, causal):
     assert float((lse - torch.logsumexp(s.detach(), dim=-1)).abs().max()) <= 3e-2
 
 
+@pytest.mark.parametrize("ordered", [False, True])
 @pytest.mark.parametrize("dtype", [F32, BF16])
-def test_attention_pooled_query_matches_reference(dtype):
+def test_attention_pooled_query_matches_reference(dtype, ordered):
     """dh_attn_pooled_fwd / _bwd: one query per sequence against its keys (kv rows row0 .. row0 + nkeys - 1): outputs, lse, dq and
-    the dkv rows; rows that belong to no sequence (padding between sequences) stay zero."""
+    the dkv rows; rows that belong to no sequence (padding between sequences) stay zero -- ordered: zeroed by the launch itself
+    (total_rows > 0, the buffer is handed over uninitialised), else by the caller's fill."""
     torch.manual_seed(1)
     heads, hd = 3, 64
     d = heads * hd
@@ -297,7 +299,7 @@ def test_attention_pooled_query_matches_reference(dtype):
     r0_t, n_t = torch.tensor(row0, dtype=torch.int32), torch.tensor(nkeys, dtype=torch.int32)
     with emulated_gpu() as ops:
         out, lse = ops.attn_pooled_fwd(q, kv, r0_t, n_t, heads, 128)
-        dq, dkv = ops.attn_pooled_bwd(q, kv, dout, lse, r0_t, n_t, heads, 128)
+        dq, dkv = ops.attn_pooled_bwd(q, kv, dout, lse, r0_t, n_t, heads, 128, ordered=ordered)
     tol = 2e-5 if dtype == F32 else 2e-2
     owned = torch.zeros(rows, dtype=torch.bool)
     for i, (r0, n) in enumerate(zip(row0, nkeys)):
