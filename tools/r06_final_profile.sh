@@ -22,6 +22,14 @@ bash tools/profile_step.sh > $O/profile_step.log 2>&1
 cp gpurun_out/prof/stats.txt $O/clip_kernel_stats.txt; cp gpurun_out/prof/pmc_summary.txt $O/clip_pmc_summary.txt
 head -30 $O/clip_kernel_stats.txt | cut -c1-160
 grep "^JSON " gpurun_out/prof/pmc_summary.txt | tail -1 | cut -c6- > $O/pmc_traffic_clip_b512.json; cat $O/pmc_traffic_clip_b512.json
+# FILIP: kernel table of its step (towers on one stream, eager: per-kernel durations alone on the chip)
+cd /tmp && export TMPDIR=/tmp
+DH_TOWER_STREAMS=0 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$O/trace_filip -o trace -- python $GRAFT_REPO_ROOT/bench.py --model filip --steps 4 --warmup 2 --no-cpu-baseline --no-loss-delta --no-roofline --graph 0 > $GRAFT_REPO_ROOT/$O/trace_filip.log 2>&1
+cd $GRAFT_REPO_ROOT
+DB=$(find $O/trace_filip -name "*.db" | head -1); python tools/rocpd_stats.py $DB > $O/filip_kernel_stats.txt 2>&1; head -24 $O/filip_kernel_stats.txt | cut -c1-160
+rm -rf $O/trace_filip
+# the torch kernels left in the step
+python tools/torch_ops_in_step.py > $O/torch_ops.txt 2>&1
 # dispatches / idle time of the default (two-stream, captured) step
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/$O/trace2 -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-loss-delta --no-roofline > $GRAFT_REPO_ROOT/$O/trace2.log 2>&1
