@@ -36,6 +36,30 @@ void dh_set_error(const char* fmt, ...);
     hipError_t e__ = hipGetLastError();                                \
     if (e__ != hipSuccess) DH_FAIL(DH_ERR_LAUNCH, "%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
   } while (0)
+// Launch helpers that return bool ("took the problem": gemm_v4.hip's dh_*_try_v4) report a failed runtime call of their own -- a
+// clearing memset in front of their launch -- through this thread-local slot; the C-ABI entry point that called them turns it into
+// its return code (DH_HELPER_FAILED).  Entry points that return int check their runtime calls with DH_RT.
+inline int& dh_helper_error() { static thread_local int e = 0; return e; }
+#define DH_RT_NOTE(expr, what)                                                       \
+  do {                                                                               \
+    const hipError_t rt__ = (expr);                                                  \
+    if (rt__ != hipSuccess) {                                                        \
+      dh_set_error("%s failed: %s", what, hipGetErrorString(rt__));                  \
+      dh_helper_error() = DH_ERR_LAUNCH;                                             \
+    }                                                                                \
+  } while (0)
+#define DH_HELPER_FAILED()                                        \
+  do {                                                            \
+    if (const int he__ = dh_helper_error()) {                     \
+      dh_helper_error() = 0;                                      \
+      return he__;                                                \
+    }                                                             \
+  } while (0)
+#define DH_RT(expr, what)                                                                                   \
+  do {                                                                                                      \
+    const hipError_t rt__ = (expr);                                                                         \
+    if (rt__ != hipSuccess) DH_FAIL(DH_ERR_LAUNCH, "%s failed: %s", what, hipGetErrorString(rt__));         \
+  } while (0)
 #define DH_REQUIRE(cond, ...)                       \
   do {                                              \
     if (!(cond)) DH_FAIL(DH_ERR_ARG, __VA_ARGS__);  \

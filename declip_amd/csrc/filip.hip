@@ -147,6 +147,7 @@ extern "C" int dh_maxsim_fused_fwd(const void* Q_bf16, const void* K_bf16, int r
   DH_REQUIRE(dh_maxsim_try_v4(Q_bf16, K_bf16, rows_pad, b, B, J, D, raw, argmax, st),
              "dh_maxsim_fused_fwd: needs rows_pad %% 256 == 0, B %% 16 == 0, D %% 64 == 0, D >= 128, J >= 19, 16-byte aligned operands (got rows_pad %d B %d D %d J %d)",
              rows_pad, B, D, J);
+  DH_HELPER_FAILED();
   DH_CHECK_LAUNCH();
   const long n = (long)b * B;
   hipLaunchKernelGGL(maxsim_scale_kernel, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, st, raw, scale_dev, logits, n);

@@ -373,6 +373,7 @@ extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
   if (a->a_colsum) DH_REQUIRE(a->a_kmajor, "dh_gemm: a_colsum needs a_kmajor");
   // v2 (LDS-DMA + transpose-read) kernel when shapes/alignments allow it (fuses a_colsum)
   if ((a->force_generic == 0 || a->force_generic == 4) && dh_gemm_try_v4(a, split, st)) {
+    DH_HELPER_FAILED();
     ++g_gemm_family_calls[0];
     DH_CHECK_LAUNCH();
     return DH_OK;
@@ -381,9 +382,9 @@ extern "C" int dh_gemm(const dh_gemm_args* a, dh_stream_t stream) {
   dh_gemm_args first_touch;
   if (a->accumulate == 2) {
     // first touch through the other kernel families (fp32 atomics into C): clear the slot here, then accumulate as usual
-    if (a->ldc == a->N) hipMemsetAsync(a->C, 0, sizeof(float) * (size_t)a->M * a->N, st);
-    else hipMemset2DAsync(a->C, sizeof(float) * a->ldc, 0, sizeof(float) * a->N, a->M, st);
-    if (a->a_colsum) hipMemsetAsync(a->a_colsum, 0, sizeof(float) * (size_t)a->M, st);
+    if (a->ldc == a->N) DH_RT(hipMemsetAsync(a->C, 0, sizeof(float) * (size_t)a->M * a->N, st), "dh_gemm: clearing a first-touch gradient");
+    else DH_RT(hipMemset2DAsync(a->C, sizeof(float) * a->ldc, 0, sizeof(float) * a->N, a->M, st), "dh_gemm: clearing a first-touch gradient");
+    if (a->a_colsum) DH_RT(hipMemsetAsync(a->a_colsum, 0, sizeof(float) * (size_t)a->M, st), "dh_gemm: clearing a first-touch bias gradient");
     first_touch = *a;
     first_touch.accumulate = 1;
     a = &first_touch;
@@ -442,7 +443,7 @@ extern "C" int dh_colsum(int dtype, const void* X, int64_t ldx, int M, int N, fl
   if (chunks > 128) chunks = 128;
   int rpb = dh_cdiv(M, chunks);
   chunks = dh_cdiv(M, rpb);
-  if (!accumulate && chunks > 1) hipMemsetAsync(out, 0, sizeof(float) * N, st);
+  if (!accumulate && chunks > 1) DH_RT(hipMemsetAsync(out, 0, sizeof(float) * N, st), "dh_colsum: clearing the output");
   dim3 grid(dh_cdiv(N, 64), chunks);
   if (dtype == DH_BF16)
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)X, (long)ldx, M, N, out, accumulate, rpb);

@@ -1651,9 +1651,10 @@ bool dh_gemm_try_v4(const dh_gemm_args* a, int split, hipStream_t st) {
     }
   }
   if (md == MODE_ATOMIC && a->accumulate == 2) {           // first touch through the atomic path: clear, then add
-    if (a->ldc == a->N) hipMemsetAsync(a->C, 0, sizeof(float) * (size_t)a->M * a->N, st);
-    else hipMemset2DAsync(a->C, sizeof(float) * a->ldc, 0, sizeof(float) * a->N, a->M, st);
-    if (a->a_colsum) hipMemsetAsync(a->a_colsum, 0, sizeof(float) * (size_t)a->M, st);
+    if (a->ldc == a->N) DH_RT_NOTE(hipMemsetAsync(a->C, 0, sizeof(float) * (size_t)a->M * a->N, st), "gemm_v4: clearing a first-touch gradient");
+    else DH_RT_NOTE(hipMemset2DAsync(a->C, sizeof(float) * a->ldc, 0, sizeof(float) * a->N, a->M, st), "gemm_v4: clearing a first-touch gradient");
+    if (a->a_colsum) DH_RT_NOTE(hipMemsetAsync(a->a_colsum, 0, sizeof(float) * (size_t)a->M, st), "gemm_v4: clearing a first-touch bias gradient");
+    if (dh_helper_error()) return true;         // (the entry point reports it: DH_HELPER_FAILED)
   }
   switch (md) {
     case MODE_ATOMIC: launch<true, true, MODE_ATOMIC>(a, e, split, kps, n_full, S, st); break;
@@ -1826,7 +1827,8 @@ bool dh_maxsim_try_v4(const void* Q, const void* Ksel, int rows_pad, int b, int 
   const int N = B * 16;
   if ((rows_pad % BM) || (N % BN) || (D % BK) || D < 2 * BK || ((uintptr_t)Q & 15) || ((uintptr_t)Ksel & 15) || ((uintptr_t)arg & 15)) return false;
   if (J < 1 || 256 / J + 2 > 16) return false;               // at most 16 sample segments per 256-row tile
-  hipMemsetAsync(raw, 0, sizeof(float) * (size_t)b * B, st);
+  DH_RT_NOTE(hipMemsetAsync(raw, 0, sizeof(float) * (size_t)b * B, st), "maxsim: clearing the raw similarities");
+  if (dh_helper_error()) return true;           // (the entry point reports it: DH_HELPER_FAILED)
   dh_gemm_args a;
   memset(&a, 0, sizeof(a));
   a.dtype = DH_BF16; a.c_dtype = DH_F32; a.M = rows_pad; a.N = N; a.K = D; a.A = Q; a.lda = D; a.B = Ksel; a.ldb = D; a.C = raw; a.ldc = B;

@@ -696,7 +696,7 @@ extern "C" int dh_infonce_bwd(const dh_nce_pair* pairs, int n_pairs, int b, int 
     if (nz > 1)
       for (int i = 0; i < n_pairs; ++i) {
         void* dst = mode == 0 ? (void*)pt.dQ[i] : (void*)pt.dK[i];
-        if (dst) hipMemsetAsync(dst, 0, sizeof(float) * (size_t)nx * D, st);
+        if (dst) DH_RT_NOTE(hipMemsetAsync(dst, 0, sizeof(float) * (size_t)nx * D, st), "dh_infonce_bwd: clearing a chunked gradient");
       }
     hipLaunchKernelGGL(nce_bwd_kernel<RT>, dim3(dh_cdiv(nx, RT), n_pairs, nz), dim3(256), lds, st, pt, mode, b, B, D, scale,
                        label0, row_lse, g_row, dscale, chunk_cols);
@@ -712,7 +712,7 @@ extern "C" int dh_infonce_bwd(const dh_nce_pair* pairs, int n_pairs, int b, int 
     if (nz > 1)
       for (int i = 0; i < n_pairs; ++i) {
         void* dst = mode == 0 ? (void*)pt.dQ[i] : (void*)pt.dK[i];
-        if (dst) hipMemsetAsync(dst, 0, sizeof(float) * (size_t)nx * D, st);
+        if (dst) DH_RT_NOTE(hipMemsetAsync(dst, 0, sizeof(float) * (size_t)nx * D, st), "dh_infonce_bwd: clearing a chunked gradient");
       }
     hipLaunchKernelGGL(kern, dim3(dh_cdiv(nx, MX) * ndc, n_pairs, nz), dim3(256), lds, st, pt, mode, b, B, D, scale, row_lse, g_row,
                        dscale, chunk_cols);
@@ -729,6 +729,7 @@ extern "C" int dh_infonce_bwd(const dh_nce_pair* pairs, int n_pairs, int b, int 
   } else {
     DH_FAIL(DH_ERR_UNSUPPORTED, "dh_infonce_bwd: D=%d > 1024", D);
   }
+  DH_HELPER_FAILED();
   DH_CHECK_LAUNCH();
   return DH_OK;
 }

@@ -233,7 +233,9 @@ class FlatParams:
         plan = self.__dict__.get("_ft_plan")
         if plan is not None and plan["key"] == (self.flat_g.data_ptr(), len(reg)):
             return plan
-        slots = sorted((self.index[i][0], (self.index[i][1] + ALIGN - 1) // ALIGN * ALIGN) for i in reg)
+        # a slot = the parameter's elements rounded up to the 16-byte vectors the clearing kernel writes: the rest of its ALIGN padding
+        # belongs to the cleared complement (the norm / all-reduce passes read the whole buffer; nothing else ever writes the padding)
+        slots = sorted((self.index[i][0], (self.index[i][1] + 3) // 4 * 4) for i in reg)
         ranges, cur = [], 0
         for o, n in slots:
             if o > cur:
@@ -241,6 +243,8 @@ class FlatParams:
             cur = max(cur, o + n)
         if cur < self.total:
             ranges.append((cur, self.total))
+        if any(a % 4 or b % 4 for a, b in ranges):         # dh_zero_ranges writes 16-byte vectors
+            raise DeclipHipError("first-touch plan: a range of the gradient buffer is not a multiple of 4 elements: %r" % ([r for r in ranges if r[0] % 4 or r[1] % 4][:3],))
         table = torch.tensor(ranges if ranges else [(0, 0)], dtype=torch.int64, device=self.flat_g.device)
         plan = dict(key=(self.flat_g.data_ptr(), len(reg)), table=table, n=len(ranges), max_len=max([b - a for a, b in ranges] + [0]), ids=list(reg))
         self._ft_plan = plan
@@ -392,8 +396,21 @@ _GEMM_WS = {}
 # Scratch buffers that were replaced by larger ones.  A hipGraph captured earlier keeps the OLD address baked into its launches; if
 # that buffer went back to the caching allocator it could be handed to an unrelated tensor that a later replay of the older graph
 # then scribbles over.  Replaced buffers are therefore kept alive for the life of the process (a handful of growths:
-# the row count of packed captions is bounded by b * L).
+# the row count of packed captions is bounded by b * L) -- but only once a capture has happened in this process (graph.GraphedStep calls
+# note_capture() before its first one): an eager-only run gives outgrown buffers back to the allocator.
 _RETIRED_SCRATCH = []
+_CAPTURE_SEEN = False
+
+
+def note_capture():
+    """A stream capture is about to record launches that hold scratch addresses: from now on outgrown scratch buffers stay alive."""
+    global _CAPTURE_SEEN
+    _CAPTURE_SEEN = True
+
+
+def _retire(buf):
+    if _CAPTURE_SEEN:
+        _RETIRED_SCRATCH.append(buf)
 
 
 def gemm_workspace(device, nbytes=256 << 20):
@@ -403,7 +420,7 @@ def gemm_workspace(device, nbytes=256 << 20):
     ws = _GEMM_WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         if ws is not None:
-            _RETIRED_SCRATCH.append(ws)          # a captured graph may hold its address (see _RETIRED_SCRATCH)
+            _retire(ws)          # a captured graph may hold its address (see _RETIRED_SCRATCH)
         ws = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
         _GEMM_WS[key] = ws
     return ws
@@ -476,7 +493,7 @@ class LnGradBatch:
             # re-growth over several steps, and the first growth does not land in a captured step's private pool when the warm-up
             # steps ran.  (A grown arena replaces the old one; slices already handed out keep the old storage alive until the flush.)
             if ar is not None:
-                _RETIRED_SCRATCH.append(ar)      # an earlier capture may hold its address
+                _retire(ar)      # an earlier capture may hold its address
             ar = torch.empty(max(self.off + n, self.n_live * ((n + 63) // 64 * 64)), device=device, dtype=torch.float32)
             arenas[key] = ar
             self.off = 0
@@ -547,7 +564,7 @@ def _bwd_scratch(device, nbytes):
     buf = _BWD_SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
-            _RETIRED_SCRATCH.append(buf)
+            _retire(buf)
         buf = torch.empty(nbytes, device=device, dtype=torch.uint8)
         _BWD_SCRATCH[key] = buf
     return buf

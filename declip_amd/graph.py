@@ -118,6 +118,8 @@ class GraphedStep(object):
             return self.out
         if self.calls <= self.warmup:
             return self.fn()
+        from . import engine
+        engine.note_capture()                   # launches recorded from here on hold scratch addresses: outgrown scratch stays alive
         if not self.fallback:
             self._check_capturable()
             torch.cuda.synchronize()

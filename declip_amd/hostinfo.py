@@ -55,25 +55,38 @@ def usable_cores(physical=True):
     return max(1, n)
 
 
+def _node_gpu_count():
+    """GPUs of this node as the kernel driver lists them (KFD topology nodes with SIMDs; else the DRM render nodes) -- read from sysfs,
+    NOT through torch.cuda / HIP: this helper runs before worker processes are forked and must not initialise the runtime."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(f):
+                if line.startswith("simd_count ") and int(line.split()[1]) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            pass
+    return n if n > 0 else len(glob.glob("/dev/dri/renderD*"))
+
+
 def local_world_size():
-    """ranks of this job on THIS node: they share the node's quota.  torchrun's LOCAL_WORLD_SIZE, else SLURM_NTASKS_PER_NODE, else
-    WORLD_SIZE as the one-node fallback -- capped by the node's GPU count, because dist.initialize() writes the GLOBAL world size
-    into WORLD_SIZE also for multi-node SLURM launches (64 ranks on 8 nodes are 8 per node, not 64)."""
+    """ranks of this job on THIS node: they share the node's quota.  torchrun's LOCAL_WORLD_SIZE, else SLURM_NTASKS_PER_NODE /
+    SLURM_TASKS_PER_NODE, else WORLD_SIZE as the one-node fallback -- capped by the node's GPU count, because dist.initialize() writes
+    the GLOBAL world size into WORLD_SIZE also for multi-node SLURM launches (64 ranks on 8 nodes are 8 per node, not 64).  The GPU
+    count is the NODE's (sysfs), not what this rank may see: a launcher that hands every rank one visible GPU (*_VISIBLE_DEVICES)
+    must not make each rank believe it owns the node's cores."""
     def _int(k):
         v = os.environ.get(k, "")
         v = v.split("(")[0].split(",")[0]           # SLURM_NTASKS_PER_NODE may read "8(x4)"
         return int(v) if v.isdigit() and int(v) > 0 else None
-    for k in ("LOCAL_WORLD_SIZE", "SLURM_NTASKS_PER_NODE"):
+    for k in ("LOCAL_WORLD_SIZE", "SLURM_NTASKS_PER_NODE", "SLURM_TASKS_PER_NODE"):
         n = _int(k)
         if n:
             return n
     n = _int("WORLD_SIZE")
     if n:
-        try:
-            import torch
-            gpus = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        except Exception:
-            gpus = 0
+        gpus = _node_gpu_count()
         return min(n, gpus) if gpus > 0 else n
     return 1
 

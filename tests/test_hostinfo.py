@@ -62,7 +62,7 @@ def test_local_world_size_prefers_per_node_counts_over_the_global_world_size(mon
     """dist.initialize() writes the GLOBAL world size into WORLD_SIZE, also for multi-node SLURM launches; the per-node
     counts win, and WORLD_SIZE alone is capped by the node's GPU count (no GPUs here: taken as is)."""
     from declip_amd import hostinfo
-    for k in ("LOCAL_WORLD_SIZE", "SLURM_NTASKS_PER_NODE", "WORLD_SIZE"):
+    for k in ("LOCAL_WORLD_SIZE", "SLURM_NTASKS_PER_NODE", "SLURM_TASKS_PER_NODE", "WORLD_SIZE"):
         monkeypatch.delenv(k, raising=False)
     assert hostinfo.local_world_size() == 1
     monkeypatch.setenv("WORLD_SIZE", "64")
@@ -72,4 +72,19 @@ def test_local_world_size_prefers_per_node_counts_over_the_global_world_size(mon
     assert hostinfo.local_world_size() == 4
     monkeypatch.delenv("LOCAL_WORLD_SIZE")
     monkeypatch.delenv("SLURM_NTASKS_PER_NODE")
-    assert hostinfo.local_world_size() == 64          # (one-node fallback; a GPU box caps it at its device count)
+    monkeypatch.setattr(hostinfo, "_node_gpu_count", lambda: 0)
+    assert hostinfo.local_world_size() == 64          # one-node fallback, no GPU listed by the driver: taken as is
+    # the cap is the NODE's GPU count (sysfs), not what this rank may see -- one visible GPU per rank must not turn into
+    # "this rank owns the node's cores" -- and the helper does not touch torch.cuda
+    monkeypatch.setattr(hostinfo, "_node_gpu_count", lambda: 8)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "3")
+    assert hostinfo.local_world_size() == 8
+    monkeypatch.setenv("SLURM_TASKS_PER_NODE", "4(x16)")
+    assert hostinfo.local_world_size() == 4
+
+
+def test_node_gpu_count_reads_sysfs_without_the_runtime():
+    import inspect
+    from declip_amd import hostinfo
+    assert isinstance(hostinfo._node_gpu_count(), int) and hostinfo._node_gpu_count() >= 0
+    assert "torch" not in inspect.getsource(hostinfo._node_gpu_count).replace("torch.cuda / HIP", "")
