@@ -27,6 +27,76 @@ template <> struct Raw8<float> {
   __device__ __forceinline__ void unpack(float* o) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
 };
 
+// Row PAIRS: when d is not a multiple of 512 elements but 2 d is (d = 768: the ViT-B width; d = 256), two consecutive rows are one
+// contiguous run of NC * 64 16-byte chunks -- every load / store of the wave is a full 1 KB request and no lane idles (the per-row
+// layout above leaves half of the wave masked in its last chunk: 4 requests and 32 elements of arithmetic per lane and pair instead
+// of 3 and 24).  Lane l holds chunks g = l + 64 k of the pair; chunk g belongs to row g / (d/8), column chunk g % (d/8).
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void ln_fwd_pair_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, T* __restrict__ y,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                          int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const int nchunk = d >> 3;                    // chunks per row; 2 * nchunk == 64 * NC
+  float wv[NC][8], bv[NC][8];
+  bool second[NC];                              // chunk k of this lane lies in the pair's second row
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int g = lane + 64 * k;
+    second[k] = g >= nchunk;
+    const int col = g - (second[k] ? nchunk : 0);
+    ld8(w + col * 8, wv[k]); ld8(b + col * 8, bv[k]);
+  }
+  Raw8<T> nxt[NC];
+  auto fetch = [&](int row0) {
+    const bool both = row0 + 1 < rows;          // an odd row count: the last pair has one row (its second-row chunks re-read the first row)
+#pragma unroll
+    for (int k = 0; k < NC; ++k) nxt[k].load(x + (long)row0 * d + (long)(lane + 64 * k) * 8 - ((second[k] && !both) ? d : 0));
+  };
+  int row0 = wave_global * 2;
+  if (row0 < rows) fetch(row0);
+  for (; row0 < rows; row0 += nwaves * 2) {
+    float v[NC][8];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      nxt[k].unpack(v[k]);
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t += v[k][i];
+      if (second[k]) s1 += t; else s0 += t;
+    }
+    if (row0 + nwaves * 2 < rows) fetch(row0 + nwaves * 2);
+    const float mu0 = wave_sum_fast(s0) / d, mu1 = wave_sum_fast(s1) / d;
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const float mu = second[k] ? mu1 : mu0;
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float u = v[k][i] - mu; t += u * u; }
+      if (second[k]) q1 += t; else q0 += t;
+    }
+    const float rs0 = rsqrtf(wave_sum_fast(q0) / d + eps), rs1 = rsqrtf(wave_sum_fast(q1) / d + eps);
+    const bool both = row0 + 1 < rows;
+    if (lane == 0) {
+      if (mean) { mean[row0] = mu0; if (both) mean[row0 + 1] = mu1; }
+      if (rstd) { rstd[row0] = rs0; if (both) rstd[row0 + 1] = rs1; }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      if (second[k] && !both) continue;
+      const float mu = second[k] ? mu1 : mu0, rs = second[k] ? rs1 : rs0;
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (v[k][i] - mu) * rs * wv[k][i] + bv[k][i];
+      st8_fast(y + (long)row0 * d + (long)(lane + 64 * k) * 8, o);
+    }
+  }
+}
+
 // NCH = 16-byte chunks per lane (d <= 512 * NCH); two rows per wave per iteration, and the NEXT iteration's two rows are
 // requested (packed, 4 registers per chunk) before the current ones are reduced: the kernel is latency-bound (load ->
 // two dependent wave reductions -> store), a wave that handles one iteration at a time leaves HBM idle most of the time
@@ -418,6 +488,23 @@ extern "C" int dh_layernorm_fwd(int dtype, const void* x, const float* w, const 
     else if (nch <= 1) hipLaunchKernelGGL((ln_fwd_kernel<TT, 1>), grid, dim3(256), 0, st, (const TT*)x, w, b, (TT*)y, mean, rstd, rows, d, eps);       \
     else if (nch == 2) hipLaunchKernelGGL((ln_fwd_kernel<TT, 2>), grid, dim3(256), 0, st, (const TT*)x, w, b, (TT*)y, mean, rstd, rows, d, eps);  \
     else hipLaunchKernelGGL((ln_fwd_kernel<TT, LN_MAXC>), grid, dim3(256), 0, st, (const TT*)x, w, b, (TT*)y, mean, rstd, rows, d, eps);          \
+  }
+  // row pairs (d = 768, 256): see ln_fwd_pair_kernel.  DH_LN_FWD_PAIR=0 (read once) keeps the per-row kernel for A/B runs.
+  static int ln_pair = -1;
+  if (ln_pair < 0) { const char* ev = getenv("DH_LN_FWD_PAIR"); ln_pair = ev ? (atoi(ev) != 0) : 1; }
+  const int pair_nc = (vec && ln_pair && ln_r == 2 && (d / 8) % 64 != 0 && (2 * (d / 8)) % 64 == 0) ? 2 * (d / 8) / 64 : 0;
+  if (pair_nc == 1 || pair_nc == 3) {
+    dim3 pgrid(ln_balanced_grid(rows, 8, ln_cap));            // 4 waves x one row pair per iteration
+#define LN_PAIR(TT)                                                                                                                                 \
+    {                                                                                                                                               \
+      if (pair_nc == 1) hipLaunchKernelGGL((ln_fwd_pair_kernel<TT, 1>), pgrid, dim3(256), 0, st, (const TT*)x, w, b, (TT*)y, mean, rstd, rows, d, eps); \
+      else hipLaunchKernelGGL((ln_fwd_pair_kernel<TT, 3>), pgrid, dim3(256), 0, st, (const TT*)x, w, b, (TT*)y, mean, rstd, rows, d, eps);             \
+    }
+    if (dtype == DH_BF16) LN_PAIR(bf16_t)
+    else LN_PAIR(float)
+#undef LN_PAIR
+    DH_CHECK_LAUNCH();
+    return DH_OK;
   }
   if (dtype == DH_BF16) {
     if (vec) LN_FWD(bf16_t)

@@ -111,7 +111,7 @@ def test_colsum():
 
 # ----------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("rows,d", [(50, 768), (77, 512), (13, 128), (9, 100)])
+@pytest.mark.parametrize("rows,d", [(50, 768), (51, 768), (1, 768), (7, 256), (77, 512), (13, 128), (9, 100)])     # 768 / 256: the row-pair forward kernel (odd counts: a last pair of one row)
 def test_layernorm(dtype, rows, d):
     ops = _ops()
     x = rnd(rows, d, seed=12).to(dtype)

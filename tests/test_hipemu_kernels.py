@@ -22,6 +22,8 @@ CASES = [
     ("test_gemm_weight_grad_accumulate_splitk", (F32,)),
     ("test_colsum", ()),
     ("test_layernorm", (BF16, 50, 768)),
+    ("test_layernorm", (BF16, 51, 768)),
+    ("test_layernorm", (F32, 7, 256)),
     ("test_layernorm", (F32, 77, 512)),
     ("test_layernorm", (BF16, 9, 100)),
     ("test_layernorm_deferred_reduce_of_many", (BF16,)),
