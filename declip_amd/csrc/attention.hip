@@ -16,6 +16,9 @@ namespace {
 
 constexpr int HD = 64;
 constexpr int RS = HD + 8;  // row stride (elements) of row-major [L][64] bf16 tiles: 144 B, 16-B aligned
+#ifndef ATTN_LINE_OUT
+#define ATTN_LINE_OUT 1     // outputs leave as whole 128-byte rows through LDS (0: 8-byte pieces straight from the MFMA fragments)
+#endif
 
 __device__ __forceinline__ bf16x8_t lds_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 __device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
@@ -201,6 +204,11 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
   __syncthreads();
   // O[q][d] = sum_key P[q][key] V[key][d]: A = P rows (this wave's queries), B = V via transpose reads
   const int nks_live = qb * 16 >= Lp ? 0 : (causal ? min((Lp + 31) >> 5, ((qb + 1) * 16 + 31) >> 5) : (Lp + 31) >> 5);   // P is zero beyond
+  // C^T layout: lane&15 = query row, registers = 4 consecutive head-dim columns 4*(lane>>4)+r.  Stored straight from there a wave writes
+  // sixteen 32-byte pieces per instruction, every 128-byte row of the head in four visits; the store path is priced per line touched
+  // (profiles/r06_epilogue_traces.txt).  LINE_OUT: the wave's 16 x 64 block goes through its OWN query rows of Qs (nobody reads them
+  // after the first MFMAs) and leaves as whole 128-byte rows, 16 bytes per lane.
+  bf16_t* Os = Qs + qb * 16 * RS;
 #pragma unroll
   for (int db = 0; db < 4; ++db) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -212,12 +220,24 @@ __global__ void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __r
       bf16x8_t vf = kmask(frag_tr(Vs, RS, ks * 32, db * 16, dead ? (lane & 31) : lane), dead);
       acc = mfma16(vf, pf, acc);            // swapped operands: the fragment comes out transposed
     }
-    // C^T layout: lane&15 = query row, registers = 4 consecutive head-dim columns 4*(lane>>4)+r -> one 8-byte store
-    const int qq = qb * 16 + (lane & 15);
-    if (qq < Lp) {
-      uint2 w;
-      w.x = pack2bf_hw(acc[0], acc[1]); w.y = pack2bf_hw(acc[2], acc[3]);
-      *reinterpret_cast<uint2*>(out + ((VL ? (long)cu[bi] : (long)bi * L) + qq) * d_model + h * HD + db * 16 + 4 * (lane >> 4)) = w;
+    uint2 w;
+    w.x = pack2bf_hw(acc[0], acc[1]); w.y = pack2bf_hw(acc[2], acc[3]);
+    if (ATTN_LINE_OUT) {
+      *reinterpret_cast<uint2*>(Os + (lane & 15) * RS + db * 16 + 4 * (lane >> 4)) = w;
+    } else {
+      const int qq = qb * 16 + (lane & 15);
+      if (qq < Lp) *reinterpret_cast<uint2*>(out + ((VL ? (long)cu[bi] : (long)bi * L) + qq) * d_model + h * HD + db * 16 + 4 * (lane >> 4)) = w;
+    }
+  }
+  if (ATTN_LINE_OUT) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS written by some lanes is read by others of the same wave
+    __builtin_amdgcn_wave_barrier();
+    bf16_t* og = out + ((VL ? (long)cu[bi] : (long)bi * L) + qb * 16) * d_model + h * HD;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int r = pass * 8 + (lane >> 3), c = lane & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(Os + r * RS + c * 8);
+      if (qb * 16 + r < Lp) *reinterpret_cast<uint4*>(og + (long)r * d_model + c * 8) = v;
     }
   }
   __syncthreads();                         // every wave is done with the tiles before the next pair overwrites them
@@ -382,6 +402,88 @@ __global__ __launch_bounds__(64 * NKB, PF == 2 ? 2 : 3) void attn_bwd_mfma_kerne
     const int rb = wave;
     bf16_t* dq_g = dqkv + row0 * gs + h * HD;
     const int nks_live = (Lp + 31) >> 5;   // contraction steps of 32 rows that hold anything: P^T / dS^T are zero beyond the sequence
+    // LINE: each of the three 16 x 64 output blocks leaves as whole 128-byte rows, staged through this wave's OWN rows of P^T (read by
+    // nobody else, and by this wave only for dV, which goes first) -- see the forward kernel.  Needs TS * 2 >= 128 bytes per row (NKB >= 4).
+    // Dense sequences only: on the packed captions (causal, 43 rows on average) the three separate passes cost more than the stores save
+    // (text backward 74.7 -> 77.4 us, image backward 85 -> 78 us; profiles/r06_attention_line_stores.txt).
+    constexpr bool LINE = ATTN_LINE_OUT && !VL && TS * 2 >= 128;
+    bf16_t* St = Pt + rb * 16 * TS;
+    auto flush = [&](long col0) {          // the staged block -> rows rb*16 .. of dqkv, columns col0 .. col0 + 63 of this head
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS written by some lanes is read by others of the same wave
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int r = pass * 8 + (lane >> 3), c = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(St + r * TS + c * 8);
+        if (rb * 16 + r < Lp) *reinterpret_cast<uint4*>(dq_g + (long)(rb * 16 + r) * gs + col0 + c * 8) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the next block's pieces overwrite what other lanes have just read
+      __builtin_amdgcn_wave_barrier();
+    };
+    auto emit = [&](const f32x4_t& a, int db, long col0) {
+      // transposed fragments: lane&15 = row (query / key), registers = 4 consecutive head-dim columns -> 8-byte pieces
+      uint2 w;
+      w.x = pack2bf_hw(a[0], a[1]); w.y = pack2bf_hw(a[2], a[3]);
+      if (LINE) {
+        *reinterpret_cast<uint2*>(St + (lane & 15) * TS + db * 16 + 4 * (lane >> 4)) = w;
+      } else {
+        const int row = rb * 16 + (lane & 15);
+        if (row < Lp) *reinterpret_cast<uint2*>(dq_g + (long)row * gs + col0 + db * 16 + 4 * (lane >> 4)) = w;
+      }
+    };
+    if (LINE) {
+      // one output at a time (same MFMAs and operand reads as the fused loop below; the P^T rows are dead once dV is done)
+      f32x4_t acc[4];
+      // dV[key][d] = sum_q P^T[key][q] dO[q][d]
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        acc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          if (ks >= nks_live) continue;
+          const bool dead = KTAIL && ks == NKS - 1 && (lane >> 4) >= 2;
+          const int ln = dead ? (lane & 31) : lane;
+          const int ro = (rb * 16 + (lane & 15)) * TS + ks * 32 + 8 * (ln >> 4);
+          bf16x8_t gB = kmask(frag_tr(Gs, RS, ks * 32, db * 16, ln), dead);
+          acc[db] = mfma16(gB, kmask(lds_frag(Pt + ro), dead), acc[db]);
+        }
+      }
+#pragma unroll
+      for (int db = 0; db < 4; ++db) emit(acc[db], db, 2 * d_model);
+      flush(2 * d_model);
+      // dK[key][d] = sum_q dS^T[key][q] Q[q][d]
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        f32x4_t ak = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          if (ks >= nks_live) continue;
+          const bool dead = KTAIL && ks == NKS - 1 && (lane >> 4) >= 2;
+          const int ln = dead ? (lane & 31) : lane;
+          const int ro = (rb * 16 + (lane & 15)) * TS + ks * 32 + 8 * (ln >> 4);
+          bf16x8_t qB = kmask(frag_tr(Qs, RS, ks * 32, db * 16, ln), dead);
+          ak = mfma16(qB, kmask(lds_frag(dSt + ro), dead), ak);
+        }
+        emit(ak, db, d_model);
+      }
+      flush(d_model);
+      // dQ[q][d] = sum_key dS[q][key] K[key][d]: A = dS via transpose read of dS^T, B = K via transpose read
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        f32x4_t aq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          if (ks >= nks_live) continue;
+          const bool dead = KTAIL && ks == NKS - 1 && (lane >> 4) >= 2;
+          const int ln = dead ? (lane & 31) : lane;
+          bf16x8_t dsA = kmask(frag_tr(dSt, TS, ks * 32, rb * 16, ln), dead);
+          bf16x8_t kB = kmask(frag_tr(Ks, RS, ks * 32, db * 16, ln), dead);
+          aq = mfma16(kB, dsA, aq);
+        }
+        emit(aq, db, 0);
+      }
+      flush(0);
+    } else {
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       f32x4_t av = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f}, aq = {0.f, 0.f, 0.f, 0.f};
@@ -401,18 +503,10 @@ __global__ __launch_bounds__(64 * NKB, PF == 2 ? 2 : 3) void attn_bwd_mfma_kerne
         bf16x8_t kB = kmask(frag_tr(Ks, RS, ks * 32, db * 16, ln), dead);
         aq = mfma16(kB, dsA, aq);
       }
-      // transposed fragments: lane&15 = row (query / key), registers = 4 consecutive head-dim columns -> 8-byte stores
-      const int row = rb * 16 + (lane & 15);
-      if (row < Lp) {
-        const long o = (long)row * gs + db * 16 + 4 * (lane >> 4);
-        uint2 w;
-        w.x = pack2bf_hw(aq[0], aq[1]); w.y = pack2bf_hw(aq[2], aq[3]);
-        *reinterpret_cast<uint2*>(dq_g + o) = w;
-        w.x = pack2bf_hw(ak[0], ak[1]); w.y = pack2bf_hw(ak[2], ak[3]);
-        *reinterpret_cast<uint2*>(dq_g + o + d_model) = w;
-        w.x = pack2bf_hw(av[0], av[1]); w.y = pack2bf_hw(av[2], av[3]);
-        *reinterpret_cast<uint2*>(dq_g + o + 2 * d_model) = w;
-      }
+      emit(aq, db, 0);
+      emit(ak, db, d_model);
+      emit(av, db, 2 * d_model);
+    }
     }
   }
   __syncthreads();                         // every wave is done with the tiles before the next pair overwrites them
