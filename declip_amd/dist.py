@@ -424,6 +424,13 @@ class RowsSync(object):
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX, group=self.group)
         return int(t[0])
 
+    def close(self):
+        """Tear the side group down (collective; after the prefetcher that used it was closed).  A process that exits with the group's
+        transport thread still alive can abort in a C++ destructor: destroy it, or the whole process group, before exiting."""
+        if self.group is not None:
+            tdist.destroy_process_group(self.group)
+            self.group = None
+
 
 def broadcast_object(obj, src=0):
     """utils/dist.py:111-126."""

@@ -697,6 +697,12 @@ def _w_rows_sync_keys(rank, world, port, out):
         assert gathered[0][1][i] < gathered[1][1][i]                      # (the ranks really differed)
     if rank == 0:
         out.put("ok")
+    # two gloo groups, one of them used from the prefetcher's worker thread: tear them down in order instead of leaving it to interpreter
+    # exit (a rank that exits while the other group's transport thread is still alive aborts in a C++ destructor: seen once in ~4 runs)
+    pf.close()
+    torch.distributed.barrier()
+    sync.close()
+    torch.distributed.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [4, 8])          # (8: the driver's largest scaling point; b = 3 per rank, B = 24)
