@@ -1,51 +1,71 @@
-"""The M = b GEMMs of the pooled last block (512 rows): which kernel family is fastest?  v4 (256 x 256 tiles cut in K over the chip
-+ fix-up launch) vs the 128 x 128 LDS-DMA kernel vs the register-staged MFMA kernel, per-launch time on an otherwise idle chip.
+"""The M = 512 GEMMs of the pooled last blocks (b pooled rows against the block's weights): gemm_v4's few-tile path (tiles cut in K over the
+chip + a fix-up launch) against the other kernel families on the same shapes, us per call in a captured graph of 20 dependent calls
+(what the step pays: no host launch overhead, kernel-to-kernel dependency latency included).
+
     python tools/bench_small_gemm.py"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: E402
+import torch
 
-from declip_amd import ops  # noqa: E402
-from declip_amd.engine import gemm_workspace  # noqa: E402
-from declip_amd.lib import EPI_DGELU, EPI_GELU, EPI_NONE  # noqa: E402
+from declip_amd import engine, ops
 
-dev, bf = torch.device("cuda"), torch.bfloat16
-ws = gemm_workspace(dev)
-SHAPES = [(512, 768, 768, 0, 0, 0), (512, 768, 768, 0, 0, 1), (512, 3072, 768, 0, 1, 0), (512, 768, 3072, 0, 0, 1), (512, 3072, 768, 1, 2, 0),
-          (512, 768, 3072, 1, 0, 0), (512, 768, 768, 1, 0, 0), (512, 512, 512, 0, 0, 1), (512, 2048, 512, 0, 1, 0), (512, 512, 2048, 0, 0, 1),
-          (512, 512, 2048, 1, 0, 0), (512, 2048, 512, 1, 2, 0)]
-
-
-def timed(fn, iters=50):
-    for _ in range(5):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / iters
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
+# (M, N, K, b_kmajor, epilogue, residual)
+SHAPES = [(512, 768, 768, 0, 0, 1), (512, 3072, 768, 0, 1, 0), (512, 768, 3072, 0, 0, 1), (512, 512, 768, 0, 0, 0),
+          (512, 768, 3072, 1, 0, 0), (512, 3072, 768, 1, 2, 0), (512, 768, 768, 1, 0, 0),
+          (512, 512, 512, 0, 0, 1), (512, 2048, 512, 0, 1, 0), (512, 512, 2048, 0, 0, 1), (512, 512, 2048, 1, 0, 0), (512, 2048, 512, 1, 2, 0)]
+ws = engine.gemm_workspace(dev)
 
 
-print("%5s %5s %5s tb epi res | %10s %10s %10s   (us per launch: v4 sliced | glds 128 | auto)" % ("M", "N", "K", "v4", "glds128", "auto"))
-for M, N, K, tb, epi, res in SHAPES:
-    A = (torch.rand(M, K, device=dev) - 0.5).to(bf)
-    B = ((torch.rand((K, N) if tb else (N, K), device=dev) - 0.5) * 0.1).to(bf)
-    bias = None if epi == 2 else torch.rand(N, device=dev)
-    r = (torch.rand(M, N, device=dev) - 0.5).to(bf) if res else None
-    aux = torch.empty(M, N, device=dev, dtype=bf) if epi == 1 else ((torch.rand(M, N, device=dev) - 0.5).to(bf) if epi == 2 else None)
-    out = torch.empty(M, N, device=dev, dtype=bf)
-    row = []
-    for fg in (4, 3, 0):
-        def f():
-            ops.gemm(A, B, b_kmajor=bool(tb), bias=bias, epilogue={0: EPI_NONE, 1: EPI_GELU, 2: EPI_DGELU}[epi], residual=r, aux=aux, out=out,
-                     force_generic=fg, ws=ws)
-        try:
-            row.append("%10.1f" % timed(f))
-        except Exception as e:  # noqa: BLE001
-            row.append("%10s" % "n/a")
-    print("%5d %5d %5d %2d %3d %3d | %s" % (M, N, K, tb, epi, res, " ".join(row)), flush=True)
+def run(shape, family):
+    M, N, K, tb, epi, res = shape
+    A = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
+    B = (torch.randn(K, N, device=dev) * 0.05).bfloat16() if tb else (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    bias = None if tb else torch.randn(N, device=dev)
+    R = (torch.randn(M, N, device=dev)).bfloat16() if res else None
+    aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == EPI_GELU else ((torch.rand(M, N, device=dev)).bfloat16() if epi == EPI_DGELU else None)
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    kw = dict(b_kmajor=bool(tb), bias=bias, epilogue=epi, residual=R, aux=aux, out=out)
+    if family == "v4":
+        kw.update(ws=ws)
+    elif family == "v4_nosplit":
+        pass
+    else:
+        kw.update(force_generic=family)
+
+    def call():
+        ops.gemm(A, B, **kw)
+    try:
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(20):
+                call()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / 200
+    except Exception as e:
+        return float("nan")
+
+
+fams = [("v4", "v4 few-tile"), ("v4_nosplit", "v4 no split"), (31, "v3 mode 31"), (32, "v3 mode 32"), (33, "v3 mode 33"), (3, "glds (v2)"), (2, "v1 mfma")]
+print("%-34s" % "M N K tb epi res" + "".join("%14s" % n for _, n in fams))
+tot = [0.0] * len(fams)
+for s in SHAPES:
+    ts = [run(s, f) for f, _ in fams]
+    for i, t in enumerate(ts):
+        tot[i] += t
+    print("%-34s" % (" ".join(str(x) for x in s)) + "".join("%14.1f" % t for t in ts))
+print("%-34s" % "sum us" + "".join("%14.1f" % t for t in tot))
