@@ -259,8 +259,8 @@ def _arm_watchdog(seconds, what):
     the driver tears down the hung queues of the old image.  The line then carries `graph_fallback`.  Returns the timer (cancel())."""
     import threading
 
-    def fire():
-        msg = "watchdog: %s made no progress in %d s; rank re-executed with --graph 0" % (what, int(seconds))
+    def fire(msg=None):
+        msg = msg or "watchdog: %s made no progress in %d s; rank re-executed with --graph 0" % (what, int(seconds))
         sys.stderr.write("bench.py: " + msg + "\n")
         sys.stderr.flush()
         env = dict(os.environ, DH_BENCH_GRAPH_FALLBACK=msg)
@@ -287,6 +287,7 @@ def _arm_watchdog(seconds, what):
         os.execve(sys.executable, [sys.executable, os.path.abspath(__file__)] + argv + ["--graph", "0"], env)
     t = threading.Timer(seconds, fire)
     t.daemon = True
+    t.reexec = fire           # the same way out for a captured step that RAISES (GraphedStep: invalidated capture / failed first launch)
     t.start()
     return t
 
@@ -538,10 +539,19 @@ def main():
             p_.data.clamp_(3, 6)
         return loss
 
-    for _ in range(args.warmup):
-        step()
-    while use_graph and graphed.enabled and graphed.graph is None:
-        step()             # fewer warm-up steps than the capture needs (2 eager + 1 captured): the capture must not land in the timed region
+    try:
+        for _ in range(args.warmup):
+            step()
+        while use_graph and graphed.enabled and graphed.graph is None:
+            step()             # fewer warm-up steps than the capture needs (2 eager + 1 captured): the capture must not land in the timed region
+    except RuntimeError as e:
+        # a data-parallel rank whose captured step cannot be used and cannot be replaced by the eager step IN THIS PROCESS (GraphedStep:
+        # the capture was invalidated, or the first launch failed after the peers entered theirs): the same way out as a hang --
+        # this rank starts over with --graph 0; its peers, stuck in a collective without it, follow through their watchdogs
+        if watchdog is None or "GraphedStep" not in str(e) or graph_fallback:
+            raise
+        watchdog.cancel()
+        watchdog.reexec("captured step unusable (%s); rank re-executed with --graph 0" % str(e).splitlines()[0][:200])
     if watchdog is not None:
         if graphed.enabled and graphed.graph is not None:
             if os.environ.get("DH_BENCH_TEST_HANG") == "1" and not graph_fallback:      # test hook: a replay that never returns (tests/test_gpu_bench_fallback.py)

@@ -28,3 +28,18 @@ extern "C" int dh_device_info(int device, int* out4) {
   out4[3] = arch;
   return DH_OK;
 }
+
+// A stream capture that was INVALIDATED (an operation that is illegal under capture ran on the capturing stream) stays open until somebody
+// ends it; torch.cuda.graph's exit raises on exactly that call and then leaves the stream behind.  graph.GraphedStep(fallback=True) calls this
+// on the abandoned capture stream before it re-runs the step eagerly.  Returns 1 if a capture was open and has been ended, 0 if none was.
+extern "C" int dh_stream_abandon_capture(dh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &status) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (status == hipStreamCaptureStatusNone) return 0;
+  hipGraph_t g = nullptr;
+  (void)hipStreamEndCapture(st, &g);          // (returns hipErrorStreamCaptureInvalidated for an invalidated capture: expected)
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  return 1;
+}

@@ -81,6 +81,20 @@ class GraphedStep(object):
         import torch.distributed as tdist
         return "thread_local" if (tdist.is_available() and tdist.is_initialized()) else "global"
 
+    @staticmethod
+    def _abandon_capture(before):
+        """A capture that was INVALIDATED (an operation that is illegal under capture ran) makes torch.cuda.graph's exit raise from
+        capture_end() -- before it restores the current stream, and with the capture still open on the side stream it used.  End
+        that capture (dh_stream_abandon_capture) and go back to the stream the step was on, so that the eager re-run is an eager run."""
+        from . import lib as L
+        cur = torch.cuda.current_stream()
+        try:
+            L.load().dh_stream_abandon_capture(cur.cuda_stream)
+        except Exception:                       # noqa: BLE001
+            pass
+        if cur.cuda_stream != before.cuda_stream:
+            torch.cuda.set_stream(before)
+
     def _check_capturable(self):
         """A data-parallel step is captured only when its three collectives run on the LIBRARY's communicator (csrc/comm.hip through
         declip_amd.comm_native: RCCL on a library-owned stream, ordered with two events).  Then no ProcessGroupNCCL work object is
@@ -146,6 +160,7 @@ class GraphedStep(object):
                 all_ok = bool(self.agree(ok))
                 return all_ok, ("a peer rank could not %s its step" % what if ok and not all_ok else None)
 
+            before = torch.cuda.current_stream()
             try:
                 self._check_capturable()
                 torch.cuda.synchronize()
@@ -154,8 +169,17 @@ class GraphedStep(object):
                     self.pool = torch.cuda.graph_pool_handle()
                 with torch.cuda.graph(g, pool=self.pool, capture_error_mode=self._capture_mode()):
                     out = self.fn()
-            except Exception as e:              # noqa: BLE001  (whatever the runtime raises: the eager step is the answer to all of it)
+            except Exception as e:              # noqa: BLE001  (whatever the step raises: the eager step is the answer to it)
                 err = "capture: %s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+                if torch.cuda.current_stream().cuda_stream != before.cuda_stream or torch.cuda.is_current_stream_capturing():
+                    # the capture itself was INVALIDATED (an operation that is illegal under capture ran): torch.cuda.graph's exit raised
+                    # from capture_end() before it restored the stream and told the allocator that the capture is over.  There is no
+                    # eager step to fall back to in this process (measured: the next synchronisation aborts it) -- end the HIP-side
+                    # capture so that teardown is clean, and fail loudly; bench.py re-executes the rank with --graph 0.
+                    self._abandon_capture(before)
+                    self.enabled, self.fallback_reason = False, "capture invalidated (%s)" % err
+                    raise RuntimeError("GraphedStep: the stream capture of the step was invalidated and cannot be recovered from in this "
+                                       "process: %s" % err) from e
             ok, peer = _agreed(err is None, "capture")
             err = err or peer
             if ok:
@@ -172,11 +196,17 @@ class GraphedStep(object):
                     for st in self.stores:
                         st.after_replay()
                     return out
+                if not ok:
+                    # THIS rank's first graph launch failed after its peers may have run the step's collectives: an eager re-run here would
+                    # enter collectives nobody else is in.  Fail loudly (the launcher ends the job) instead of hanging.
+                    self.enabled, self.fallback_reason = False, "first replay failed (%s)" % err
+                    raise RuntimeError("GraphedStep: the first launch of the captured data-parallel step failed on this rank: %s" % err)
             if not ok:
                 self.enabled, self.fallback_reason = False, "capture failed, step runs eagerly (%s)" % err
                 for st in self.stores:          # a backward that died inside the capture never reached its end-of-pass callback
                     st._in_backward = False
-                assert not torch.cuda.is_current_stream_capturing(), "GraphedStep: the stream is still capturing after a failed capture"
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("GraphedStep: the stream is still capturing after a failed capture (%s)" % err)
                 return self.fn()
         self.captures += 1
         self.graphs[k] = (g, out)

@@ -68,6 +68,7 @@ _PROTOS = {
     "dh_last_error": (c_char_p, []),
     "dh_version": (c_int, []),
     "dh_device_info": (c_int, [c_int, POINTER(c_int)]),
+    "dh_stream_abandon_capture": (c_int, [_P]),
     "dh_gemm": (c_int, [POINTER(GemmArgs), _P]),
     "dh_gemm_group": (c_int, [POINTER(GemmArgs), c_int, _P]),
     "dh_gemm_v4_enable": (c_int, [c_int]),

@@ -40,6 +40,9 @@ const char* dh_last_error(void);
 int dh_version(void);
 /* device properties the host needs for grid sizing: out[0]=CUs, out[1]=clock kHz, out[2]=LDS bytes/CU, out[3]=gfx arch number */
 int dh_device_info(int device, int* out4);
+/* Ends a stream capture that was left open on `stream` (an invalidated capture that its owner gave up on: declip_amd/graph.py, the
+ * fallback of a data-parallel step whose capture failed); 1 = a capture was open and is ended now, 0 = the stream was not capturing. */
+int dh_stream_abandon_capture(dh_stream_t stream);
 
 /* ---------------------------------------------------------------- GEMM ------------------
  * C[M,N] (+)= epi( alpha * sum_k A(m,k) * B(n,k) + bias[n] )

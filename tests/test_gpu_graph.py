@@ -267,3 +267,78 @@ def test_graphed_multiview_step_equals_eager_step(family, cfg_name, b):
         gtol = max(gtol, 2.5 * floor)
         assert gtol < 1.0, floor
     assert gdiff <= gtol, (gdiff, gtol)
+
+
+def _toy_step():
+    """A step small enough to reason about: y = (x * w).sum() accumulated into a buffer; `bad` makes the step RAISE while it is being
+    captured (what a library call that refuses its arguments, or a collective that reports an error, does) while the eager run works."""
+    x = torch.arange(8, device="cuda", dtype=torch.float32)
+    acc = torch.zeros(1, device="cuda")
+    state = dict(bad=False, runs=0)
+
+    def fn():
+        state["runs"] += 1
+        if state["bad"] and torch.cuda.is_current_stream_capturing():
+            raise ValueError("refused under capture")
+        acc.add_((x * 2).sum())
+        return acc
+    return fn, acc, state
+
+
+def test_fallback_capture_failure_runs_the_eager_step_on_every_rank():
+    """GraphedStep(fallback=True): a capture that raises -- here, or on a peer rank (agree() says so) -- turns into the eager step, the
+    stepper stays usable, and the stream is not left capturing."""
+    from declip_amd.graph import GraphedStep
+    for who in ("local", "peer"):
+        fn, acc, state = _toy_step()
+        state["bad"] = who == "local"
+        seen = []
+
+        def agree(ok, who=who, seen=seen):
+            seen.append(ok)
+            return ok and who != "peer"
+        st = GraphedStep(fn, warmup=1, enabled=True, modules=(), fallback=True, agree=agree)
+        for _ in range(4):
+            st()
+        torch.cuda.synchronize()
+        assert not st.enabled and st.graph is None and st.fallback_reason.startswith("capture failed"), st.fallback_reason
+        assert seen == [who != "local"]                       # one agreement round (the capture), none for a replay that never happened
+        assert not torch.cuda.is_current_stream_capturing()
+        # every call contributed exactly one step's worth (the failed LOCAL capture recorded nothing that ran; a successful local
+        # capture that a peer vetoes never launched its graph)
+        assert float(acc) == 4 * 56.0, (who, float(acc))
+
+
+def test_fallback_first_replay_failure_on_a_peer_keeps_this_ranks_step_and_goes_eager():
+    from declip_amd.graph import GraphedStep
+    fn, acc, state = _toy_step()
+    votes = iter([True, False])                               # capture agreed, then a peer reports that its first replay failed
+
+    def agree(ok):
+        assert ok
+        return next(votes)
+    st = GraphedStep(fn, warmup=1, enabled=True, modules=(), fallback=True, agree=agree)
+    for _ in range(4):
+        st()
+    torch.cuda.synchronize()
+    assert not st.enabled and "peer" in st.fallback_reason
+    assert float(acc) == 4 * 56.0                             # call 2 = this rank's replay (kept), calls 3-4 eager
+
+
+def test_fallback_first_replay_failure_on_this_rank_raises_instead_of_rerunning():
+    """The peers may already be inside the replayed step's collectives: an eager re-run here would enter collectives nobody joins."""
+    from declip_amd import graph as G
+    fn, acc, state = _toy_step()
+    st = G.GraphedStep(fn, warmup=1, enabled=True, modules=(), fallback=True, agree=lambda ok: ok)
+    st()
+    orig = torch.cuda.CUDAGraph.replay
+
+    def boom(self):
+        raise RuntimeError("injected launch failure")
+    torch.cuda.CUDAGraph.replay = boom
+    try:
+        with pytest.raises(RuntimeError, match="first launch of the captured"):
+            st()
+    finally:
+        torch.cuda.CUDAGraph.replay = orig
+    assert not st.enabled and st.fallback_reason.startswith("first replay failed")
