@@ -80,7 +80,7 @@ ALL_SOURCES = ["embed.hip", "fill.hip", "layernorm.hip", "declip_ops.hip", "fili
 # ... and the same with the benchmarked persistent GEMM itself (gemm_v4.hip keeps its inline ISA behind macros): kernel-level tests only
 V4_SOURCES = [s for s in ALL_SOURCES if s != "emu_stubs_v4.cpp"] + ["gemm_v4.hip"]
 _NOT_EMULATED = {"dh_bpe_create", "dh_bpe_destroy", "dh_bpe_vocab_size", "dh_bpe_encode", "dh_version", "dh_device_info", "dh_gemm_v4_enable",
-                 "dh_last_error",
+                 "dh_last_error", "dh_stream_abandon_capture",           # (stream capture: a runtime notion)
                  # the communicator context is RCCL + HIP streams / events: nothing of it exists on the host
                  "dh_comm_unique_id", "dh_init", "dh_finalize", "dh_ctx_info", "dh_comm_stream", "dh_comm_wait", "dh_allgather_packed",
                  "dh_reducescatter_packed", "dh_allreduce_bucket"}
