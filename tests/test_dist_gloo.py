@@ -705,12 +705,23 @@ def _w_rows_sync_keys(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
+def _entry(name, rank, world, port, out):
+    """Process target of every multi-rank test: the worker, then an ORDERLY end of the process group (barrier + destroy).  A rank that
+    simply returns leaves the teardown of gloo's transport threads to interpreter exit, where it races with the peer closing its
+    sockets: 'terminate called without an active exception' (SIGABRT) once in a few runs on a loaded box."""
+    globals()[name](rank, world, port, out)
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("world", [4, 8])          # (8: the driver's largest scaling point; b = 3 per rank, B = 24)
 def test_world4_clip_step(world):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_w_clip_world4, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_entry, args=("_w_clip_world4", r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -725,7 +736,7 @@ def test_world2(fn):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=fn, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_entry, args=(fn.__name__, r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
