@@ -26,6 +26,19 @@ class ClipInfoCELoss(nn.Module):
     def __init__(self):
         super().__init__()
         self.last_correct = None
+        self._labels = {}            # (batch, first label, device) -> labels: the same tensor every step (two launches less per step)
+
+    def _label_row(self, bs, label0, dev):
+        key = (bs, int(label0), str(dev))
+        lab = self._labels.get(key)
+        if lab is None:
+            lab = label0 + torch.arange(bs, device=dev, dtype=torch.long)
+            capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+            if not capturing:            # (a tensor made inside a capture lives in the graph's pool: not kept beyond it)
+                if len(self._labels) > 8:
+                    self._labels.clear()
+                self._labels[key] = lab
+        return lab
 
     def forward(self, logits_per_image, logits_per_text):
         bs, l_bs = logits_per_image.shape
@@ -33,7 +46,7 @@ class ClipInfoCELoss(nn.Module):
         if _is_lazy(logits_per_image) and _is_lazy(logits_per_text):
             li, lt = logits_per_image, logits_per_text
             label0 = li.label0
-            labels = label0 + torch.arange(bs, device=dev, dtype=torch.long)
+            labels = self._label_row(bs, label0, dev)
             same_scale = li.scale is lt.scale
             if same_scale:
                 row_loss, c1, c5 = engine.InfoNCEFn.apply(li.scale, label0, 2, li.Q, li.K, lt.Q, lt.K)
