@@ -438,7 +438,10 @@ __global__ __launch_bounds__(256) void nce_bwd_mfma_kernel(PairTable pt, int mod
   float* Ys = Xs + MX * XS;              // [128][132]
   float* Gt = Ys + MY * (MW + 4);        // [128][36]  G transposed
   float* red = Gt + MY * GS;             // [8]
-  const int pair = blockIdx.y;
+  // mode 2: BOTH directions in one launch (b == B: the two have the same shape) -- blockIdx.y = direction * pairs + pair
+  const int npairs = mode == 2 ? gridDim.y / 2 : gridDim.y;
+  const int pair = blockIdx.y % npairs;
+  if (mode == 2) mode = blockIdx.y / npairs;
   const int label0 = pt.label0[pair], excl0 = pt.excl0[pair];
   const float* X = mode == 0 ? pt.Q[pair] : pt.K[pair];
   const float* Y = mode == 0 ? pt.K[pair] : pt.Q[pair];
@@ -701,25 +704,34 @@ extern "C" int dh_infonce_bwd(const dh_nce_pair* pairs, int n_pairs, int b, int 
     hipLaunchKernelGGL(nce_bwd_kernel<RT>, dim3(dh_cdiv(nx, RT), n_pairs, nz), dim3(256), lds, st, pt, mode, b, B, D, scale,
                        label0, row_lse, g_row, dscale, chunk_cols);
   };
-  auto launch_mfma = [&](int mode) {
+  auto launch_mfma = [&](int mode) {       // mode 2: both directions in ONE launch (b == B only: same shape, twice the blocks)
     const size_t lds = nce_bwd_mfma_lds(D);
     auto kern = nce_xres(D) ? nce_bwd_mfma_kernel<true> : nce_bwd_mfma_kernel<false>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int nx = mode == 0 ? b : B, ny = mode == 0 ? B : b;
+    const int nx = mode == 1 ? B : b, ny = mode == 1 ? b : B;
     const int ndc = nce_xres(D) ? 1 : dh_cdiv(dh_cdiv(D, MW), 4);          // 512-column chunks of dX, one block each
-    const int chunk_cols = nce_chunk_cols_mfma(nx * ndc, ny, n_pairs);
+    const int ndir = mode == 2 ? 2 : 1;
+    const int chunk_cols = nce_chunk_cols_mfma(nx * ndc, ny, n_pairs * ndir);
     const int nz = dh_cdiv(ny, chunk_cols);
     if (nz > 1)
       for (int i = 0; i < n_pairs; ++i) {
-        void* dst = mode == 0 ? (void*)pt.dQ[i] : (void*)pt.dK[i];
-        if (dst) DH_RT_NOTE(hipMemsetAsync(dst, 0, sizeof(float) * (size_t)nx * D, st), "dh_infonce_bwd: clearing a chunked gradient");
+        void* dq = (void*)pt.dQ[i];
+        void* dk = (void*)pt.dK[i];
+        if (mode != 1 && dq) DH_RT_NOTE(hipMemsetAsync(dq, 0, sizeof(float) * (size_t)nx * D, st), "dh_infonce_bwd: clearing a chunked gradient");
+        if (mode != 0 && dk) DH_RT_NOTE(hipMemsetAsync(dk, 0, sizeof(float) * (size_t)nx * D, st), "dh_infonce_bwd: clearing a chunked gradient");
       }
-    hipLaunchKernelGGL(kern, dim3(dh_cdiv(nx, MX) * ndc, n_pairs, nz), dim3(256), lds, st, pt, mode, b, B, D, scale, row_lse, g_row,
+    hipLaunchKernelGGL(kern, dim3(dh_cdiv(nx, MX) * ndc, n_pairs * ndir, nz), dim3(256), lds, st, pt, mode, b, B, D, scale, row_lse, g_row,
                        dscale, chunk_cols);
   };
+  static int merged = -1;      // DH_NCE_BWD_MERGED (read once): 1 (default) = one launch for both directions when b == B; 0 = two launches
+  if (merged < 0) { const char* ev = getenv("DH_NCE_BWD_MERGED"); merged = ev ? (atoi(ev) != 0) : 1; }
   if (nce_mfma_ok(D)) {
-    launch_mfma(0);
-    launch_mfma(1);
+    if (merged && b == B) {
+      launch_mfma(2);
+    } else {
+      launch_mfma(0);
+      launch_mfma(1);
+    }
   } else if (D <= 512) {
     launch(std::integral_constant<int, 32>{}, 0);
     launch(std::integral_constant<int, 32>{}, 1);
