@@ -1107,9 +1107,11 @@ class PackedCaptions:
 
 
 def _buckets(pk, x, heads):
-    """(order, ranges, L_short) when the length-bucketed attention kernels apply (bf16, head dimension 64, a context longer than the
-    short bucket; DH_ATTN_BUCKETS=0 switches them off), else None."""
-    if x.dtype != torch.bfloat16 or x.shape[1] // heads != 64 or pk.L <= pk.L_SHORT or os.environ.get("DH_ATTN_BUCKETS", "1") != "1":
+    """(order, ranges, L_short) when the length-bucketed attention kernels are asked for (DH_ATTN_BUCKETS=1) and apply (bf16, head
+    dimension 64, a context longer than the short bucket), else None.  Default OFF since round 6: the two launches per call are faster
+    alone (fwd 43 -> 38 us, bwd 82 -> 73 us) and slower in the step, where the text tower's launches count through the CUs they hold
+    (22.33 -> 22.27 ms, six of six interleaved pairs; profiles/r06_attention_variants.txt) -- and 22 dispatches fewer per step."""
+    if x.dtype != torch.bfloat16 or x.shape[1] // heads != 64 or pk.L <= pk.L_SHORT or os.environ.get("DH_ATTN_BUCKETS", "0") != "1":
         return None
     return pk.order, pk.ranges, pk.L_SHORT
 
