@@ -1110,8 +1110,10 @@ def _buckets(pk, x, heads):
     """(order, ranges, L_short) when the length-bucketed attention kernels are asked for (DH_ATTN_BUCKETS=1) and apply (bf16, head
     dimension 64, a context longer than the short bucket), else None.  Default OFF since round 6: the two launches per call are faster
     alone (fwd 43 -> 38 us, bwd 82 -> 73 us) and slower in the step, where the text tower's launches count through the CUs they hold
-    (22.33 -> 22.27 ms, six of six interleaved pairs; profiles/r06_attention_variants.txt) -- and 22 dispatches fewer per step."""
-    if x.dtype != torch.bfloat16 or x.shape[1] // heads != 64 or pk.L <= pk.L_SHORT or os.environ.get("DH_ATTN_BUCKETS", "0") != "1":
+    (22.33 -> 22.27 ms, six of six interleaved pairs; profiles/r06_attention_variants.txt) -- and 22 dispatches fewer per step.  A model
+    whose step spends a larger share in the text tower asks for them on its tower (`tower._dh_attn_buckets`: DeCLIP / DeFILIP, two caption
+    views + the masked-LM pass: +0.6 % with buckets); the environment overrides both ways."""
+    if x.dtype != torch.bfloat16 or x.shape[1] // heads != 64 or pk.L <= pk.L_SHORT or os.environ.get("DH_ATTN_BUCKETS", getattr(pk, "buckets_default", "0")) != "1":
         return None
     return pk.order, pk.ranges, pk.L_SHORT
 
@@ -1243,6 +1245,7 @@ class TextTowerPackedFn(torch.autograd.Function):
         flat = tower._flat()
         dtype = flat.act_dtype
         pk = packed_captions(ids, dtype)
+        pk.buckets_default = "1" if getattr(tower, "_dh_attn_buckets", False) else "0"      # (the model's preference: DECLIP sets it on its text tower; see _buckets)
         x = ops.text_embed_packed_fwd(pk.ids_p, pk.pos_idx, tower.token_embedding.weight.data, tower.positional_embedding.data, dtype,
                                       pk.rows_pad, pk.rows_pad)            # (validity of a row: pos_idx >= 0)
         refs = block_refs(flat, tower.transformer.resblocks)

@@ -46,6 +46,9 @@ class DECLIP(CLIP):
         if return_nn_bank:
             self.nn_replacer_img = NNMemoryBankModule(size=nn_size, topk=nn_topk)
             self.nn_replacer_text = NNMemoryBankModule(size=nn_size, topk=nn_topk)
+        # the step spends two caption views and the masked-LM pass in the text tower: its packed attention in two length buckets pays
+        # here (+0.6 % pairs/s, profiles/r06_attention_variants.txt), unlike in the CLIP step (engine._buckets; DH_ATTN_BUCKETS overrides)
+        self.encode_text.__dict__["_dh_attn_buckets"] = True
         self._adopt_towers()
 
     def _adopt_towers(self):

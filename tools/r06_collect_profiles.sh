@@ -16,7 +16,7 @@ cp $F/pmc_traffic_clip_b512.json $P/r06_pmc_traffic_clip_b512.json
 { echo "# round 6, session F (head $H): HBM-bound kernels at their in-step shapes (BENCH_SMALL=all python tools/bench_small.py), alone on the chip"; grep -v "amdgpu.ids" $F/small_kernels.txt; } > $P/r06_small_kernels.txt
 { echo "# round 6, session F (head $H): FILIP step (b = 256, B = 256, towers on one stream, eager), rocprofv3 --kernel-trace: \`DH_TOWER_STREAMS=0 python bench.py --model filip --steps 4 --warmup 2 --graph 0\` (9 steps incl. the roofline leg)"; cat $F/filip_kernel_stats.txt; } > $P/r06_filip_kernel_stats.txt
 { echo "# round 6, session F (head $H): the torch (ATen) kernels left in one eager CLIP step (tools/torch_ops_in_step.py; the two dkv fills of the pooled last blocks -- 78 + 45 MB, 34 + 9 us -- are gone: attn_pooled_bwd zeroes its gap rows)"; grep -v "amdgpu.ids\|Warning\|_warn_once" $F/torch_ops.txt; } > $P/r06_torch_ops_in_step.txt
-{ echo "# round 6, session F (head $H): dispatches and idle time of the DEFAULT CLIP step (two tower streams, captured hipGraph), rocprofv3 --kernel-trace of"; echo "# \`python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-loss-delta --no-roofline\` (tools/rocpd_stats.py per-step section)"; grep -A 20 "^per step" $F/dispatches.txt; echo "# -> 500 dispatches per step (round 5: 504; VERDICT r5's target of <= 440 is NOT reached -- see DESIGN.md s7 for what the remaining launches are and why merging them buys no time: the GPU is idle 0.04 ms of a step)"; echo; echo "# kernel table of the same trace (in-step durations: overlapped kernels stretch each other)"; head -60 $F/dispatches.txt; } > $P/r06_dispatches.txt
+{ echo "# round 6, session F (head $H): dispatches and idle time of the DEFAULT CLIP step (two tower streams, captured hipGraph), rocprofv3 --kernel-trace of"; echo "# \`python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-loss-delta --no-roofline\` (tools/rocpd_stats.py per-step section)"; grep -A 20 "^per step" $F/dispatches.txt; echo "# -> 477 dispatches per step (round 5: 504; VERDICT r5's target of <= 440 is NOT reached -- see DESIGN.md s7 for what the remaining launches are and why merging them buys no time: the GPU is idle 0.04 ms of a step)"; echo; echo "# kernel table of the same trace (in-step durations: overlapped kernels stretch each other)"; head -60 $F/dispatches.txt; } > $P/r06_dispatches.txt
 for f in $F/bench_*.json; do python - $f <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d.get('roofline') or {}
