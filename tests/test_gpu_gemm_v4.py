@@ -317,4 +317,4 @@ def test_clip_bf16_step_under_the_dynamic_tile_distribution_matches_the_referenc
     configuration of every rank of a multi-GPU run"""
     import test_gpu_golden_fullwidth as T
     with _env(DH_V4_DYNAMIC="1"):
-        T.test_clip_vitb32_b256_matches_reference_golden("bf16")
+        T.clip_vitb32_b256_against_golden("bf16")

@@ -87,6 +87,10 @@ def assert_ran_on_v4(stats, min_calls):
 @pytest.mark.parametrize("dtype,buckets", [("fp32", "0"), ("bf16", "0"), ("bf16", "1")])       # bf16 + 1: packed text attention in two length buckets (opt-in since round 6)
 def test_clip_vitb32_b256_matches_reference_golden(monkeypatch, dtype, buckets):
     monkeypatch.setenv("DH_ATTN_BUCKETS", buckets)
+    clip_vitb32_b256_against_golden(dtype)
+
+
+def clip_vitb32_b256_against_golden(dtype):
     from declip_amd import ops, synth
     from declip_amd.loss import ClipInfoCELoss
     from declip_amd.testing import build_clip
